@@ -1,0 +1,77 @@
+"""ctypes binding of libfami_hip.so (C ABI declared in include/fami.h).
+
+The signatures are read from the header itself so the binding cannot drift from
+the declaration.  There is NO fallback: if the shared library is missing the
+import of any compute entry point raises, and every call checks the return code.
+"""
+import ctypes
+import os
+import re
+
+import torch  # loads torch's HIP runtime first; libfami_hip.so binds to the same libamdhip64 (soname match)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfami_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'fami.h')
+
+_SCALAR = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
+           'fami_stream_t': ctypes.c_void_p}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every fami_* prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'(const\s+char\s*\*|int|long)\s+(fami_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if '*' in ret else _SCALAR[ret.strip()]
+        argtypes = []
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    toks = a.replace('const', ' ').split()
+                    argtypes.append(_SCALAR[toks[0]])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class FamiError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.isfile(LIB_PATH):
+            raise FamiError(
+                "libfami_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C fami-pose_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (restype, argtypes) in self.protos.items():
+            fn = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if self.protos[name][0] is ctypes.c_int and rc != 0:
+            raise FamiError('%s failed (%d): %s' % (name, rc, self.cdll.fami_last_error().decode()))
+        return rc
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def loaded():
+    return _lib is not None

@@ -1,0 +1,431 @@
+// Temporal alignment kernels: the global bilinear shift and the modulated
+// deformable convolution (DCNv2), NHWC fp32.  Both are gather kernels bound by
+// HBM traffic; activations are NHWC so the cg channels of one offset group at
+// one bilinear corner are contiguous (16 bytes for cg = 4).
+//
+// Replaces
+//   kornia.geometry.warp_affine with M = [[1,0,tx],[0,1,ty]]   (Alignment_V15.py:133-135)
+//   torchvision.ops.DeformConv2d(48,48,3,padding=3,dilation=3) (Alignment_V15.py:83,89,95,101;
+//   calls :146,150,154,158), offset groups = offset.shape[1]/18, raw (un-sigmoided) masks.
+//
+// DCN forward: one wave owns 16 output pixels.  Lane (pixel = lane&15, kq = lane>>4)
+// produces the modulated bilinear sample of channel kq of the current (group, tap)
+// -- exactly the A operand v_mfma_f32_16x16x4_f32 wants -- so the sampled
+// "column" never exists in memory: gather and contraction are fused, the only
+// HBM traffic is input + offsets + masks + output (the algorithmic bytes of
+// SURVEY.md 8d).  The 4 kq lanes of a pixel share offset/mask addresses (one
+// broadcast load) and read 4 adjacent floats per corner.
+#include "common.h"
+
+// ------------------------------------------------------------------ bilinear shift
+__global__ __launch_bounds__(256) void shift_fwd_kernel(const float* __restrict__ src, const float* __restrict__ t,
+                                                        float* __restrict__ out, int B, int H, int W, int C) {
+  const int CV = C >> 2;
+  const long total = (long)B * H * W * CV;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    const float py = (float)y - t[b * 2 + 1], px = (float)x - t[b * 2 + 0];
+    const float fy = floorf(py), fx = floorf(px);
+    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const float* base = src + (long)b * H * W * C + cv * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      const float w = ((k >> 1) ? ly : hy) * ((k & 1) ? lx : hx);
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        acc += *reinterpret_cast<const f32x4*>(base + ((long)yy * W + xx) * C) * w;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+  }
+}
+
+// grad wrt src, gather form (deterministic): every output pixel that touches (ys,xs) re-evaluates the
+// forward weights exactly as shift_fwd_kernel does.
+__global__ __launch_bounds__(256) void shift_bwd_src_kernel(const float* __restrict__ gout,
+                                                            const float* __restrict__ t, float* __restrict__ gsrc,
+                                                            int B, int H, int W, int C, int accumulate) {
+  const int CV = C >> 2;
+  const long total = (long)B * H * W * CV;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xs = (int)(p % W);
+    p /= W;
+    const int ys = (int)(p % H);
+    const int b = (int)(p / H);
+    const float ty = t[b * 2 + 1], tx = t[b * 2 + 0];
+    const int yb = (int)floorf((float)ys + ty) - 1, xb = (int)floorf((float)xs + tx) - 1;
+    const float* base = gout + (long)b * H * W * C + cv * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) {
+      const int y = yb + a;
+      if ((unsigned)y >= (unsigned)H) continue;
+      const float py = (float)y - ty;
+      const float fy = floorf(py);
+      const float ly = py - fy;
+      const int y0 = (int)fy;
+      float wy;
+      if (y0 == ys) wy = 1.f - ly;
+      else if (y0 + 1 == ys) wy = ly;
+      else continue;
+      for (int c = 0; c < 4; ++c) {
+        const int x = xb + c;
+        if ((unsigned)x >= (unsigned)W) continue;
+        const float px = (float)x - tx;
+        const float fx = floorf(px);
+        const float lx = px - fx;
+        const int x0 = (int)fx;
+        float wx;
+        if (x0 == xs) wx = 1.f - lx;
+        else if (x0 + 1 == xs) wx = lx;
+        else continue;
+        acc += *reinterpret_cast<const f32x4*>(base + ((long)y * W + x) * C) * (wy * wx);
+      }
+    }
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(gsrc + i * 4);
+    *reinterpret_cast<f32x4*>(gsrc + i * 4) = acc;
+  }
+}
+
+// grad wrt (tx,ty): partial[b][blk][2]
+__global__ __launch_bounds__(256) void shift_bwd_t_kernel(const float* __restrict__ gout,
+                                                          const float* __restrict__ src,
+                                                          const float* __restrict__ t, float* __restrict__ partial,
+                                                          int H, int W, int C) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.y;
+  const int CV = C >> 2;
+  const long total = (long)H * W * CV;
+  const float ty = t[b * 2 + 1], tx = t[b * 2 + 0];
+  const float* sb = src + (long)b * H * W * C;
+  const float* gb = gout + (long)b * H * W * C;
+  float gx = 0.f, gy = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int x = (int)(p % W);
+    const int y = (int)(p / W);
+    const float py = (float)y - ty, px = (float)x - tx;
+    const float fy = floorf(py), fx = floorf(px);
+    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      v[k] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                 ? *reinterpret_cast<const f32x4*>(sb + ((long)yy * W + xx) * C + cv * 4)
+                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gb + i * 4);
+    const f32x4 dpy = hx * (v[2] - v[0]) + lx * (v[3] - v[1]);  // d out / d py
+    const f32x4 dpx = hy * (v[1] - v[0]) + ly * (v[3] - v[2]);  // d out / d px
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gy -= g[k] * dpy[k];  // py = y - ty
+      gx -= g[k] * dpx[k];
+    }
+  }
+  gx = wave_sum(gx);
+  gy = wave_sum(gy);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = gx;
+    red[1][wave] = gy;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = partial + ((long)b * gridDim.x + blockIdx.x) * 2;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void shift_bwd_t_finalize_kernel(const float* __restrict__ partial, int G, int B, float* gt,
+                                            int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 2) return;
+  const int b = i >> 1, k = i & 1;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += (double)partial[((long)b * G + g) * 2 + k];
+  gt[i] = accumulate ? gt[i] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------ DCN
+struct DcnArgs {
+  const float* x;     // [B,H,W,C]
+  const float* off;   // [B,Ho,Wo,2*G*K]
+  const float* msk;   // [B,Ho,Wo,G*K]   (may be null => mask 1)
+  const float* wp;    // packed [ksteps/4][NTt][64][4]
+  const float* bias;  // [Co] or null
+  float* y;           // [B,Ho,Wo,Co]
+  int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil;
+  int cg, KS, NTt, P;  // KS = number of 4-wide k-steps = G*K*cg/4
+};
+
+// k ordering: k = ((g*K + tap)*cg + cc); packed[(ks4*NTt + nt)*64 + lane][t] = W[co = nt*16 + (lane&15)]
+//                                                                          [c(k), tap(k)], k = (ks4*4 + t)*4 + (lane>>4)
+__global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int C, int K, int cg,
+                                  int KS, int NTt) {
+  const int KS4 = (KS + 3) / 4;
+  const long total = (long)KS4 * NTt * 256;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long r = i >> 8;
+    const int nt = (int)(r % NTt), ks4 = (int)(r / NTt);
+    const int ks = ks4 * 4 + t;
+    const int co = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (ks < KS && co < Co) {
+      const int k = ks * 4 + (lane >> 4);
+      const int cc = k % cg, gt = k / cg;
+      const int tap = gt % K, g = gt / K;
+      v = w[((long)co * C + g * cg + cc) * K + tap];
+    }
+    wp[i] = v;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  const int m0 = (blockIdx.x * 4 + wave) * 16;
+  if (m0 >= p.P) return;
+  const int K = p.kh * p.kw, GK = p.G * K;
+  const int m = m0 + row;
+  const bool pv = m < p.P;
+  const int mm = pv ? m : 0;
+  const int HoWo = p.Ho * p.Wo;
+  const int b = mm / HoWo, r = mm - b * HoWo;
+  const int oy = r / p.Wo, ox = r - oy * p.Wo;
+  const float* xb = p.x + (long)b * p.H * p.W * p.C;
+  const float* offp = p.off + (long)mm * 2 * GK;
+  const float* mskp = p.msk ? p.msk + (long)mm * GK : nullptr;
+  const int steps_per_gt = p.cg >> 2;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int KS4 = (p.KS + 3) / 4;
+  for (int ks4 = 0; ks4 < KS4; ++ks4) {
+    f32x4 bw[NT];
+    const float* wb = p.wp + ((long)ks4 * p.NTt) * 256 + lane * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
+    float a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ks = ks4 * 4 + t;
+      float v = 0.f;
+      if (pv && ks < p.KS) {
+        const int gt = ks / steps_per_gt, ccb = (ks - gt * steps_per_gt) * 4;
+        const int g = gt / K, tap = gt - g * K;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const float py = (float)(oy * p.stride - p.pad + ky * p.dil) + offp[2 * gt];
+        const float px = (float)(ox * p.stride - p.pad + kx * p.dil) + offp[2 * gt + 1];
+        const float mk = mskp ? mskp[gt] : 1.f;
+        const float fy = floorf(py), fx = floorf(px);
+        const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const float* cb = xb + g * p.cg + ccb + kq;
+        const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+        const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+        if (yv0 && xv0) v += hy * hx * cb[((long)y0 * p.W + x0) * p.C];
+        if (yv0 && xv1) v += hy * lx * cb[((long)y0 * p.W + x0 + 1) * p.C];
+        if (yv1 && xv0) v += ly * hx * cb[((long)(y0 + 1) * p.W + x0) * p.C];
+        if (yv1 && xv1) v += ly * lx * cb[((long)(y0 + 1) * p.W + x0 + 1) * p.C];
+        v *= mk;
+      }
+      a[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bw[nt][t], acc[nt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int mo = m0 + kq * 4 + r4;
+    if (mo >= p.P) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = nt * 16 + row;
+      if (co >= p.Co) continue;
+      float v = acc[nt][r4];
+      if (p.bias) v += p.bias[co];
+      p.y[(long)mo * p.Co + co] = v;
+    }
+  }
+}
+
+// backward gather: one thread per (pixel, group, tap).
+//   gcol [P][C*K]   gradient of the (c,tap)-ordered column (from the 1x1 dgrad)
+//   col  [P][C*K]   out: modulated sample (for the weight gradient)
+//   gx   [B,H,W,C]  += scattered input gradient (atomics; caller zero-fills or accumulates)
+//   goff [P][2GK], gmsk [P][GK] (=|+=)
+__global__ __launch_bounds__(256) void dcn_bwd_gather_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ off,
+                                                             const float* __restrict__ msk,
+                                                             const float* __restrict__ gcol, float* __restrict__ col,
+                                                             float* __restrict__ gx, float* __restrict__ goff,
+                                                             float* __restrict__ gmsk, int B, int H, int W, int C,
+                                                             int Ho, int Wo, int G, int kh, int kw, int stride,
+                                                             int pad, int dil, int acc_off) {
+  const int K = kh * kw, GK = G * K, cg = C / G, CK = C * K;
+  const long total = (long)B * Ho * Wo * GK;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int gt = (int)(i % GK);
+    const long m = i / GK;
+    const int g = gt / K, tap = gt - g * K;
+    const int ky = tap / kw, kx = tap - ky * kw;
+    const int HoWo = Ho * Wo;
+    const int b = (int)(m / HoWo);
+    const int r = (int)(m - (long)b * HoWo);
+    const int oy = r / Wo, ox = r - oy * Wo;
+    const float py = (float)(oy * stride - pad + ky * dil) + off[m * 2 * GK + 2 * gt];
+    const float px = (float)(ox * stride - pad + kx * dil) + off[m * 2 * GK + 2 * gt + 1];
+    const float mk = msk ? msk[m * GK + gt] : 1.f;
+    const float fy = floorf(py), fx = floorf(px);
+    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const bool yv0 = (unsigned)y0 < (unsigned)H, yv1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const bool xv0 = (unsigned)x0 < (unsigned)W, xv1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool v00 = yv0 && xv0, v01 = yv0 && xv1, v10 = yv1 && xv0, v11 = yv1 && xv1;
+    const long o00 = ((long)y0 * W + x0) * C, o01 = o00 + C, o10 = o00 + (long)W * C, o11 = o10 + C;
+    const float* xb = x + (long)b * H * W * C + g * cg;
+    float* gxb = gx ? gx + (long)b * H * W * C + g * cg : nullptr;
+    float gm = 0.f, gpy = 0.f, gpx = 0.f;
+    for (int cc = 0; cc < cg; ++cc) {
+      const float a00 = v00 ? xb[o00 + cc] : 0.f, a01 = v01 ? xb[o01 + cc] : 0.f;
+      const float a10 = v10 ? xb[o10 + cc] : 0.f, a11 = v11 ? xb[o11 + cc] : 0.f;
+      const float val = hy * hx * a00 + hy * lx * a01 + ly * hx * a10 + ly * lx * a11;
+      const long ci = m * CK + (long)(g * cg + cc) * K + tap;
+      const float gc = gcol[ci];
+      if (col) col[ci] = val * mk;
+      gm += gc * val;
+      const float gv = gc * mk;
+      gpy += gv * (hx * (a10 - a00) + lx * (a11 - a01));
+      gpx += gv * (hy * (a01 - a00) + ly * (a11 - a10));
+      if (gxb) {
+        if (v00) atomicAdd(gxb + o00 + cc, gv * hy * hx);
+        if (v01) atomicAdd(gxb + o01 + cc, gv * hy * lx);
+        if (v10) atomicAdd(gxb + o10 + cc, gv * ly * hx);
+        if (v11) atomicAdd(gxb + o11 + cc, gv * ly * lx);
+      }
+    }
+    if (goff) {
+      float* q = goff + m * 2 * GK + 2 * gt;
+      q[0] = acc_off ? q[0] + gpy : gpy;
+      q[1] = acc_off ? q[1] + gpx : gpx;
+    }
+    if (gmsk) {
+      float* q = gmsk + m * GK + gt;
+      *q = acc_off ? *q + gm : gm;
+    }
+  }
+}
+
+extern "C" {
+
+long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
+
+// out[b,y,x,:] = bilinear(src[b], y - t[b,1], x - t[b,0]) ; t device [B,2] = (tx,ty)
+int fami_shift_bilinear_fwd_f32(const float* src, const float* t, float* out, int B, int H, int W, int C,
+                                hipStream_t s) {
+  FAMI_REQUIRE(src && t && out && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "fami_shift_bilinear_fwd_f32", "bad argument");
+  hipLaunchKernelGGL(shift_fwd_kernel, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, src, t, out, B, H, W, C);
+  FAMI_CHECK_LAUNCH("fami_shift_bilinear_fwd_f32");
+  return FAMI_OK;
+}
+
+// gsrc (=|+=) d/dsrc ; gt[B,2] (=|+=) d/d(tx,ty).  Either output may be null.
+int fami_shift_bilinear_bwd_f32(const float* gout, const float* src, const float* t, float* gsrc, float* gt, int B,
+                                int H, int W, int C, int acc_src, int acc_t, float* ws, hipStream_t s) {
+  FAMI_REQUIRE(gout && src && t && B > 0 && (C % 4) == 0, "fami_shift_bilinear_bwd_f32", "bad argument");
+  if (gsrc) {
+    hipLaunchKernelGGL(shift_bwd_src_kernel, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, gout, t, gsrc, B, H, W, C, acc_src);
+    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/src");
+  }
+  if (gt) {
+    FAMI_REQUIRE(ws, "fami_shift_bilinear_bwd_f32", "workspace required for gt");
+    long g = ((long)H * W * (C / 4) + 255) / 256;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(shift_bwd_t_kernel, dim3((int)g, B), dim3(256), 0, s, gout, src, t, ws, H, W, C);
+    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/t");
+    hipLaunchKernelGGL(shift_bwd_t_finalize_kernel, dim3(fami_cdiv(B * 2, 64)), dim3(64), 0, s, ws, (int)g, B, gt, acc_t);
+    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/t_finalize");
+  }
+  return FAMI_OK;
+}
+
+long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
+  const int KS = C * kh * kw / 4;
+  return (long)((KS + 3) / 4) * fami_cdiv(Co, 16) * 256;
+}
+
+int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wp && G > 0 && C % G == 0 && ((C / G) % 4) == 0, "fami_dcn_pack_weight_f32", "channels per offset group must be a multiple of 4");
+  const int K = kh * kw, cg = C / G, KS = C * K / 4, NTt = fami_cdiv(Co, 16);
+  const long total = (long)((KS + 3) / 4) * NTt * 256;
+  hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS, NTt);
+  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
+  return FAMI_OK;
+}
+
+// y[B,Ho,Wo,Co] = deform_conv2d(x[B,H,W,C], off[B,Ho,Wo,2GK], msk[B,Ho,Wo,GK], W, bias)
+int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
+                     int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
+                     hipStream_t s) {
+  FAMI_REQUIRE(x && off && wp && y && B > 0 && G > 0 && C % G == 0, "fami_dcn_fwd_f32", "bad argument");
+  DcnArgs a;
+  a.x = x; a.off = off; a.msk = msk; a.wp = wp; a.bias = bias; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
+  a.stride = stride; a.pad = pad; a.dil = dil;
+  a.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+  a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  a.cg = C / G;
+  if ((a.cg % 4) != 0 || Co > 96) {
+    fami_set_error("fami_dcn_fwd_f32", "channels per offset group must be a multiple of 4 and Co <= 96");
+    return FAMI_ESHAPE;
+  }
+  a.KS = C * kh * kw / 4;
+  a.NTt = fami_cdiv(Co, 16);
+  const long P = (long)B * a.Ho * a.Wo;
+  FAMI_REQUIRE(P < (1L << 31), "fami_dcn_fwd_f32", "size out of range");
+  a.P = (int)P;
+  const dim3 grid(fami_cdiv(P, 64));
+  switch (a.NTt) {
+    case 1: hipLaunchKernelGGL(dcn_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(dcn_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(dcn_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(dcn_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL(dcn_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(dcn_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
+  }
+  FAMI_CHECK_LAUNCH("fami_dcn_fwd_f32");
+  return FAMI_OK;
+}
+
+// see dcn_bwd_gather_kernel.  gx is accumulated with atomics (zero it first unless accumulating).
+int fami_dcn_bwd_gather_f32(const float* x, const float* off, const float* msk, const float* gcol, float* col,
+                            float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int G, int kh, int kw,
+                            int stride, int pad, int dil, int acc_off, hipStream_t s) {
+  FAMI_REQUIRE(x && off && gcol && B > 0 && G > 0 && C % G == 0, "fami_dcn_bwd_gather_f32", "bad argument");
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  const long total = (long)B * Ho * Wo * G * kh * kw;
+  hipLaunchKernelGGL(dcn_bwd_gather_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, x, off, msk, gcol, col, gx, goff, gmsk, B, H, W, C, Ho, Wo, G, kh, kw, stride, pad, dil, acc_off);
+  FAMI_CHECK_LAUNCH("fami_dcn_bwd_gather_f32");
+  return FAMI_OK;
+}
+
+}  // extern "C"

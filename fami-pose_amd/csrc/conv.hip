@@ -1,0 +1,518 @@
+// Convolution family for the HRNet branches and the alignment head, fp32,
+// NHWC activations, implicit GEMM on the CDNA4 f32-input matrix core
+// (v_mfma_f32_16x16x4_f32: exact f32, one rounding per product).
+//
+// Replaces: every nn.Conv2d on the hot path of the reference
+//   posetimation/backbones/hrnet.py:569-629 (293 convs of HRNet-W48),
+//   posetimation/layers/basic_model.py:21-23,25-63,66-113 and
+//   posetimation/layers/basic_layer.py:18-19 (conv_bn_relu.conv), plus their
+//   autograd (dgrad / wgrad).
+//
+// Mapping (forward): GEMM M = N*Ho*Wo output pixels (rows), N = Cout (cols),
+// K = kh*kw*Cin walked tap-major.  A wave owns MT 16-pixel row tiles x NT
+// 16-channel column tiles.  A-fragments are read straight from the NHWC
+// activation (each lane: one pixel, 4 consecutive channels = one 16-byte load,
+// zero outside the image); B-fragments come from a weight image pre-packed in
+// fragment order (pack_w_kernel) so a wave-load is one contiguous 1 KiB line
+// that stays L2-resident across the grid.  The K order inside a 16-channel
+// chunk is permuted identically on both operands so the 4 values of a lane's
+// 16-byte load feed 4 consecutive MFMAs.  No LDS, no barriers: at the f32 MFMA
+// rate (32 cycles / instruction / SIMD) operand traffic is ~25 B/clk/CU.
+// dgrad is the same kernel with the transposed position map (MODE 1).
+#include "common.h"
+
+struct ConvArgs {
+  const float* x;       // GEMM input activation  [N,Hi,Wi,Ci]
+  const float* wp;      // packed weights [taps][KC][NTt][64][4]
+  float* y;             // GEMM output activation [N,Ho,Wo,Co]
+  const float* bias;    // [Co] or null
+  const float* addend;  // [N,Ho,Wo,Co] or null (added before relu)
+  int N, Hi, Wi, Ci, Ho, Wo, Co;
+  int kh, kw, sh, pad, dil;  // sh = log2(stride)
+  int KC, NTt, relu, accumulate, P;
+};
+
+// packed[tap][kc][nt][lane][t] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int taps,
+                              int KC, int NTt, int mode) {
+  const long total = (long)taps * KC * NTt * 256;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int kc = (int)(r % KC), tap = (int)(r / KC);
+    const int kidx = kc * 16 + (lane >> 4) * 4 + t, nidx = nt * 16 + (lane & 15);
+    const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = w[((long)co * Ci + ci) * taps + tap];
+    wp[i] = v;
+  }
+}
+
+template <int MT, int NT, int MODE, int VEC>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  const int m0 = (blockIdx.x * 4 + wave) * (MT * 16);
+  if (m0 >= p.P) return;  // wave-uniform
+  const int ntg0 = blockIdx.y * NT;
+  const int HoWo = p.Ho * p.Wo;
+
+  int pn[MT], py[MT], px[MT];
+  bool pv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + row;
+    pv[mt] = m < p.P;
+    const int mm = pv[mt] ? m : 0;
+    const int n = mm / HoWo, r = mm - n * HoWo;
+    const int oy = r / p.Wo;
+    pn[mt] = n;
+    py[mt] = oy;
+    px[mt] = r - oy * p.Wo;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* ptr[MT];
+  bool ok[MT];
+  const int taps = p.kh * p.kw;
+  int tap = 0, kc = 0;
+
+  auto tap_setup = [&](int tp) {
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      bool v = pv[mt];
+      int iy, ix;
+      if (MODE == 0) {
+        iy = (py[mt] << p.sh) - p.pad + ky * p.dil;
+        ix = (px[mt] << p.sh) - p.pad + kx * p.dil;
+        v = v && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      } else {
+        const int ty = py[mt] + p.pad - ky * p.dil, tx = px[mt] + p.pad - kx * p.dil;
+        iy = ty >> p.sh;
+        ix = tx >> p.sh;
+        v = v && ty >= 0 && tx >= 0 && (iy << p.sh) == ty && (ix << p.sh) == tx && iy < p.Hi && ix < p.Wi;
+      }
+      ok[mt] = v;
+      const long off = v ? (((long)pn[mt] * p.Hi + iy) * p.Wi + ix) * p.Ci : 0;
+      ptr[mt] = p.x + off + kq * 4;
+    }
+  };
+
+  auto load = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
+    const int cbase = kc * 16 + kq * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (VEC) {
+        a[mt] = (ok[mt] && cbase < p.Ci) ? *reinterpret_cast<const f32x4*>(ptr[mt] + kc * 16)
+                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[mt][t] = (ok[mt] && cbase + t < p.Ci) ? ptr[mt][kc * 16 + t] : 0.f;
+      }
+    }
+    const float* wb = p.wp + ((long)(tap * p.KC + kc) * p.NTt) * 256 + lane * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = (ntg0 + nt < p.NTt) ? *reinterpret_cast<const f32x4*>(wb + (long)(ntg0 + nt) * 256)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (++kc == p.KC) {
+      kc = 0;
+      if (++tap < taps) tap_setup(tap);
+    }
+  };
+
+  auto mma = [&](const f32x4(&a)[MT], const f32x4(&b)[NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+  };
+
+  f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+  const int T = taps * p.KC;
+  tap_setup(0);
+  load(a0, b0);
+  for (int it = 0; it < T; it += 2) {
+    if (it + 1 < T) load(a1, b1);
+    mma(a0, b0);
+    if (it + 2 < T) load(a0, b0);
+    if (it + 1 < T) mma(a1, b1);
+  }
+
+  // epilogue: D row = kq*4 + r (pixel), col = row (channel)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + mt * 16 + kq * 4 + r;
+      if (m >= p.P) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = (ntg0 + nt) * 16 + row;
+        if (co >= p.Co) continue;
+        const long idx = (long)m * p.Co + co;
+        float v = acc[mt][nt][r];
+        if (p.bias) v += p.bias[co];
+        if (p.addend) v += p.addend[idx];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.accumulate) v += p.y[idx];
+        p.y[idx] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  const float* x;   // [N,H,W,Ci]
+  const float* dy;  // [N,Ho,Wo,Co]
+  float* part;      // [psplit][Co][Ci][taps]
+  int N, H, W, Ci, Ho, Wo, Co, kh, kw, sh, pad, dil;
+  int P, chunk, ciBlocks, coBlocks;
+};
+
+// dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
+  __shared__ float red[4 * MT * NT * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int ps = blockIdx.x;
+  int by = blockIdx.y;
+  const int cob = by % p.coBlocks;
+  by /= p.coBlocks;
+  const int cib = by % p.ciBlocks;
+  const int tap = by / p.ciBlocks;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int taps = p.kh * p.kw;
+
+  const int p_lo = ps * p.chunk;
+  const int p_hi = min(p.P, p_lo + p.chunk);
+  const int sub = p.chunk >> 2;  // chunk is a multiple of 16
+  const int w_lo = p_lo + wave * sub;
+  const int w_hi = min(p_hi, w_lo + sub);
+
+  int ci[MT], co[NT];
+  bool civ[MT], cov[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    ci[mt] = (cib * MT + mt) * 16 + c16;
+    civ[mt] = ci[mt] < p.Ci;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    co[nt] = (cob * NT + nt) * 16 + c16;
+    cov[nt] = co[nt] < p.Co;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane walks pixels w_lo + kq, +4, +8, ...
+  int pix = w_lo + kq;
+  int n, oy, ox;
+  {
+    const int HoWo = p.Ho * p.Wo;
+    const int pp = pix < p.P ? pix : 0;
+    n = pp / HoWo;
+    const int r = pp - n * HoWo;
+    oy = r / p.Wo;
+    ox = r - oy * p.Wo;
+  }
+
+  auto load = [&](float(&a)[MT], float(&b)[NT]) {
+    const bool pvalid = pix < w_hi;
+    const int iy = (oy << p.sh) - p.pad + ky * p.dil, ix = (ox << p.sh) - p.pad + kx * p.dil;
+    const bool xin = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const long xoff = xin ? (((long)n * p.H + iy) * p.W + ix) * p.Ci : 0;
+    const long yoff = pvalid ? (long)pix * p.Co : 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = (xin && civ[mt]) ? p.x[xoff + ci[mt]] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = (pvalid && cov[nt]) ? p.dy[yoff + co[nt]] : 0.f;
+    pix += 4;
+    ox += 4;
+    while (ox >= p.Wo) {
+      ox -= p.Wo;
+      ++oy;
+    }
+    while (oy >= p.Ho) {
+      oy -= p.Ho;
+      ++n;
+    }
+  };
+  auto mma = [&](const float(&a)[MT], const float(&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  };
+
+  const int T = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
+  float a0[MT], b0[NT], a1[MT], b1[NT];
+  if (T > 0) load(a0, b0);
+  for (int it = 0; it < T; it += 2) {
+    if (it + 1 < T) load(a1, b1);
+    mma(a0, b0);
+    if (it + 2 < T) load(a0, b0);
+    if (it + 1 < T) mma(a1, b1);
+  }
+
+  // cross-wave reduction through LDS, then scatter into the OIHW-ordered partial slab
+  float* mine = red + wave * (MT * NT * 256);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+  __syncthreads();
+  float* slab = p.part + (long)ps * p.Co * p.Ci * taps;
+  for (int e = threadIdx.x; e < MT * NT * 256; e += 256) {
+    const float v = red[e] + red[MT * NT * 256 + e] + red[2 * MT * NT * 256 + e] + red[3 * MT * NT * 256 + e];
+    const int l = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+    const int mt = tile / NT, nt = tile - mt * NT;
+    const int cci = (cib * MT + mt) * 16 + (l >> 4) * 4 + r;
+    const int cco = (cob * NT + nt) * 16 + (l & 15);
+    if (cci < p.Ci && cco < p.Co) slab[((long)cco * p.Ci + cci) * taps + tap] = v;
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int psplit,
+                                    int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < psplit; ++k) s += part[(long)k * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static int pick_nt(int tiles) {
+  const int cand[5] = {6, 4, 3, 2, 1};
+  int best = 1;
+  double bs = 1e30;
+  for (int i = 0; i < 5; ++i) {
+    const int c = cand[i];
+    const int padded = ((tiles + c - 1) / c) * c;
+    const double s = padded * (1.0 + 0.5 / c);
+    if (s < bs - 1e-9) {
+      bs = s;
+      best = c;
+    }
+  }
+  return best;
+}
+
+static int pick_small(int tiles) {  // wgrad tile counts in {4,3,2,1}
+  int best = 1;
+  double bs = 1e30;
+  for (int c = 4; c >= 1; --c) {
+    const int padded = ((tiles + c - 1) / c) * c;
+    const double s = padded * (1.0 + 0.3 / c);
+    if (s < bs - 1e-9) {
+      bs = s;
+      best = c;
+    }
+  }
+  return best;
+}
+
+template <int MODE, int VEC>
+static int launch_igemm(const ConvArgs& a, int MT, int NT, hipStream_t s) {
+  const dim3 grid(fami_cdiv(a.P, 4 * MT * 16), fami_cdiv(a.NTt, NT));
+#define FAMI_CASE(mt, nt)                                                                   \
+  if (MT == mt && NT == nt) {                                                               \
+    hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC>), grid, dim3(256), 0, s, a);      \
+    return 0;                                                                               \
+  }
+  if constexpr (VEC) {
+    FAMI_CASE(1, 1) FAMI_CASE(1, 2) FAMI_CASE(1, 3) FAMI_CASE(1, 4) FAMI_CASE(1, 6)
+    FAMI_CASE(2, 1) FAMI_CASE(2, 2) FAMI_CASE(2, 3) FAMI_CASE(2, 4) FAMI_CASE(2, 6)
+    FAMI_CASE(4, 1) FAMI_CASE(4, 2) FAMI_CASE(4, 3) FAMI_CASE(4, 4)
+  } else {
+    FAMI_CASE(2, 1) FAMI_CASE(2, 2) FAMI_CASE(2, 3) FAMI_CASE(2, 4)
+  }
+#undef FAMI_CASE
+  return -1;
+}
+
+static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
+  const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+  int NT = pick_nt(a.NTt);
+  int MT;
+  if (!vec) {
+    MT = 2;
+    if (NT > 4) NT = 4;
+  } else {
+    const long nblk = fami_cdiv(a.NTt, NT);
+    MT = 4;
+    if (NT > 4 || (long)fami_cdiv(a.P, 4 * 64) * nblk < 512) MT = 2;
+    if (MT == 2 && (long)fami_cdiv(a.P, 4 * 32) * nblk < 512) MT = 1;
+  }
+  int rc;
+  if (mode == 0)
+    rc = vec ? launch_igemm<0, 1>(a, MT, NT, s) : launch_igemm<0, 0>(a, MT, NT, s);
+  else
+    rc = vec ? launch_igemm<1, 1>(a, MT, NT, s) : launch_igemm<1, 0>(a, MT, NT, s);
+  if (rc != 0) {
+    fami_set_error(name, "no kernel instance for tile shape");
+    return FAMI_ESHAPE;
+  }
+  FAMI_CHECK_LAUNCH(name);
+  return FAMI_OK;
+}
+
+static bool geom_ok(int kh, int kw, int stride, int pad, int dil) {
+  return kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7 && (stride == 1 || stride == 2) && pad >= 0 && dil >= 1;
+}
+static inline int out_dim(int i, int k, int stride, int pad, int dil) {
+  return (i + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+}
+
+extern "C" {
+
+long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  return (long)kh * kw * fami_cdiv(kd, 16) * fami_cdiv(nd, 16) * 256;
+}
+
+int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
+                              hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wp && Co > 0 && Ci > 0 && (mode == 0 || mode == 1), "fami_pack_conv_weight_f32", "bad argument");
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  const int KC = fami_cdiv(kd, 16), NTt = fami_cdiv(nd, 16);
+  const long total = (long)kh * kw * KC * NTt * 256;
+  hipLaunchKernelGGL(pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, KC, NTt, mode);
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weight_f32");
+  return FAMI_OK;
+}
+
+// y[N,Ho,Wo,Co] = conv(x[N,H,W,Ci], W) (+bias) (+addend) (relu) ; wp packed with mode 0
+int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* addend, float* y, int N,
+                        int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                        int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_fwd_f32", "bad argument");
+  if (!geom_ok(kh, kw, stride, pad, dil)) {
+    fami_set_error("fami_conv2d_fwd_f32", "unsupported geometry");
+    return FAMI_ESHAPE;
+  }
+  ConvArgs a;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias; a.addend = addend;
+  a.N = N; a.Hi = H; a.Wi = W; a.Ci = Ci;
+  a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
+  a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
+  a.KC = fami_cdiv(Ci, 16); a.NTt = fami_cdiv(Co, 16); a.relu = relu; a.accumulate = accumulate;
+  const long P = (long)N * a.Ho * a.Wo;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && P * Co < (1L << 40), "fami_conv2d_fwd_f32", "size out of range");
+  a.P = (int)P;
+  return run_igemm(a, 0, s, "fami_conv2d_fwd_f32");
+}
+
+// dx[N,H,W,Ci] = conv^T(dy[N,Ho,Wo,Co], W) (+addend) ; wp packed with mode 1
+int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend, float* dx, int N, int H, int W,
+                          int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                          hipStream_t s) {
+  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_dgrad_f32", "bad argument");
+  if (!geom_ok(kh, kw, stride, pad, dil)) {
+    fami_set_error("fami_conv2d_dgrad_f32", "unsupported geometry");
+    return FAMI_ESHAPE;
+  }
+  ConvArgs a;
+  a.x = dy; a.wp = wp; a.y = dx; a.bias = nullptr; a.addend = addend;
+  a.N = N; a.Hi = out_dim(H, kh, stride, pad, dil); a.Wi = out_dim(W, kw, stride, pad, dil); a.Ci = Co;
+  a.Ho = H; a.Wo = W; a.Co = Ci;
+  a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
+  a.KC = fami_cdiv(Co, 16); a.NTt = fami_cdiv(Ci, 16); a.relu = 0; a.accumulate = accumulate;
+  const long P = (long)N * H * W;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31), "fami_conv2d_dgrad_f32", "size out of range");
+  a.P = (int)P;
+  return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
+}
+
+struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk; long P; };
+static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  WgradPlan q;
+  const int Ho = out_dim(H, kh, stride, pad, dil), Wo = out_dim(W, kw, stride, pad, dil);
+  q.P = (long)N * Ho * Wo;
+  q.MT = pick_small(fami_cdiv(Ci, 16));
+  q.NT = pick_small(fami_cdiv(Co, 16));
+  q.ciBlocks = fami_cdiv(fami_cdiv(Ci, 16), q.MT);
+  q.coBlocks = fami_cdiv(fami_cdiv(Co, 16), q.NT);
+  const long by = (long)kh * kw * q.ciBlocks * q.coBlocks;
+  long ps = (1024 + by - 1) / by;
+  const long maxps = (q.P + 255) / 256;
+  if (ps > maxps) ps = maxps;
+  if (ps < 1) ps = 1;
+  long chunk = (q.P + ps - 1) / ps;
+  chunk = ((chunk + 15) / 16) * 16;
+  ps = (q.P + chunk - 1) / chunk;
+  q.psplit = (int)ps;
+  q.chunk = (int)chunk;
+  return q;
+}
+
+long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  if (!geom_ok(kh, kw, stride, pad, dil)) return -1;
+  const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
+  return (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
+}
+
+// dw[Co,Ci,kh,kw] (=|+=) sum_pixels x (*) dy ; workspace from fami_conv2d_wgrad_workspace
+int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                          int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                          hipStream_t s) {
+  FAMI_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_wgrad_f32", "bad argument");
+  if (!geom_ok(kh, kw, stride, pad, dil)) {
+    fami_set_error("fami_conv2d_wgrad_f32", "unsupported geometry");
+    return FAMI_ESHAPE;
+  }
+  const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
+  const long need = (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
+  FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_f32", "workspace too small");
+  FAMI_REQUIRE(q.P < (1L << 31), "fami_conv2d_wgrad_f32", "size out of range");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.part = workspace;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci;
+  a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
+  a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
+  a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
+  const dim3 grid(q.psplit, kh * kw * q.ciBlocks * q.coBlocks);
+  bool done = false;
+#define FAMI_WCASE(mt, nt)                                                                  \
+  if (q.MT == mt && q.NT == nt) {                                                           \
+    hipLaunchKernelGGL((conv_wgrad_f32<mt, nt>), grid, dim3(256), 0, s, a);                 \
+    done = true;                                                                            \
+  }
+  FAMI_WCASE(1, 1) FAMI_WCASE(1, 2) FAMI_WCASE(1, 3) FAMI_WCASE(1, 4)
+  FAMI_WCASE(2, 1) FAMI_WCASE(2, 2) FAMI_WCASE(2, 3) FAMI_WCASE(2, 4)
+  FAMI_WCASE(3, 1) FAMI_WCASE(3, 2) FAMI_WCASE(3, 3) FAMI_WCASE(3, 4)
+  FAMI_WCASE(4, 1) FAMI_WCASE(4, 2) FAMI_WCASE(4, 3) FAMI_WCASE(4, 4)
+#undef FAMI_WCASE
+  if (!done) {
+    fami_set_error("fami_conv2d_wgrad_f32", "no kernel instance");
+    return FAMI_ESHAPE;
+  }
+  FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32");
+  const long n = (long)Co * Ci * kh * kw;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, workspace, dw, n, q.psplit, accumulate);
+  FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
+  return FAMI_OK;
+}
+
+}  // extern "C"

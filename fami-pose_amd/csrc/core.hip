@@ -1,0 +1,97 @@
+// Library core: version / error reporting / device info, and the three tiny
+// dense layers of the global-translation regressor (nn.Linear 16*h5*w5->64->64->2,
+// Alignment_V15.py:69-71, no activations in between).  M = batch (<= a few
+// dozen rows): a thread per output element is the right size; no MFMA.
+#include "common.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+extern "C" void fami_set_error(const char* where, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where ? where : "?", what ? what : "?");
+}
+
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                  const float* __restrict__ b, float* __restrict__ y, int M, int K, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int m = i / N, n = i - m * N;
+  float s = b ? b[n] : 0.f;
+  for (int k = 0; k < K; ++k) s += x[m * K + k] * w[n * K + k];
+  y[i] = s;
+}
+__global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* dx, int M,
+                                    int K, int N, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * K) return;
+  const int m = i / K, k = i - m * K;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dy[m * N + n] * w[n * K + k];
+  dx[i] = accumulate ? dx[i] + s : s;
+}
+__global__ void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* dw, float* db,
+                                    int M, int K, int N, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (K + 1)) return;
+  const int n = i / (K + 1), k = i - n * (K + 1);
+  float s = 0.f;
+  if (k < K) {
+    for (int m = 0; m < M; ++m) s += dy[m * N + n] * x[m * K + k];
+    dw[n * K + k] = accumulate ? dw[n * K + k] + s : s;
+  } else if (db) {
+    for (int m = 0; m < M; ++m) s += dy[m * N + n];
+    db[n] = accumulate ? db[n] + s : s;
+  }
+}
+
+extern "C" {
+
+const char* fami_version(void) { return "fami-pose_amd 0.1 (gfx950)"; }
+const char* fami_last_error(void) { return g_err; }
+
+// info[0]=CU count, [1]=wavefront size, [2]=LDS bytes per workgroup, [3]=clock kHz; name optional
+int fami_device_info(int device, int* info, char* name, int name_len) {
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, device);
+  if (e != hipSuccess) {
+    fami_set_error("fami_device_info", hipGetErrorString(e));
+    return FAMI_EHIP;
+  }
+  if (info) {
+    info[0] = p.multiProcessorCount;
+    info[1] = p.warpSize;
+    info[2] = (int)p.sharedMemPerBlock;
+    info[3] = p.clockRate;
+  }
+  if (name && name_len > 0) {
+    strncpy(name, p.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return FAMI_OK;
+}
+
+// y[M,N] = x[M,K] w[N,K]^T + b
+int fami_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
+                        hipStream_t s) {
+  FAMI_REQUIRE(x && w && y && M > 0 && K > 0 && N > 0, "fami_linear_fwd_f32", "bad argument");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(fami_cdiv((long)M * N, 64)), dim3(64), 0, s, x, w, b, y, M, K, N);
+  FAMI_CHECK_LAUNCH("fami_linear_fwd_f32");
+  return FAMI_OK;
+}
+// dx (=|+=) dy w ; dw (=|+=) dy^T x ; db (=|+=) sum_m dy.  Any of dx / (dw,db) may be null.
+int fami_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int M,
+                        int K, int N, int acc_dx, int acc_param, hipStream_t s) {
+  FAMI_REQUIRE(dy && x && w && M > 0 && K > 0 && N > 0, "fami_linear_bwd_f32", "bad argument");
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(fami_cdiv((long)M * K, 64)), dim3(64), 0, s, dy, w, dx, M, K, N, acc_dx);
+    FAMI_CHECK_LAUNCH("fami_linear_bwd_f32/dx");
+  }
+  if (dw) {
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(fami_cdiv((long)N * (K + 1), 64)), dim3(64), 0, s, dy, x, dw, db, M, K, N, acc_param);
+    FAMI_CHECK_LAUNCH("fami_linear_bwd_f32/dw");
+  }
+  return FAMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// On-device targets, losses and decode for the heatmap head.  All tensors here
+// are at the NCHW boundary: rows are (b, joint) or (b, channel) with H*W
+// contiguous, which is what every reduction below runs over.
+//
+// Replaces
+//   datasets/process/heatmaps_process.py:146-203  generate_heatmaps (Gaussian targets, sigma 3)
+//   posetimation/loss/mse_loss.py:21-40           JointMSELoss.forward
+//   posetimation/zoo/Alignment/Alignment_V15.py:250-277  the two MI estimators
+//       kl_div(input=softmax(A/T) (probabilities!), target=softmax(Bt/T), 'mean'), T = 0.05
+//   datasets/process/heatmaps_process.py:16-44    get_max_preds (flat argmax, first max on ties)
+#include "common.h"
+
+// joints [B,J,2] (x,y in input-image pixels), vis [B,J] -> target [B,J,Hh,Wh], weight [B,J]
+__global__ void gauss_target_kernel(const float* __restrict__ joints, const float* __restrict__ vis,
+                                    float* __restrict__ target, float* __restrict__ weight, int B, int J, int Hh,
+                                    int Wh, double stride_x, double stride_y, int sigma) {
+  const long HW = (long)Hh * Wh;
+  const long total = (long)B * J * HW;
+  const int r = sigma * 3;
+  const float inv = (float)(2 * sigma * sigma);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long bj = i / HW;
+    const int hw = (int)(i - bj * HW);
+    const int y = hw / Wh, x = hw - y * Wh;
+    // int(v + 0.5) of the reference truncates toward zero, in double
+    const int mx = (int)((double)joints[bj * 2 + 0] / stride_x + 0.5);
+    const int my = (int)((double)joints[bj * 2 + 1] / stride_y + 0.5);
+    const int x0 = mx - r, y0 = my - r, x1 = mx + r + 1, y1 = my + r + 1;
+    float w = vis[bj];
+    const bool outside = x0 >= Wh || y0 >= Hh || x1 < 0 || y1 < 0;
+    if (outside) w = 0.f;
+    float v = 0.f;
+    if (!outside && w > 0.5f && x >= x0 && x < x1 && y >= y0 && y < y1) {
+      const int dx = x - mx, dy = y - my;
+      v = expf(-((float)(dx * dx + dy * dy)) / inv);
+    }
+    target[i] = v;
+    if (hw == 0) weight[bj] = w;
+  }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// rowsum[r] = sum_p (w_r * (pred - gt))^2
+__global__ __launch_bounds__(256) void wmse_rows_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                        const float* __restrict__ w, float* __restrict__ rowsum,
+                                                        int L) {
+  __shared__ float sm[4];
+  const long r = blockIdx.x;
+  const float wr = w ? w[r] : 1.f;
+  float s = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float d = pred[r * L + l] * wr - gt[r * L + l] * wr;
+    s += d * d;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) rowsum[r] = s;
+}
+__global__ void scalar_sum_kernel(const float* __restrict__ rows, int R, double scale, float* out) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < R; i += 256) s += (double)rows[i];
+  s = wave_sum_d(s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) * scale);
+}
+// dpred = g * 2 w^2 (pred - gt) * scale
+__global__ void wmse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                const float* __restrict__ w, float* __restrict__ dpred, long n, int L, float scale,
+                                const float* gdev, int accumulate) {
+  const float g = gdev ? gdev[0] * scale : scale;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float wr = w ? w[i / L] : 1.f;
+    const float v = 2.f * g * wr * (pred[i] * wr - gt[i] * wr);
+    dpred[i] = accumulate ? dpred[i] + v : v;
+  }
+}
+
+// per row: stats[r] = {max_a, sum_a, max_b, sum_b, S = sum_l t_l*(log t_l + 1 - a_l)}, rowval[r] = sum_l t(log t - a)
+__global__ __launch_bounds__(256) void softmax_kl_rows_kernel(const float* __restrict__ A,
+                                                              const float* __restrict__ Bt,
+                                                              float* __restrict__ stats, float* __restrict__ rowval,
+                                                              int L, float temperature) {
+  __shared__ float sm[4];
+  const long r = blockIdx.x;
+  const float* a = A + r * L;
+  const float* b = Bt + r * L;
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    ma = fmaxf(ma, a[l] / temperature);
+    mb = fmaxf(mb, b[l] / temperature);
+  }
+  ma = block_max(ma, sm);
+  mb = block_max(mb, sm);
+  float sa = 0.f, sb = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    sa += expf(a[l] / temperature - ma);
+    sb += expf(b[l] / temperature - mb);
+  }
+  sa = block_sum(sa, sm);
+  sb = block_sum(sb, sm);
+  float val = 0.f, S = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float pa = expf(a[l] / temperature - ma) / sa;
+    const float t = expf(b[l] / temperature - mb) / sb;
+    if (t > 0.f) {
+      const float lt = logf(t);
+      val += t * lt - t * pa;
+      S += t * (lt + 1.f - pa);
+    }
+  }
+  val = block_sum(val, sm);
+  S = block_sum(S, sm);
+  if (threadIdx.x == 0) {
+    stats[r * 5 + 0] = ma;
+    stats[r * 5 + 1] = sa;
+    stats[r * 5 + 2] = mb;
+    stats[r * 5 + 3] = sb;
+    stats[r * 5 + 4] = S;
+    rowval[r] = val;
+  }
+}
+// dBt[r,l] (=|+=) g/(R*L*T) * t_l * (log t_l + 1 - a_l - S_r)   (0 where t_l underflows to 0)
+__global__ __launch_bounds__(256) void softmax_kl_bwd_kernel(const float* __restrict__ A,
+                                                             const float* __restrict__ Bt,
+                                                             const float* __restrict__ stats,
+                                                             float* __restrict__ dBt, int L, float temperature,
+                                                             float scale, const float* gdev, int accumulate) {
+  const long r = blockIdx.x;
+  const float g = (gdev ? gdev[0] * scale : scale) / temperature;
+  const float ma = stats[r * 5 + 0], sa = stats[r * 5 + 1], mb = stats[r * 5 + 2], sb = stats[r * 5 + 3],
+              S = stats[r * 5 + 4];
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float pa = expf(A[r * L + l] / temperature - ma) / sa;
+    const float t = expf(Bt[r * L + l] / temperature - mb) / sb;
+    float v = 0.f;
+    if (t > 0.f) v = g * t * (logf(t) + 1.f - pa - S);
+    float* d = dBt + r * L + l;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// flat argmax per row, first max on ties
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ hm, long long* __restrict__ idx,
+                                                          float* __restrict__ maxval, int L) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const long r = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float v = hm[r * L + l];
+    if (v > bv) {
+      bv = v;
+      bi = l;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sv[wave] = bv;
+    si[wave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (sv[k] > bv || (sv[k] == bv && si[k] < bi)) {
+        bv = sv[k];
+        bi = si[k];
+      }
+    idx[r] = bi == 0x7fffffff ? 0 : bi;
+    if (maxval) maxval[r] = bv;
+  }
+}
+
+extern "C" {
+
+// joints [B,J,2] px, vis [B,J] -> target [B,J,Hh,Wh] (NCHW), weight [B,J]
+int fami_gauss_target_f32(const float* joints, const float* vis, float* target, float* weight, int B, int J, int Hh,
+                          int Wh, int img_h, int img_w, int sigma, hipStream_t s) {
+  FAMI_REQUIRE(joints && vis && target && weight && B > 0 && J > 0 && Hh > 0 && Wh > 0 && sigma > 0,
+               "fami_gauss_target_f32", "bad argument");
+  hipLaunchKernelGGL(gauss_target_kernel, dim3(fami_ew_grid((long)B * J * Hh * Wh)), dim3(256), 0, s, joints, vis,
+                     target, weight, B, J, Hh, Wh, (double)img_w / (double)Wh, (double)img_h / (double)Hh, sigma);
+  FAMI_CHECK_LAUNCH("fami_gauss_target_f32");
+  return FAMI_OK;
+}
+
+// loss[0] = scale * sum_{r,l} (w_r (pred-gt))^2 ; pred/gt [R,L], w [R] or null; ws >= R floats
+int fami_wmse_fwd_f32(const float* pred, const float* gt, const float* w, float* loss, int R, int L, double scale,
+                      float* ws, hipStream_t s) {
+  FAMI_REQUIRE(pred && gt && loss && ws && R > 0 && L > 0, "fami_wmse_fwd_f32", "bad argument");
+  hipLaunchKernelGGL(wmse_rows_kernel, dim3(R), dim3(256), 0, s, pred, gt, w, ws, L);
+  FAMI_CHECK_LAUNCH("fami_wmse_fwd_f32/rows");
+  hipLaunchKernelGGL(scalar_sum_kernel, dim3(1), dim3(256), 0, s, ws, R, scale, loss);
+  FAMI_CHECK_LAUNCH("fami_wmse_fwd_f32/sum");
+  return FAMI_OK;
+}
+// dpred (=|+=) (gdev? gdev[0] : 1) * scale * 2 w^2 (pred - gt)
+int fami_wmse_bwd_f32(const float* pred, const float* gt, const float* w, float* dpred, int R, int L, float scale,
+                      const float* gdev, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(pred && gt && dpred && R > 0 && L > 0, "fami_wmse_bwd_f32", "bad argument");
+  hipLaunchKernelGGL(wmse_bwd_kernel, dim3(fami_ew_grid((long)R * L)), dim3(256), 0, s, pred, gt, w, dpred, (long)R * L, L, scale, gdev, accumulate);
+  FAMI_CHECK_LAUNCH("fami_wmse_bwd_f32");
+  return FAMI_OK;
+}
+
+// value[0] = mean over R*L of t*(log t - a), a = softmax(A/T) rows, t = softmax(Bt/T) rows.
+// stats [R,5] saved for the backward; ws >= R floats.
+int fami_softmax_kl_fwd_f32(const float* A, const float* Bt, float* value, float* stats, int R, int L,
+                            float temperature, float* ws, hipStream_t s) {
+  FAMI_REQUIRE(A && Bt && value && stats && ws && R > 0 && L > 0 && temperature > 0.f, "fami_softmax_kl_fwd_f32", "bad argument");
+  hipLaunchKernelGGL(softmax_kl_rows_kernel, dim3(R), dim3(256), 0, s, A, Bt, stats, ws, L, temperature);
+  FAMI_CHECK_LAUNCH("fami_softmax_kl_fwd_f32/rows");
+  hipLaunchKernelGGL(scalar_sum_kernel, dim3(1), dim3(256), 0, s, ws, R, 1.0 / ((double)R * (double)L), value);
+  FAMI_CHECK_LAUNCH("fami_softmax_kl_fwd_f32/sum");
+  return FAMI_OK;
+}
+// dBt (=|+=) gscale * d value / d Bt (gradient flows through the target only, as in the reference)
+int fami_softmax_kl_bwd_f32(const float* A, const float* Bt, const float* stats, float* dBt, int R, int L,
+                            float temperature, float gscale, const float* gdev, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(A && Bt && stats && dBt && R > 0 && L > 0, "fami_softmax_kl_bwd_f32", "bad argument");
+  hipLaunchKernelGGL(softmax_kl_bwd_kernel, dim3(R), dim3(256), 0, s, A, Bt, stats, dBt, L, temperature,
+                     (float)((double)gscale / ((double)R * (double)L)), gdev, accumulate);
+  FAMI_CHECK_LAUNCH("fami_softmax_kl_bwd_f32");
+  return FAMI_OK;
+}
+
+// idx[r] = first flat argmax of row r, maxval[r] (optional); hm [R,L]
+int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int L, hipStream_t s) {
+  FAMI_REQUIRE(hm && idx && R > 0 && L > 0, "fami_argmax2d_f32", "bad argument");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(R), dim3(256), 0, s, hm, idx, maxval, L);
+  FAMI_CHECK_LAUNCH("fami_argmax2d_f32");
+  return FAMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// BatchNorm (train-mode batch statistics + running-stat update, eval-mode
+// apply) and its backward, fused with ReLU and the residual add, for NHWC fp32
+// activations viewed as a [P = N*H*W][C] matrix.  HBM-bound streaming kernels:
+// each thread owns one 4-channel vector column and strides over pixels, so a
+// wave reads whole 16-byte-per-lane contiguous rows.
+//
+// Replaces nn.BatchNorm2d (+ nn.ReLU, `out += residual`) as used by
+//   posetimation/layers/basic_model.py:25-63 (BasicBlock), :66-113 (Bottleneck),
+//   posetimation/layers/basic_layer.py:25-26 (conv_bn_relu.bn),
+//   posetimation/backbones/hrnet.py:99-143 (fuse layers), :724-762 (transitions)
+// with momentum 0.1, eps 1e-5, biased variance for normalisation and unbiased
+// variance for running_var (torch.nn.BatchNorm2d semantics).
+#include "common.h"
+
+#define BN_MAXG 1024
+
+struct ColMap {
+  int cv, prow, rows, CV;
+  bool active;
+};
+__device__ __forceinline__ ColMap col_map(int C) {
+  ColMap m;
+  m.CV = C >> 2;
+  m.rows = 256 / m.CV;
+  m.cv = threadIdx.x % m.CV;
+  m.prow = threadIdx.x / m.CV;
+  m.active = m.prow < m.rows;
+  return m;
+}
+
+// partial[g][0][c] = sum x, partial[g][1][c] = sum x^2 over this block's pixels
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                         long P, int C) {
+  extern __shared__ float sm[];  // [rows][2][C]
+  const ColMap m = col_map(C);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * C + m.cv * 4);
+      s += v;
+      q += v * v;
+    }
+    float* d = sm + (long)m.prow * 2 * C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d[m.cv * 4 + t] = s[t];
+      d[C + m.cv * 4 + t] = q[t];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    float tot = 0.f;
+    for (int r = 0; r < m.rows; ++r) tot += sm[(long)r * 2 * C + e];
+    partial[(long)blockIdx.x * 2 * C + e] = tot;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* mean,
+                                   float* invstd, float* running_mean, float* running_var, float momentum,
+                                   float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < G; ++g) {
+    s += (double)partial[(long)g * 2 * C + c];
+    q += (double)partial[(long)g * 2 * C + C + c];
+  }
+  const double mu = s / (double)P;
+  double var = q / (double)P - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* mean, float* invstd,
+                                     int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       long P, int C, int relu) {
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  f32x4 sc, sf;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = m.cv * 4 + t;
+    sc[t] = invstd[c] * gamma[c];
+    sf[t] = beta[c] - mean[c] * sc[t];
+  }
+  for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    const long o = p * C + m.cv * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + o) * sc + sf;
+    if (residual) v += *reinterpret_cast<const f32x4*>(residual + o);
+    if (relu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + o) = v;
+  }
+}
+
+// backward pass 1: partial[g][0][c] = sum dz, partial[g][1][c] = sum dz*xhat ; dz = relu ? dy*(y>0) : dy
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             float* __restrict__ partial, long P, int C, int relu) {
+  extern __shared__ float sm[];
+  const ColMap m = col_map(C);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    f32x4 mu, is;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      mu[t] = mean[m.cv * 4 + t];
+      is[t] = invstd[m.cv * 4 + t];
+    }
+    for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+      const long o = p * C + m.cv * 4;
+      f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+      if (relu) {
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
+      }
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+      s += g;
+      q += g * xh;
+    }
+    float* d = sm + (long)m.prow * 2 * C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d[m.cv * 4 + t] = s[t];
+      d[C + m.cv * 4 + t] = q[t];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    float tot = 0.f;
+    for (int r = 0; r < m.rows; ++r) tot += sm[(long)r * 2 * C + e];
+    partial[(long)blockIdx.x * 2 * C + e] = tot;
+  }
+}
+
+// coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); dgamma/dbeta optional
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* coef,
+                                       float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < G; ++g) {
+    s += (double)partial[(long)g * 2 * C + c];
+    q += (double)partial[(long)g * 2 * C + C + c];
+  }
+  coef[c] = (float)(s / (double)P);
+  coef[C + c] = (float)(q / (double)P);
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+}
+
+// backward pass 2: dx = gamma*invstd*(dz - c1 - xhat*c2) ; dres (=|+=) dz
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long P, int C, int relu,
+                                                           int acc_dx, int acc_dres) {
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  f32x4 mu, is, gi, c1, c2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = m.cv * 4 + t;
+    mu[t] = mean[c];
+    is[t] = invstd[c];
+    gi[t] = gamma[c] * invstd[c];
+    c1[t] = coef[c];
+    c2[t] = coef[C + c];
+  }
+  for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    const long o = p * C + m.cv * 4;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+    if (relu) {
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
+    }
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+    f32x4 d = gi * (g - c1 - xh * c2);
+    if (acc_dx) d += *reinterpret_cast<const f32x4*>(dx + o);
+    *reinterpret_cast<f32x4*>(dx + o) = d;
+    if (dres) {
+      f32x4 r = g;
+      if (acc_dres) r += *reinterpret_cast<const f32x4*>(dres + o);
+      *reinterpret_cast<f32x4*>(dres + o) = r;
+    }
+  }
+}
+
+// per-channel sum over pixels (bias gradients): partial then finalize
+__global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ partial, long P, int C) {
+  // scalar-channel version: works for any C (17, 2, ...)
+  extern __shared__ float sm[];  // [rows][C]
+  const int rows = max(1, 256 / C);
+  const int c = threadIdx.x % C, prow = threadIdx.x / C;
+  const bool active = prow < rows && C <= 256;
+  float s = 0.f;
+  if (active) {
+    for (long p = (long)blockIdx.x * rows + prow; p < P; p += (long)gridDim.x * rows) s += x[p * C + c];
+    sm[prow * C + c] = s;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C; e += 256) {
+    float tot = 0.f;
+    for (int r = 0; r < rows; ++r) tot += sm[r * C + e];
+    partial[(long)blockIdx.x * C + e] = tot;
+  }
+}
+__global__ void chan_sum_finalize_kernel(const float* __restrict__ partial, int G, int C, float* out,
+                                         int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += (double)partial[(long)g * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+static inline int bn_grid(long P, int C) {
+  const int rows = 256 / (C >> 2);
+  long g = (P + rows - 1) / rows;
+  if (g > BN_MAXG) g = BN_MAXG;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+static inline bool bn_shape_ok(long P, int C) { return P > 0 && C >= 4 && (C % 4) == 0 && C <= 1024; }
+
+extern "C" {
+
+long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
+
+// train-mode statistics: mean/invstd out, running stats updated in place (may be null)
+int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd, float* running_mean,
+                      float* running_var, float momentum, float eps, float* ws, hipStream_t s) {
+  FAMI_REQUIRE(x && mean && invstd && ws, "fami_bn_stats_f32", "null pointer");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error("fami_bn_stats_f32", "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  const int G = bn_grid(P, C);
+  const int rows = 256 / (C >> 2);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x, ws, P, C);
+  FAMI_CHECK_LAUNCH("fami_bn_stats_f32/partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, G, P, C, mean, invstd,
+                     running_mean, running_var, momentum, eps);
+  FAMI_CHECK_LAUNCH("fami_bn_stats_f32/finalize");
+  return FAMI_OK;
+}
+
+int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
+                           float eps, hipStream_t s) {
+  FAMI_REQUIRE(running_mean && running_var && mean && invstd && C > 0, "fami_bn_eval_stats_f32", "bad argument");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var, mean,
+                     invstd, C, eps);
+  FAMI_CHECK_LAUNCH("fami_bn_eval_stats_f32");
+  return FAMI_OK;
+}
+
+int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* residual, float* y, long P, int C, int relu, hipStream_t s) {
+  FAMI_REQUIRE(x && mean && invstd && gamma && beta && y, "fami_bn_apply_f32", "null pointer");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error("fami_bn_apply_f32", "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  const int rows = 256 / (C >> 2);
+  long g = (P + rows - 1) / rows;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)g), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, y, P, C,
+                     relu);
+  FAMI_CHECK_LAUNCH("fami_bn_apply_f32");
+  return FAMI_OK;
+}
+
+// dz = relu ? dy*(y>0) : dy ; dx (=|+=) BN-backward(dz) ; dgamma/dbeta (=|+=) ; dres (=|+=) dz
+int fami_bn_bwd_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long P, int C, int relu,
+                    int acc_dx, int acc_param, int acc_dres, float* ws, hipStream_t s) {
+  FAMI_REQUIRE(dy && x && mean && invstd && gamma && dx && ws, "fami_bn_bwd_f32", "null pointer");
+  FAMI_REQUIRE(!relu || y, "fami_bn_bwd_f32", "relu needs y");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error("fami_bn_bwd_f32", "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  const int G = bn_grid(P, C);
+  const int rows = 256 / (C >> 2);
+  float* coef = ws + (long)BN_MAXG * 2 * C - 2 * C;  // tail of the workspace (G < BN_MAXG leaves it free)
+  const int Gp = G < BN_MAXG ? G : BN_MAXG - 1;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(Gp), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y,
+                     mean, invstd, ws, P, C, relu);
+  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/partial");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma,
+                     dbeta, acc_param);
+  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/finalize");
+  long g = (P + rows - 1) / rows;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)g), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, dx,
+                     dres, P, C, relu, acc_dx, acc_dres);
+  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/apply");
+  return FAMI_OK;
+}
+
+long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
+
+// out[c] (=|+=) sum_p x[p][c], any C <= 256
+int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {
+  FAMI_REQUIRE(x && out && ws && P > 0 && C > 0, "fami_channel_sum_f32", "bad argument");
+  if (C > 256) {
+    fami_set_error("fami_channel_sum_f32", "C > 256 unsupported");
+    return FAMI_ESHAPE;
+  }
+  const int rows = 256 / C;
+  long g = (P + rows - 1) / rows;
+  if (g > BN_MAXG) g = BN_MAXG;
+  hipLaunchKernelGGL(chan_sum_partial_kernel, dim3((int)g), dim3(256), (size_t)rows * C * sizeof(float), s, x, ws, P, C);
+  FAMI_CHECK_LAUNCH("fami_channel_sum_f32/partial");
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
+  FAMI_CHECK_LAUNCH("fami_channel_sum_f32/finalize");
+  return FAMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+"""Host-side execution engine of the hot path: a tape of HIP kernel launches.
+
+Every op below enqueues kernels of libfami_hip.so (through the C ABI) on the
+current HIP stream and records the matching backward launch sequence; walking
+the tape in reverse is the backward pass.  There is no tracing compiler and no
+torch compute op on this path: torch provides device memory (tensors), the
+stream and (optionally) hipGraph capture of the whole launch sequence.
+
+Activations are fp32 NHWC (`T.data` of shape [N,H,W,C]); small dense tensors
+(the translation regressor) are [M,K].
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib
+
+BN_EPS = 1e-5
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class T:
+    """Engine tensor: NHWC (or 2-D) fp32 storage + lazily allocated gradient."""
+    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1')
+
+    def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0):
+        self.data = data
+        self.grad = None
+        self.requires_grad = requires_grad
+        self.parent, self.n0, self.n1 = parent, n0, n1
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+
+class Engine:
+    def __init__(self, device, grad_views=None, record=True):
+        self.L = lib()
+        self.record = record           # False: forward only (no tape, no gradient flags)
+        self.dev = device
+        self.tape = []
+        self.param_grads = {}          # id(param) -> grad tensor written this step
+        self.grad_views = grad_views   # optional {id(param): preallocated view (flat gradient arena)}
+        self.stream = None
+        self.aux = {}                  # handles a model body leaves for the trainer (final T, MI seeds, ...)
+        self.bn_trained = []           # BatchNorm modules that consumed a training batch this forward
+        self.sync_stream()
+
+    # ------------------------------------------------------------------ plumbing
+    def rq(self, p):
+        return self.record and p is not None and p.requires_grad
+
+    def sync_stream(self):
+        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def call(self, name, *args):
+        self.L.call(name, *args, self.stream)
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.dev)
+
+    def ws(self, nbytes):
+        return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=self.dev)
+
+    def fill(self, t, v=0.0):
+        self.call('fami_fill_f32', _p(t), t.numel(), float(v))
+        return t
+
+    def gbuf(self, t):
+        """-> (gradient buffer of t, accumulate flag)."""
+        if t.grad is None:
+            if t.parent is not None:
+                par = t.parent
+                if par.grad is None:
+                    par.grad = self.fill(torch.empty_like(par.data))
+                t.grad = par.grad[t.n0:t.n1]
+                return t.grad, 1
+            t.grad = torch.empty_like(t.data)
+            return t.grad, 0
+        return t.grad, 1
+
+    def pgrad(self, p):
+        """-> (gradient buffer of parameter p, accumulate flag) for this step."""
+        g = self.param_grads.get(id(p))
+        if g is not None:
+            return g, 1
+        if self.grad_views is not None:
+            g = self.grad_views[id(p)]
+        else:
+            g = torch.empty_like(p.data)
+        self.param_grads[id(p)] = g
+        return g, 0
+
+    # packed weights: frozen parameters are packed once, trainable ones every forward
+    _pack_cache = {}
+
+    def packed(self, w, mode):
+        Co, Ci, kh, kw = w.shape
+        key = (w.data_ptr(), mode, w.shape)
+        if not w.requires_grad:
+            hit = Engine._pack_cache.get(key)
+            if hit is not None and hit[0] == w._version:
+                return hit[1]
+        n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
+        wp = self.empty(n)
+        self.call('fami_pack_conv_weight_f32', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
+        if not w.requires_grad:
+            Engine._pack_cache[key] = (w._version, wp)
+        return wp
+
+    # ------------------------------------------------------------------ inputs / boundary
+    def frames(self, kf_x, sup_x):
+        """Alignment_V15.py:115-119: key + S supporting frames stacked on the batch axis (frame-major)."""
+        B, _, H, W = kf_x.shape
+        S = 0 if sup_x is None else sup_x.shape[1] // 3
+        out = self.empty((1 + S) * B, H, W, 3)
+        self.call('fami_pack_frames_f32', _p(kf_x.contiguous()), _p(None if sup_x is None else sup_x.contiguous()),
+                  _p(out), B, S, H, W)
+        return T(out)
+
+    def from_nchw(self, x, requires_grad=False):
+        N, C, H, W = x.shape
+        out = self.empty(N, H, W, C)
+        self.call('fami_nchw_to_nhwc_f32', _p(x.contiguous()), _p(out), N, C, H, W)
+        return T(out, requires_grad)
+
+    def to_nchw(self, x):
+        """-> torch tensor [N,C,H,W]; gradient comes back through seed()."""
+        N, H, W, C = x.shape
+        out = self.empty(N, C, H, W)
+        self.call('fami_nhwc_to_nchw_f32', _p(x.data), _p(out), N, C, H, W, 0)
+        return out
+
+    def seed_nchw(self, x, g_nchw):
+        """Add an NCHW gradient to NHWC tensor x."""
+        if g_nchw is None or not x.requires_grad:
+            return
+        N, H, W, C = x.shape
+        g, acc = self.gbuf(x)
+        if acc:
+            tmp = self.empty(N, H, W, C)
+            self.call('fami_nchw_to_nhwc_f32', _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
+            self.call('fami_axpby_f32', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
+        else:
+            self.call('fami_nchw_to_nhwc_f32', _p(g_nchw.contiguous()), _p(g), N, C, H, W)
+
+    # ------------------------------------------------------------------ conv / bn
+    def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False):
+        N, H, W, Ci = x.shape
+        Co, Ci2, kh, kw = weight.shape
+        assert Ci2 == Ci, (x.shape, weight.shape)
+        Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        y = self.empty(N, Ho, Wo, Co)
+        wp = self.packed(weight, 0)
+        self.call('fami_conv2d_fwd_f32', _p(x.data), _p(wp), _p(None if bias is None else bias.data), None, _p(y),
+                  N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0)
+        need_w = self.rq(weight) or self.rq(bias)
+        out = T(y, x.requires_grad or need_w)
+        if out.requires_grad:
+            assert not relu, "fused relu epilogue is forward-only"
+            geo = (N, H, W, Ci, Co, kh, kw, stride, pad, dil)
+
+            def bwd():
+                if out.grad is None:
+                    return
+                dy = out.grad
+                if self.rq(weight):
+                    g, acc = self.pgrad(weight)
+                    nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
+                    ws = self.ws(nb)
+                    self.call('fami_conv2d_wgrad_f32', _p(x.data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                if self.rq(bias):
+                    g, acc = self.pgrad(bias)
+                    ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
+                    self.call('fami_channel_sum_f32', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
+                if x.requires_grad:
+                    gx, acc = self.gbuf(x)
+                    wpd = self.packed(weight, 1)
+                    self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
+            self.tape.append((bwd, [weight, bias]))
+        return out
+
+    def bn(self, x, bn, relu=False, residual=None):
+        """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update."""
+        shp = x.shape
+        C = shp[-1]
+        P = x.data.numel() // C
+        mean, invstd = self.empty(C), self.empty(C)
+        if bn.training:
+            ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            self.call('fami_bn_stats_f32', _p(x.data), P, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                      _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+            self.bn_trained.append(bn)
+        else:
+            self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd), C,
+                      float(bn.eps))
+        y = torch.empty_like(x.data)
+        self.call('fami_bn_apply_f32', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
+                  _p(None if residual is None else residual.data), _p(y), P, C, int(relu))
+        need_p = self.rq(bn.weight)
+        rg = x.requires_grad or need_p or (residual is not None and residual.requires_grad)
+        out = T(y, rg)
+        if rg:
+            training = bn.training
+
+            def bwd():
+                if out.grad is None:
+                    return
+                if not training:
+                    raise NotImplementedError("backward through eval-mode BatchNorm is outside the training hot path")
+                gx, accx = self.gbuf(x) if x.requires_grad else (self.empty(*shp), 0)
+                gg = gb = None
+                accp = 0
+                if need_p:
+                    gg, accp = self.pgrad(bn.weight)
+                    gb, _ = self.pgrad(bn.bias)
+                gr, accr = (None, 0)
+                if residual is not None and residual.requires_grad:
+                    gr, accr = self.gbuf(residual)
+                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                self.call('fami_bn_bwd_f32', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
+                          _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
+                          _p(ws))
+            self.tape.append((bwd, [bn.weight, bn.bias]))
+        return out
+
+    # ------------------------------------------------------------------ fuse (hrnet.py:159-168)
+    def fuse(self, terms):
+        """terms: list of (T x_k, bn_k or None, shift_k); returns relu(sum_k up_{2^shift}(bn_k(x_k)))."""
+        k = len(terms)
+        assert 1 <= k <= 4
+        big = [t for t in terms if t[2] == 0][0][0]
+        N, H, W, C = big.shape
+        stats = []
+        for (x, bn, s) in terms:
+            if bn is None:
+                stats.append(None)
+                continue
+            Pk = x.data.numel() // C
+            mean, invstd = self.empty(C), self.empty(C)
+            if bn.training:
+                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                self.call('fami_bn_stats_f32', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                          _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+                self.bn_trained.append(bn)
+            else:
+                self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
+                          C, float(bn.eps))
+            stats.append((mean, invstd))
+        PA = ctypes.c_void_p * k
+        xs = PA(*[_p(t[0].data) for t in terms])
+        mean_a = PA(*[None if s is None else _p(s[0]) for s in stats])
+        inv_a = PA(*[None if s is None else _p(s[1]) for s in stats])
+        gam_a = PA(*[None if t[1] is None else _p(t[1].weight.data) for t in terms])
+        bet_a = PA(*[None if t[1] is None else _p(t[1].bias.data) for t in terms])
+        sh_a = (ctypes.c_int * k)(*[t[2] for t in terms])
+        y = self.empty(N, H, W, C)
+        self.call('fami_fuse_sum_f32', k, xs, mean_a, inv_a, gam_a, bet_a, sh_a, _p(y), N, H, W, C, 1)
+        rg = any(t[0].requires_grad or (t[1] is not None and self.rq(t[1].weight)) for t in terms)
+        out = T(y, rg)
+        if rg:
+            def bwd():
+                if out.grad is None:
+                    return
+                dy = out.grad
+                for (x, bn, s), st in zip(terms, stats):
+                    if bn is None:
+                        if x.requires_grad:
+                            g, acc = self.gbuf(x)
+                            self.call('fami_relu_bwd_f32', _p(dy), _p(y), _p(g), y.numel(), acc)
+                        continue
+                    if not bn.training:
+                        raise NotImplementedError("backward through eval-mode BatchNorm")
+                    need_p = self.rq(bn.weight)
+                    if not (x.requires_grad or need_p):
+                        continue
+                    Pk = x.data.numel() // C
+                    gx, accx = self.gbuf(x) if x.requires_grad else (torch.empty_like(x.data), 0)
+                    gg = gb = None
+                    accp = 0
+                    if need_p:
+                        gg, accp = self.pgrad(bn.weight)
+                        gb, _ = self.pgrad(bn.bias)
+                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                    if s == 0:
+                        self.call('fami_bn_bwd_f32', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
+                                  _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
+                    else:
+                        low = torch.empty_like(x.data)
+                        self.call('fami_pool_relu_bwd_f32', _p(dy), _p(y), _p(low), N, H >> s, W >> s, C, s, 1)
+                        self.call('fami_bn_bwd_f32', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
+                                  _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
+            self.tape.append((bwd, [q for t in terms if t[1] is not None for q in (t[1].weight, t[1].bias)]))
+        return out
+
+    # ------------------------------------------------------------------ glue ops
+    def batch_slice(self, x, n0, n1):
+        """torch.chunk on the batch axis (Alignment_V15.py:121-125): a view; gradients land in the parent slice."""
+        return T(x.data[n0:n1], x.requires_grad, parent=x, n0=n0, n1=n1)
+
+    def sub(self, a, b):
+        y = torch.empty_like(a.data)
+        self.call('fami_axpby_f32', _p(a.data), _p(b.data), _p(y), y.numel(), 1.0, -1.0)
+        out = T(y, a.requires_grad or b.requires_grad)
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                for t, sgn in ((a, 1.0), (b, -1.0)):
+                    if t.requires_grad:
+                        g, acc = self.gbuf(t)
+                        self.call('fami_axpby_f32', _p(out.grad), _p(g) if acc else None, _p(g), g.numel(), sgn, 1.0)
+            self.tape.append((bwd, ()))
+        return out
+
+    def concat(self, xs):
+        """torch.cat on channels (Alignment_V15.py:139,143,160)."""
+        N, H, W, _ = xs[0].shape
+        Ct = sum(x.shape[3] for x in xs)
+        P = N * H * W
+        y = self.empty(N, H, W, Ct)
+        off = 0
+        for x in xs:
+            c = x.shape[3]
+            self.call('fami_copy_channels_f32', _p(x.data), _p(y), P, c, 0, Ct, off, c, 0)
+            off += c
+        out = T(y, any(x.requires_grad for x in xs))
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                o = 0
+                for x in xs:
+                    c = x.shape[3]
+                    if x.requires_grad:
+                        g, acc = self.gbuf(x)
+                        self.call('fami_copy_channels_f32', _p(out.grad), _p(g), P, Ct, o, c, 0, c, acc)
+                    o += c
+            self.tape.append((bwd, ()))
+        return out
+
+    def flatten_chw(self, x):
+        """nn.Flatten on an NCHW tensor: [N,H,W,C] -> [N, C*H*W] in (c,h,w) order (Alignment_V15.py:68)."""
+        N, H, W, C = x.shape
+        y = self.empty(N, C * H * W)
+        self.call('fami_nhwc_to_nchw_f32', _p(x.data), _p(y), N, C, H, W, 0)
+        out = T(y, x.requires_grad)
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                g, acc = self.gbuf(x)
+                if acc:
+                    tmp = torch.empty_like(g)
+                    self.call('fami_nchw_to_nhwc_f32', _p(out.grad), _p(tmp), N, C, H, W)
+                    self.call('fami_axpby_f32', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
+                else:
+                    self.call('fami_nchw_to_nhwc_f32', _p(out.grad), _p(g), N, C, H, W)
+            self.tape.append((bwd, ()))
+        return out
+
+    def linear(self, x, lin):
+        M, K = x.shape
+        Nn = lin.out_features
+        y = self.empty(M, Nn)
+        self.call('fami_linear_fwd_f32', _p(x.data), _p(lin.weight.data), _p(None if lin.bias is None else lin.bias.data),
+                  _p(y), M, K, Nn)
+        need_p = self.rq(lin.weight)
+        out = T(y, x.requires_grad or need_p)
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                gx = gw = gb = None
+                accx = accp = 0
+                if x.requires_grad:
+                    gx, accx = self.gbuf(x)
+                if need_p:
+                    gw, accp = self.pgrad(lin.weight)
+                    if lin.bias is not None:
+                        gb, _ = self.pgrad(lin.bias)
+                self.call('fami_linear_bwd_f32', _p(out.grad), _p(x.data), _p(lin.weight.data), _p(gx), _p(gw),
+                          _p(gb), M, K, Nn, accx, accp)
+            self.tape.append((bwd, [lin.weight, lin.bias]))
+        return out
+
+    # ------------------------------------------------------------------ alignment ops
+    def shift(self, x, t):
+        """kornia warp_affine with a pure translation t=[B,2]=(tx,ty) (Alignment_V15.py:133-135)."""
+        B, H, W, C = x.shape
+        y = torch.empty_like(x.data)
+        self.call('fami_shift_bilinear_fwd_f32', _p(x.data), _p(t.data), _p(y), B, H, W, C)
+        out = T(y, x.requires_grad or t.requires_grad)
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                gs = gt = None
+                accs = acct = 0
+                if x.requires_grad:
+                    gs, accs = self.gbuf(x)
+                if t.requires_grad:
+                    gt, acct = self.gbuf(t)
+                ws = self.ws(self.L.cdll.fami_shift_workspace(B))
+                self.call('fami_shift_bilinear_bwd_f32', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
+                          W, C, accs, acct, _p(ws))
+            self.tape.append((bwd, ()))
+        return out
+
+    def dcn(self, x, off, msk, weight, bias, G, pad=3, dil=3):
+        """torchvision DeformConv2d(C,Co,3,padding=3,dilation=3)(x, off, msk) (Alignment_V15.py:146-158)."""
+        B, H, W, C = x.shape
+        Co, _, kh, kw = weight.shape
+        K = kh * kw
+        n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
+        wp = self.empty(n)
+        self.call('fami_dcn_pack_weight_f32', _p(weight.data), _p(wp), Co, C, kh, kw, G)
+        y = self.empty(B, H, W, Co)
+        self.call('fami_dcn_fwd_f32', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
+                  C, Co, G, kh, kw, 1, pad, dil)
+        rg = x.requires_grad or off.requires_grad or msk.requires_grad or self.rq(weight)
+        out = T(y, rg)
+        if rg:
+            def bwd():
+                if out.grad is None:
+                    return
+                dy = out.grad
+                P = B * H * W
+                CK = C * K
+                # gcol[P, C*K] = dy[P,Co] x W[Co, C*K]: dgrad of the 1x1 conv whose weight is W.view(Co, C*K, 1, 1)
+                w2 = weight.data.view(Co, CK, 1, 1)
+                nwp = self.L.cdll.fami_packed_weight_elems(Co, CK, 1, 1, 1)
+                wpd = self.empty(nwp)
+                self.call('fami_pack_conv_weight_f32', _p(w2), _p(wpd), Co, CK, 1, 1, 1)
+                gcol = self.empty(P, CK)
+                self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gcol), 1, 1, P, CK, Co, 1, 1, 1, 0, 1, 0)
+                col = self.empty(P, CK) if self.rq(weight) else None
+                gx = goff = gmsk = None
+                acco = 0
+                if x.requires_grad:
+                    gx, accx = self.gbuf(x)
+                    if not accx:
+                        self.fill(gx)
+                if off.requires_grad:
+                    goff, acco = self.gbuf(off)
+                    gmsk, accm = self.gbuf(msk)
+                    assert acco == accm
+                self.call('fami_dcn_bwd_gather_f32', _p(x.data), _p(off.data), _p(msk.data), _p(gcol), _p(col),
+                          _p(gx), _p(goff), _p(gmsk), B, H, W, C, G, kh, kw, 1, pad, dil, acco)
+                if self.rq(weight):
+                    g, acc = self.pgrad(weight)
+                    geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)
+                    ws = self.ws(self.L.cdll.fami_conv2d_wgrad_workspace(*geo))
+                    self.call('fami_conv2d_wgrad_f32', _p(col), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                    gb, accb = self.pgrad(bias)
+                    ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
+                    self.call('fami_channel_sum_f32', _p(dy), P, Co, _p(gb), accb, _p(ws2))
+            self.tape.append((bwd, [weight, bias]))
+        return out
+
+    # ------------------------------------------------------------------ MI estimators (Alignment_V15.py:250-277)
+    def softmax_kl(self, a_nchw, b, temperature=0.05):
+        """value = mean_{rows,l} t*(log t - a), a = softmax(A/T) (detached), t = softmax(Bt/T); rows = (n,c), l = h*w.
+        a_nchw: torch tensor [N,C,H,W]; b: T (NHWC).  Returns (scalar tensor [1], seed function(gscale))."""
+        N, H, W, C = b.shape
+        bt = self.to_nchw(b)
+        R, Ln = N * C, H * W
+        val = self.empty(1)
+        stats = self.empty(R, 5)
+        ws = self.ws(R * 4)
+        self.call('fami_softmax_kl_fwd_f32', _p(a_nchw), _p(bt), _p(val), _p(stats), R, Ln, float(temperature), _p(ws))
+
+        def seed(gscale, gdev=None):
+            if not b.requires_grad:
+                return
+            d = self.empty(N, C, H, W)
+            self.call('fami_softmax_kl_bwd_f32', _p(a_nchw), _p(bt), _p(stats), _p(d), R, Ln, float(temperature),
+                      float(gscale), _p(gdev), 0)
+            self.seed_nchw(b, d)
+        return val, seed
+
+    # ------------------------------------------------------------------ backward driver
+    def backward(self, on_params_done=None):
+        """Walk the tape in reverse.  `on_params_done(list_of_params)` (optional) fires once a parameter's
+        last gradient contribution has been enqueued -- the hook the data-parallel bucket all-reduce hangs on."""
+        self.sync_stream()
+        remaining = None
+        if on_params_done is not None:
+            remaining = {}
+            for _, ps in self.tape:
+                for p in ps:
+                    if p is not None and p.requires_grad:
+                        remaining[id(p)] = remaining.get(id(p), 0) + 1
+        for fn, ps in reversed(self.tape):
+            fn()
+            if remaining is not None and ps:
+                done = []
+                for p in ps:
+                    if p is not None and p.requires_grad:
+                        remaining[id(p)] -= 1
+                        if remaining[id(p)] == 0:
+                            done.append(p)
+                if done:
+                    on_params_done(done)
+        self.tape = []

@@ -1,0 +1,85 @@
+"""Glue between the nn.Module boundary (torch tensors, torch autograd) and the
+HIP engine: one autograd node per model call.  Its forward runs the whole
+forward launch sequence, its backward walks the engine tape; torch's own
+autograd only sees this single node plus whatever the caller does with the
+outputs (callers do `loss.backward(); optimizer.step()`).
+"""
+import torch
+import torch.nn as nn
+
+from .engine import Engine, _p
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, body, n_in, *tensors):
+        inputs, params = tensors[:n_in], tensors[n_in:]
+        eng = Engine(inputs[0].device, grad_views=getattr(owner, '_grad_views', None), record=True)
+        outs, seeds = body(eng, *inputs)
+        owner._advance_bn_counters(eng)
+        ctx.eng, ctx.seeds, ctx.params, ctx.n_in = eng, seeds, params, n_in
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng = ctx.eng
+        eng.sync_stream()
+        for fn, g in zip(ctx.seeds, gouts):
+            if fn is not None and g is not None:
+                fn(g)
+        eng.backward()
+        grads = [eng.param_grads.get(id(p)) for p in ctx.params]
+        ctx.eng = ctx.seeds = None
+        return (None, None, None) + (None,) * ctx.n_in + tuple(grads)
+
+
+class EngineModule(nn.Module):
+    """Base class of the drop-in models: runs `body(eng, *inputs)` on the HIP engine."""
+
+    _nbt_flat = None
+    _nbt_index = None
+    _nbt_inc = None
+
+    def _trainable(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def _launch(self, body, *inputs):
+        if not inputs[0].is_cuda:
+            raise RuntimeError("fami_pose_amd models run on the MI355X HIP path only; move the model and inputs to "
+                               "'cuda' (there is no CPU fallback)")
+        inputs = tuple(t.float().contiguous() for t in inputs)
+        params = self._trainable() if torch.is_grad_enabled() else []
+        if not params:
+            eng = Engine(inputs[0].device, record=False)
+            outs, _ = body(eng, *inputs)
+            self._advance_bn_counters(eng)
+            return tuple(outs)
+        return _EngineFn.apply(self, body, len(inputs), *inputs, *params)
+
+    # nn.BatchNorm2d.num_batches_tracked: all counters live in one int64 arena and advance in ONE launch
+    def _advance_bn_counters(self, eng):
+        if not eng.bn_trained:
+            return
+        dev = eng.dev
+        if self._nbt_flat is None or self._nbt_flat.device != dev:
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+            flat = torch.stack([m.num_batches_tracked.to(dev) for m in bns]) if bns else None
+            self._nbt_index = {}
+            for i, m in enumerate(bns):
+                m._buffers['num_batches_tracked'] = flat[i]
+                self._nbt_index[id(m)] = i
+            self._nbt_flat = flat
+            self._nbt_inc = {}
+        counts = {}
+        for m in eng.bn_trained:
+            i = self._nbt_index[id(m)]
+            counts[i] = counts.get(i, 0) + 1
+        key = tuple(sorted(counts.items()))
+        inc = self._nbt_inc.get(key)
+        if inc is None:
+            host = torch.zeros(self._nbt_flat.numel(), dtype=torch.int64)
+            for i, c in counts.items():
+                host[i] = c
+            inc = host.to(dev)
+            self._nbt_inc[key] = inc
+        eng.call('fami_add_i64', _p(self._nbt_flat), _p(inc), self._nbt_flat.numel())

@@ -1,0 +1,268 @@
+"""The training step of the hot path, MI355X-first.
+
+Restates engine/core/functions/alignment_mi_function_term6_1.py:104-156
+(model call, JointMSELoss * W_mse, MI combination with alpha 0.5 / beta 0.1,
+zero_grad / backward / Adam step) -- the reference loop itself is not importable
+ -- with these design choices:
+
+* parameters, gradients and both Adam moments live in four flat fp32 arenas
+  (one allocation each); nn.Parameter objects are views, so state_dict() is
+  unchanged.  Adam is ONE kernel over the arena; the data-parallel all-reduce
+  needs no flatten/unflatten copies: a bucket is a slice of the gradient arena.
+* one process per GPU; gradients are averaged with RCCL all-reduce over xGMI,
+  bucket by bucket, each bucket launched as soon as the backward tape has
+  enqueued the last contribution to it (reverse registration order: the head
+  and stage 4 first), overlapping with the rest of backward.  BatchNorm
+  statistics stay per replica (what the reference's nn.DataParallel does).
+* the whole launch sequence of a step is captured once into hipGraphs and
+  replayed (torch.cuda.CUDAGraph is used purely as the capture/replay handle).
+  With world_size > 1 the backward is cut into one graph per bucket so the
+  collectives run between graph launches on RCCL's stream.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from ._lib import lib
+from .engine import Engine, _p
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) on one flat fp32 arena."""
+
+    def __init__(self, flat_param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.p = flat_param
+        self.grad = torch.zeros_like(flat_param)
+        self.m = torch.zeros_like(flat_param)
+        self.v = torch.zeros_like(flat_param)
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.state = torch.tensor([0.0, lr, 1.0, 1.0], device=flat_param.device)   # step, lr, bc1, bc2
+
+    def set_lr(self, lr):
+        self.state[1] = lr
+
+    def step(self):
+        s = _stream(self.p.device)
+        lib().call('fami_adam_prep_f32', _p(self.state), self.betas[0], self.betas[1], s)
+        lib().call('fami_adam_f32', _p(self.p), _p(self.grad), _p(self.m), _p(self.v), self.p.numel(), _p(self.state),
+                   self.betas[0], self.betas[1], self.eps, self.wd, s)
+
+
+def flatten_parameters(model):
+    """Move every trainable parameter into one flat arena (views keep names/shapes). -> (flat, [(param, off, n)])"""
+    ps = [p for p in model.parameters() if p.requires_grad]
+    total = sum(p.numel() for p in ps)
+    flat = torch.empty(total, dtype=torch.float32, device=ps[0].device)
+    table, off = [], 0
+    for p in ps:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        table.append((p, off, n))
+        off += n
+    return flat, table
+
+
+class Trainer:
+    """One optimisation step per call: forward, loss, backward, (all-reduce), Adam -- all HIP kernels."""
+
+    def __init__(self, model, lr=1e-3, mse_weight=1.0, alpha=0.5, beta=0.1, use_mi=True, bucket_mb=32,
+                 process_group=None, use_graph=True):
+        self.model = model
+        self.dev = next(model.parameters()).device
+        if self.dev.type != 'cuda':
+            raise RuntimeError('Trainer needs the model on the GPU (HIP path only)')
+        self.mse_weight, self.alpha, self.beta, self.use_mi = mse_weight, alpha, beta, use_mi
+        self.flat, self.table = flatten_parameters(model)
+        self.opt = FlatAdam(self.flat, lr=lr)
+        self.grad = self.opt.grad
+        self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
+        self.offset = {id(p): (o, n) for p, o, n in self.table}
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        if self.world > 1 and process_group is None:
+            self.pg = dist.group.WORLD
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.use_graph = use_graph
+        self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
+        self._graphs = None
+        self._static = None
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    # ------------------------------------------------------------------ data parallel
+    def broadcast_parameters(self):
+        dist.broadcast(self.flat, src=0, group=self.pg)
+        for b in self.model.buffers():
+            if b.dtype.is_floating_point:
+                dist.broadcast(b, src=0, group=self.pg)
+
+    def _bucket_ranges(self):
+        """Arena slices, tail first (the order backward completes them)."""
+        total = self.flat.numel()
+        ranges, hi = [], total
+        while hi > 0:
+            lo = max(0, hi - self.bucket_elems)
+            ranges.append((lo, hi))
+            hi = lo
+        return ranges
+
+    # ------------------------------------------------------------------ the step (eager launch sequence)
+    def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
+        model = self.model
+        eng = Engine(self.dev, grad_views=self.views)
+        outs, _ = model._body(eng, kf_x, sup_x)
+        model._advance_bn_counters(eng)
+        aux = eng.aux
+        final_nchw = outs[0]
+        B, J = final_nchw.shape[:2]
+        L = final_nchw[0, 0].numel()
+        scale = self.mse_weight / (B * L * J)
+        w = weight.reshape(B * J)
+        ws = eng.ws(B * J * 4)
+        eng.call('fami_wmse_fwd_f32', _p(final_nchw), _p(target), _p(w), _p(self.loss_parts[0:1]), B * J, L,
+                 float(scale), _p(ws))
+        dpred = torch.empty_like(final_nchw)
+        eng.call('fami_wmse_bwd_f32', _p(final_nchw), _p(target), _p(w), _p(dpred), B * J, L, float(scale), None, 0)
+        eng.seed_nchw(aux['final'], dpred)
+        if self.use_mi and aux['mis']:
+            a, b = self.alpha, self.beta
+            coef = [-b * a, b * a, a, -a, a, -a]        # core fn :119-148
+            for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
+                eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
+                seed(c)
+        # bucket hooks
+        hook = None
+        if on_bucket is not None:
+            ranges = self._bucket_ranges()
+            state = {'next': 0, 'done_lo': self.flat.numel()}
+            pending = {}
+
+            def hook(done_params):
+                for p in done_params:
+                    o, n = self.offset[id(p)]
+                    pending[o] = n
+                # advance the contiguous "complete" frontier from the arena tail
+                moved = True
+                while moved:
+                    moved = False
+                    for o, n in list(pending.items()):
+                        if o + n == state['done_lo']:
+                            state['done_lo'] = o
+                            del pending[o]
+                            moved = True
+                while state['next'] < len(ranges) and ranges[state['next']][0] >= state['done_lo']:
+                    on_bucket(*ranges[state['next']])
+                    state['next'] += 1
+            self._hook_state = (state, ranges)
+        eng.backward(on_params_done=hook)
+        if on_bucket is not None:
+            state, ranges = self._hook_state
+            while state['next'] < len(ranges):          # parameters that never receive a gradient (hrnet.final_layer)
+                on_bucket(*ranges[state['next']])
+                state['next'] += 1
+        return outs
+
+    def _allreduce(self, lo, hi):
+        g = self.grad[lo:hi]
+        return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _eager_step(self, kf_x, sup_x, target, weight):
+        works = []
+        if self.world > 1:
+            outs = self._forward_backward(kf_x, sup_x, target, weight,
+                                          on_bucket=lambda lo, hi: works.append(self._allreduce(lo, hi)))
+            for wk in works:
+                wk.wait()
+            lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world, 0.0,
+                       _stream(self.dev))
+        else:
+            outs = self._forward_backward(kf_x, sup_x, target, weight)
+        self.opt.step()
+        return outs
+
+    # ------------------------------------------------------------------ hipGraph capture / replay
+    def _capture(self, kf_x, sup_x, target, weight):
+        st = {'kf': kf_x.clone(), 'sup': sup_x.clone(), 'target': target.clone(), 'weight': weight.clone()}
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                     # warm-up on a side stream (allocator + pack caches)
+            for _ in range(2):
+                self._eager_step(st['kf'], st['sup'], st['target'], st['weight'])
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
+                self.opt.step()
+            self._graphs = [('graph', g)]
+        else:
+            # one graph per bucket boundary; collectives run between graph launches
+            pool = torch.cuda.graph_pool_handle()
+            plan = []
+            cur = {'g': None, 'ctx': None}
+
+            def begin():
+                cur['g'] = torch.cuda.CUDAGraph()
+                cur['ctx'] = torch.cuda.graph(cur['g'], pool=pool)
+                cur['ctx'].__enter__()
+
+            def end():
+                cur['ctx'].__exit__(None, None, None)
+                plan.append(('graph', cur['g']))
+
+            def on_bucket(lo, hi):
+                end()
+                plan.append(('allreduce', (lo, hi)))
+                begin()
+
+            begin()
+            outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], on_bucket=on_bucket)
+            end()
+            plan.append(('wait', None))
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=pool):
+                lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world,
+                           0.0, _stream(self.dev))
+                self.opt.step()
+            plan.append(('graph', g2))
+            self._graphs = plan
+        self._static = st
+        self._static_outs = outs
+        return outs
+
+    def step(self, kf_x, sup_x, target, weight):
+        """-> (final_hm, kf_bb_hm, ...) of this step; self.loss_parts holds [mse*W, mi_1..mi_6] on device."""
+        weight = weight.reshape(weight.shape[0], -1).float().contiguous()
+        if not self.use_graph:
+            return self._eager_step(kf_x, sup_x, target, weight)
+        if self._graphs is None:
+            self._capture(kf_x, sup_x, target, weight)
+        st = self._static
+        st['kf'].copy_(kf_x, non_blocking=True)
+        st['sup'].copy_(sup_x, non_blocking=True)
+        st['target'].copy_(target, non_blocking=True)
+        st['weight'].copy_(weight, non_blocking=True)
+        works = []
+        for kind, obj in self._graphs:
+            if kind == 'graph':
+                obj.replay()
+            elif kind == 'allreduce':
+                works.append(self._allreduce(*obj))
+            else:
+                for wk in works:
+                    wk.wait()
+        return self._static_outs
+
+    def loss_value(self):
+        """Total loss of the last step (host float; forces a sync -- logging only)."""
+        p = self.loss_parts.tolist()
+        a, b = self.alpha, self.beta
+        mi = a * (-b * p[1] + b * p[2] + p[3] - p[4] + p[5] - p[6]) if self.use_mi else 0.0
+        return p[0] + mi

@@ -1,0 +1,152 @@
+/* fami.h -- C ABI of libfami_hip.so: the MI355X (gfx950) kernels behind the
+ * FAMI-Pose temporal-alignment training hot path.
+ *
+ * The reference has NO native FFI on this path: its compute is
+ * reached through torch.nn modules, torchvision's registered op
+ * torchvision::deform_conv2d and kornia.geometry.warp_affine.  Each entry point
+ * below therefore names the reference *call site / module* it replaces
+ * (file:line relative to the reference tree).  A reference maintainer binds
+ * them with ctypes; fami-pose_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch tensors'
+ *    data_ptr()); the library never allocates, frees or synchronises;
+ *  - activations are fp32 NHWC ("[N,H,W,C]") unless stated; tensors at the
+ *    drop-in boundary (network input, heatmaps, targets) are NCHW;
+ *  - `stream` is a hipStream_t; every call only enqueues kernels on it and is
+ *    therefore hipGraph-capturable;
+ *  - `accumulate`/`acc_*` = 0: overwrite the output, 1: add into it;
+ *  - returns 0, or FAMI_EARG (-1) bad argument, FAMI_ESHAPE (-2) unsupported
+ *    shape, FAMI_EHIP (-3) HIP error; fami_last_error() has the text
+ *    (thread-local);
+ *  - workspaces: size from the matching fami_*_workspace() query (bytes).
+ */
+#ifndef FAMI_H
+#define FAMI_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fami_stream_t; /* hipStream_t */
+
+const char* fami_version(void);
+const char* fami_last_error(void);
+/* info[0]=CUs, [1]=wavefront, [2]=LDS bytes/workgroup, [3]=clock kHz */
+int fami_device_info(int device, int* info, char* name, int name_len);
+
+/* ---- convolution family: nn.Conv2d fwd + autograd --------------------------------------
+ * replaces every nn.Conv2d of posetimation/backbones/hrnet.py:569-629 (HRNet-W48: 293 convs),
+ * posetimation/layers/basic_model.py:21-23,38-41,74-77 and basic_layer.py:18-19, and the 3x3
+ * dilation-3 offset/mask predictors of posetimation/zoo/Alignment/Alignment_V15.py:79-100.
+ * Weights are consumed in a fragment-packed image (mode 0 = forward, 1 = dgrad). */
+long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
+int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
+                              fami_stream_t stream);
+/* y[N,Ho,Wo,Co] (=|+=) relu?( conv(x[N,H,W,Ci]) + bias + addend ) ; bias/addend may be NULL */
+int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* addend, float* y, int N,
+                        int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                        int accumulate, fami_stream_t stream);
+/* dx[N,H,W,Ci] (=|+=) conv_transpose(dy[N,Ho,Wo,Co]) + addend */
+int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend, float* dx, int N, int H, int W,
+                          int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                          fami_stream_t stream);
+long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+/* dw[Co,Ci,kh,kw] (OIHW, =|+=) */
+int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                          int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                          fami_stream_t stream);
+
+/* ---- BatchNorm (+ReLU, +residual) : nn.BatchNorm2d(momentum 0.1, eps 1e-5) ---------------
+ * replaces basic_model.py:34,42 (BasicBlock.bn1/bn2 + `out += residual` + ReLU :46-63),
+ * :75-79 (Bottleneck), basic_layer.py:25-26, hrnet.py:107,127,138 (fuse BNs).  x is [P,C]. */
+long fami_bn_workspace(int C);
+int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd, float* running_mean,
+                      float* running_var, float momentum, float eps, float* ws, fami_stream_t stream);
+int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
+                           float eps, fami_stream_t stream);
+int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* residual, float* y, long P, int C, int relu, fami_stream_t stream);
+int fami_bn_bwd_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                    const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long P, int C, int relu,
+                    int acc_dx, int acc_param, int acc_dres, float* ws, fami_stream_t stream);
+long fami_channel_sum_workspace(int C);
+/* out[c] (=|+=) sum_p x[p][c] : bias gradients of the biased convs */
+int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumulate, float* ws, fami_stream_t stream);
+
+/* ---- streaming helpers ---------------------------------------------------------------------
+ * boundary layout converts, torch.cat/chunk (Alignment_V15.py:117-125,139,143,160), `sup - kf`
+ * (:132), HighResolutionModule fuse sum + Interpolate(nearest) + ReLU (hrnet.py:159-168,
+ * basic_model.py:116-125), torch.optim.Adam (posetimation/optimizer/optimizer.py:66-68). */
+int fami_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, fami_stream_t stream);
+int fami_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int accumulate,
+                          fami_stream_t stream);
+int fami_pack_frames_f32(const float* kf_nchw, const float* sup_nchw, float* frames_nhwc, int B, int S, int H, int W,
+                         fami_stream_t stream);
+int fami_copy_channels_f32(const float* src, float* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,
+                           int accumulate, fami_stream_t stream);
+int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alpha, float beta,
+                   fami_stream_t stream);
+int fami_fill_f32(float* out, long n, float v, fami_stream_t stream);
+int fami_incr_i64(long long* v, long n, fami_stream_t stream);
+/* v[i] += inc[i] : BatchNorm num_batches_tracked counters, all layers in one launch */
+int fami_add_i64(long long* v, const long long* inc, long n, fami_stream_t stream);
+int fami_fuse_sum_f32(int nterms, const float* const* x, const float* const* mean, const float* const* invstd,
+                      const float* const* gamma, const float* const* beta, const int* shift, float* y, int N, int H,
+                      int W, int C, int relu, fami_stream_t stream);
+int fami_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, int accumulate, fami_stream_t stream);
+int fami_pool_relu_bwd_f32(const float* dy, const float* y, float* out, int N, int Hl, int Wl, int C, int shift,
+                           int relu, fami_stream_t stream);
+int fami_adam_prep_f32(float* state4, float beta1, float beta2, fami_stream_t stream);
+int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* state4, float beta1,
+                  float beta2, float eps, float weight_decay, fami_stream_t stream);
+
+/* ---- temporal alignment ----------------------------------------------------------------------
+ * fami_shift_bilinear_*: kornia.geometry.warp_affine(src, [[1,0,tx],[0,1,ty]], dsize) at
+ *   Alignment_V15.py:133-135 (differentiable wrt src and (tx,ty)); t is a device [B,2] = (tx,ty).
+ * fami_dcn_*: torchvision.ops.DeformConv2d(C,C,3,padding=3,dilation=3).forward(x, offset, mask)
+ *   at Alignment_V15.py:146,150,154,158 and its autograd; offset [B,Ho,Wo,2*G*K] ordered
+ *   (group, tap, (dy,dx)), mask [B,Ho,Wo,G*K] raw (no sigmoid), G = offset groups (12). */
+long fami_shift_workspace(int B);
+int fami_shift_bilinear_fwd_f32(const float* src, const float* t, float* out, int B, int H, int W, int C,
+                                fami_stream_t stream);
+int fami_shift_bilinear_bwd_f32(const float* gout, const float* src, const float* t, float* gsrc, float* gt, int B,
+                                int H, int W, int C, int acc_src, int acc_t, float* ws, fami_stream_t stream);
+long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G);
+int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G,
+                             fami_stream_t stream);
+int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
+                     int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
+                     fami_stream_t stream);
+/* gcol/col are [P, C*K] in (channel, tap) order == weight.view(Co, C*K); gx accumulated with atomics */
+int fami_dcn_bwd_gather_f32(const float* x, const float* off, const float* msk, const float* gcol, float* col,
+                            float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int G, int kh, int kw,
+                            int stride, int pad, int dil, int acc_off, fami_stream_t stream);
+
+/* ---- dense layers of the translation regressor: nn.Linear x3 (Alignment_V15.py:69-71) ------- */
+int fami_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
+                        fami_stream_t stream);
+int fami_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int M,
+                        int K, int N, int acc_dx, int acc_param, fami_stream_t stream);
+
+/* ---- targets / losses / decode (NCHW rows) ----------------------------------------------------
+ * fami_gauss_target : datasets/process/heatmaps_process.py:146-203 (generate_heatmaps)
+ * fami_wmse_*       : posetimation/loss/mse_loss.py:21-40 (JointMSELoss.forward)
+ * fami_softmax_kl_* : Alignment_V15.py:250-277 (feat_label/feat_feat MI estimators, T = 0.05)
+ * fami_argmax2d      : datasets/process/heatmaps_process.py:16-44 (get_max_preds) */
+int fami_gauss_target_f32(const float* joints_xy, const float* vis, float* target, float* weight, int B, int J,
+                          int Hh, int Wh, int img_h, int img_w, int sigma, fami_stream_t stream);
+int fami_wmse_fwd_f32(const float* pred, const float* gt, const float* w, float* loss, int R, int L, double scale,
+                      float* ws, fami_stream_t stream);
+int fami_wmse_bwd_f32(const float* pred, const float* gt, const float* w, float* dpred, int R, int L, float scale,
+                      const float* gdev, int accumulate, fami_stream_t stream);
+int fami_softmax_kl_fwd_f32(const float* A, const float* Bt, float* value, float* stats, int R, int L,
+                            float temperature, float* ws, fami_stream_t stream);
+int fami_softmax_kl_bwd_f32(const float* A, const float* Bt, const float* stats, float* dBt, int R, int L,
+                            float temperature, float gscale, const float* gdev, int accumulate,
+                            fami_stream_t stream);
+int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int L, fami_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAMI_H */

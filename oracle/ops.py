@@ -1,0 +1,278 @@
+"""Oracle (test infrastructure): op-level CPU restatements, torch fp32 / numpy.
+
+Reference citations are relative to /root/reference.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# modulated deformable convolution
+# --------------------------------------------------------------------------
+def _bilinear_zero(img, y, x):
+    """img [B,C,H,W]; y,x [B,G,K,Ho,Wo] float sample positions, one set per
+    offset group G (C = G*cg).  Returns [B,G,cg,K,Ho,Wo].  A corner contributes
+    only when it lies inside the map (torchvision deform_conv2d bilinear rule).
+    """
+    B, C, H, W = img.shape
+    G = y.shape[1]
+    cg = C // G
+    y0 = torch.floor(y)
+    x0 = torch.floor(x)
+    ly, lx = y - y0, x - x0
+    hy, hx = 1.0 - ly, 1.0 - lx
+    y0, x0 = y0.long(), x0.long()
+    flat = img.reshape(B, G, cg, H * W)
+    out = 0
+    for dy, dx, wgt in ((0, 0, hy * hx), (0, 1, hy * lx), (1, 0, ly * hx), (1, 1, ly * lx)):
+        yy, xx = y0 + dy, x0 + dx
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1))          # [B,G,K,Ho,Wo]
+        shp = idx.shape
+        g = torch.gather(flat, 3, idx.reshape(B, G, 1, -1).expand(B, G, cg, -1))
+        g = g.reshape(B, G, cg, *shp[2:])
+        out = out + g * (wgt * ok.to(img.dtype)).unsqueeze(2)
+    return out
+
+
+def deform_conv2d(inp, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
+    """Modulated deformable conv, torchvision.ops.deform_conv2d semantics, as
+    called at posetimation/zoo/Alignment/Alignment_V15.py:146,150,154,158
+    (ctor :83,89,95,101: 48->48, 3x3, padding 3, dilation 3, weight groups 1).
+
+    offset [B, 2*G*kh*kw, Ho, Wo] ordered (group, tap row-major, (dy,dx));
+    mask   [B,   G*kh*kw, Ho, Wo] multiplicative (NO sigmoid: the reference
+    feeds raw conv outputs, Alignment_V15.py:81-82); weight [Co,Ci,kh,kw].
+    """
+    B, C, H, W = inp.shape
+    Co, Ci, kh, kw = weight.shape
+    assert Ci == C, "weight groups == 1 only"
+    K = kh * kw
+    G = offset.shape[1] // (2 * K)
+    Ho = (H + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
+    off = offset.reshape(B, G, K, 2, Ho, Wo)
+    ky = torch.arange(kh, dtype=inp.dtype).repeat_interleave(kw) * dilation
+    kx = torch.arange(kw, dtype=inp.dtype).repeat(kh) * dilation
+    oy = torch.arange(Ho, dtype=inp.dtype) * stride - padding
+    ox = torch.arange(Wo, dtype=inp.dtype) * stride - padding
+    py = oy.view(1, 1, 1, Ho, 1) + ky.view(1, 1, K, 1, 1) + off[:, :, :, 0]
+    px = ox.view(1, 1, 1, 1, Wo) + kx.view(1, 1, K, 1, 1) + off[:, :, :, 1]
+    samp = _bilinear_zero(inp, py, px)                                # [B,G,cg,K,Ho,Wo]
+    if mask is not None:
+        samp = samp * mask.reshape(B, G, 1, K, Ho, Wo)
+    cols = samp.reshape(B, C * K, Ho * Wo)                            # (c, tap) major = weight.view(Co,-1)
+    out = torch.matmul(weight.reshape(Co, C * K), cols).reshape(B, Co, Ho, Wo)
+    if bias is not None:
+        out = out + bias.view(1, Co, 1, 1)
+    return out
+
+
+def deform_conv2d_gridsample(inp, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
+    """Independent formulation of the same op through F.grid_sample
+    (align_corners=True, zeros padding, pixel units) used only to cross-check
+    deform_conv2d above."""
+    B, C, H, W = inp.shape
+    Co, _, kh, kw = weight.shape
+    K = kh * kw
+    G = offset.shape[1] // (2 * K)
+    cg = C // G
+    Ho, Wo = offset.shape[2:]
+    out = torch.zeros(B, Co, Ho, Wo, dtype=inp.dtype)
+    ys = torch.arange(Ho, dtype=inp.dtype).view(1, Ho, 1) * stride - padding
+    xs = torch.arange(Wo, dtype=inp.dtype).view(1, 1, Wo) * stride - padding
+    for g in range(G):
+        sub = inp[:, g * cg:(g + 1) * cg]
+        for i in range(kh):
+            for j in range(kw):
+                t = g * K + i * kw + j
+                py = ys + i * dilation + offset[:, 2 * t]
+                px = xs + j * dilation + offset[:, 2 * t + 1]
+                grid = torch.stack([2 * px / max(W - 1, 1) - 1, 2 * py / max(H - 1, 1) - 1], -1)
+                s = F.grid_sample(sub, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+                if mask is not None:
+                    s = s * mask[:, t:t + 1]
+                out = out + torch.einsum('oc,bchw->bohw', weight[:, g * cg:(g + 1) * cg, i, j], s)
+    if bias is not None:
+        out = out + bias.view(1, Co, 1, 1)
+    return out
+
+
+# --------------------------------------------------------------------------
+# global translation (kornia.geometry.warp_affine with M = [[1,0,tx],[0,1,ty]])
+# --------------------------------------------------------------------------
+def warp_translate(src, t):
+    """out[b,c,y,x] = bilinear(src[b,c], y - ty, x - tx), zero padding, same
+    size.  Call site Alignment_V15.py:133-135: M maps src->dst pixel coords, so
+    the sampling position is M^-1 x_dst.  Pixel-exact (align_corners=True)
+    semantics fixed by this build.  t [B,2] = (tx, ty)."""
+    B, C, H, W = src.shape
+    ys = torch.arange(H, dtype=src.dtype).view(1, 1, 1, H, 1) - t[:, 1].view(B, 1, 1, 1, 1)
+    xs = torch.arange(W, dtype=src.dtype).view(1, 1, 1, 1, W) - t[:, 0].view(B, 1, 1, 1, 1)
+    py = ys.expand(B, 1, 1, H, W)
+    px = xs.expand(B, 1, 1, H, W)
+    return _bilinear_zero(src, py, px).reshape(B, C, H, W)
+
+
+def warp_affine_like(src, M, dsize):
+    """Signature-compatible stand-in for kornia.geometry.warp_affine restricted
+    to pure translations (what Alignment_V15.py:133-135 builds)."""
+    assert tuple(dsize) == tuple(src.shape[2:])
+    return warp_translate(src, torch.stack([M[:, 0, 2], M[:, 1, 2]], 1))
+
+
+def warp_translate_gridsample(src, t):
+    B, C, H, W = src.shape
+    ys = torch.arange(H, dtype=src.dtype).view(1, H, 1) - t[:, 1].view(B, 1, 1)
+    xs = torch.arange(W, dtype=src.dtype).view(1, 1, W) - t[:, 0].view(B, 1, 1)
+    grid = torch.stack([(2 * xs / (W - 1) - 1).expand(B, H, W), (2 * ys / (H - 1) - 1).expand(B, H, W)], -1)
+    return F.grid_sample(src, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+
+
+# --------------------------------------------------------------------------
+# MI surrogate (softmax / KL)
+# --------------------------------------------------------------------------
+MI_TEMPERATURE = 0.05
+
+
+def softmax_kl_rows(a_rows, b_rows, temperature=MI_TEMPERATURE):
+    """mean over ALL elements of t*(log t - a) with a = softmax(A/T) (probabilities,
+    not log-probabilities -- reference behaviour, Alignment_V15.py:260,275) and
+    t = softmax(Bt/T); rows = dim 0, softmax over dim 1.  Gradient flows only
+    through b_rows (a is detached in the reference)."""
+    a = torch.softmax(a_rows.detach() / temperature, dim=1)
+    t = torch.softmax(b_rows / temperature, dim=1)
+    ref_form = (torch.xlogy(t, t) - t * a).mean()          # value: bit-identical to F.kl_div(a, t, 'mean')
+    # Gradient: wherever softmax(Bt/T) underflows to exactly 0 the reference's
+    # autograd yields NaN (0 * log 0 in the xlogy/mul backward).  The build
+    # defines the analytical limit there (t*(log t + 1 - a) -> 0); the two agree
+    # whenever the reference is finite.  log_softmax keeps log t finite.
+    logt = torch.log_softmax(b_rows / temperature, dim=1)
+    safe = (torch.exp(logt) * (logt - a)).mean()
+    return safe + (ref_form - safe).detach()
+
+
+def feat_label_mi(feat, y, final_w, final_b, temperature=MI_TEMPERATURE):
+    """Alignment_V15.feat_label_mi_estimation (Alignment_V15.py:250-263):
+    A = hrnet.final_layer(Feat) (1x1 conv, detached), Bt = Y; rows [B*J, H*W]."""
+    B = feat.shape[0]
+    pred = F.conv2d(feat, final_w, final_b)
+    J = pred.shape[1]
+    return softmax_kl_rows(pred.reshape(B * J, -1), y.reshape(B * J, -1), temperature)
+
+
+def feat_feat_mi(f1, f2, temperature=MI_TEMPERATURE):
+    """Alignment_V15.feat_feat_mi_estimation (Alignment_V15.py:265-277)."""
+    B, C = f1.shape[:2]
+    return softmax_kl_rows(f1.reshape(B * C, -1), f2.reshape(B * C, -1), temperature)
+
+
+# --------------------------------------------------------------------------
+# heatmap loss / targets / decode
+# --------------------------------------------------------------------------
+def joint_mse(pred, gt, weight, use_target_weight=True, divided_num_joints=True):
+    """JointMSELoss.forward (posetimation/loss/mse_loss.py:21-40):
+    (1/J) sum_j mean_{b,p} (w_bj * (pred - gt))^2."""
+    B, J = pred.shape[:2]
+    p = pred.reshape(B, J, -1)
+    g = gt.reshape(B, J, -1)
+    if use_target_weight:
+        w = weight.reshape(B, J, 1)
+        p, g = p * w, g * w
+    per_joint = ((p - g) ** 2).mean(dim=(0, 2))
+    loss = per_joint.sum()
+    return loss / J if divided_num_joints else loss
+
+
+def generate_heatmaps(joints, joints_vis, sigma, image_size, heatmap_size, num_joints):
+    """datasets/process/heatmaps_process.py:146-203.  joints [J,3], joints_vis
+    [J,3], image_size/heatmap_size (w,h) -> target [J,Hh,Wh] f32, weight [J,1]."""
+    image_size = np.asarray(image_size, dtype=np.float64)
+    heatmap_size = np.asarray(heatmap_size)
+    Wh, Hh = int(heatmap_size[0]), int(heatmap_size[1])
+    weight = np.ones((num_joints, 1), np.float32)
+    weight[:, 0] = joints_vis[:, 0]
+    target = np.zeros((num_joints, Hh, Wh), np.float32)
+    r = sigma * 3
+    size = 2 * r + 1
+    ax = np.arange(0, size, 1, np.float32)
+    g = np.exp(-((ax[None, :] - size // 2) ** 2 + (ax[:, None] - size // 2) ** 2) / (2 * sigma ** 2))
+    stride = image_size / heatmap_size
+    for j in range(num_joints):
+        mx = int(joints[j][0] / stride[0] + 0.5)
+        my = int(joints[j][1] / stride[1] + 0.5)
+        x0, y0 = int(mx - r), int(my - r)
+        x1, y1 = int(mx + r + 1), int(my + r + 1)
+        if x0 >= Wh or y0 >= Hh or x1 < 0 or y1 < 0:
+            weight[j] = 0
+            continue
+        if weight[j] > 0.5:
+            gx0, gx1 = max(0, -x0), min(x1, Wh) - x0
+            gy0, gy1 = max(0, -y0), min(y1, Hh) - y0
+            target[j][max(0, y0):min(y1, Hh), max(0, x0):min(x1, Wh)] = g[gy0:gy1, gx0:gx1]
+    return target, weight
+
+
+def get_max_preds(hm):
+    """datasets/process/heatmaps_process.py:16-44: row-major flat argmax (first
+    max on ties); coords zeroed where max <= 0.  hm ndarray [B,J,H,W]."""
+    B, J, H, W = hm.shape
+    flat = hm.reshape(B, J, -1)
+    idx = np.argmax(flat, 2)
+    maxvals = np.amax(flat, 2).reshape(B, J, 1)
+    preds = np.zeros((B, J, 2), np.float32)
+    preds[:, :, 0] = (idx % W).astype(np.float32)
+    preds[:, :, 1] = np.floor(idx.astype(np.float32) / W)
+    preds *= (maxvals > 0.0).astype(np.float32)
+    return preds, maxvals
+
+
+def argmax_indices(hm):
+    """flat argmax indices [B,J] int64 (the bit-exact contract of north_star)."""
+    B, J = hm.shape[:2]
+    return np.argmax(hm.reshape(B, J, -1), 2)
+
+
+def accuracy(output, target, thr=0.5):
+    """engine/core/utils/evaluate.py:39-75 (hm_type='gaussian'): PCK on heatmap
+    argmax, norm = (H,W)/10, targets with x<=1 or y<=1 ignored."""
+    pred, _ = get_max_preds(output)
+    tgt, _ = get_max_preds(target)
+    B, J = pred.shape[:2]
+    h, w = output.shape[2], output.shape[3]
+    norm = np.ones((B, 2)) * np.array([h, w]) / 10
+    dists = np.zeros((J, B))
+    for n in range(B):
+        for c in range(J):
+            if tgt[n, c, 0] > 1 and tgt[n, c, 1] > 1:
+                dists[c, n] = np.linalg.norm(pred[n, c].astype(np.float32) / norm[n] - tgt[n, c].astype(np.float32) / norm[n])
+            else:
+                dists[c, n] = -1
+    acc = np.zeros(J + 1)
+    avg, cnt = 0.0, 0
+    for c in range(J):
+        use = dists[c] != -1
+        if use.sum() > 0:
+            acc[c + 1] = (dists[c][use] < thr).sum() * 1.0 / use.sum()
+        else:
+            acc[c + 1] = -1
+        if acc[c + 1] >= 0:
+            avg += acc[c + 1]
+            cnt += 1
+    avg = avg / cnt if cnt != 0 else 0
+    if cnt != 0:
+        acc[0] = avg
+    return acc, avg, cnt, pred
+
+
+def total_loss(final_hm, target, weight, mi_list, mse_weight=1.0, alpha=0.5, beta=0.1):
+    """Loss assembly of engine/core/functions/alignment_mi_function_term6_1.py:108-148
+    (local_warped_sup_hm_list is empty for Alignment_V15)."""
+    loss = joint_mse(final_hm, target, weight) * mse_weight
+    if len(mi_list) > 0:
+        m1, m2, m3, m4, m5, m6 = mi_list
+        loss = loss + alpha * (-beta * m1 + beta * m2 + m3 - m4 + m5 - m6)
+    return loss

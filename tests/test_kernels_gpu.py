@@ -1,0 +1,356 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle /
+torch fp32 reference of the same op.  fp32 tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(dev):
+    from fami_pose_amd.engine import Engine
+    return Engine(dev)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, dil, bias
+    (2, 24, 18, 48, 48, 3, 1, 1, 1, False),
+    (2, 12, 9, 96, 96, 3, 1, 1, 1, False),
+    (1, 12, 9, 192, 192, 3, 1, 1, 1, False),
+    (2, 6, 5, 384, 384, 3, 1, 1, 1, False),
+    (2, 32, 24, 3, 64, 3, 2, 1, 1, False),      # stem (scalar path, Ci = 3)
+    (2, 16, 12, 64, 64, 3, 2, 1, 1, False),
+    (2, 16, 12, 64, 256, 1, 1, 0, 1, False),
+    (2, 16, 12, 256, 64, 1, 1, 0, 1, False),
+    (2, 16, 12, 256, 48, 3, 1, 1, 1, False),
+    (2, 16, 12, 48, 96, 3, 2, 1, 1, False),
+    (2, 13, 9, 96, 192, 3, 2, 1, 1, False),     # odd sizes, stride 2
+    (2, 24, 18, 48, 216, 3, 1, 3, 3, True),     # DCN offset predictor (dilation 3)
+    (2, 24, 18, 48, 108, 3, 1, 3, 3, True),
+    (2, 24, 18, 48, 17, 1, 1, 0, 1, True),      # final layer (Co = 17)
+    (2, 24, 18, 48, 17, 3, 1, 1, 1, True),
+    (3, 7, 5, 16, 16, 3, 2, 1, 1, True),
+    (2, 24, 18, 192, 48, 3, 1, 1, 1, False),
+    (1, 5, 7, 20, 36, 3, 1, 1, 1, True),        # channel tails (Ci % 16 != 0)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_bwd(dev, case):
+    N, H, W, Ci, Co, k, s, p, d, has_bias = case
+    torch.manual_seed(hash(case) % 1000)
+    conv = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias)
+    x = torch.randn(N, Ci, H, W, requires_grad=True)
+    y = conv(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    cd = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias).to(dev)
+    cd.load_state_dict(conv.state_dict())
+    xt = T(nhwc(x.detach()).to(dev), True)
+    yt = eng.conv(xt, cd.weight, cd.bias, s, p, d)
+    assert relerr(nchw(yt.data), y) < 2e-5
+    yt.grad = nhwc(gy).to(dev)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < 2e-5
+    assert relerr(eng.param_grads[id(cd.weight)], conv.weight.grad) < 5e-5
+    if has_bias:
+        assert relerr(eng.param_grads[id(cd.bias)], conv.bias.grad) < 5e-5
+
+
+@pytest.mark.parametrize("C,relu,res", [(48, True, True), (48, True, False), (96, False, False), (16, True, False),
+                                        (384, True, True), (256, False, True)])
+def test_bn_train_fwd_bwd(dev, C, relu, res):
+    torch.manual_seed(C)
+    N, H, W = 3, 10, 7
+    bn = nn.BatchNorm2d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    bd = nn.BatchNorm2d(C, momentum=0.1).to(dev)
+    bd.load_state_dict(bn.state_dict())
+    x = (torch.randn(N, C, H, W) * 2 + 0.7).requires_grad_(True)
+    r = torch.randn(N, C, H, W, requires_grad=True) if res else None
+    y = bn(x)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    xt = T(nhwc(x.detach()).to(dev), True)
+    rt = T(nhwc(r.detach()).to(dev), True) if res else None
+    yt = eng.bn(xt, bd, relu=relu, residual=rt)
+    assert relerr(nchw(yt.data), y) < 1e-5
+    assert relerr(bd.running_mean, bn.running_mean) < 1e-5
+    assert relerr(bd.running_var, bn.running_var) < 1e-5
+    yt.grad = nhwc(gy).to(dev)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < 5e-5
+    assert relerr(eng.param_grads[id(bd.weight)], bn.weight.grad) < 5e-5
+    assert relerr(eng.param_grads[id(bd.bias)], bn.bias.grad) < 5e-5
+    if res:
+        assert relerr(nchw(rt.grad), r.grad) < 1e-6
+
+
+def test_bn_eval_forward(dev):
+    torch.manual_seed(0)
+    C = 48
+    bn = nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    bd = nn.BatchNorm2d(C).to(dev).eval()
+    bd.load_state_dict(bn.state_dict())
+    x = torch.randn(2, C, 6, 5)
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    yt = eng.bn(T(nhwc(x).to(dev)), bd, relu=True)
+    assert relerr(nchw(yt.data), F.relu(bn(x))) < 1e-5
+
+
+def test_fuse_sum_fwd_bwd(dev):
+    """hrnet.py:159-168: y0 = relu(x0 + up2(bn(z1)) + up4(bn(z2))) ; y1 = relu(bn(z0) + x1)."""
+    torch.manual_seed(1)
+    N, C, H, W = 2, 48, 16, 12
+    bns = [nn.BatchNorm2d(C) for _ in range(3)]
+    for b in bns:
+        with torch.no_grad():
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.2)
+    x0 = torch.randn(N, C, H, W, requires_grad=True)
+    z1 = torch.randn(N, C, H // 2, W // 2, requires_grad=True)
+    z2 = torch.randn(N, C, H // 4, W // 4, requires_grad=True)
+    z3 = torch.randn(N, C, H, W, requires_grad=True)
+    y = F.relu(x0 + F.interpolate(bns[0](z1), scale_factor=2, mode='nearest')
+               + F.interpolate(bns[1](z2), scale_factor=4, mode='nearest') + bns[2](z3))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    bd = []
+    for b in bns:
+        d = nn.BatchNorm2d(C).to(dev)
+        d.load_state_dict(b.state_dict())
+        bd.append(d)
+    ts = [T(nhwc(t.detach()).to(dev), True) for t in (x0, z1, z2, z3)]
+    yt = eng.fuse([(ts[0], None, 0), (ts[1], bd[0], 1), (ts[2], bd[1], 2), (ts[3], bd[2], 0)])
+    assert relerr(nchw(yt.data), y) < 1e-5
+    yt.grad = nhwc(gy).to(dev)
+    eng.backward()
+    for t, ref in zip(ts, (x0, z1, z2, z3)):
+        assert relerr(nchw(t.grad), ref.grad) < 5e-5
+    for d, b in zip(bd, bns):
+        assert relerr(eng.param_grads[id(d.weight)], b.weight.grad) < 5e-5
+        assert relerr(eng.param_grads[id(d.bias)], b.bias.grad) < 5e-5
+
+
+def test_glue_ops(dev):
+    torch.manual_seed(2)
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    a = torch.randn(4, 48, 6, 5, requires_grad=True)
+    b = torch.randn(2, 48, 6, 5, requires_grad=True)
+    # slices of a, sub, concat
+    s0, s1 = a[0:2], a[2:4]
+    out = torch.cat([s0 - b, s1, b], 1)
+    g = torch.randn_like(out)
+    out.backward(g)
+    at, bt = T(nhwc(a.detach()).to(dev), True), T(nhwc(b.detach()).to(dev), True)
+    t0, t1 = eng.batch_slice(at, 0, 2), eng.batch_slice(at, 2, 4)
+    ot = eng.concat([eng.sub(t0, bt), t1, bt])
+    assert relerr(nchw(ot.data), out) < 1e-6
+    ot.grad = nhwc(g).to(dev)
+    eng.backward()
+    assert relerr(nchw(at.grad), a.grad) < 1e-6
+    assert relerr(nchw(bt.grad), b.grad) < 1e-6
+    # frames packing
+    kf, sup = torch.randn(2, 3, 8, 6), torch.randn(2, 9, 8, 6)
+    fr = eng.frames(kf.to(dev), sup.to(dev))
+    ref = torch.cat([kf] + list(torch.chunk(sup, 3, 1)), 0)
+    assert torch.equal(nchw(fr.data).cpu(), ref)
+    # layout round trip
+    x = torch.randn(3, 17, 9, 7)
+    assert torch.equal(eng.to_nchw(eng.from_nchw(x.to(dev))).cpu(), x)
+
+
+def test_linear_chain(dev):
+    torch.manual_seed(3)
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    l1, l2 = nn.Linear(144, 64), nn.Linear(64, 2)
+    d1, d2 = nn.Linear(144, 64).to(dev), nn.Linear(64, 2).to(dev)
+    d1.load_state_dict(l1.state_dict())
+    d2.load_state_dict(l2.state_dict())
+    x = torch.randn(3, 16, 3, 3, requires_grad=True)
+    y = l2(l1(x.flatten(1)))
+    g = torch.randn_like(y)
+    y.backward(g)
+    xt = T(nhwc(x.detach()).to(dev), True)
+    yt = eng.linear(eng.linear(eng.flatten_chw(xt), d1), d2)
+    assert relerr(yt.data, y) < 1e-5
+    yt.grad = g.to(dev)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < 1e-5
+    assert relerr(eng.param_grads[id(d1.weight)], l1.weight.grad) < 1e-5
+    assert relerr(eng.param_grads[id(d2.bias)], l2.bias.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 24, 18), (1, 16, 7, 9)])
+def test_shift_bilinear(dev, shape):
+    from oracle import ops as O
+    from fami_pose_amd.engine import T
+    torch.manual_seed(4)
+    B = shape[0]
+    src = torch.randn(*shape, requires_grad=True)
+    t = torch.tensor([[1.3, -2.6], [-0.25, 3.0]][:B], requires_grad=True)
+    y = O.warp_translate(src, t)
+    g = torch.randn_like(y)
+    y.backward(g)
+    eng = _eng(dev)
+    st, tt = T(nhwc(src.detach()).to(dev), True), T(t.detach().to(dev), True)
+    yt = eng.shift(st, tt)
+    assert relerr(nchw(yt.data), y) < 1e-5
+    yt.grad = nhwc(g).to(dev)
+    eng.backward()
+    assert relerr(nchw(st.grad), src.grad) < 1e-5
+    assert relerr(tt.grad, t.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(2, 48, 12, 12, 9), (1, 32, 8, 10, 7), (1, 96, 12, 6, 5)])
+def test_dcn_fwd_bwd(dev, cfg):
+    """DeformConv2d(C,C,3,padding=3,dilation=3) with G offset groups vs oracle.deform_conv2d."""
+    from oracle import ops as O
+    from fami_pose_amd.engine import T
+    B, C, G, H, W = cfg
+    torch.manual_seed(5)
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    off = (torch.randn(B, 18 * G, H, W) * 2.0).requires_grad_(True)     # reaches outside the map
+    msk = torch.randn(B, 9 * G, H, W, requires_grad=True)
+    w = (torch.randn(C, C, 3, 3) * 0.1).requires_grad_(True)
+    b = torch.randn(C, requires_grad=True)
+    y = O.deform_conv2d(x, off, msk, w, b, 1, 3, 3)
+    g = torch.randn_like(y)
+    y.backward(g)
+    eng = _eng(dev)
+    wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(b.detach().to(dev))
+    xt = T(nhwc(x.detach()).to(dev), True)
+    ot = T(nhwc(off.detach()).to(dev), True)
+    mt = T(nhwc(msk.detach()).to(dev), True)
+    yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+    assert relerr(nchw(yt.data), y) < 2e-5
+    yt.grad = nhwc(g).to(dev)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < 5e-5
+    assert relerr(nchw(ot.grad), off.grad) < 5e-5
+    assert relerr(nchw(mt.grad), msk.grad) < 5e-5
+    assert relerr(eng.param_grads[id(wd)], w.grad) < 5e-5
+    assert relerr(eng.param_grads[id(bd)], b.grad) < 5e-5
+
+
+def test_softmax_kl(dev):
+    from oracle import ops as O
+    from fami_pose_amd.engine import T
+    torch.manual_seed(6)
+    N, C, H, W = 2, 17, 12, 9
+    a = torch.randn(N, C, H, W) * 0.2
+    b = (torch.randn(N, C, H, W) * 0.2).requires_grad_(True)
+    v = O.softmax_kl_rows(a.reshape(N * C, -1), b.reshape(N * C, -1))
+    v.backward()
+    eng = _eng(dev)
+    bt = T(nhwc(b.detach()).to(dev), True)
+    val, seed = eng.softmax_kl(a.to(dev), bt)
+    assert abs(val.item() - v.item()) < 1e-6 + 1e-4 * abs(v.item())
+    seed(1.0)
+    assert relerr(nchw(bt.grad), b.grad) < 1e-4
+    # underflow regime: target softmax hits exact zeros -> finite (limit) gradient, finite value
+    b2 = torch.randn(N, C, H, W) * 8.0
+    bt2 = T(nhwc(b2).to(dev), True)
+    val2, seed2 = eng.softmax_kl(a.to(dev), bt2)
+    seed2(1.0)
+    assert torch.isfinite(val2).all() and torch.isfinite(bt2.grad).all()
+    ref2 = O.softmax_kl_rows(a.reshape(N * C, -1), b2.reshape(N * C, -1))
+    assert abs(val2.item() - ref2.item()) < 1e-6 + 1e-4 * abs(ref2.item())
+
+
+def test_losses_targets_decode(dev):
+    from oracle import ops as O
+    from fami_pose_amd import loss as FL
+    torch.manual_seed(7)
+    B, J, Hh, Wh = 3, 17, 24, 18
+    pred = torch.randn(B, J, Hh, Wh, requires_grad=True)
+    gt = torch.rand(B, J, Hh, Wh)
+    w = (torch.rand(B, J, 1) > 0.3).float()
+    ref = O.joint_mse(pred, gt, w)
+    ref.backward()
+    pd = pred.detach().to(dev).requires_grad_(True)
+    crit = FL.JointMSELoss()
+    val = crit(pd, gt.to(dev), w.to(dev))
+    assert abs(val.item() - ref.item()) < 1e-6 + 1e-5 * abs(ref.item())
+    val.backward()
+    assert relerr(pd.grad, pred.grad) < 1e-5
+    # targets
+    joints = torch.tensor(np.random.RandomState(0).uniform(-10, 110, size=(B, J, 2)).astype(np.float32))
+    joints[0, 0] = torch.tensor([35.5, 47.5])     # half-integer rounding int(x/4 + 0.5)
+    joints[0, 1] = torch.tensor([-40.0, 10.0])    # patch fully outside -> weight 0
+    vis = (torch.rand(B, J) > 0.2).float()
+    tg, tw = FL.generate_heatmaps(joints.to(dev), vis.to(dev), sigma=3, image_size=(Wh * 4, Hh * 4), heatmap_size=(Wh, Hh))
+    for b in range(B):
+        j3 = np.concatenate([joints[b].numpy(), np.zeros((J, 1), np.float32)], 1)
+        v3 = np.repeat(vis[b].numpy()[:, None], 3, 1)
+        rt, rw = O.generate_heatmaps(j3, v3, 3, np.array([Wh * 4, Hh * 4]), np.array([Wh, Hh]), J)
+        assert np.abs(tg[b].cpu().numpy() - rt).max() < 1e-6
+        assert np.array_equal(tw[b].cpu().numpy().reshape(-1), rw.reshape(-1))
+    # argmax: ties and all-negative maps
+    hm = torch.randn(B, J, Hh, Wh)
+    hm[0, 0] = -1.0
+    hm[0, 1, 3, 4] = hm[0, 1, 7, 2] = 9.0
+    preds, maxvals = FL.get_max_preds(hm.to(dev))
+    rp, rm = O.get_max_preds(hm.numpy())
+    assert np.array_equal(preds.cpu().numpy(), rp) and np.array_equal(maxvals.cpu().numpy(), rm)
+    idx = FL.argmax_indices(hm.to(dev))
+    assert np.array_equal(idx.cpu().numpy(), O.argmax_indices(hm.numpy()))
+    acc = FL.accuracy(hm.to(dev), tg)
+    racc = O.accuracy(hm.numpy(), tg.cpu().numpy())
+    assert np.allclose(acc[0], racc[0]) and acc[1] == racc[1] and acc[2] == racc[2]
+
+
+def test_adam_matches_torch(dev):
+    from fami_pose_amd.train import FlatAdam
+    torch.manual_seed(8)
+    p = torch.randn(1000)
+    ref = nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    flat = p.clone().to(dev)
+    ad = FlatAdam(flat, lr=1e-3)
+    for it in range(5):
+        g = torch.randn(1000)
+        ref.grad = g.clone()
+        opt.step()
+        ad.grad.copy_(g.to(dev))
+        ad.step()
+    assert relerr(flat, ref.data) < 1e-6
