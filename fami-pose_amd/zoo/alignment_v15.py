@@ -143,10 +143,11 @@ class Alignment_V15(EngineModule):
         feat = feats[0]
         kf_hm = eng.batch_slice(hm, 0, B)
         kf = eng.batch_slice(feat, 0, B)
-        aligned = []
+        aligned, shifts = [], []
         for i in range(S):
             sup = eng.batch_slice(feat, (1 + i) * B, (2 + i) * B)
             t = self._translation(eng, eng.sub(sup, kf))
+            shifts.append(t)
             aligned.append(eng.shift(sup, t))
         agg_sup = self.sup_agg_block.run(eng, eng.concat(aligned))
         comb = self.combined_feat_layers.run(eng, eng.concat([agg_sup, kf]))
@@ -159,7 +160,8 @@ class Alignment_V15(EngineModule):
 
         outs = [eng.to_nchw(final), eng.to_nchw(kf_hm)]
         seeds = [lambda g: eng.seed_nchw(final, g), lambda g: eng.seed_nchw(kf_hm, g)]
-        eng.aux = {'final': final, 'kf_hm': kf_hm, 'mis': []}
+        eng.aux = {'final': final, 'kf_hm': kf_hm, 'mis': [], 'shifts': shifts, 'agg_sup': agg_sup, 'aligned': al,
+                   'all_agg': all_agg, 'kf_feat': kf}
         if self.is_train:
             fl = self.hrnet.final_layer
 
