@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Headline benchmark: train clips/sec of the FAMI-Pose temporal-alignment step
+(5-frame 384x288 HRNet-W48 clips, MI loss on, backbone unfrozen, Adam) on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimisation step on a per-GPU batch of synthetic clips already resident
+in HBM (targets are generated on device from synthetic joints inside the step).
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job clips/s,
+plus `roofline` (dominant kernel, live HIP-event timing) and, at N=1, `cpu_baseline`
+(the oracle's CPU restatement timed on the host cores; baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def synth_batch(B, S, H, W, J, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    kf = torch.randn(B, 3, H, W, generator=g)
+    sup = torch.randn(B, 3 * S, H, W, generator=g)
+    joints = torch.rand(B, J, 2, generator=g) * torch.tensor([W, H], dtype=torch.float32)
+    vis = (torch.rand(B, J, generator=g) < 0.8).float()
+    return kf.to(dev), sup.to(dev), joints.to(dev), vis.to(dev)
+
+
+def build(args, dev):
+    import fami_pose_amd as fp
+    from oracle import model as om   # only realistic_init_ (weights at realistic scale)
+    cfg = fp.default_cfg(args.width, image_size=(args.img_w, args.img_h), num_sup=args.sup,
+                         freeze_backbone=args.freeze_backbone)
+    torch.manual_seed(19970808)
+    model = fp.build_model(cfg, 'train')
+    om.realistic_init_(model, seed=19970808)
+    return model.to(dev)
+
+
+def conv_roofline(dev, N, reps=30):
+    """Live HIP-event timing of the dominant kernel: the 48->48 3x3 branch conv at 96x72 (26 % of the
+    step's conv FLOPs, 64 forward launches per step) on the stream it is launched on."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    H, W, C = 96, 72, 48
+    x = torch.randn(N, H, W, C, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    y = torch.empty(N, H, W, C, device=dev)
+    wp = torch.empty(L.cdll.fami_packed_weight_elems(C, C, 3, 3, 0), device=dev)
+    s = torch.cuda.current_stream(dev)
+    L.call('fami_pack_conv_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+
+    def launch():
+        L.call('fami_conv2d_fwd_f32', x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 3, 3, 1,
+               1, 1, 0, 0, s.cuda_stream)
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        launch()
+    e1.record(s)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * N * H * W * C * 9 * C
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_f32 (48->48 3x3 @96x72, N=%d frames)" % N,
+            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def dcn_roofline(dev, B, reps=30):
+    """Secondary roofline: the fused DCNv2 gather+contraction (HBM-bound; SURVEY.md 8d algorithmic bytes)."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    H, W, C, G = 96, 72, 48, 12
+    x = torch.randn(B, H, W, C, device=dev)
+    off = torch.randn(B, H, W, 18 * G, device=dev)
+    msk = torch.randn(B, H, W, 9 * G, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    bias = torch.zeros(C, device=dev)
+    y = torch.empty(B, H, W, C, device=dev)
+    wp = torch.empty(L.cdll.fami_dcn_packed_weight_elems(C, C, 3, 3, G), device=dev)
+    s = torch.cuda.current_stream(dev)
+    L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
+
+    def launch():
+        L.call('fami_dcn_fwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),
+               y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream)
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        launch()
+    e1.record(s)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = (C + 3 * G * 9 + C) * H * W * 4.0 * B
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "dcn_fwd_kernel (48ch, 12 groups, 96x72, B=%d)" % B, "achieved": round(ach, 1),
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+            "avg_launch_us": round(ms * 1e3, 2)}
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores: ONE clip,
+    forward + loss + backward + Adam, fp32.  Baseline only."""
+    from oracle import model as om, ops as oops
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = om.AlignmentOracle(om.make_cfg(args.width), True, args.sup, (args.img_h, args.img_w))
+    om.realistic_init_(m, 1)
+    oops.DCN_IMPL = 'gridsample'      # faster CPU formulation of the same op (cross-checked in tests/test_oracle.py)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    B = 1
+    kf = torch.randn(B, 3, args.img_h, args.img_w)
+    sup = torch.randn(B, 3 * args.sup, args.img_h, args.img_w)
+    tgt = torch.rand(B, 17, args.img_h // 4, args.img_w // 4)
+    w = torch.ones(B, 17, 1)
+    t0 = time.time()
+    f, k, mi = m(kf, sup)
+    loss = oops.total_loss(f, tgt, w, mi)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "1 clip (%d-frame %dx%d W%d), one fwd+loss+bwd+Adam step, fp32, torch CPU, %.1f s" %
+                      (args.sup + 1, args.img_h, args.img_w, args.width, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4, help='clips per GPU')
+    ap.add_argument('--sup', type=int, default=4, help='supporting frames (4 => 5-frame clips)')
+    ap.add_argument('--width', type=int, default=48)
+    ap.add_argument('--img-h', type=int, default=384)
+    ap.add_argument('--img-w', type=int, default=288)
+    ap.add_argument('--freeze-backbone', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bucket-mb', type=int, default=32)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from fami_pose_amd.train import Trainer
+    model = build(args, dev)
+    trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=not args.no_graph, targets_from_joints=True,
+                      bucket_mb=args.bucket_mb)
+    kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        trainer.step(kf, sup, joints, vis)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(kf, sup, joints, vis)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = trainer.loss_value()
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        out = {
+            "metric": "train clips/sec (5-frame 384x288 HRNet-W48)", "value": round(clips / dt, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "HRNet-W%d %dx%d, %d-frame clips + MI loss, batch %d/GPU, backbone %s, Adam, "
+                                   "on-device Gaussian targets" % (args.width, args.img_h, args.img_w, args.sup + 1,
+                                                                   args.batch, "frozen" if args.freeze_backbone else "unfrozen"),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hipgraph": not args.no_graph},
+            "loss": round(loss, 6),
+        }
+        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1))
+        out["roofline_dcn"] = dcn_roofline(dev, args.batch)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

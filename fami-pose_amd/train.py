@@ -72,8 +72,9 @@ class Trainer:
     """One optimisation step per call: forward, loss, backward, (all-reduce), Adam -- all HIP kernels."""
 
     def __init__(self, model, lr=1e-3, mse_weight=1.0, alpha=0.5, beta=0.1, use_mi=True, bucket_mb=32,
-                 process_group=None, use_graph=True):
+                 process_group=None, use_graph=True, targets_from_joints=False, sigma=3):
         self.model = model
+        self.targets_from_joints, self.sigma = targets_from_joints, sigma
         self.dev = next(model.parameters()).device
         if self.dev.type != 'cuda':
             raise RuntimeError('Trainer needs the model on the GPU (HIP path only)')
@@ -116,6 +117,15 @@ class Trainer:
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
         model = self.model
         eng = Engine(self.dev, grad_views=self.views)
+        if self.targets_from_joints:
+            # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
+            joints, vis = target, weight
+            B, J = joints.shape[:2]
+            Hh, Wh = kf_x.shape[2] // 4, kf_x.shape[3] // 4
+            target = eng.empty(B, J, Hh, Wh)
+            weight = eng.empty(B, J)
+            eng.call('fami_gauss_target_f32', _p(joints), _p(vis), _p(target), _p(weight), B, J, Hh, Wh,
+                     kf_x.shape[2], kf_x.shape[3], self.sigma)
         outs, _ = model._body(eng, kf_x, sup_x)
         model._advance_bn_counters(eng)
         aux = eng.aux
@@ -240,6 +250,7 @@ class Trainer:
     def step(self, kf_x, sup_x, target, weight):
         """-> (final_hm, kf_bb_hm, ...) of this step; self.loss_parts holds [mse*W, mi_1..mi_6] on device."""
         weight = weight.reshape(weight.shape[0], -1).float().contiguous()
+        target = target.float().contiguous()
         if not self.use_graph:
             return self._eager_step(kf_x, sup_x, target, weight)
         if self._graphs is None:

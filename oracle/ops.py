@@ -38,6 +38,9 @@ def _bilinear_zero(img, y, x):
     return out
 
 
+DCN_IMPL = 'gather'   # 'gridsample' selects the (faster on CPU) F.grid_sample formulation of the same op
+
+
 def deform_conv2d(inp, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
     """Modulated deformable conv, torchvision.ops.deform_conv2d semantics, as
     called at posetimation/zoo/Alignment/Alignment_V15.py:146,150,154,158
@@ -47,6 +50,8 @@ def deform_conv2d(inp, offset, mask, weight, bias=None, stride=1, padding=0, dil
     mask   [B,   G*kh*kw, Ho, Wo] multiplicative (NO sigmoid: the reference
     feeds raw conv outputs, Alignment_V15.py:81-82); weight [Co,Ci,kh,kw].
     """
+    if DCN_IMPL == 'gridsample':
+        return deform_conv2d_gridsample(inp, offset, mask, weight, bias, stride, padding, dilation)
     B, C, H, W = inp.shape
     Co, Ci, kh, kw = weight.shape
     assert Ci == C, "weight groups == 1 only"
