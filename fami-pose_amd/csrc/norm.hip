@@ -12,7 +12,7 @@
 // variance for running_var (torch.nn.BatchNorm2d semantics).
 #include "common.h"
 
-#define BN_MAXG 1024
+#define BN_MAXG 512
 
 struct ColMap {
   int cv, prow, rows, CV;
@@ -58,13 +58,15 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* mean,
                                    float* invstd, float* running_mean, float* running_var, float momentum,
                                    float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;  // one wave per channel
   double s = 0.0, q = 0.0;
-  for (int g = 0; g < G; ++g) {
+  for (int g = threadIdx.x; g < G; g += 64) {
     s += (double)partial[(long)g * 2 * C + c];
     q += (double)partial[(long)g * 2 * C + C + c];
   }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (threadIdx.x != 0) return;
   const double mu = s / (double)P;
   double var = q / (double)P - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -160,13 +162,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 // coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); dgamma/dbeta optional
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* coef,
                                        float* dgamma, float* dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;  // one wave per channel
   double s = 0.0, q = 0.0;
-  for (int g = 0; g < G; ++g) {
+  for (int g = threadIdx.x; g < G; g += 64) {
     s += (double)partial[(long)g * 2 * C + c];
     q += (double)partial[(long)g * 2 * C + C + c];
   }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (threadIdx.x != 0) return;
   coef[c] = (float)(s / (double)P);
   coef[C + c] = (float)(q / (double)P);
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
@@ -236,10 +240,11 @@ __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float* __re
 }
 __global__ void chan_sum_finalize_kernel(const float* __restrict__ partial, int G, int C, float* out,
                                          int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;  // one wave per channel
   double s = 0.0;
-  for (int g = 0; g < G; ++g) s += (double)partial[(long)g * C + c];
+  for (int g = threadIdx.x; g < G; g += 64) s += (double)partial[(long)g * C + c];
+  s = wave_sum_d(s);
+  if (threadIdx.x != 0) return;
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -268,7 +273,7 @@ int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd,
   const int rows = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x, ws, P, C);
   FAMI_CHECK_LAUNCH("fami_bn_stats_f32/partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, G, P, C, mean, invstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, ws, G, P, C, mean, invstd,
                      running_mean, running_var, momentum, eps);
   FAMI_CHECK_LAUNCH("fami_bn_stats_f32/finalize");
   return FAMI_OK;
@@ -316,7 +321,7 @@ int fami_bn_bwd_f32(const float* dy, const float* x, const float* y, const float
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(Gp), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y,
                      mean, invstd, ws, P, C, relu);
   FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma,
                      dbeta, acc_param);
   FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/finalize");
   long g = (P + rows - 1) / rows;
@@ -341,7 +346,7 @@ int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumula
   if (g > BN_MAXG) g = BN_MAXG;
   hipLaunchKernelGGL(chan_sum_partial_kernel, dim3((int)g), dim3(256), (size_t)rows * C * sizeof(float), s, x, ws, P, C);
   FAMI_CHECK_LAUNCH("fami_channel_sum_f32/partial");
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
   FAMI_CHECK_LAUNCH("fami_channel_sum_f32/finalize");
   return FAMI_OK;
 }
