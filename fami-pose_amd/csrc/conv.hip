@@ -30,6 +30,7 @@ struct ConvArgs {
   int N, Hi, Wi, Ci, Ho, Wo, Co;
   int kh, kw, sh, pad, dil;  // sh = log2(stride)
   int KC, NTt, relu, accumulate, P;
+  unsigned x_bytes, wp_bytes;  // buffer-descriptor extents (out-of-range lanes read 0)
 };
 
 // packed[tap][kc][nt][lane][t] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
@@ -50,12 +51,20 @@ __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ w
   }
 }
 
-template <int MT, int NT, int MODE, int VEC>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define FAMI_OOB 0x80000000u  // byte offset beyond any tensor: the buffer unit returns 0 for it
+
+// KS = number of K partitions among the 4 waves of a workgroup (split-K for the low-resolution
+// branches, whose pixel count alone cannot fill 1024 SIMDs); partial accumulators meet in LDS.
+template <int MT, int NT, int MODE, int VEC, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+  __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 15, kq = lane >> 4;
-  const int m0 = (blockIdx.x * 4 + wave) * (MT * 16);
-  if (m0 >= p.P) return;  // wave-uniform
+  const int kpart = wave % KS, mgrp = wave / KS;
+  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
+  const bool active = m0 < p.P;  // wave-uniform
+  if (KS == 1 && !active) return;
   const int ntg0 = blockIdx.y * NT;
   const int HoWo = p.Ho * p.Wo;
 
@@ -79,16 +88,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* ptr[MT];
-  bool ok[MT];
+  // branch-free operand fetch through buffer descriptors: a lane outside the image (padding), past the
+  // tensor or in a channel tail carries the out-of-range offset and the hardware returns 0 for it
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  unsigned aoff[MT];
   const int taps = p.kh * p.kw;
-  int tap = 0, kc = 0;
+  int tap = 0, kc = kpart;
+  while (kc >= p.KC) {
+    kc -= p.KC;
+    ++tap;
+  }
+  unsigned boff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) boff[nt] = (unsigned)(min(ntg0 + nt, p.NTt - 1) * 256 + lane * 4) * 4u;
 
   auto tap_setup = [&](int tp) {
     const int ky = tp / p.kw, kx = tp - ky * p.kw;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      bool v = pv[mt];
+      bool v = pv[mt] && tp < taps;  // past the last tap (pipeline drain): everything reads 0
       int iy, ix;
       if (MODE == 0) {
         iy = (py[mt] << p.sh) - p.pad + ky * p.dil;
@@ -100,9 +119,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
         ix = tx >> p.sh;
         v = v && ty >= 0 && tx >= 0 && (iy << p.sh) == ty && (ix << p.sh) == tx && iy < p.Hi && ix < p.Wi;
       }
-      ok[mt] = v;
-      const long off = v ? (((long)pn[mt] * p.Hi + iy) * p.Wi + ix) * p.Ci : 0;
-      ptr[mt] = p.x + off + kq * 4;
+      aoff[mt] = v ? (unsigned)((((pn[mt] * p.Hi + iy) * p.Wi + ix) * p.Ci + kq * 4) * 4) : FAMI_OOB;
     }
   };
 
@@ -111,21 +128,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (VEC) {
-        a[mt] = (ok[mt] && cbase < p.Ci) ? *reinterpret_cast<const f32x4*>(ptr[mt] + kc * 16)
-                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned o = cbase < p.Ci ? aoff[mt] + kc * 64 : FAMI_OOB;
+        a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
       } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a[mt][t] = (ok[mt] && cbase + t < p.Ci) ? ptr[mt][kc * 16 + t] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const unsigned o = cbase + q < p.Ci ? aoff[mt] + kc * 64 + q * 4 : FAMI_OOB;
+          a[mt][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        }
       }
     }
-    const float* wb = p.wp + ((long)(tap * p.KC + kc) * p.NTt) * 256 + lane * 4;
+    const unsigned wb = (unsigned)((tap * p.KC + kc) * p.NTt) * 1024u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      b[nt] = (ntg0 + nt < p.NTt) ? *reinterpret_cast<const f32x4*>(wb + (long)(ntg0 + nt) * 256)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (++kc == p.KC) {
-      kc = 0;
-      if (++tap < taps) tap_setup(tap);
+      b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wb + boff[nt], 0, 0));
+    kc += KS;
+    if (kc >= p.KC) {
+      do {
+        kc -= p.KC;
+        ++tap;
+      } while (kc >= p.KC);
+      tap_setup(tap);
     }
   };
 
@@ -140,17 +163,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   };
 
   f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
-  const int T = taps * p.KC;
-  tap_setup(0);
-  load(a0, b0);
-  for (int it = 0; it < T; it += 2) {
-    if (it + 1 < T) load(a1, b1);
-    mma(a0, b0);
-    if (it + 2 < T) load(a0, b0);
-    if (it + 1 < T) mma(a1, b1);
+  const int Tall = taps * p.KC;
+  const int T = active ? (Tall - kpart + KS - 1) / KS : 0;  // iterations owned by this wave
+  // two-stage register pipeline with an unconditional body: loads issued past the last iteration carry
+  // out-of-range offsets (zeros), so an odd T costs one MFMA group on zeros instead of a branch in the loop
+  if (T > 0) {
+    tap_setup(tap);
+    load(a0, b0);
+    for (int it = 0; it < T; it += 2) {
+      load(a1, b1);
+      mma(a0, b0);
+      load(a0, b0);
+      mma(a1, b1);
+    }
+  }
+
+  if (KS > 1) {
+    // partial sums of k-parts 1..KS-1 go through LDS to the k-part-0 wave of the same pixel group
+    if (kpart > 0) {
+      float* dst = red + ((mgrp * (KS - 1)) + (kpart - 1)) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (kpart > 0 || !active) return;
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) {
+      const float* src = red + ((mgrp * (KS - 1)) + k) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 4 + r) * 64 + lane];
+    }
   }
 
   // epilogue: D row = kq*4 + r (pixel), col = row (channel)
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (ntg0 + nt) * 16 + row;
+    bv[nt] = (p.bias && co < p.Co) ? p.bias[co] : 0.f;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -162,8 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
         const int co = (ntg0 + nt) * 16 + row;
         if (co >= p.Co) continue;
         const long idx = (long)m * p.Co + co;
-        float v = acc[mt][nt][r];
-        if (p.bias) v += p.bias[co];
+        float v = acc[mt][nt][r] + bv[nt];
         if (p.addend) v += p.addend[idx];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.accumulate) v += p.y[idx];
@@ -334,42 +392,53 @@ static int pick_small(int tiles) {  // wgrad tile counts in {4,3,2,1}
 }
 
 template <int MODE, int VEC>
-static int launch_igemm(const ConvArgs& a, int MT, int NT, hipStream_t s) {
-  const dim3 grid(fami_cdiv(a.P, 4 * MT * 16), fami_cdiv(a.NTt, NT));
-#define FAMI_CASE(mt, nt)                                                                   \
-  if (MT == mt && NT == nt) {                                                               \
-    hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC>), grid, dim3(256), 0, s, a);      \
-    return 0;                                                                               \
+static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, hipStream_t s) {
+  const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
+#define FAMI_CASE(mt, nt, ks)                                                                \
+  if (MT == mt && NT == nt && KS == ks) {                                                    \
+    hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks>), grid, dim3(256), 0, s, a);   \
+    return 0;                                                                                \
   }
   if constexpr (VEC) {
-    FAMI_CASE(1, 1) FAMI_CASE(1, 2) FAMI_CASE(1, 3) FAMI_CASE(1, 4) FAMI_CASE(1, 6)
-    FAMI_CASE(2, 1) FAMI_CASE(2, 2) FAMI_CASE(2, 3) FAMI_CASE(2, 4) FAMI_CASE(2, 6)
-    FAMI_CASE(4, 1) FAMI_CASE(4, 2) FAMI_CASE(4, 3) FAMI_CASE(4, 4)
+#define FAMI_ROW(nt) FAMI_CASE(1, nt, 1) FAMI_CASE(1, nt, 2) FAMI_CASE(1, nt, 4) FAMI_CASE(2, nt, 1) FAMI_CASE(2, nt, 2) FAMI_CASE(2, nt, 4)
+    FAMI_ROW(1) FAMI_ROW(2) FAMI_ROW(3) FAMI_ROW(4) FAMI_ROW(6)
+    FAMI_CASE(4, 3, 1) FAMI_CASE(4, 4, 1)
+#undef FAMI_ROW
   } else {
-    FAMI_CASE(2, 1) FAMI_CASE(2, 2) FAMI_CASE(2, 3) FAMI_CASE(2, 4)
+    FAMI_CASE(2, 1, 1) FAMI_CASE(2, 2, 1) FAMI_CASE(2, 3, 1) FAMI_CASE(2, 4, 1)
   }
 #undef FAMI_CASE
   return -1;
 }
 
+static int g_force_mt = 0, g_force_nt = 0, g_force_ks = 0;  // tuning overrides (fami_conv_tune)
+
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   int NT = pick_nt(a.NTt);
-  int MT;
+  int MT, KS = 1;
   if (!vec) {
     MT = 2;
     if (NT > 4) NT = 4;
   } else {
+    // Measured on MI355X (tests/bench_conv.py): the kernel is latency-bound, so the smallest register tile
+    // (highest occupancy) wins; split-K restores parallelism on the low-resolution branches.
+    if (NT == 6) NT = 3;
     const long nblk = fami_cdiv(a.NTt, NT);
-    MT = 4;
-    if (NT > 4 || (long)fami_cdiv(a.P, 4 * 64) * nblk < 512) MT = 2;
-    if (MT == 2 && (long)fami_cdiv(a.P, 4 * 32) * nblk < 512) MT = 1;
+    const long waves = (long)fami_cdiv(a.P, 16) * nblk;
+    MT = 1;
+    const long iters = (long)a.kh * a.kw * a.KC;
+    if (iters >= 16) {
+      if (waves < 3000) KS = 4;
+      else if (waves < 6000) KS = 2;
+    }
   }
+  if (vec && g_force_mt) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
   int rc;
   if (mode == 0)
-    rc = vec ? launch_igemm<0, 1>(a, MT, NT, s) : launch_igemm<0, 0>(a, MT, NT, s);
+    rc = vec ? launch_igemm<0, 1>(a, MT, NT, KS, s) : launch_igemm<0, 0>(a, MT, NT, KS, s);
   else
-    rc = vec ? launch_igemm<1, 1>(a, MT, NT, s) : launch_igemm<1, 0>(a, MT, NT, s);
+    rc = vec ? launch_igemm<1, 1>(a, MT, NT, KS, s) : launch_igemm<1, 0>(a, MT, NT, KS, s);
   if (rc != 0) {
     fami_set_error(name, "no kernel instance for tile shape");
     return FAMI_ESHAPE;
@@ -386,6 +455,12 @@ static inline int out_dim(int i, int k, int stride, int pad, int dil) {
 }
 
 extern "C" {
+
+// tuning hook (benchmarks only): force the implicit-GEMM tile (0 = heuristic)
+int fami_conv_tune(int mt, int nt, int ks) {
+  g_force_mt = mt; g_force_nt = nt; g_force_ks = ks;
+  return FAMI_OK;
+}
 
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
@@ -419,8 +494,9 @@ int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, cons
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
   a.KC = fami_cdiv(Ci, 16); a.NTt = fami_cdiv(Co, 16); a.relu = relu; a.accumulate = accumulate;
   const long P = (long)N * a.Ho * a.Wo;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31) && P * Co < (1L << 40), "fami_conv2d_fwd_f32", "size out of range");
-  a.P = (int)P;
+  const long xb = (long)N * H * W * Ci * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_f32", "tensor >= 2 GiB");
+  a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   return run_igemm(a, 0, s, "fami_conv2d_fwd_f32");
 }
 
@@ -440,8 +516,9 @@ int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend,
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
   a.KC = fami_cdiv(Co, 16); a.NTt = fami_cdiv(Ci, 16); a.relu = 0; a.accumulate = accumulate;
   const long P = (long)N * H * W;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31), "fami_conv2d_dgrad_f32", "size out of range");
-  a.P = (int)P;
+  const long xb = (long)N * a.Hi * a.Wi * Co * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_f32", "tensor >= 2 GiB");
+  a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
 }
 

@@ -39,6 +39,8 @@ int fami_device_info(int device, int* info, char* name, int name_len);
  * posetimation/layers/basic_model.py:21-23,38-41,74-77 and basic_layer.py:18-19, and the 3x3
  * dilation-3 offset/mask predictors of posetimation/zoo/Alignment/Alignment_V15.py:79-100.
  * Weights are consumed in a fragment-packed image (mode 0 = forward, 1 = dgrad). */
+/* benchmarks only: force the implicit-GEMM tile (MT x NT 16x16 tiles per wave, KS-way split-K); 0 = heuristic */
+int fami_conv_tune(int mt, int nt, int ks);
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);
