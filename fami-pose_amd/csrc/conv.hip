@@ -238,6 +238,7 @@ struct WgradArgs {
   float* part;      // [psplit][Co][Ci][taps]
   int N, H, W, Ci, Ho, Wo, Co, kh, kw, sh, pad, dil;
   int P, chunk, ciBlocks, coBlocks;
+  unsigned x_bytes, dy_bytes;
 };
 
 // dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
@@ -261,17 +262,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
   const int w_lo = p_lo + wave * sub;
   const int w_hi = min(p_hi, w_lo + sub);
 
-  int ci[MT], co[NT];
-  bool civ[MT], cov[NT];
+  // operands come through buffer descriptors: a lane whose pixel is outside the image / past the wave's range
+  // or whose channel is past Ci / Co carries the out-of-range offset and reads 0 (no branches in the loop)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+  unsigned cio[MT], coo[NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    ci[mt] = (cib * MT + mt) * 16 + c16;
-    civ[mt] = ci[mt] < p.Ci;
+    const int c = (cib * MT + mt) * 16 + c16;
+    cio[mt] = c < p.Ci ? (unsigned)c * 4u : FAMI_OOB;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    co[nt] = (cob * NT + nt) * 16 + c16;
-    cov[nt] = co[nt] < p.Co;
+    const int c = (cob * NT + nt) * 16 + c16;
+    coo[nt] = c < p.Co ? (unsigned)c * 4u : FAMI_OOB;
   }
 
   f32x4 acc[MT][NT];
@@ -291,27 +295,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
     oy = r / p.Wo;
     ox = r - oy * p.Wo;
   }
+  const int wrap_x = p.Wo >= 4 ? 1 : 4;  // how many row wraps a +4 step can cross (Wo >= 1)
 
   auto load = [&](float(&a)[MT], float(&b)[NT]) {
     const bool pvalid = pix < w_hi;
     const int iy = (oy << p.sh) - p.pad + ky * p.dil, ix = (ox << p.sh) - p.pad + kx * p.dil;
     const bool xin = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const long xoff = xin ? (((long)n * p.H + iy) * p.W + ix) * p.Ci : 0;
-    const long yoff = pvalid ? (long)pix * p.Co : 0;
+    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * 4u : FAMI_OOB;
+    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * 4u : FAMI_OOB;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = (xin && civ[mt]) ? p.x[xoff + ci[mt]] : 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+      a[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff + cio[mt], 0, 0));
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = (pvalid && cov[nt]) ? p.dy[yoff + co[nt]] : 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + coo[nt], 0, 0));
     pix += 4;
     ox += 4;
-    while (ox >= p.Wo) {
-      ox -= p.Wo;
-      ++oy;
+    for (int k = 0; k < wrap_x; ++k) {
+      const bool w = ox >= p.Wo;
+      ox -= w ? p.Wo : 0;
+      oy += w ? 1 : 0;
     }
-    while (oy >= p.Ho) {
-      oy -= p.Ho;
-      ++n;
-    }
+    const bool wy = oy >= p.Ho;
+    oy -= wy ? p.Ho : 0;
+    n += wy ? 1 : 0;
   };
   auto mma = [&](const float(&a)[MT], const float(&b)[NT]) {
 #pragma unroll
@@ -321,14 +328,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   };
 
+  // unconditional two-stage pipeline; steps past the wave's range load zeros (pvalid false)
   const int T = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
   float a0[MT], b0[NT], a1[MT], b1[NT];
-  if (T > 0) load(a0, b0);
-  for (int it = 0; it < T; it += 2) {
-    if (it + 1 < T) load(a1, b1);
-    mma(a0, b0);
-    if (it + 2 < T) load(a0, b0);
-    if (it + 1 < T) mma(a1, b1);
+  if (T > 0) {
+    load(a0, b0);
+    for (int it = 0; it < T; it += 2) {
+      load(a1, b1);
+      mma(a0, b0);
+      load(a0, b0);
+      mma(a1, b1);
+    }
   }
 
   // cross-wave reduction through LDS, then scatter into the OIHW-ordered partial slab
@@ -351,11 +361,153 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int psplit,
-                                    int accumulate) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+// 3x3 (any kh*kw > 1) weight gradient, one WAVE PER TAP: the kh*kw waves of a workgroup walk the same pixel
+// chunk, so dY and the shifted X rows are fetched from HBM/MALL once and served to the other taps by L1/L2
+// (the one-tap-per-workgroup layout above re-read both tensors kh*kw times: 478 MB per 48->48 conv).
+// Slab layout [psplit][tap][ci][co] (co contiguous => 64-byte stores); the reduce kernel transposes to OIHW.
+template <int MT, int NT>
+__global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs p) {
+  const int lane = threadIdx.x & 63, tap = threadIdx.x >> 6;
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int ps = blockIdx.x;
+  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int taps = p.kh * p.kw;
+  const int w_lo = ps * p.chunk;
+  const int w_hi = min(p.P, w_lo + p.chunk);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+  unsigned cio[MT], coo[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int c = (cib * MT + mt) * 16 + c16;
+    cio[mt] = c < p.Ci ? (unsigned)c * 4u : FAMI_OOB;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = (cob * NT + nt) * 16 + c16;
+    coo[nt] = c < p.Co ? (unsigned)c * 4u : FAMI_OOB;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int pix = w_lo + kq;
+  int n, oy, ox;
+  {
+    const int HoWo = p.Ho * p.Wo;
+    const int pp = pix < p.P ? pix : 0;
+    n = pp / HoWo;
+    const int r = pp - n * HoWo;
+    oy = r / p.Wo;
+    ox = r - oy * p.Wo;
+  }
+  const int wrap_x = p.Wo >= 4 ? 1 : 4;
+  auto load = [&](float(&a)[MT], float(&b)[NT]) {
+    const bool pvalid = pix < w_hi;
+    const int iy = (oy << p.sh) - p.pad + ky * p.dil, ix = (ox << p.sh) - p.pad + kx * p.dil;
+    const bool xin = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * 4u : FAMI_OOB;
+    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * 4u : FAMI_OOB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      a[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff + cio[mt], 0, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + coo[nt], 0, 0));
+    pix += 4;
+    ox += 4;
+    for (int k = 0; k < wrap_x; ++k) {
+      const bool w = ox >= p.Wo;
+      ox -= w ? p.Wo : 0;
+      oy += w ? 1 : 0;
+    }
+    const bool wy = oy >= p.Ho;
+    oy -= wy ? p.Ho : 0;
+    n += wy ? 1 : 0;
+  };
+  auto mma = [&](const float(&a)[MT], const float(&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  };
+  const int T = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
+  float a0[MT], b0[NT], a1[MT], b1[NT];
+  if (T > 0) {
+    load(a0, b0);
+    for (int it = 0; it < T; it += 2) {
+      load(a1, b1);
+      mma(a0, b0);
+      load(a0, b0);
+      mma(a1, b1);
+    }
+  }
+  // D row = ci (kq*4 + r), col = co (c16)
+  float* slab = p.part + ((long)ps * taps + tap) * p.Ci * p.Co;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cci = (cib * MT + mt) * 16 + kq * 4 + r;
+      if (cci >= p.Ci) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cco = (cob * NT + nt) * 16 + c16;
+        if (cco < p.Co) slab[(long)cci * p.Co + cco] = acc[mt][nt][r];
+      }
+    }
+}
+
+// slabs [psplit][tap][ci][co] -> dw OIHW (=|+=).  64 outputs x 16 slab groups per block: the reduction is
+// latency-bound (each output owns a strided column), so parallelism comes from splitting the slab axis.
+__global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __restrict__ part,
+                                                                 float* __restrict__ dw, int Co, int Ci, int taps,
+                                                                 int psplit, int accumulate) {
+  __shared__ float sm[1024];
+  const long n = (long)taps * Ci * Co;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int k = g;
+    for (; k + 16 < psplit; k += 32) {
+      s0 += part[(long)k * n + i];
+      s1 += part[(long)(k + 16) * n + i];
+    }
+    if (k < psplit) s0 += part[(long)k * n + i];
+  }
+  sm[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && i < n) {
     float s = 0.f;
-    for (int k = 0; k < psplit; ++k) s += part[(long)k * n + i];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sm[q * 64 + o];
+    const int co = (int)(i % Co);
+    const long r = i / Co;
+    const int ci = (int)(r % Ci), tap = (int)(r / Ci);
+    float* d = dw + ((long)co * Ci + ci) * taps + tap;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// dw[i] (=|+=) sum_k part[k][i]; 64 outputs x 4 slab groups per block so the serial chain is psplit/4 long
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           long n, int psplit, int accumulate) {
+  __shared__ float sm[256];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < n)
+    for (int k = g; k < psplit; k += 4) s += part[(long)k * n + i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    s = sm[o] + sm[64 + o] + sm[128 + o] + sm[192 + o];
     dw[i] = accumulate ? dw[i] + s : s;
   }
 }
@@ -522,7 +674,7 @@ int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend,
   return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
 }
 
-struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk; long P; };
+struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk, pertap; long P; };
 static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
   WgradPlan q;
   const int Ho = out_dim(H, kh, stride, pad, dil), Wo = out_dim(W, kw, stride, pad, dil);
@@ -531,9 +683,10 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   q.NT = pick_small(fami_cdiv(Co, 16));
   q.ciBlocks = fami_cdiv(fami_cdiv(Ci, 16), q.MT);
   q.coBlocks = fami_cdiv(fami_cdiv(Co, 16), q.NT);
-  const long by = (long)kh * kw * q.ciBlocks * q.coBlocks;
-  long ps = (1024 + by - 1) / by;
-  const long maxps = (q.P + 255) / 256;
+  q.pertap = (kh * kw > 1 && kh * kw <= 9) ? 1 : 0;   // one wave per tap (3x3): workgroups of kh*kw waves
+  const long by = q.pertap ? (long)q.ciBlocks * q.coBlocks : (long)kh * kw * q.ciBlocks * q.coBlocks;
+  long ps = ((q.pertap ? 512 : 1024) + by - 1) / by;
+  const long maxps = q.pertap ? (q.P + 63) / 64 : (q.P + 255) / 256;
   if (ps > maxps) ps = maxps;
   if (ps < 1) ps = 1;
   long chunk = (q.P + ps - 1) / ps;
@@ -569,6 +722,32 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
   a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
+  const long xb = (long)N * H * W * Ci * 4, yb = q.P * Co * 4;
+  FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), "fami_conv2d_wgrad_f32", "tensor >= 2 GiB");
+  a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+  const long n = (long)Co * Ci * kh * kw;
+  if (q.pertap) {
+    const dim3 grid(q.psplit, q.ciBlocks * q.coBlocks), block(kh * kw * 64);
+    bool ok = false;
+#define FAMI_TCASE(mt, nt)                                                                  \
+  if (q.MT == mt && q.NT == nt) {                                                           \
+    hipLaunchKernelGGL((conv_wgrad_taps_f32<mt, nt>), grid, block, 0, s, a);                \
+    ok = true;                                                                              \
+  }
+    FAMI_TCASE(1, 1) FAMI_TCASE(1, 2) FAMI_TCASE(1, 3) FAMI_TCASE(1, 4)
+    FAMI_TCASE(2, 1) FAMI_TCASE(2, 2) FAMI_TCASE(2, 3) FAMI_TCASE(2, 4)
+    FAMI_TCASE(3, 1) FAMI_TCASE(3, 2) FAMI_TCASE(3, 3) FAMI_TCASE(3, 4)
+    FAMI_TCASE(4, 1) FAMI_TCASE(4, 2) FAMI_TCASE(4, 3) FAMI_TCASE(4, 4)
+#undef FAMI_TCASE
+    if (!ok) {
+      fami_set_error("fami_conv2d_wgrad_f32", "no kernel instance");
+      return FAMI_ESHAPE;
+    }
+    FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/taps");
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, workspace, dw, Co, Ci, kh * kw, q.psplit, accumulate);
+    FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce_taps");
+    return FAMI_OK;
+  }
   const dim3 grid(q.psplit, kh * kw * q.ciBlocks * q.coBlocks);
   bool done = false;
 #define FAMI_WCASE(mt, nt)                                                                  \
@@ -586,8 +765,7 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
     return FAMI_ESHAPE;
   }
   FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32");
-  const long n = (long)Co * Ci * kh * kw;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, workspace, dw, n, q.psplit, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, workspace, dw, n, q.psplit, accumulate);
   FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
   return FAMI_OK;
 }
