@@ -115,11 +115,11 @@ def dcn_roofline(dev, B, reps=30):
             "avg_launch_us": round(ms * 1e3, 2)}
 
 
-def cpu_baseline(args):
+def cpu_baseline_worker(args):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores: ONE clip,
-    forward + loss + backward + Adam, fp32.  Baseline only."""
+    forward + loss + backward + Adam, fp32.  Baseline only.  Runs in its own process (see cpu_baseline)."""
     from oracle import model as om, ops as oops
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = om.AlignmentOracle(om.make_cfg(args.width), True, args.sup, (args.img_h, args.img_w))
@@ -138,9 +138,31 @@ def cpu_baseline(args):
     loss.backward()
     opt.step()
     dt = time.time() - t0
-    return {"value": round(B / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "1 clip (%d-frame %dx%d W%d), one fwd+loss+bwd+Adam step, fp32, torch CPU, %.1f s" %
-                      (args.sup + 1, args.img_h, args.img_w, args.width, dt)}
+    print(json.dumps({"value": round(B / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                      "sample": "1 clip (%d-frame %dx%d W%d), one fwd+loss+bwd+Adam step, fp32, torch CPU "
+                                "(%d threads of %d host cores), %.1f s" %
+                                (args.sup + 1, args.img_h, args.img_w, args.width, cores, os.cpu_count() or 1, dt)}),
+          flush=True)
+
+
+def cpu_baseline(args):
+    """Run the CPU baseline in a child process with a hard time limit, so a slow or oversubscribed host can
+    never stall the benchmark line (the child never touches the GPU)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--sup', str(args.sup), '--width',
+           str(args.width), '--img-h', str(args.img_h), '--img-w', str(args.img_w), '--cpu-threads',
+           str(args.cpu_threads)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_timeout)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return {"value": None, "unit": "clips/s", "cores": args.cpu_threads, "kind": "port",
+                "sample": "failed: " + out.stderr.strip()[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "clips/s", "cores": args.cpu_threads, "kind": "port",
+                "sample": "1 clip fwd+bwd+Adam did not finish within %d s" % args.cpu_timeout}
 
 
 def main():
@@ -157,7 +179,12 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bucket-mb', type=int, default=32)
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-threads', type=int, default=32, help='host threads for the CPU baseline (capped at the core count)')
+    ap.add_argument('--cpu-timeout', type=int, default=240)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        return cpu_baseline_worker(args)
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -172,7 +199,10 @@ def main():
 
     from fami_pose_amd.train import Trainer
     model = build(args, dev)
-    trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=not args.no_graph, targets_from_joints=True,
+    # N>1: the eager launch sequence with RCCL all-reduces overlapped on RCCL's stream is the default; the
+    # per-bucket hipGraph plan (train.py) is opt-in until it has been exercised on a multi-GPU node.
+    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH') == '1')
+    trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=use_graph, targets_from_joints=True,
                       bucket_mb=args.bucket_mb)
     kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
 
@@ -205,7 +235,7 @@ def main():
                                    "on-device Gaussian targets" % (args.width, args.img_h, args.img_w, args.sup + 1,
                                                                    args.batch, "frozen" if args.freeze_backbone else "unfrozen"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hipgraph": not args.no_graph},
+                       "hipgraph": use_graph},
             "loss": round(loss, 6),
         }
         out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1))

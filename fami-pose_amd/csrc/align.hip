@@ -8,13 +8,11 @@
 //   torchvision.ops.DeformConv2d(48,48,3,padding=3,dilation=3) (Alignment_V15.py:83,89,95,101;
 //   calls :146,150,154,158), offset groups = offset.shape[1]/18, raw (un-sigmoided) masks.
 //
-// DCN forward: one wave owns 16 output pixels.  Lane (pixel = lane&15, kq = lane>>4)
-// produces the modulated bilinear sample of channel kq of the current (group, tap)
-// -- exactly the A operand v_mfma_f32_16x16x4_f32 wants -- so the sampled
-// "column" never exists in memory: gather and contraction are fused, the only
-// HBM traffic is input + offsets + masks + output (the algorithmic bytes of
-// SURVEY.md 8d).  The 4 kq lanes of a pixel share offset/mask addresses (one
-// broadcast load) and read 4 adjacent floats per corner.
+// DCN forward (dcn_fwd_kernel): a workgroup owns 16 output pixels; offsets and masks (77 % of the
+// algorithmic bytes) are streamed with fully coalesced loads, every bilinear corner is one 16-byte
+// load, the modulated samples are staged in an LDS column tile and contracted with the weights on
+// v_mfma_f32_16x16x4_f32 -- the sampled "column" never exists in HBM, so the traffic is
+// input + offsets + masks + output (the algorithmic bytes of SURVEY.md 8d).
 #include "common.h"
 
 // ------------------------------------------------------------------ bilinear shift
@@ -162,29 +160,30 @@ struct DcnArgs {
   const float* x;     // [B,H,W,C]
   const float* off;   // [B,Ho,Wo,2*G*K]
   const float* msk;   // [B,Ho,Wo,G*K]   (may be null => mask 1)
-  const float* wp;    // packed [ksteps/4][NTt][64][4]
+  const float* wp;    // packed [KS][NTt][64][4]
   const float* bias;  // [Co] or null
   float* y;           // [B,Ho,Wo,Co]
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil;
-  int cg, KS, NTt, P;  // KS = number of 4-wide k-steps = G*K*cg/4
+  int cg, KS, NTt, P;  // KS = ceil(C*K / 16): 16-wide k groups of the contraction
 };
 
-// k ordering: k = ((g*K + tap)*cg + cc); packed[(ks4*NTt + nt)*64 + lane][t] = W[co = nt*16 + (lane&15)]
-//                                                                          [c(k), tap(k)], k = (ks4*4 + t)*4 + (lane>>4)
+// Column index of the contraction: kidx = (g*K + tap)*cg + cc  (channel c = g*cg + cc), KS16 = ceil(C*K / 16).
+// packed[((ks16*NTt + nt)*64 + lane)*4 + t] = W[co = nt*16 + (lane&15)][kidx = (ks16*4 + (lane>>4))*4 + t]:
+// lane (row, kq) of the A operand reads ONE float4 = kidx (ks16*4 + kq)*4 .. +3 of its pixel from the LDS column
+// tile and feeds it to 4 consecutive MFMAs; the weight image carries the same K permutation.
 __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int C, int K, int cg,
-                                  int KS, int NTt) {
-  const int KS4 = (KS + 3) / 4;
-  const long total = (long)KS4 * NTt * 256;
+                                  int KS16, int NTt) {
+  const long total = (long)KS16 * NTt * 256;
+  const int CK = C * K;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
     const long r = i >> 8;
-    const int nt = (int)(r % NTt), ks4 = (int)(r / NTt);
-    const int ks = ks4 * 4 + t;
+    const int nt = (int)(r % NTt), ks16 = (int)(r / NTt);
+    const int kidx = (ks16 * 4 + (lane >> 4)) * 4 + t;
     const int co = nt * 16 + (lane & 15);
     float v = 0.f;
-    if (ks < KS && co < Co) {
-      const int k = ks * 4 + (lane >> 4);
-      const int cc = k % cg, gt = k / cg;
+    if (kidx < CK && co < Co) {
+      const int cc = kidx % cg, gt = kidx / cg;
       const int tap = gt % K, g = gt / K;
       v = w[((long)co * C + g * cg + cc) * K + tap];
     }
@@ -192,77 +191,108 @@ __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict
   }
 }
 
+#define DCN_PIX 16  // output pixels per workgroup (= one MFMA row tile)
+
+// Forward, two phases per workgroup of DCN_PIX consecutive output pixels:
+//  1. gather: one work item per (pixel, group*tap, 4-channel block).  Consecutive lanes walk consecutive
+//     (group, tap) of one pixel, so the offset (float2) and mask loads of a wave are one contiguous stream --
+//     offsets + masks are 77 % of the algorithmic bytes -- and each bilinear corner is one 16-byte load of
+//     the cg-contiguous NHWC channels.  The modulated samples land in an LDS column tile col[pixel][kidx].
+//  2. contraction: y[16, Co] = col[16, C*K] x W^T on v_mfma_f32_16x16x4_f32 (exact f32); the 4 waves split
+//     K, partial tiles meet in LDS, bias is added and the [16, Co] block is stored as one contiguous run.
+// The column tile never exists in HBM: traffic = x + offsets + masks + y (SURVEY.md 8d algorithmic bytes).
 template <int NT>
 __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row = lane & 15, kq = lane >> 4;
-  const int m0 = (blockIdx.x * 4 + wave) * 16;
-  if (m0 >= p.P) return;
-  const int K = p.kh * p.kw, GK = p.G * K;
-  const int m = m0 + row;
-  const bool pv = m < p.P;
-  const int mm = pv ? m : 0;
-  const int HoWo = p.Ho * p.Wo;
-  const int b = mm / HoWo, r = mm - b * HoWo;
-  const int oy = r / p.Wo, ox = r - oy * p.Wo;
-  const float* xb = p.x + (long)b * p.H * p.W * p.C;
-  const float* offp = p.off + (long)mm * 2 * GK;
-  const float* mskp = p.msk ? p.msk + (long)mm * GK : nullptr;
-  const int steps_per_gt = p.cg >> 2;
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2;
+  const int KS16 = p.KS, stride = KS16 * 16 + 4;
+  float* col = smem;                       // [DCN_PIX][stride]
+  float* red = smem + DCN_PIX * stride;    // [4][NT*256]
+  __shared__ int pcoord[DCN_PIX][4];       // b, oy*stride-pad, ox*stride-pad, valid
+  const int m0 = blockIdx.x * DCN_PIX;
+  if (tid < DCN_PIX) {
+    const int m = m0 + tid;
+    const bool v = m < p.P;
+    const int mm = v ? m : 0;
+    const int HoWo = p.Ho * p.Wo;
+    const int b = mm / HoWo, r = mm - b * HoWo;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    pcoord[tid][0] = b;
+    pcoord[tid][1] = oy * p.stride - p.pad;
+    pcoord[tid][2] = ox * p.stride - p.pad;
+    pcoord[tid][3] = v ? 1 : 0;
+  }
+  if (p.C * K < KS16 * 16) {               // zero the K tail (C*K not a multiple of 16)
+    const int tail = KS16 * 16 - p.C * K;
+    for (int i = tid; i < DCN_PIX * tail; i += 256) col[(i / tail) * stride + p.C * K + (i % tail)] = 0.f;
+  }
+  __syncthreads();
 
+  const int per_pix = GK * q4;
+  const int items = DCN_PIX * per_pix;
+  for (int i = tid; i < items; i += 256) {
+    const int pix = i / per_pix, r = i - pix * per_pix;
+    const int gt = r / q4, q = r - gt * q4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (pcoord[pix][3]) {
+      const long m = m0 + pix;
+      const int g = gt / K, tap = gt - g * K;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const float2 o = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
+      const float mk = p.msk ? p.msk[m * GK + gt] : 1.f;
+      const float py = (float)(pcoord[pix][1] + ky * p.dil) + o.x;
+      const float px = (float)(pcoord[pix][2] + kx * p.dil) + o.y;
+      const float fy = floorf(py), fx = floorf(px);
+      const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const float* cb = p.x + (long)pcoord[pix][0] * p.H * p.W * p.C + g * p.cg + q * 4;
+      const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+      const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+      const long o00 = ((long)y0 * p.W + x0) * p.C;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 a00 = (yv0 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
+      const f32x4 a01 = (yv0 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + p.C) : z;
+      const f32x4 a10 = (yv1 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C) : z;
+      const f32x4 a11 = (yv1 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C + p.C) : z;
+      // same association as the oracle's sum over corners: ((hy*hx)*a00 + (hy*lx)*a01) + (ly*hx)*a10) + (ly*lx)*a11
+      v = ((a00 * (hy * hx) + a01 * (hy * lx)) + a10 * (ly * hx)) + a11 * (ly * lx);
+      v *= mk;
+    }
+    *reinterpret_cast<f32x4*>(col + pix * stride + r * 4) = v;
+  }
+  __syncthreads();
+
+  const int row = lane & 15, kq = lane >> 4;
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int KS4 = (p.KS + 3) / 4;
-  for (int ks4 = 0; ks4 < KS4; ++ks4) {
+  for (int ks = wave; ks < KS16; ks += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(col + row * stride + (ks * 4 + kq) * 4);
     f32x4 bw[NT];
-    const float* wb = p.wp + ((long)ks4 * p.NTt) * 256 + lane * 4;
+    const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
-    float a[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int ks = ks4 * 4 + t;
-      float v = 0.f;
-      if (pv && ks < p.KS) {
-        const int gt = ks / steps_per_gt, ccb = (ks - gt * steps_per_gt) * 4;
-        const int g = gt / K, tap = gt - g * K;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        const float py = (float)(oy * p.stride - p.pad + ky * p.dil) + offp[2 * gt];
-        const float px = (float)(ox * p.stride - p.pad + kx * p.dil) + offp[2 * gt + 1];
-        const float mk = mskp ? mskp[gt] : 1.f;
-        const float fy = floorf(py), fx = floorf(px);
-        const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const float* cb = xb + g * p.cg + ccb + kq;
-        const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
-        const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
-        if (yv0 && xv0) v += hy * hx * cb[((long)y0 * p.W + x0) * p.C];
-        if (yv0 && xv1) v += hy * lx * cb[((long)y0 * p.W + x0 + 1) * p.C];
-        if (yv1 && xv0) v += ly * hx * cb[((long)(y0 + 1) * p.W + x0) * p.C];
-        if (yv1 && xv1) v += ly * lx * cb[((long)(y0 + 1) * p.W + x0 + 1) * p.C];
-        v *= mk;
-      }
-      a[t] = v;
-    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bw[nt][t], acc[nt], 0, 0, 0);
   }
+  // D row = kq*4 + r (pixel), col = row (channel of tile nt)
 #pragma unroll
-  for (int r4 = 0; r4 < 4; ++r4) {
-    const int mo = m0 + kq * 4 + r4;
-    if (mo >= p.P) continue;
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int co = nt * 16 + row;
-      if (co >= p.Co) continue;
-      float v = acc[nt][r4];
+    for (int r = 0; r < 4; ++r) red[wave * (NT * 256) + (nt * 4 + r) * 64 + lane] = acc[nt][r];
+  __syncthreads();
+  for (int e = tid; e < DCN_PIX * NT * 16; e += 256) {
+    const int co = e % (NT * 16), pix = e / (NT * 16);
+    const int nt = co >> 4, c16 = co & 15;
+    const int idx = (nt * 4 + (pix & 3)) * 64 + (pix >> 2) * 16 + c16;
+    if (co < p.Co && m0 + pix < p.P) {
+      float v = (red[idx] + red[NT * 256 + idx]) + (red[2 * NT * 256 + idx] + red[3 * NT * 256 + idx]);
       if (p.bias) v += p.bias[co];
-      p.y[(long)mo * p.Co + co] = v;
+      p.y[(long)(m0 + pix) * p.Co + co] = v;
     }
   }
 }
@@ -368,15 +398,14 @@ int fami_shift_bilinear_bwd_f32(const float* gout, const float* src, const float
 }
 
 long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
-  const int KS = C * kh * kw / 4;
-  return (long)((KS + 3) / 4) * fami_cdiv(Co, 16) * 256;
+  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
 }
 
 int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
   FAMI_REQUIRE(w_oihw && wp && G > 0 && C % G == 0 && ((C / G) % 4) == 0, "fami_dcn_pack_weight_f32", "channels per offset group must be a multiple of 4");
-  const int K = kh * kw, cg = C / G, KS = C * K / 4, NTt = fami_cdiv(Co, 16);
-  const long total = (long)((KS + 3) / 4) * NTt * 256;
-  hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS, NTt);
+  const int K = kh * kw, cg = C / G, KS16 = fami_cdiv((long)C * K, 16), NTt = fami_cdiv(Co, 16);
+  const long total = (long)KS16 * NTt * 256;
+  hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS16, NTt);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
   return FAMI_OK;
 }
@@ -397,20 +426,31 @@ int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const f
     fami_set_error("fami_dcn_fwd_f32", "channels per offset group must be a multiple of 4 and Co <= 96");
     return FAMI_ESHAPE;
   }
-  a.KS = C * kh * kw / 4;
+  a.KS = fami_cdiv((long)C * kh * kw, 16);
   a.NTt = fami_cdiv(Co, 16);
   const long P = (long)B * a.Ho * a.Wo;
   FAMI_REQUIRE(P < (1L << 31), "fami_dcn_fwd_f32", "size out of range");
   a.P = (int)P;
-  const dim3 grid(fami_cdiv(P, 64));
-  switch (a.NTt) {
-    case 1: hipLaunchKernelGGL(dcn_fwd_kernel<1>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(dcn_fwd_kernel<2>, grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(dcn_fwd_kernel<3>, grid, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(dcn_fwd_kernel<4>, grid, dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL(dcn_fwd_kernel<5>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(dcn_fwd_kernel<6>, grid, dim3(256), 0, s, a); break;
+  const dim3 grid(fami_cdiv(P, DCN_PIX));
+  const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
+  if (lds > 150 * 1024) {
+    fami_set_error("fami_dcn_fwd_f32", "C*kh*kw too large for the LDS column tile");
+    return FAMI_ESHAPE;
   }
+#define FAMI_DCN_CASE(nt)                                                                              \
+  case nt: {                                                                                           \
+    static bool attr_set = false;                                                                      \
+    if (!attr_set) {                                                                                   \
+      (void)hipFuncSetAttribute((const void*)dcn_fwd_kernel<nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      attr_set = true;                                                                                 \
+    }                                                                                                  \
+    hipLaunchKernelGGL(dcn_fwd_kernel<nt>, grid, dim3(256), lds, s, a);                                \
+  } break;
+  switch (a.NTt) {
+    FAMI_DCN_CASE(1) FAMI_DCN_CASE(2) FAMI_DCN_CASE(3) FAMI_DCN_CASE(4) FAMI_DCN_CASE(5)
+    default: hipLaunchKernelGGL(dcn_fwd_kernel<6>, grid, dim3(256), lds, s, a); break;
+  }
+#undef FAMI_DCN_CASE
   FAMI_CHECK_LAUNCH("fami_dcn_fwd_f32");
   return FAMI_OK;
 }

@@ -68,6 +68,73 @@ def flatten_parameters(model):
     return flat, table
 
 
+class BucketReducer:
+    """Data-parallel gradient exchange over one flat gradient arena (pure host logic + torch.distributed;
+    no HIP dependency, so the N>1 path is covered by gloo tests on CPU).
+
+    The arena is cut into fixed-size slices from the TAIL (parameters register head-last, so backward
+    completes the tail first).  `hook(done_params)` is what Engine.backward calls when a parameter's last
+    gradient contribution has been enqueued; once every parameter overlapping a slice is complete the slice
+    is handed to `on_bucket(lo, hi)` (an async all-reduce, or a graph cut during capture)."""
+
+    def __init__(self, grad, table, bucket_elems, process_group=None):
+        self.grad = grad
+        self.offset = {id(p): (o, n) for p, o, n in table}
+        self.total = grad.numel()
+        self.bucket_elems = max(1, int(bucket_elems))
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.works = []
+
+    def ranges(self):
+        out, hi = [], self.total
+        while hi > 0:
+            lo = max(0, hi - self.bucket_elems)
+            out.append((lo, hi))
+            hi = lo
+        return out
+
+    def begin(self, on_bucket=None):
+        """-> hook for Engine.backward(on_params_done=...)."""
+        self._on_bucket = on_bucket or self.allreduce
+        self._ranges = self.ranges()
+        self._next, self._done_lo, self._pending = 0, self.total, {}
+        self.works = []
+        return self._hook
+
+    def _hook(self, done_params):
+        for p in done_params:
+            o, n = self.offset[id(p)]
+            self._pending[o] = n
+        while self._done_lo in _ends(self._pending):        # advance the contiguous frontier from the tail
+            o = _ends(self._pending)[self._done_lo]
+            self._done_lo = o
+            del self._pending[o]
+        while self._next < len(self._ranges) and self._ranges[self._next][0] >= self._done_lo:
+            self._on_bucket(*self._ranges[self._next])
+            self._next += 1
+
+    def flush(self):
+        """Slices whose parameters never receive a gradient (hrnet.final_layer feeds only detached MI terms)."""
+        while self._next < len(self._ranges):
+            self._on_bucket(*self._ranges[self._next])
+            self._next += 1
+
+    def allreduce(self, lo, hi):
+        wk = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.works.append(wk)
+        return wk
+
+    def wait(self):
+        for wk in self.works:
+            wk.wait()
+        self.works = []
+
+
+def _ends(pending):
+    return {o + n: o for o, n in pending.items()}
+
+
 class Trainer:
     """One optimisation step per call: forward, loss, backward, (all-reduce), Adam -- all HIP kernels."""
 
@@ -83,12 +150,11 @@ class Trainer:
         self.opt = FlatAdam(self.flat, lr=lr)
         self.grad = self.opt.grad
         self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
-        self.offset = {id(p): (o, n) for p, o, n in self.table}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         if self.world > 1 and process_group is None:
             self.pg = dist.group.WORLD
-        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.reducer = BucketReducer(self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg)
         self.use_graph = use_graph
         self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
         self._graphs = None
@@ -102,16 +168,6 @@ class Trainer:
         for b in self.model.buffers():
             if b.dtype.is_floating_point:
                 dist.broadcast(b, src=0, group=self.pg)
-
-    def _bucket_ranges(self):
-        """Arena slices, tail first (the order backward completes them)."""
-        total = self.flat.numel()
-        ranges, hi = [], total
-        while hi > 0:
-            lo = max(0, hi - self.bucket_elems)
-            ranges.append((lo, hi))
-            hi = lo
-        return ranges
 
     # ------------------------------------------------------------------ the step (eager launch sequence)
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
@@ -146,49 +202,16 @@ class Trainer:
             for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
                 eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
                 seed(c)
-        # bucket hooks
-        hook = None
-        if on_bucket is not None:
-            ranges = self._bucket_ranges()
-            state = {'next': 0, 'done_lo': self.flat.numel()}
-            pending = {}
-
-            def hook(done_params):
-                for p in done_params:
-                    o, n = self.offset[id(p)]
-                    pending[o] = n
-                # advance the contiguous "complete" frontier from the arena tail
-                moved = True
-                while moved:
-                    moved = False
-                    for o, n in list(pending.items()):
-                        if o + n == state['done_lo']:
-                            state['done_lo'] = o
-                            del pending[o]
-                            moved = True
-                while state['next'] < len(ranges) and ranges[state['next']][0] >= state['done_lo']:
-                    on_bucket(*ranges[state['next']])
-                    state['next'] += 1
-            self._hook_state = (state, ranges)
+        hook = self.reducer.begin(on_bucket) if on_bucket is not None else None
         eng.backward(on_params_done=hook)
         if on_bucket is not None:
-            state, ranges = self._hook_state
-            while state['next'] < len(ranges):          # parameters that never receive a gradient (hrnet.final_layer)
-                on_bucket(*ranges[state['next']])
-                state['next'] += 1
+            self.reducer.flush()
         return outs
 
-    def _allreduce(self, lo, hi):
-        g = self.grad[lo:hi]
-        return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-
     def _eager_step(self, kf_x, sup_x, target, weight):
-        works = []
         if self.world > 1:
-            outs = self._forward_backward(kf_x, sup_x, target, weight,
-                                          on_bucket=lambda lo, hi: works.append(self._allreduce(lo, hi)))
-            for wk in works:
-                wk.wait()
+            outs = self._forward_backward(kf_x, sup_x, target, weight, on_bucket=self.reducer.allreduce)
+            self.reducer.wait()
             lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world, 0.0,
                        _stream(self.dev))
         else:
@@ -260,15 +283,13 @@ class Trainer:
         st['sup'].copy_(sup_x, non_blocking=True)
         st['target'].copy_(target, non_blocking=True)
         st['weight'].copy_(weight, non_blocking=True)
-        works = []
         for kind, obj in self._graphs:
             if kind == 'graph':
                 obj.replay()
             elif kind == 'allreduce':
-                works.append(self._allreduce(*obj))
+                self.reducer.allreduce(*obj)
             else:
-                for wk in works:
-                    wk.wait()
+                self.reducer.wait()
         return self._static_outs
 
     def loss_value(self):

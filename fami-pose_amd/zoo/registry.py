@@ -1,35 +1,35 @@
 """Name -> class registries: the front door the reference's engine uses.
 
-Mirrors utils/utils_registry.py:14-76 and engine/defaults/constant.py:9-11
-(same behaviour: `@MODEL_REGISTRY.register()` decorator or call form, duplicate
-names assert, unknown names raise KeyError)."""
+Same observable behaviour as utils/utils_registry.py:14-76 and the three instances of
+engine/defaults/constant.py:9-11: `@REG.register()` decorator or `REG.register(cls)` call form keyed by
+`cls.__name__`; registering a name twice is an AssertionError; looking up an unknown name is a KeyError
+(messages kept, callers and logs match on them)."""
 
 TRAIN_PHASE, VAL_PHASE, TEST_PHASE = 'train', 'validate', 'test'
 
 
-class Registry(object):
-    def __init__(self, name):
-        self._name = name
-        self._obj_map = {}
+class Registry(dict):
+    """A dict of classes that knows its own label."""
 
-    def _do_register(self, name, obj):
-        assert name not in self._obj_map, \
-            "An object named '{}' was already registered in '{}' registry!".format(name, self._name)
-        self._obj_map[name] = obj
+    def __init__(self, label):
+        super().__init__()
+        self.label = label
 
-    def register(self, obj=None):
-        if obj is None:
-            def deco(cls):
-                self._do_register(cls.__name__, cls)
-                return cls
-            return deco
-        self._do_register(obj.__name__, obj)
+    def _add(self, cls):
+        key = cls.__name__
+        assert key not in self, "An object named '{}' was already registered in '{}' registry!".format(key, self.label)
+        self[key] = cls
+        return cls
 
-    def get(self, name):
-        ret = self._obj_map.get(name)
-        if ret is None:
-            raise KeyError("No object named '{}' found in '{}' registry!".format(name, self._name))
-        return ret
+    def register(self, cls=None):
+        if cls is None:
+            return self._add          # decorator form
+        self._add(cls)
+
+    def get(self, key, default=None):
+        if key not in self:
+            raise KeyError("No object named '{}' found in '{}' registry!".format(key, self.label))
+        return self[key]
 
 
 MODEL_REGISTRY = Registry("MODEL")

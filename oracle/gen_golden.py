@@ -1,0 +1,348 @@
+#!/usr/bin/env python
+"""Oracle (test infrastructure, BUILD CONTAINER ONLY): generate the golden vectors of
+tests/golden/ by running the REFERENCE's own modules (imported from /root/reference through
+oracle/ref_harness.py) on seeded inputs.
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz|*.txt
+
+What a fixture holds is data only: inputs (or the seed they are drawn from), the seed of the
+weight initialisation (oracle.model.realistic_init_, applied to the reference module) and the
+reference's outputs.  tests/test_oracle.py rebuilds the same weights on the oracle's restatement
+and must reproduce the outputs; that pins the restatement to the reference.
+For every fixture this script first asserts that the seeded init yields identical state_dicts on
+the reference module and on the oracle module (same keys, same values), so "seed" is a faithful
+stand-in for "weights".
+
+The two third-party ops (torchvision DeformConv2d, kornia warp_affine) are not importable here:
+the reference class runs with oracle/ops.py injected for them -- parity there is UNPINNED
+(oracle/__init__.py).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import model as om, ops as oops, ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+warnings.filterwarnings('ignore')
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _same_state(a, b):
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys()), 'state_dict keys differ'
+    for k in sa:
+        assert sa[k].shape == sb[k].shape and torch.equal(sa[k], sb[k]), k
+
+
+def _save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def _fwd_bwd(mod, x, gy_seed, train):
+    mod.train(train)
+    x = x.clone().requires_grad_(True)
+    y = mod(x)
+    g = torch.Generator().manual_seed(gy_seed)
+    gy = torch.randn(y.shape, generator=g)
+    mod.zero_grad()
+    y.backward(gy)
+    gsum = {k: p.grad.double().sum().item() for k, p in mod.named_parameters()}
+    gabs = {k: p.grad.double().abs().sum().item() for k, p in mod.named_parameters()}
+    return y, x.grad, gsum, gabs
+
+
+# ------------------------------------------------------------------ G1 blocks
+def g1_blocks(ns):
+    cases = {
+        'basic': (lambda: ns.BasicBlock(16, 16), lambda: om.Basic(16, 16), (2, 16, 12, 9)),
+        'neck': (lambda: ns.Bottleneck(32, 8), lambda: om.Neck(32, 8), (2, 32, 12, 9)),
+        'neck_ds': (lambda: ns.Bottleneck(16, 8, 1, nn.Sequential(nn.Conv2d(16, 32, 1, bias=False),
+                                                                 nn.BatchNorm2d(32, momentum=0.1))),
+                    lambda: om.Neck(16, 8, 1, om._proj(16, 32)), (2, 16, 8, 8)),
+        'chain': (lambda: ns.ChainOfBasicBlocks(24, 16, num_blocks=2), lambda: om.BlockChain(24, 16, 2),
+                  (2, 24, 24, 18)),
+        'cbr': (lambda: ns.conv_bn_relu(16, 16, 3, 2, 1, 1), lambda: om.ConvUnit(16, 16, 3, 2, 1, 1), (3, 16, 13, 9)),
+        'cbr_dil': (lambda: ns.conv_bn_relu(12, 20, 3, 1, 3, 3, has_bn=False, has_relu=False),
+                    lambda: om.ConvUnit(12, 20, 3, 1, 3, 3, bn=False, relu=False), (2, 12, 16, 12)),
+    }
+    out = {}
+    for i, (name, (mk_ref, mk_orc, shp)) in enumerate(cases.items()):
+        ref, orc = mk_ref(), mk_orc()
+        om.realistic_init_(ref, 100 + i)
+        om.realistic_init_(orc, 100 + i)
+        _same_state(ref, orc)
+        x = torch.randn(shp, generator=torch.Generator().manual_seed(200 + i))
+        out[name + '.x'] = _np(x)
+        for mode in ('train', 'eval'):
+            y, gx, gsum, gabs = _fwd_bwd(ref, x, 300 + i, mode == 'train')
+            out['%s.%s.y' % (name, mode)] = _np(y)
+            out['%s.%s.gx' % (name, mode)] = _np(gx)
+            out['%s.%s.gsum' % (name, mode)] = np.array([gsum[k] for k in sorted(gsum)])
+            out['%s.%s.gabs' % (name, mode)] = np.array([gabs[k] for k in sorted(gabs)])
+        sd = ref.state_dict()      # running stats after ONE train-mode forward (momentum 0.1)
+        for k in sd:
+            if 'running' in k:
+                out['%s.after.%s' % (name, k)] = _np(sd[k])
+    _save('g1_blocks.npz', **out)
+
+
+# ------------------------------------------------------------------ G2 HighResolutionModule
+def g2_hrmodule(ns):
+    out = {}
+    for nb in (2, 3, 4):
+        ch = [8 * 2 ** b for b in range(nb)]
+        for mso in (True, False):
+            tag = 'nb%d_%s' % (nb, 'multi' if mso else 'single')
+            ref = ns.HighResolutionModule(nb, ns.BasicBlock, [1] * nb, list(ch), list(ch), 'SUM', mso)
+            orc = om.HRModule(ch, [1] * nb, mso)
+            om.realistic_init_(ref, 400 + nb)
+            om.realistic_init_(orc, 400 + nb)
+            _same_state(ref, orc)
+            g = torch.Generator().manual_seed(500 + nb)
+            xs = [torch.randn(2, ch[b], 16 >> b, 16 >> b, generator=g) for b in range(nb)]
+            ref.train()
+            ys = ref([x.clone() for x in xs])
+            for b, x in enumerate(xs):
+                out['%s.x%d' % (tag, b)] = _np(x)
+            for b, y in enumerate(ys):
+                out['%s.y%d' % (tag, b)] = _np(y)
+    _save('g2_hrmodule.npz', **out)
+
+
+# ------------------------------------------------------------------ G3 HRNet-W32 (BASELINE config 1) / G4 HRNetPlus-W48
+def _hm_summary(hm):
+    B, J = hm.shape[:2]
+    flat = hm.reshape(B, J, -1)
+    return dict(argmax=flat.argmax(2).numpy().astype(np.int64), maxval=_np(flat.max(2).values),
+                sum=_np(hm.double().sum((2, 3))), abssum=_np(hm.double().abs().sum((2, 3))))
+
+
+def g3_hrnet_w32(ns):
+    cfg = rh.ref_cfg(32)
+    ref = ns.HRNet(cfg, True)
+    orc = om.HRNetOracle(om.make_cfg(32), plus=False)
+    om.realistic_init_(ref, 32)
+    om.realistic_init_(orc, 32)
+    _same_state(ref, orc)
+    x = torch.randn(1, 3, 256, 192, generator=torch.Generator().manual_seed(3200))
+    ref.eval()
+    with torch.no_grad():
+        hm, feats = ref(x)
+    g = torch.Generator().manual_seed(3201)
+    tgt = torch.rand(1, 17, 64, 48, generator=g)
+    w = (torch.rand(1, 17, 1, generator=g) < 0.8).float()
+    mse = ns.JointMSELoss()(hm, tgt, w)
+    out = dict(hm=_np(hm), mse=np.array(mse.item()), x_seed=np.array(3200), tw_seed=np.array(3201))
+    for i, f in enumerate(feats):
+        out['feat%d_sum' % i] = np.array(f.double().sum().item())
+        out['feat%d_abssum' % i] = np.array(f.double().abs().sum().item())
+    out.update(_hm_summary(hm))
+    _save('g3_hrnet_w32.npz', **out)
+
+
+def g4_hrnetplus_w48(ns):
+    cfg = rh.ref_cfg(48)
+    ref = ns.HRNetPlus(cfg, True)
+    orc = om.HRNetOracle(om.make_cfg(48), plus=True)
+    om.realistic_init_(ref, 48)
+    om.realistic_init_(orc, 48)
+    _same_state(ref, orc)
+    x = torch.randn(2, 3, 384, 288, generator=torch.Generator().manual_seed(4800))
+    ref.train()
+    with torch.no_grad():
+        hm, feats = ref(x)
+    out = dict(x_seed=np.array(4800), hm_j0=_np(hm[:, 0]), hm_j9=_np(hm[:, 9]), feat0_c5=_np(feats[0][:, 5]))
+    for i, f in enumerate(feats):
+        out['feat%d_sum' % i] = np.array(f.double().sum().item())
+        out['feat%d_abssum' % i] = np.array(f.double().abs().sum().item())
+    out.update(_hm_summary(hm))
+    _save('g4_hrnetplus_w48.npz', **out)
+
+
+# ------------------------------------------------------------------ G5 MSE / G6 targets / G7 decode
+def g5_mse(ns):
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for name, B in (('b4', 4), ('b1', 1)):          # b1 exercises the squeeze() path of mse_loss.py:29-33
+        p, t = torch.randn(B, 17, 12, 9, generator=g), torch.rand(B, 17, 12, 9, generator=g)
+        w = (torch.rand(B, 17, 1, generator=g) < 0.7).float()
+        out[name + '.pred'], out[name + '.gt'], out[name + '.w'] = _np(p), _np(t), _np(w)
+        out[name + '.loss'] = np.array(ns.JointMSELoss()(p, t, w).item())
+        out[name + '.loss_nodiv'] = np.array(ns.JointMSELoss(True, False)(p, t, w).item())
+        out[name + '.loss_nowt'] = np.array(ns.JointMSELoss(False, True)(p, t, w).item())
+        pp = p.clone().requires_grad_(True)
+        ns.JointMSELoss()(pp, t, w).backward()
+        out[name + '.gpred'] = _np(pp.grad)
+    _save('g5_mse.npz', **out)
+
+
+def g6_targets(ns):
+    img, hm = np.array([288, 384]), np.array([72, 96])
+    rng = np.random.RandomState(6)
+    J = 17
+    joints = np.zeros((J, 3), np.float32)
+    joints[:, 0] = rng.uniform(0, 288, J)
+    joints[:, 1] = rng.uniform(0, 384, J)
+    # hand-placed edge cases: centre, corners, just outside, far outside, half-integer rounding, negative
+    joints[0, :2] = (144, 192)
+    joints[1, :2] = (0, 0)
+    joints[2, :2] = (287.9, 383.9)
+    joints[3, :2] = (-30, 100)        # patch partially inside on the left?  mu_x = int(-7.5+0.5) = -7 -> ul=-16, br=3
+    joints[4, :2] = (-60, -60)        # fully outside -> weight 0
+    joints[5, :2] = (330, 100)        # right outside: mu_x = 83 -> ul = 74 >= 72 -> weight 0
+    joints[6, :2] = (6.0, 10.0)       # x/4 + .5 = 2.0 exactly
+    joints[7, :2] = (5.99, 9.99)
+    joints[8, :2] = (-1.0, -3.0)      # int() truncation toward zero on negatives: int(-0.25+0.5)=0, int(-0.75+0.5)=0
+    joints[9, :2] = (-3.0, -5.0)      # int(-0.75+.5)=0 ; int(-1.25+.5) = 0 (trunc toward zero, not floor)
+    vis = np.ones((J, 3), np.float32)
+    vis[10] = 0
+    vis[11] = 0.5                     # weight 0.5 is NOT > 0.5: no patch drawn but weight stays 0.5
+    out = {'joints': joints, 'vis': vis}
+    for sigma in (3, 2):
+        t, w = ns.generate_heatmaps(joints, vis, sigma, img, hm, J)
+        out['s%d.target' % sigma], out['s%d.weight' % sigma] = t, w
+    _save('g6_targets.npz', **out)
+
+
+def g7_decode(ns):
+    rng = np.random.RandomState(7)
+    B, J, H, W = 3, 17, 24, 18
+    out_hm = rng.randn(B, J, H, W).astype(np.float32)
+    tgt = rng.rand(B, J, H, W).astype(np.float32)
+    out_hm[0, 0] = -np.abs(out_hm[0, 0])             # all-negative map -> coords zeroed
+    out_hm[0, 1] = 0.0                               # all ties at 0 -> index 0, max 0 -> zeroed
+    out_hm[0, 2] = 0.0
+    out_hm[0, 2, 5, 7] = out_hm[0, 2, 9, 3] = 2.5    # tie: first (row-major) wins
+    tgt[1, 3] = 0.0
+    tgt[1, 3, 0, 5] = 1.0                            # target at y<=1 -> ignored by accuracy
+    tgt[1, 4] = 0.0
+    tgt[1, 4, 10, 1] = 1.0                           # target at x<=1 -> ignored
+    for j in range(5, 12):                           # plant near-hits so accuracy is not trivially 0
+        for b in range(B):
+            iy, ix = np.unravel_index(tgt[b, j].argmax(), (H, W))
+            out_hm[b, j, min(iy + (j % 2), H - 1), ix] = 9.0
+    preds, maxvals = ns.get_max_preds(out_hm)
+    acc, avg, cnt, pred = ns.accuracy(out_hm, tgt)
+    _save('g7_decode.npz', out=out_hm, tgt=tgt, preds=preds, maxvals=maxvals, acc=acc, avg=np.array(avg),
+          cnt=np.array(cnt), pred=pred)
+
+
+# ------------------------------------------------------------------ G8 MI / G9 whole model / G10 keys / G11 init stats
+def g9_alignment(ns):
+    cfg = rh.ref_cfg(48)
+    torch.manual_seed(9)
+    ref = ns.Alignment_V15(cfg, 'train')
+
+    # G11: reference init statistics (Alignment_V15.py:185-214) before re-initialisation
+    stats = {}
+    sd = ref.state_dict()
+    for key in ('hrnet.conv1.weight', 'hrnet.stage3.2.branches.1.0.conv1.weight', 'dcn_offset_1.conv.weight',
+                'sup_agg_block.layers.0.conv1.weight', 'agg_final_layer.weight', 'dcn_1.weight',
+                'feat_global_offset_layers.7.weight'):
+        stats[key + '.std'] = np.array(sd[key].double().std().item())
+        stats[key + '.mean'] = np.array(sd[key].double().mean().item())
+    for key in ('dcn_offset_1.conv.bias', 'agg_final_layer.bias', 'dcn_1.bias', 'feat_global_offset_layers.7.bias',
+                'hrnet.bn1.bias'):
+        stats[key + '.absmax'] = np.array(sd[key].abs().max().item())
+    stats['hrnet.bn1.weight.min'] = np.array(sd['hrnet.bn1.weight'].min().item())
+    stats['hrnet.bn1.weight.max'] = np.array(sd['hrnet.bn1.weight'].max().item())
+    _save('g11_init_stats.npz', **stats)
+
+    # G10: state_dict keys + shapes
+    with open(os.path.join(OUT, 'g10_state_dict_keys.txt'), 'w') as f:
+        for k, v in sd.items():
+            f.write('%s %s %s\n' % (k, 'x'.join(map(str, v.shape)) or 'scalar', str(v.dtype).replace('torch.', '')))
+    f32 = [v for v in sd.values() if v.dtype == torch.float32]
+    print('g10_state_dict_keys.txt      %d keys, %d params+buffers' % (len(sd), sum(v.numel() for v in f32)))
+
+    orc = om.AlignmentOracle(om.make_cfg(48), True, 4, (384, 288))
+    om.realistic_init_(ref, 15)
+    om.realistic_init_(orc, 15)
+    _same_state(ref, orc)
+
+    # G8: the two MI estimators, extracted from the reference class, incl. gradient wrt the target side
+    g = torch.Generator().manual_seed(8)
+    Bm = 2
+    feat = torch.randn(Bm, 48, 96, 72, generator=g) * 0.5
+    f2 = (torch.randn(Bm, 48, 96, 72, generator=g) * 0.5).requires_grad_(True)
+    yy = (torch.rand(Bm, 17, 96, 72, generator=g) * 0.8).requires_grad_(True)
+    m1 = ref.feat_label_mi_estimation(feat, yy)
+    m2 = ref.feat_feat_mi_estimation(feat, f2)
+    (3.0 * m1 - 2.0 * m2).backward()
+    _save('g8_mi.npz', seed=np.array(8), feat_label=np.array(m1.item()), feat_feat=np.array(m2.item()),
+          gy_c3=_np(yy.grad[:, 3]), gf2_c7=_np(f2.grad[:, 7]),
+          gy_abssum=np.array(yy.grad.double().abs().sum().item()),
+          gf2_abssum=np.array(f2.grad.double().abs().sum().item()),
+          gy_finite=np.array(bool(torch.isfinite(yy.grad).all())),
+          gf2_finite=np.array(bool(torch.isfinite(f2.grad).all())))
+
+    # G9: whole model, train-mode 3-tuple (+ loss and gradients) and the 2-tuple of a val-phase instance
+    g = torch.Generator().manual_seed(90)
+    B = 1
+    kf = torch.randn(B, 3, 384, 288, generator=g)
+    sup = torch.randn(B, 12, 384, 288, generator=g)
+    tgt = torch.rand(B, 17, 96, 72, generator=g)
+    w = (torch.rand(B, 17, 1, generator=g) < 0.8).float()
+    ref.train()
+    final, kf_hm, mi = ref(kf, sup)
+    loss = oops.total_loss(final, tgt, w, mi)   # loss assembly is the build's restatement (core fn not importable)
+    ref.zero_grad()
+    loss.backward()
+    grads = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    out = dict(seed=np.array(90), init_seed=np.array(15), final=_np(final), kf_hm=_np(kf_hm),
+               mi=np.array([m.item() for m in mi]), loss=np.array(loss.item()),
+               final_argmax=_hm_summary(final.detach())['argmax'], kf_argmax=_hm_summary(kf_hm.detach())['argmax'])
+    for k in ('agg_final_layer.weight', 'dcn_1.weight', 'dcn_offset_3.conv.weight', 'dcn_mask_4.conv.bias',
+              'feat_global_offset_layers.9.weight', 'sup_agg_block.layers.0.conv1.weight', 'hrnet.conv1.weight',
+              'hrnet.stage4.2.fuse_layers.0.3.0.weight', 'hrnet.layer1.0.bn1.weight'):
+        out['grad.' + k + '.abssum'] = np.array(grads[k].double().abs().sum().item())
+        out['grad.' + k + '.sum'] = np.array(grads[k].double().sum().item())
+    out['grad.agg_final_layer.weight'] = _np(grads['agg_final_layer.weight'])
+    out['grad.dcn_1.bias'] = _np(grads['dcn_1.bias'])
+    out['n_params_with_grad'] = np.array(len(grads))
+    # running stats moved by the train-mode forward
+    out['after.hrnet.bn1.running_mean'] = _np(ref.state_dict()['hrnet.bn1.running_mean'])
+    out['after.sup_agg_block.layers.0.bn1.running_var'] = _np(ref.state_dict()['sup_agg_block.layers.0.bn1.running_var'])
+
+    val = ns.Alignment_V15(cfg, 'validate')
+    om.realistic_init_(val, 15)
+    val.eval()
+    with torch.no_grad():
+        res = val(kf, sup)
+    assert len(res) == 2
+    out['eval.final'], out['eval.kf_hm'] = _np(res[0]), _np(res[1])
+    out['eval.final_argmax'] = _hm_summary(res[0])['argmax']
+    _save('g9_alignment_v15.npz', **out)
+
+
+def main():
+    assert rh.available(), 'needs /root/reference (build container only)'
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ns = rh.load()
+    g1_blocks(ns)
+    g2_hrmodule(ns)
+    g3_hrnet_w32(ns)
+    g4_hrnetplus_w48(ns)
+    g5_mse(ns)
+    g6_targets(ns)
+    g7_decode(ns)
+    g9_alignment(ns)
+
+
+if __name__ == '__main__':
+    main()

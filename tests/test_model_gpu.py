@@ -1,0 +1,204 @@
+"""Whole-model parity of the HIP path (through the C ABI) on the MI355X:
+  * against the committed golden vectors generated from the REFERENCE class (tests/golden/g3, g9),
+  * against the CPU oracle on the same seeded inputs (BASELINE configs 2-like 3-frame case, generalised heads),
+  * at BASELINE's full size through size-independent properties (eval-mode batch independence, run-to-run
+    determinism, hipGraph replay == eager launch sequence, a Trainer step == oracle + torch.optim.Adam).
+Tolerances (fp32): heatmaps <= 1e-3 absolute on O(1) heatmaps (north_star), argmax indices bit-exact.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import fami_pose_amd as fp
+from oracle import model as om, ops as oops
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings('ignore')
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+HM_TOL = 1e-3
+
+
+def _argmax(hm):
+    return hm.reshape(hm.shape[0], hm.shape[1], -1).argmax(2).cpu().numpy()
+
+
+def _pair(width, S, hw, phase, seed, freeze=False):
+    """HIP model + oracle carrying the same realistic-scale weights."""
+    H, W = hw
+    orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(width), phase == 'train', S, (H, W)), seed)
+    model = fp.build_model(fp.default_cfg(width, image_size=(W, H), num_sup=S, freeze_backbone=freeze), phase)
+    model.load_state_dict(orc.state_dict())
+    return model, orc
+
+
+def test_g9_alignment_v15_golden(dev):
+    """Reference class outputs (train 3-tuple, loss, gradients; val-phase 2-tuple) on the 5-frame 384x288 W48 model."""
+    g = np.load(os.path.join(GOLD, 'g9_alignment_v15.npz'))
+    gen = torch.Generator().manual_seed(int(g['seed']))
+    kf = torch.randn(1, 3, 384, 288, generator=gen)
+    sup = torch.randn(1, 12, 384, 288, generator=gen)
+    tgt = torch.rand(1, 17, 96, 72, generator=gen)
+    w = (torch.rand(1, 17, 1, generator=gen) < 0.8).float()
+    model, _ = _pair(48, 4, (384, 288), 'train', int(g['init_seed']))
+    model = model.to(dev)
+    final, kf_hm, mi = model(kf.to(dev), sup.to(dev))
+    assert (final.cpu() - torch.from_numpy(g['final'])).abs().max().item() < HM_TOL
+    assert (kf_hm.cpu() - torch.from_numpy(g['kf_hm'])).abs().max().item() < HM_TOL
+    assert np.array_equal(_argmax(final), g['final_argmax'])          # bit-exact keypoint indices
+    assert np.array_equal(_argmax(kf_hm), g['kf_argmax'])
+    assert np.allclose([m.item() for m in mi], g['mi'], rtol=2e-3, atol=1e-9)
+    from fami_pose_amd.loss import JointMSELoss
+    loss = JointMSELoss()(final, tgt.to(dev), w.to(dev)) + \
+        0.5 * (-0.1 * mi[0] + 0.1 * mi[1] + mi[2] - mi[3] + mi[4] - mi[5])
+    assert loss.item() == pytest.approx(float(g['loss']), rel=1e-4)
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    ref = torch.from_numpy(g['grad.agg_final_layer.weight'])
+    assert ((grads['agg_final_layer.weight'].cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-3
+    ref = torch.from_numpy(g['grad.dcn_1.bias'])
+    assert ((grads['dcn_1.bias'].cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-3
+    for key in g.files:
+        if key.startswith('grad.') and key.endswith('.abssum'):
+            name = key[5:-7]
+            assert grads[name].double().abs().sum().item() == pytest.approx(float(g[key]), rel=2e-3), name
+    sd = model.state_dict()
+    assert (sd['hrnet.bn1.running_mean'].cpu() - torch.from_numpy(g['after.hrnet.bn1.running_mean'])).abs().max() < 1e-5
+    assert int(sd['hrnet.bn1.num_batches_tracked']) == 1
+
+    val, _ = _pair(48, 4, (384, 288), fp.VAL_PHASE, int(g['init_seed']))
+    val = val.to(dev)
+    with torch.no_grad():
+        res = val(kf.to(dev), sup.to(dev))
+    assert len(res) == 2
+    assert (res[0].cpu() - torch.from_numpy(g['eval.final'])).abs().max().item() < HM_TOL
+    assert (res[1].cpu() - torch.from_numpy(g['eval.kf_hm'])).abs().max().item() < HM_TOL
+    assert np.array_equal(_argmax(res[0]), g['eval.final_argmax'])
+
+
+def test_g3_hrnet_w32_config1_golden(dev):
+    """BASELINE configs[0] (HRNet-W32 256x192 single-frame heatmaps + MSE) on the HIP path vs the reference."""
+    g = np.load(os.path.join(GOLD, 'g3_hrnet_w32.npz'))
+    orc = om.realistic_init_(om.HRNetOracle(om.make_cfg(32), plus=False), 32)
+    cfg = fp.default_cfg(32, name='HRNet', image_size=(192, 256))
+    net = fp.build_model(cfg, fp.VAL_PHASE)
+    net.load_state_dict(orc.state_dict())
+    net = net.to(dev)
+    x = torch.randn(1, 3, 256, 192, generator=torch.Generator().manual_seed(int(g['x_seed'])))
+    with torch.no_grad():
+        hm, feats = net(x.to(dev))
+    assert (hm.cpu() - torch.from_numpy(g['hm'])).abs().max().item() < HM_TOL
+    assert np.array_equal(_argmax(hm), g['argmax'])
+    gen = torch.Generator().manual_seed(int(g['tw_seed']))
+    tgt = torch.rand(1, 17, 64, 48, generator=gen)
+    w = (torch.rand(1, 17, 1, generator=gen) < 0.8).float()
+    from fami_pose_amd.loss import JointMSELoss
+    assert JointMSELoss()(hm, tgt.to(dev), w.to(dev)).item() == pytest.approx(float(g['mse']), rel=1e-4)
+    assert len(feats) == 4
+    for i, f in enumerate(feats):
+        assert f.double().abs().sum().item() == pytest.approx(float(g['feat%d_abssum' % i]), rel=1e-4)
+
+
+@pytest.mark.parametrize('S,hw,B', [(2, (384, 288), 2), (7, (128, 96), 1), (1, (256, 192), 2)])
+def test_model_vs_oracle(dev, S, hw, B):
+    """BASELINE configs[1] (3-frame W48 384x288) and generalised heads (7 / 1 supporting frames, other input sizes)
+    against the CPU oracle: forward, loss, and gradients of head, DCN, translation regressor and backbone."""
+    H, W = hw
+    model, orc = _pair(48, S, hw, 'train', 3 + S)
+    model = model.to(dev)
+    gen = torch.Generator().manual_seed(50 + S)
+    kf, sup = torch.randn(B, 3, H, W, generator=gen), torch.randn(B, 3 * S, H, W, generator=gen)
+    tgt = torch.rand(B, 17, H // 4, W // 4, generator=gen)
+    w = (torch.rand(B, 17, 1, generator=gen) < 0.8).float()
+    f0, k0, mi0 = orc(kf, sup)
+    l0 = oops.total_loss(f0, tgt, w, mi0)
+    l0.backward()
+    f1, k1, mi1 = model(kf.to(dev), sup.to(dev))
+    from fami_pose_amd.loss import JointMSELoss
+    l1 = JointMSELoss()(f1, tgt.to(dev), w.to(dev)) + 0.5 * (-0.1 * mi1[0] + 0.1 * mi1[1] + mi1[2] - mi1[3] + mi1[4] - mi1[5])
+    l1.backward()
+    assert (f1.cpu() - f0).abs().max().item() < HM_TOL and (k1.cpu() - k0).abs().max().item() < HM_TOL
+    assert np.array_equal(_argmax(f1), _argmax(f0.detach())) and np.array_equal(_argmax(k1), _argmax(k0.detach()))
+    assert l1.item() == pytest.approx(l0.item(), rel=1e-4)
+    ref = dict(orc.named_parameters())
+    for name in ('agg_final_layer.weight', 'dcn_4.weight', 'dcn_offset_2.conv.weight', 'dcn_mask_1.conv.bias',
+                 'feat_global_offset_layers.9.weight', 'feat_global_offset_layers.1.conv.weight',
+                 'sup_agg_block.layers.0.conv1.weight', 'combined_feat_layers.layers.0.bn1.weight',
+                 'hrnet.stage4.2.fuse_layers.0.1.0.weight', 'hrnet.stage2.0.branches.1.3.bn2.bias',
+                 'hrnet.layer1.0.conv1.weight', 'hrnet.conv1.weight'):
+        g0 = ref[name].grad
+        g1 = dict(model.named_parameters())[name].grad.cpu()
+        assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 2e-3, name
+    assert model.hrnet.final_layer.weight.grad is None or float(model.hrnet.final_layer.weight.grad.abs().max()) == 0.0 \
+        or ref['hrnet.final_layer.weight'].grad is not None
+
+
+def test_full_size_properties(dev):
+    """BASELINE's full per-GPU batch (4 five-frame 384x288 clips): properties that need no CPU reference."""
+    model, _ = _pair(48, 4, (384, 288), fp.VAL_PHASE, 21)
+    model = model.to(dev)
+    gen = torch.Generator().manual_seed(77)
+    kf, sup = torch.randn(4, 3, 384, 288, generator=gen).to(dev), torch.randn(4, 12, 384, 288, generator=gen).to(dev)
+    with torch.no_grad():
+        a = model(kf, sup)
+        b = model(kf, sup)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])              # deterministic (no atomics in forward)
+        one = model(kf[2:3], sup[2:3])                                          # eval BN: clips are independent
+    assert (one[0] - a[0][2:3]).abs().max().item() < 1e-4
+    assert (one[1] - a[1][2:3]).abs().max().item() < 1e-4
+    assert np.array_equal(_argmax(one[0]), _argmax(a[0][2:3]))
+    assert torch.isfinite(a[0]).all() and a[0].shape == (4, 17, 96, 72)
+
+
+def test_trainer_step_matches_oracle_adam(dev):
+    """Trainer.step (fwd, on-device targets, MSE + MI, bwd, Adam in flat arenas) vs oracle + torch.optim.Adam, and
+    the hipGraph replay vs the eager launch sequence."""
+    from fami_pose_amd.train import Trainer
+    S, H, W, B = 2, 128, 96, 2
+    gen = torch.Generator().manual_seed(9)
+    kf, sup = torch.randn(B, 3, H, W, generator=gen), torch.randn(B, 3 * S, H, W, generator=gen)
+    joints = torch.rand(B, 17, 2, generator=gen) * torch.tensor([W, H], dtype=torch.float32)
+    vis = (torch.rand(B, 17, generator=gen) < 0.8).float()
+
+    model, orc = _pair(48, S, (H, W), 'train', 5)
+    opt = torch.optim.Adam(orc.parameters(), lr=1e-3)
+    tg = np.zeros((B, 17, H // 4, W // 4), np.float32)
+    tw = np.zeros((B, 17, 1), np.float32)
+    for b in range(B):
+        j3 = np.concatenate([joints[b].numpy(), np.zeros((17, 1), np.float32)], 1)
+        v3 = np.repeat(vis[b].numpy()[:, None], 3, 1)
+        tg[b], tw[b] = oops.generate_heatmaps(j3, v3, 3, np.array([W, H]), np.array([W // 4, H // 4]), 17)
+    f0, k0, mi0 = orc(kf, sup)
+    l0 = oops.total_loss(f0, torch.from_numpy(tg), torch.from_numpy(tw), mi0)
+    opt.zero_grad()
+    l0.backward()
+    g_ref = orc.agg_final_layer.weight.grad.clone()
+    opt.step()
+
+    tr = Trainer(model.to(dev), lr=1e-3, use_graph=False, targets_from_joints=True)
+    tr.step(kf.to(dev), sup.to(dev), joints.to(dev), vis.to(dev))
+    assert tr.loss_value() == pytest.approx(l0.item(), rel=1e-4)
+    g1 = tr.views[id(model.agg_final_layer.weight)].cpu()
+    assert ((g1 - g_ref).abs().max() / g_ref.abs().max()).item() < 1e-3
+    # Adam's first step is lr*g/(|g|+eps): compare where the gradient is not at the noise floor
+    p0, p1 = orc.agg_final_layer.weight.data, model.agg_final_layer.weight.data.cpu()
+    big = g_ref.abs() > 1e-3 * g_ref.abs().max()
+    assert (p1 - p0)[big].abs().max().item() < 1e-5
+    rm0, rm1 = orc.hrnet.bn1.running_mean, model.hrnet.bn1.running_mean.cpu()
+    assert (rm0 - rm1).abs().max().item() < 1e-5
+
+    # graph replay == eager, three steps from identical starts
+    losses = []
+    for use_graph in (False, True):
+        m2, _ = _pair(48, S, (H, W), 'train', 5)
+        t2 = Trainer(m2.to(dev), lr=1e-3, use_graph=use_graph, targets_from_joints=True)
+        ls = []
+        for _ in range(3 if not use_graph else 5):      # graph mode spends 2 eager warm-up steps inside capture
+            t2.step(kf.to(dev), sup.to(dev), joints.to(dev), vis.to(dev))
+            ls.append(t2.loss_value())
+        losses.append(ls)
+    assert all(np.isfinite(losses[0])) and all(np.isfinite(losses[1]))
+    assert losses[0][0] == pytest.approx(l0.item(), rel=1e-4)
+    assert losses[0][2] < losses[0][0]                                           # the step optimises
