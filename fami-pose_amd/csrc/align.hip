@@ -231,35 +231,63 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
 
   const int per_pix = GK * q4;
   const int items = DCN_PIX * per_pix;
-  for (int i = tid; i < items; i += 256) {
-    const int pix = i / per_pix, r = i - pix * per_pix;
-    const int gt = r / q4, q = r - gt * q4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (pcoord[pix][3]) {
-      const long m = m0 + pix;
+  // DCN_U items per thread per pass, software-pipelined by hand: all offset/mask loads of the pass are issued
+  // first, then all 4*DCN_U corner loads, so a pass costs two memory latencies instead of 2*DCN_U.
+  constexpr int DCN_U = 4;
+  for (int base = tid; base < items; base += 256 * DCN_U) {
+    int pixv[DCN_U], rv[DCN_U];
+    float2 ov[DCN_U];
+    float mv[DCN_U];
+    bool okv[DCN_U];
+#pragma unroll
+    for (int u = 0; u < DCN_U; ++u) {
+      const int i = base + u * 256;
+      const bool in = i < items;
+      const int ii = in ? i : 0;
+      pixv[u] = ii / per_pix;
+      rv[u] = ii - pixv[u] * per_pix;
+      okv[u] = in && pcoord[pixv[u]][3];
+      ov[u] = float2{0.f, 0.f};
+      mv[u] = 1.f;
+      if (okv[u]) {
+        const long m = m0 + pixv[u];
+        const int gt = rv[u] / q4;
+        ov[u] = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
+        if (p.msk) mv[u] = p.msk[m * GK + gt];
+      }
+    }
+    f32x4 a[DCN_U][4];
+    float wgt[DCN_U][4];
+#pragma unroll
+    for (int u = 0; u < DCN_U; ++u) {
+      const int gt = rv[u] / q4, q = rv[u] - gt * q4;
       const int g = gt / K, tap = gt - g * K;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const float2 o = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
-      const float mk = p.msk ? p.msk[m * GK + gt] : 1.f;
-      const float py = (float)(pcoord[pix][1] + ky * p.dil) + o.x;
-      const float px = (float)(pcoord[pix][2] + kx * p.dil) + o.y;
+      const float py = (float)(pcoord[pixv[u]][1] + ky * p.dil) + ov[u].x;
+      const float px = (float)(pcoord[pixv[u]][2] + kx * p.dil) + ov[u].y;
       const float fy = floorf(py), fx = floorf(px);
       const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-      const int y0 = (int)fy, x0 = (int)fx;
-      const float* cb = p.x + (long)pcoord[pix][0] * p.H * p.W * p.C + g * p.cg + q * 4;
-      const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+      const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
+      const float* cb = p.x + (long)pcoord[pixv[u]][0] * p.H * p.W * p.C + g * p.cg + q * 4;
+      const bool yv0 = okv[u] && (unsigned)y0 < (unsigned)p.H, yv1 = okv[u] && (unsigned)(y0 + 1) < (unsigned)p.H;
       const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
       const long o00 = ((long)y0 * p.W + x0) * p.C;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 a00 = (yv0 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
-      const f32x4 a01 = (yv0 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + p.C) : z;
-      const f32x4 a10 = (yv1 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C) : z;
-      const f32x4 a11 = (yv1 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C + p.C) : z;
-      // same association as the oracle's sum over corners: ((hy*hx)*a00 + (hy*lx)*a01) + (ly*hx)*a10) + (ly*lx)*a11
-      v = ((a00 * (hy * hx) + a01 * (hy * lx)) + a10 * (ly * hx)) + a11 * (ly * lx);
-      v *= mk;
+      a[u][0] = (yv0 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
+      a[u][1] = (yv0 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + p.C) : z;
+      a[u][2] = (yv1 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C) : z;
+      a[u][3] = (yv1 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C + p.C) : z;
+      wgt[u][0] = hy * hx; wgt[u][1] = hy * lx; wgt[u][2] = ly * hx; wgt[u][3] = ly * lx;
     }
-    *reinterpret_cast<f32x4*>(col + pix * stride + r * 4) = v;
+#pragma unroll
+    for (int u = 0; u < DCN_U; ++u) {
+      if (base + u * 256 < items) {
+        // same association as the oracle's sum over corners
+        f32x4 v = ((a[u][0] * wgt[u][0] + a[u][1] * wgt[u][1]) + a[u][2] * wgt[u][2]) + a[u][3] * wgt[u][3];
+        v *= mv[u];
+        *reinterpret_cast<f32x4*>(col + pixv[u] * stride + rv[u] * 4) = v;
+      }
+    }
   }
   __syncthreads();
 
@@ -297,69 +325,221 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
   }
 }
 
-// backward gather: one thread per (pixel, group, tap).
-//   gcol [P][C*K]   gradient of the (c,tap)-ordered column (from the 1x1 dgrad)
-//   col  [P][C*K]   out: modulated sample (for the weight gradient)
-//   gx   [B,H,W,C]  += scattered input gradient (atomics; caller zero-fills or accumulates)
-//   goff [P][2GK], gmsk [P][GK] (=|+=)
-__global__ __launch_bounds__(256) void dcn_bwd_gather_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ off,
-                                                             const float* __restrict__ msk,
-                                                             const float* __restrict__ gcol, float* __restrict__ col,
-                                                             float* __restrict__ gx, float* __restrict__ goff,
-                                                             float* __restrict__ gmsk, int B, int H, int W, int C,
-                                                             int Ho, int Wo, int G, int kh, int kw, int stride,
-                                                             int pad, int dil, int acc_off) {
-  const int K = kh * kw, GK = G * K, cg = C / G, CK = C * K;
-  const long total = (long)B * Ho * Wo * GK;
+// ------------------------------------------------------------------ DCN backward (fused)
+// One workgroup owns a TILE x TILE block of output pixels of one sample and one CHUNK of offset groups
+// (GC groups = Cc channels = CKc = Cc*K columns, a multiple of 16).  Per 16-pixel sub-tile:
+//   A. gcol[16, CKc] = dy[16, Co] x W[Co, CKc]  on v_mfma_f32_16x16x4_f32, kept in LDS (the column gradient
+//      never exists in HBM);
+//   B. one work item per (pixel, group*tap): coalesced offset/mask stream, four 16-byte corner loads, then
+//        gmask = <gcol, sample>, goffset = <gcol*mask, d sample / d(y,x)>  (stored, 1 contiguous run / pixel)
+//        col   = sample*mask  (overwrites gcol in LDS; flushed for the weight gradient)
+//        gx   += gcol*mask*bilinear weights, scattered with LDS atomics into a privatised input-gradient
+//                region (tile + dilation halo + DCN_RO pixels of offset reach); samples that leave the region
+//                fall back to global atomics, so any offset magnitude stays correct;
+//   C. the col tile is flushed in contiguous runs.
+// At the end the region is added to gx with coalesced global atomics: ~6x fewer atomics than scattering from
+// the items, 16 consecutive channels per request instead of one address per lane, and no same-address pile-up.
+#define DCN_TILE 8
+#define DCN_RO 3
+struct DcnBwdArgs {
+  const float* x;    // [B,H,W,C]
+  const float* off;  // [B,Ho,Wo,2GK]
+  const float* msk;  // [B,Ho,Wo,GK] or null
+  const float* dy;   // [B,Ho,Wo,Co]
+  const float* wpb;  // packed [nchunk][NTc][KSo][64][4]
+  float* col;        // [P, C*K] or null
+  float* gx;         // [B,H,W,C] accumulated (atomics) or null
+  float* goff;       // [B,Ho,Wo,2GK] or null
+  float* gmsk;       // [B,Ho,Wo,GK] or null
+  int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil, cg;
+  int GC, NTc, KSo, tilesX, tilesY, RH, RW, acc_off;
+};
+
+// wpb[((chunk*NTc + nt)*KSo + ks)*256 + lane*4 + t] = W[co = (ks*4 + (lane>>4))*4 + t][kidx = (chunk*NTc + nt)*16 + (lane&15)],
+// kidx = c*K + tap (the OIHW order of weight.view(Co, C*K))
+__global__ void dcn_pack_wb_kernel(const float* __restrict__ w, float* __restrict__ wpb, int Co, int C, int K, int cg,
+                                   int NT, int KSo) {
+  const long total = (long)NT * KSo * 256;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int gt = (int)(i % GK);
-    const long m = i / GK;
-    const int g = gt / K, tap = gt - g * K;
-    const int ky = tap / kw, kx = tap - ky * kw;
-    const int HoWo = Ho * Wo;
-    const int b = (int)(m / HoWo);
-    const int r = (int)(m - (long)b * HoWo);
-    const int oy = r / Wo, ox = r - oy * Wo;
-    const float py = (float)(oy * stride - pad + ky * dil) + off[m * 2 * GK + 2 * gt];
-    const float px = (float)(ox * stride - pad + kx * dil) + off[m * 2 * GK + 2 * gt + 1];
-    const float mk = msk ? msk[m * GK + gt] : 1.f;
-    const float fy = floorf(py), fx = floorf(px);
-    const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const bool yv0 = (unsigned)y0 < (unsigned)H, yv1 = (unsigned)(y0 + 1) < (unsigned)H;
-    const bool xv0 = (unsigned)x0 < (unsigned)W, xv1 = (unsigned)(x0 + 1) < (unsigned)W;
-    const bool v00 = yv0 && xv0, v01 = yv0 && xv1, v10 = yv1 && xv0, v11 = yv1 && xv1;
-    const long o00 = ((long)y0 * W + x0) * C, o01 = o00 + C, o10 = o00 + (long)W * C, o11 = o10 + C;
-    const float* xb = x + (long)b * H * W * C + g * cg;
-    float* gxb = gx ? gx + (long)b * H * W * C + g * cg : nullptr;
-    float gm = 0.f, gpy = 0.f, gpx = 0.f;
-    for (int cc = 0; cc < cg; ++cc) {
-      const float a00 = v00 ? xb[o00 + cc] : 0.f, a01 = v01 ? xb[o01 + cc] : 0.f;
-      const float a10 = v10 ? xb[o10 + cc] : 0.f, a11 = v11 ? xb[o11 + cc] : 0.f;
-      const float val = hy * hx * a00 + hy * lx * a01 + ly * hx * a10 + ly * lx * a11;
-      const long ci = m * CK + (long)(g * cg + cc) * K + tap;
-      const float gc = gcol[ci];
-      if (col) col[ci] = val * mk;
-      gm += gc * val;
-      const float gv = gc * mk;
-      gpy += gv * (hx * (a10 - a00) + lx * (a11 - a01));
-      gpx += gv * (hy * (a01 - a00) + ly * (a11 - a10));
-      if (gxb) {
-        if (v00) atomicAdd(gxb + o00 + cc, gv * hy * hx);
-        if (v01) atomicAdd(gxb + o01 + cc, gv * hy * lx);
-        if (v10) atomicAdd(gxb + o10 + cc, gv * ly * hx);
-        if (v11) atomicAdd(gxb + o11 + cc, gv * ly * lx);
+    const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long r = i >> 8;
+    const int ks = (int)(r % KSo), nt = (int)(r / KSo);
+    const int co = (ks * 4 + (lane >> 4)) * 4 + t, kidx = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (co < Co && kidx < C * K) v = w[(long)co * C * K + kidx];  // column order (channel, tap) == weight.view(Co, C*K)
+    wpb[i] = v;
+  }
+}
+
+template <int KSO>
+__global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2;
+  const int CKc = p.NTc * 16, gstride = CKc + 4, Cc = p.GC * p.cg, CK = p.C * K;
+  float* gcol = smem;                   // [16][gstride]
+  float* region = smem + 16 * gstride;  // [RH][RW][Cc]
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY, b = t / p.tilesY;
+  const int chunk = blockIdx.y;
+  const int oy0 = ty * DCN_TILE, ox0 = tx * DCN_TILE;
+  const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
+  const int rsize = p.RH * p.RW * Cc;
+  for (int i = tid; i < rsize; i += 256) region[i] = 0.f;
+  const float* xb = p.x + (long)b * p.H * p.W * p.C;
+  float* gxb = p.gx ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
+  const int gtl_n = p.GC * K;  // (group, tap) pairs of this chunk
+  __syncthreads();
+
+  for (int sub = 0; sub < (DCN_TILE * DCN_TILE) / 16; ++sub) {
+    // ---- A: column gradient of this sub-tile (2 rows x 8 cols)
+    {
+      const int py = oy0 + sub * 2 + (row >> 3), px = ox0 + (row & 7);
+      const bool pv = py < p.Ho && px < p.Wo;
+      const long m = ((long)b * p.Ho + py) * p.Wo + px;
+      f32x4 a[KSO];
+#pragma unroll
+      for (int ks = 0; ks < KSO; ++ks) {
+        const int c0 = (ks * 4 + kq) * 4;
+        a[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pv) {
+          if (c0 + 3 < p.Co) a[ks] = *reinterpret_cast<const f32x4*>(p.dy + m * p.Co + c0);
+          else
+            for (int q = 0; q < 4; ++q)
+              if (c0 + q < p.Co) a[ks][q] = p.dy[m * p.Co + c0 + q];
+        }
+      }
+      for (int nt = wave; nt < p.NTc; nt += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* wb = p.wpb + ((long)(chunk * p.NTc + nt) * KSO) * 256 + lane * 4;
+#pragma unroll
+        for (int ks = 0; ks < KSO; ++ks) {
+          const f32x4 bw = *reinterpret_cast<const f32x4*>(wb + ks * 256);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks][q], bw[q], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gcol[(kq * 4 + r) * gstride + nt * 16 + row] = acc[r];
       }
     }
-    if (goff) {
-      float* q = goff + m * 2 * GK + 2 * gt;
-      q[0] = acc_off ? q[0] + gpy : gpy;
-      q[1] = acc_off ? q[1] + gpx : gpx;
+    __syncthreads();
+    // ---- B: gather / scatter
+    for (int i = tid; i < 16 * gtl_n; i += 256) {
+      const int pix = i / gtl_n, gtl = i - pix * gtl_n;
+      const int py = oy0 + sub * 2 + (pix >> 3), px = ox0 + (pix & 7);
+      if (py >= p.Ho || px >= p.Wo) continue;
+      const long m = ((long)b * p.Ho + py) * p.Wo + px;
+      const int gt = chunk * gtl_n + gtl;
+      const int g = gt / K, tap = gt - g * K;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      const float2 o = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
+      const float mk = p.msk ? p.msk[m * GK + gt] : 1.f;
+      const float sy = (float)(py * p.stride - p.pad + ky * p.dil) + o.x;
+      const float sx = (float)(px * p.stride - p.pad + kx * p.dil) + o.y;
+      const float fy = floorf(sy), fx = floorf(sx);
+      const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx;
+      // clamp so the int conversion cannot overflow for wild offsets; clamped values are out of range anyway
+      const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
+      const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+      const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+      const bool v00 = yv0 && xv0, v01 = yv0 && xv1, v10 = yv1 && xv0, v11 = yv1 && xv1;
+      const long o00 = ((long)y0 * p.W + x0) * p.C;
+      const long o01 = o00 + p.C, o10 = o00 + (long)p.W * p.C, o11 = o10 + p.C;
+      const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+      // region coordinates of the (y0, x0) corner; the four corners are inside iff 0 <= r < R-1
+      const int ry = y0 - ry0, rx = x0 - rx0;
+      const bool inreg = ry >= 0 && ry + 1 < p.RH && rx >= 0 && rx + 1 < p.RW;
+      float gm = 0.f, gpy = 0.f, gpx = 0.f;
+      for (int q = 0; q < q4; ++q) {
+        const int cl = (gtl / K) * p.cg + q * 4;  // channel within the chunk
+        const float* cb = xb + chunk * Cc + cl;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a00 = v00 ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
+        const f32x4 a01 = v01 ? *reinterpret_cast<const f32x4*>(cb + o01) : z;
+        const f32x4 a10 = v10 ? *reinterpret_cast<const f32x4*>(cb + o10) : z;
+        const f32x4 a11 = v11 ? *reinterpret_cast<const f32x4*>(cb + o11) : z;
+        float* gp = gcol + pix * gstride + cl * K + tap;  // column (channel, tap): 4 channels are K apart
+        const f32x4 gc = {gp[0], gp[K], gp[2 * K], gp[3 * K]};
+        const f32x4 val = ((a00 * w00 + a01 * w01) + a10 * w10) + a11 * w11;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gp[c * K] = val[c] * mk;
+        const f32x4 gv = gc * mk;
+        const f32x4 dpy = hx * (a10 - a00) + lx * (a11 - a01);
+        const f32x4 dpx = hy * (a01 - a00) + ly * (a11 - a10);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gm += gc[c] * val[c];
+          gpy += gv[c] * dpy[c];
+          gpx += gv[c] * dpx[c];
+        }
+        if (gxb) {
+          if (inreg) {
+            float* r00 = region + ((long)ry * p.RW + rx) * Cc + cl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (v00) atomicAdd(r00 + c, gv[c] * w00);
+              if (v01) atomicAdd(r00 + Cc + c, gv[c] * w01);
+              if (v10) atomicAdd(r00 + p.RW * Cc + c, gv[c] * w10);
+              if (v11) atomicAdd(r00 + p.RW * Cc + Cc + c, gv[c] * w11);
+            }
+          } else {
+            float* g00 = gxb + chunk * Cc + cl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (v00) unsafeAtomicAdd(g00 + o00 + c, gv[c] * w00);
+              if (v01) unsafeAtomicAdd(g00 + o01 + c, gv[c] * w01);
+              if (v10) unsafeAtomicAdd(g00 + o10 + c, gv[c] * w10);
+              if (v11) unsafeAtomicAdd(g00 + o11 + c, gv[c] * w11);
+            }
+          }
+        }
+      }
+      if (p.goff) {
+        float* qo = p.goff + (m * GK + gt) * 2;
+        float2 go = {gpy, gpx};
+        if (p.acc_off) {
+          go.x += qo[0];
+          go.y += qo[1];
+        }
+        *reinterpret_cast<float2*>(qo) = go;
+      }
+      if (p.gmsk) {
+        float* qm = p.gmsk + m * GK + gt;
+        *qm = p.acc_off ? *qm + gm : gm;
+      }
     }
-    if (gmsk) {
-      float* q = gmsk + m * GK + gt;
-      *q = acc_off ? *q + gm : gm;
+    __syncthreads();
+    // ---- C: flush the modulated samples (weight-gradient operand)
+    if (p.col) {
+      const int v4 = CKc >> 2;
+      for (int e = tid; e < 16 * v4; e += 256) {
+        const int pix = e / v4, j = e - pix * v4;
+        const int py = oy0 + sub * 2 + (pix >> 3), px = ox0 + (pix & 7);
+        if (py >= p.Ho || px >= p.Wo) continue;
+        const long m = ((long)b * p.Ho + py) * p.Wo + px;
+        const long kbase = (long)chunk * CKc + j * 4;
+        if (kbase + 3 < CK)
+          *reinterpret_cast<f32x4*>(p.col + m * CK + kbase) = *reinterpret_cast<const f32x4*>(gcol + pix * gstride + j * 4);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- region -> gx
+  if (gxb) {
+    const int c4n = Cc >> 2;
+    for (int e = tid; e < p.RH * p.RW * c4n; e += 256) {
+      const int c4 = e % c4n, pos = e / c4n;
+      const int ry = pos / p.RW, rx = pos - ry * p.RW;
+      const int gy = ry0 + ry, gxx = rx0 + rx;
+      if ((unsigned)gy >= (unsigned)p.H || (unsigned)gxx >= (unsigned)p.W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(region + (long)pos * Cc + c4 * 4);
+      float* dst = gxb + ((long)gy * p.W + gxx) * p.C + chunk * Cc + c4 * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (v[c] != 0.f) unsafeAtomicAdd(dst + c, v[c]);
     }
   }
 }
@@ -455,16 +635,75 @@ int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const f
   return FAMI_OK;
 }
 
-// see dcn_bwd_gather_kernel.  gx is accumulated with atomics (zero it first unless accumulating).
-int fami_dcn_bwd_gather_f32(const float* x, const float* off, const float* msk, const float* gcol, float* col,
-                            float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int G, int kh, int kw,
-                            int stride, int pad, int dil, int acc_off, hipStream_t s) {
-  FAMI_REQUIRE(x && off && gcol && B > 0 && G > 0 && C % G == 0, "fami_dcn_bwd_gather_f32", "bad argument");
-  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
-  const int Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  const long total = (long)B * Ho * Wo * G * kh * kw;
-  hipLaunchKernelGGL(dcn_bwd_gather_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, x, off, msk, gcol, col, gx, goff, gmsk, B, H, W, C, Ho, Wo, G, kh, kw, stride, pad, dil, acc_off);
-  FAMI_CHECK_LAUNCH("fami_dcn_bwd_gather_f32");
+static int dcn_bwd_chunk_groups(int G, int cg, int K) {
+  // smallest group count whose column span cg*K*GC is a multiple of 16 and divides G
+  for (int gc = 1; gc <= G; ++gc)
+    if (G % gc == 0 && (gc * cg * K) % 16 == 0) return gc;
+  return 0;
+}
+
+long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G) {
+  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
+}
+
+// weight image of the backward column-gradient GEMM (see dcn_pack_wb_kernel)
+int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
+                                 hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wpb && G > 0 && C % G == 0 && ((C / G) % 4) == 0, "fami_dcn_pack_weight_bwd_f32", "channels per offset group must be a multiple of 4");
+  const int K = kh * kw, cg = C / G, NT = fami_cdiv((long)C * K, 16), KSo = fami_cdiv(Co, 16);
+  const long total = (long)NT * KSo * 256;
+  hipLaunchKernelGGL(dcn_pack_wb_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wpb, Co, C, K, cg, NT, KSo);
+  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32");
+  return FAMI_OK;
+}
+
+// Backward of fami_dcn_fwd_f32 wrt x, offsets and masks, plus the modulated-sample matrix `col` [P, C*K]
+// (column order (channel, tap) == weight.view(Co, C*K)) for the weight gradient:
+//   dW[co, kidx] = sum_p dy[p, co] * col[p, kidx].
+// gx is ACCUMULATED with atomics (zero it first unless accumulating); goff/gmsk (=|+=) per acc_off.
+// Any of col / gx / goff+gmsk may be null.  wpb from fami_dcn_pack_weight_bwd_f32.
+int fami_dcn_bwd_f32(const float* x, const float* off, const float* msk, const float* dy, const float* wpb,
+                     float* col, float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int Co, int G,
+                     int kh, int kw, int stride, int pad, int dil, int acc_off, hipStream_t s) {
+  FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, "fami_dcn_bwd_f32", "bad argument");
+  DcnBwdArgs a;
+  a.x = x; a.off = off; a.msk = msk; a.dy = dy; a.wpb = wpb; a.col = col; a.gx = gx; a.goff = goff; a.gmsk = gmsk;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
+  a.stride = stride; a.pad = pad; a.dil = dil; a.acc_off = acc_off;
+  a.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+  a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  a.cg = C / G;
+  const int K = kh * kw;
+  a.GC = (a.cg % 4 == 0) ? dcn_bwd_chunk_groups(G, a.cg, K) : 0;
+  a.KSo = fami_cdiv(Co, 16);
+  if (a.GC == 0 || a.KSo > 6) {
+    fami_set_error("fami_dcn_bwd_f32", "unsupported channel grouping (need cg % 4 == 0, a 16-aligned group chunk, Co <= 96)");
+    return FAMI_ESHAPE;
+  }
+  a.NTc = a.GC * a.cg * K / 16;
+  a.tilesX = fami_cdiv(a.Wo, DCN_TILE); a.tilesY = fami_cdiv(a.Ho, DCN_TILE);
+  a.RH = (DCN_TILE - 1) * stride + (kh - 1) * dil + 2 + 2 * DCN_RO;
+  a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
+  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
+  if (lds > 150 * 1024) {
+    fami_set_error("fami_dcn_bwd_f32", "tile does not fit LDS");
+    return FAMI_ESHAPE;
+  }
+  const dim3 grid(a.tilesX * a.tilesY * B, G / a.GC);
+#define FAMI_DCNB_CASE(kso)                                                                                   \
+  case kso: {                                                                                                 \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set) {                                                                                          \
+      (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<kso>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL(dcn_bwd_kernel<kso>, grid, dim3(256), lds, s, a);                                      \
+  } break;
+  switch (a.KSo) {
+    FAMI_DCNB_CASE(1) FAMI_DCNB_CASE(2) FAMI_DCNB_CASE(3) FAMI_DCNB_CASE(4) FAMI_DCNB_CASE(5) FAMI_DCNB_CASE(6)
+  }
+#undef FAMI_DCNB_CASE
+  FAMI_CHECK_LAUNCH("fami_dcn_bwd_f32");
   return FAMI_OK;
 }
 

@@ -434,13 +434,9 @@ class Engine:
                 dy = out.grad
                 P = B * H * W
                 CK = C * K
-                # gcol[P, C*K] = dy[P,Co] x W[Co, C*K]: dgrad of the 1x1 conv whose weight is W.view(Co, C*K, 1, 1)
-                w2 = weight.data.view(Co, CK, 1, 1)
-                nwp = self.L.cdll.fami_packed_weight_elems(Co, CK, 1, 1, 1)
-                wpd = self.empty(nwp)
-                self.call('fami_pack_conv_weight_f32', _p(w2), _p(wpd), Co, CK, 1, 1, 1)
-                gcol = self.empty(P, CK)
-                self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gcol), 1, 1, P, CK, Co, 1, 1, 1, 0, 1, 0)
+                nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
+                wpb = self.empty(nwp)
+                self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
                 col = self.empty(P, CK) if self.rq(weight) else None
                 gx = goff = gmsk = None
                 acco = 0
@@ -452,8 +448,8 @@ class Engine:
                     goff, acco = self.gbuf(off)
                     gmsk, accm = self.gbuf(msk)
                     assert acco == accm
-                self.call('fami_dcn_bwd_gather_f32', _p(x.data), _p(off.data), _p(msk.data), _p(gcol), _p(col),
-                          _p(gx), _p(goff), _p(gmsk), B, H, W, C, G, kh, kw, 1, pad, dil, acco)
+                self.call('fami_dcn_bwd_f32', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                          _p(gx), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)

@@ -119,10 +119,16 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
                      fami_stream_t stream);
-/* gcol/col are [P, C*K] in (channel, tap) order == weight.view(Co, C*K); gx accumulated with atomics */
-int fami_dcn_bwd_gather_f32(const float* x, const float* off, const float* msk, const float* gcol, float* col,
-                            float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int G, int kh, int kw,
-                            int stride, int pad, int dil, int acc_off, fami_stream_t stream);
+long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G);
+int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
+                                 fami_stream_t stream);
+/* autograd of DeformConv2d wrt input / offsets / masks (fused: column gradient dy x W stays in LDS).
+ * col [P, C*K] (out, may be NULL) = modulated samples, column order (channel, tap) == weight.view(Co, C*K):
+ * dW[co, kidx] = sum_p dy[p,co] * col[p,kidx], the caller runs that GEMM (fami_conv2d_wgrad_f32, 1x1).
+ * gx [B,H,W,C] is ACCUMULATED with atomics (zero it first); goff/gmsk (=|+=) per acc_off; each may be NULL. */
+int fami_dcn_bwd_f32(const float* x, const float* off, const float* msk, const float* dy, const float* wpb,
+                     float* col, float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int Co, int G,
+                     int kh, int kw, int stride, int pad, int dil, int acc_off, fami_stream_t stream);
 
 /* ---- dense layers of the translation regressor: nn.Linear x3 (Alignment_V15.py:69-71) ------- */
 int fami_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int N,

@@ -34,16 +34,19 @@ us = time_it(lambda: L.call('fami_dcn_fwd_f32', x.data_ptr(), off.data_ptr(), ms
                             y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream))
 print('dcn fwd            %8.1f us  %7.1f GB/s algorithmic (%.1f MB)' % (us, fwd_bytes / us / 1e3, fwd_bytes / 1e6))
 
-gcol = torch.randn(P, C * 9, device=dev)
+dy = torch.randn(B, H, W, C, device=dev)
 col = torch.empty(P, C * 9, device=dev)
 gx = torch.zeros(B, H, W, C, device=dev)
 goff = torch.empty_like(off)
 gmsk = torch.empty_like(msk)
+wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
+L.call('fami_dcn_pack_weight_bwd_f32', w.data_ptr(), wpb.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
 bwd_bytes = (2 * C + 54 * G + C) * P * 4.0
-for name, a_col, a_gx in (('bwd gather full', col, gx), ('bwd gather no-gx', col, None), ('bwd gather no-gx no-col', None, None)):
-    us = time_it(lambda: L.call('fami_dcn_bwd_gather_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), gcol.data_ptr(),
+for name, a_col, a_gx in (('bwd fused full', col, gx), ('bwd fused no-gx', col, None), ('bwd fused no-gx no-col', None, None),
+                          ('bwd fused gx no-col', None, gx)):
+    us = time_it(lambda: L.call('fami_dcn_bwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
                                 None if a_col is None else a_col.data_ptr(), None if a_gx is None else a_gx.data_ptr(),
-                                goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream))
+                                goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream))
     print('%-24s %8.1f us  %7.1f GB/s algorithmic' % (name, us, bwd_bytes / us / 1e3))
 
 t = torch.randn(B, 2, device=dev)
