@@ -16,8 +16,9 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ bilinear shift
-__global__ __launch_bounds__(256) void shift_fwd_kernel(const float* __restrict__ src, const float* __restrict__ t,
-                                                        float* __restrict__ out, int B, int H, int W, int C) {
+template <typename T>
+__global__ __launch_bounds__(256) void shift_fwd_kernel(const T* __restrict__ src, const float* __restrict__ t,
+                                                        T* __restrict__ out, int B, int H, int W, int C) {
   const int CV = C >> 2;
   const long total = (long)B * H * W * CV;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -31,23 +32,23 @@ __global__ __launch_bounds__(256) void shift_fwd_kernel(const float* __restrict_
     const float fy = floorf(py), fx = floorf(px);
     const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
     const int y0 = (int)fy, x0 = (int)fx;
-    const float* base = src + (long)b * H * W * C + cv * 4;
+    const T* base = src + (long)b * H * W * C + cv * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
       const float w = ((k >> 1) ? ly : hy) * ((k & 1) ? lx : hx);
-      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-        acc += *reinterpret_cast<const f32x4*>(base + ((long)yy * W + xx) * C) * w;
+      if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) acc += ld4(base + ((long)yy * W + xx) * C) * w;
     }
-    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+    st4(out + i * 4, acc);
   }
 }
 
 // grad wrt src, gather form (deterministic): every output pixel that touches (ys,xs) re-evaluates the
 // forward weights exactly as shift_fwd_kernel does.
-__global__ __launch_bounds__(256) void shift_bwd_src_kernel(const float* __restrict__ gout,
-                                                            const float* __restrict__ t, float* __restrict__ gsrc,
+template <typename T>
+__global__ __launch_bounds__(256) void shift_bwd_src_kernel(const T* __restrict__ gout,
+                                                            const float* __restrict__ t, T* __restrict__ gsrc,
                                                             int B, int H, int W, int C, int accumulate) {
   const int CV = C >> 2;
   const long total = (long)B * H * W * CV;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void shift_bwd_src_kernel(const float* __restr
     const int b = (int)(p / H);
     const float ty = t[b * 2 + 1], tx = t[b * 2 + 0];
     const int yb = (int)floorf((float)ys + ty) - 1, xb = (int)floorf((float)xs + tx) - 1;
-    const float* base = gout + (long)b * H * W * C + cv * 4;
+    const T* base = gout + (long)b * H * W * C + cv * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < 4; ++a) {
       const int y = yb + a;
@@ -84,17 +85,18 @@ __global__ __launch_bounds__(256) void shift_bwd_src_kernel(const float* __restr
         if (x0 == xs) wx = 1.f - lx;
         else if (x0 + 1 == xs) wx = lx;
         else continue;
-        acc += *reinterpret_cast<const f32x4*>(base + ((long)y * W + x) * C) * (wy * wx);
+        acc += ld4(base + ((long)y * W + x) * C) * (wy * wx);
       }
     }
-    if (accumulate) acc += *reinterpret_cast<const f32x4*>(gsrc + i * 4);
-    *reinterpret_cast<f32x4*>(gsrc + i * 4) = acc;
+    if (accumulate) acc += ld4(gsrc + i * 4);
+    st4(gsrc + i * 4, acc);
   }
 }
 
 // grad wrt (tx,ty): partial[b][blk][2]
-__global__ __launch_bounds__(256) void shift_bwd_t_kernel(const float* __restrict__ gout,
-                                                          const float* __restrict__ src,
+template <typename T>
+__global__ __launch_bounds__(256) void shift_bwd_t_kernel(const T* __restrict__ gout,
+                                                          const T* __restrict__ src,
                                                           const float* __restrict__ t, float* __restrict__ partial,
                                                           int H, int W, int C) {
   __shared__ float red[2][4];
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(256) void shift_bwd_t_kernel(const float* __restric
   const int CV = C >> 2;
   const long total = (long)H * W * CV;
   const float ty = t[b * 2 + 1], tx = t[b * 2 + 0];
-  const float* sb = src + (long)b * H * W * C;
-  const float* gb = gout + (long)b * H * W * C;
+  const T* sb = src + (long)b * H * W * C;
+  const T* gb = gout + (long)b * H * W * C;
   float gx = 0.f, gy = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void shift_bwd_t_kernel(const float* __restric
     for (int k = 0; k < 4; ++k) {
       const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
       v[k] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                 ? *reinterpret_cast<const f32x4*>(sb + ((long)yy * W + xx) * C + cv * 4)
+                 ? ld4(sb + ((long)yy * W + xx) * C + cv * 4)
                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gb + i * 4);
+    const f32x4 g = ld4(gb + i * 4);
     const f32x4 dpy = hx * (v[2] - v[0]) + lx * (v[3] - v[1]);  // d out / d py
     const f32x4 dpx = hy * (v[1] - v[0]) + ly * (v[3] - v[2]);  // d out / d px
 #pragma unroll
@@ -156,13 +158,14 @@ __global__ void shift_bwd_t_finalize_kernel(const float* __restrict__ partial, i
 }
 
 // ------------------------------------------------------------------ DCN
+template <typename T>
 struct DcnArgs {
-  const float* x;     // [B,H,W,C]
-  const float* off;   // [B,Ho,Wo,2*G*K]
-  const float* msk;   // [B,Ho,Wo,G*K]   (may be null => mask 1)
+  const T* x;         // [B,H,W,C]
+  const T* off;       // [B,Ho,Wo,2*G*K]
+  const T* msk;       // [B,Ho,Wo,G*K]   (may be null => mask 1)
   const float* wp;    // packed [KS][NTt][64][4]
   const float* bias;  // [Co] or null
-  float* y;           // [B,Ho,Wo,Co]
+  T* y;               // [B,Ho,Wo,Co]
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil;
   int cg, KS, NTt, P;  // KS = ceil(C*K / 16): 16-wide k groups of the contraction
 };
@@ -201,8 +204,8 @@ __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict
 //  2. contraction: y[16, Co] = col[16, C*K] x W^T on v_mfma_f32_16x16x4_f32 (exact f32); the 4 waves split
 //     K, partial tiles meet in LDS, bias is added and the [16, Co] block is stored as one contiguous run.
 // The column tile never exists in HBM: traffic = x + offsets + masks + y (SURVEY.md 8d algorithmic bytes).
-template <int NT>
-__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
   constexpr int DCN_U = 4;
   for (int base = tid; base < items; base += 256 * DCN_U) {
     int pixv[DCN_U], rv[DCN_U];
-    float2 ov[DCN_U];
+    f32x2 ov[DCN_U];
     float mv[DCN_U];
     bool okv[DCN_U];
 #pragma unroll
@@ -247,13 +250,13 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
       pixv[u] = ii / per_pix;
       rv[u] = ii - pixv[u] * per_pix;
       okv[u] = in && pcoord[pixv[u]][3];
-      ov[u] = float2{0.f, 0.f};
+      ov[u] = f32x2{0.f, 0.f};
       mv[u] = 1.f;
       if (okv[u]) {
         const long m = m0 + pixv[u];
         const int gt = rv[u] / q4;
-        ov[u] = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
-        if (p.msk) mv[u] = p.msk[m * GK + gt];
+        ov[u] = ld2(p.off + (m * GK + gt) * 2);
+        if (p.msk) mv[u] = ld1(p.msk + m * GK + gt);
       }
     }
     f32x4 a[DCN_U][4];
@@ -268,15 +271,15 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
       const float fy = floorf(py), fx = floorf(px);
       const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
       const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
-      const float* cb = p.x + (long)pcoord[pixv[u]][0] * p.H * p.W * p.C + g * p.cg + q * 4;
+      const T* cb = p.x + (long)pcoord[pixv[u]][0] * p.H * p.W * p.C + g * p.cg + q * 4;
       const bool yv0 = okv[u] && (unsigned)y0 < (unsigned)p.H, yv1 = okv[u] && (unsigned)(y0 + 1) < (unsigned)p.H;
       const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
       const long o00 = ((long)y0 * p.W + x0) * p.C;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      a[u][0] = (yv0 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
-      a[u][1] = (yv0 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + p.C) : z;
-      a[u][2] = (yv1 && xv0) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C) : z;
-      a[u][3] = (yv1 && xv1) ? *reinterpret_cast<const f32x4*>(cb + o00 + (long)p.W * p.C + p.C) : z;
+      a[u][0] = (yv0 && xv0) ? ld4(cb + o00) : z;
+      a[u][1] = (yv0 && xv1) ? ld4(cb + o00 + p.C) : z;
+      a[u][2] = (yv1 && xv0) ? ld4(cb + o00 + (long)p.W * p.C) : z;
+      a[u][3] = (yv1 && xv1) ? ld4(cb + o00 + (long)p.W * p.C + p.C) : z;
       wgt[u][0] = hy * hx; wgt[u][1] = hy * lx; wgt[u][2] = ly * hx; wgt[u][3] = ly * lx;
     }
 #pragma unroll
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
     if (co < p.Co && m0 + pix < p.P) {
       float v = (red[idx] + red[NT * 256 + idx]) + (red[2 * NT * 256 + idx] + red[3 * NT * 256 + idx]);
       if (p.bias) v += p.bias[co];
-      p.y[(long)(m0 + pix) * p.Co + co] = v;
+      st1(p.y + (long)(m0 + pix) * p.Co + co, v);
     }
   }
 }
@@ -341,16 +344,17 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs p) {
 // the items, 16 consecutive channels per request instead of one address per lane, and no same-address pile-up.
 #define DCN_TILE 8
 #define DCN_RO 3
+template <typename T>
 struct DcnBwdArgs {
-  const float* x;    // [B,H,W,C]
-  const float* off;  // [B,Ho,Wo,2GK]
-  const float* msk;  // [B,Ho,Wo,GK] or null
-  const float* dy;   // [B,Ho,Wo,Co]
+  const T* x;        // [B,H,W,C]
+  const T* off;      // [B,Ho,Wo,2GK]
+  const T* msk;      // [B,Ho,Wo,GK] or null
+  const T* dy;       // [B,Ho,Wo,Co]
   const float* wpb;  // packed [nchunk][NTc][KSo][64][4]
-  float* col;        // [P, C*K] or null
-  float* gx;         // [B,H,W,C] accumulated (atomics) or null
-  float* goff;       // [B,Ho,Wo,2GK] or null
-  float* gmsk;       // [B,Ho,Wo,GK] or null
+  T* col;            // [P, C*K] or null
+  float* gx;         // [B,H,W,C] fp32, accumulated (atomics) or null
+  T* goff;           // [B,Ho,Wo,2GK] or null
+  T* gmsk;           // [B,Ho,Wo,GK] or null
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil, cg;
   int GC, NTc, KSo, tilesX, tilesY, RH, RW, acc_off;
 };
@@ -371,8 +375,8 @@ __global__ void dcn_pack_wb_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <int KSO>
-__global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
+template <typename T, int KSO>
+__global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = lane & 15, kq = lane >> 4;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
   const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
   const int rsize = p.RH * p.RW * Cc;
   for (int i = tid; i < rsize; i += 256) region[i] = 0.f;
-  const float* xb = p.x + (long)b * p.H * p.W * p.C;
+  const T* xb = p.x + (long)b * p.H * p.W * p.C;
   float* gxb = p.gx ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
   const int gtl_n = p.GC * K;  // (group, tap) pairs of this chunk
   __syncthreads();
@@ -406,10 +410,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
         const int c0 = (ks * 4 + kq) * 4;
         a[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (pv) {
-          if (c0 + 3 < p.Co) a[ks] = *reinterpret_cast<const f32x4*>(p.dy + m * p.Co + c0);
+          if (c0 + 3 < p.Co) a[ks] = ld4(p.dy + m * p.Co + c0);
           else
             for (int q = 0; q < 4; ++q)
-              if (c0 + q < p.Co) a[ks][q] = p.dy[m * p.Co + c0 + q];
+              if (c0 + q < p.Co) a[ks][q] = ld1(p.dy + m * p.Co + c0 + q);
         }
       }
       for (int nt = wave; nt < p.NTc; nt += 4) {
@@ -435,8 +439,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
       const int gt = chunk * gtl_n + gtl;
       const int g = gt / K, tap = gt - g * K;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const float2 o = *reinterpret_cast<const float2*>(p.off + (m * GK + gt) * 2);
-      const float mk = p.msk ? p.msk[m * GK + gt] : 1.f;
+      const f32x2 o = ld2(p.off + (m * GK + gt) * 2);
+      const float mk = p.msk ? ld1(p.msk + m * GK + gt) : 1.f;
       const float sy = (float)(py * p.stride - p.pad + ky * p.dil) + o.x;
       const float sx = (float)(px * p.stride - p.pad + kx * p.dil) + o.y;
       const float fy = floorf(sy), fx = floorf(sx);
@@ -455,12 +459,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
       float gm = 0.f, gpy = 0.f, gpx = 0.f;
       for (int q = 0; q < q4; ++q) {
         const int cl = (gtl / K) * p.cg + q * 4;  // channel within the chunk
-        const float* cb = xb + chunk * Cc + cl;
+        const T* cb = xb + chunk * Cc + cl;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a00 = v00 ? *reinterpret_cast<const f32x4*>(cb + o00) : z;
-        const f32x4 a01 = v01 ? *reinterpret_cast<const f32x4*>(cb + o01) : z;
-        const f32x4 a10 = v10 ? *reinterpret_cast<const f32x4*>(cb + o10) : z;
-        const f32x4 a11 = v11 ? *reinterpret_cast<const f32x4*>(cb + o11) : z;
+        const f32x4 a00 = v00 ? ld4(cb + o00) : z;
+        const f32x4 a01 = v01 ? ld4(cb + o01) : z;
+        const f32x4 a10 = v10 ? ld4(cb + o10) : z;
+        const f32x4 a11 = v11 ? ld4(cb + o11) : z;
         float* gp = gcol + pix * gstride + cl * K + tap;  // column (channel, tap): 4 channels are K apart
         const f32x4 gc = {gp[0], gp[K], gp[2 * K], gp[3 * K]};
         const f32x4 val = ((a00 * w00 + a01 * w01) + a10 * w10) + a11 * w11;
@@ -498,17 +502,14 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
         }
       }
       if (p.goff) {
-        float* qo = p.goff + (m * GK + gt) * 2;
-        float2 go = {gpy, gpx};
-        if (p.acc_off) {
-          go.x += qo[0];
-          go.y += qo[1];
-        }
-        *reinterpret_cast<float2*>(qo) = go;
+        T* qo = p.goff + (m * GK + gt) * 2;
+        f32x2 go = {gpy, gpx};
+        if (p.acc_off) go += ld2(qo);
+        st2(qo, go);
       }
       if (p.gmsk) {
-        float* qm = p.gmsk + m * GK + gt;
-        *qm = p.acc_off ? *qm + gm : gm;
+        T* qm = p.gmsk + m * GK + gt;
+        st1(qm, p.acc_off ? ld1(qm) + gm : gm);
       }
     }
     __syncthreads();
@@ -521,8 +522,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
         if (py >= p.Ho || px >= p.Wo) continue;
         const long m = ((long)b * p.Ho + py) * p.Wo + px;
         const long kbase = (long)chunk * CKc + j * 4;
-        if (kbase + 3 < CK)
-          *reinterpret_cast<f32x4*>(p.col + m * CK + kbase) = *reinterpret_cast<const f32x4*>(gcol + pix * gstride + j * 4);
+        if (kbase + 3 < CK) st4(p.col + m * CK + kbase, *reinterpret_cast<const f32x4*>(gcol + pix * gstride + j * 4));
       }
     }
     __syncthreads();
@@ -544,58 +544,52 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs p) {
   }
 }
 
-extern "C" {
-
-long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
-
-// out[b,y,x,:] = bilinear(src[b], y - t[b,1], x - t[b,0]) ; t device [B,2] = (tx,ty)
-int fami_shift_bilinear_fwd_f32(const float* src, const float* t, float* out, int B, int H, int W, int C,
-                                hipStream_t s) {
-  FAMI_REQUIRE(src && t && out && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "fami_shift_bilinear_fwd_f32", "bad argument");
-  hipLaunchKernelGGL(shift_fwd_kernel, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, src, t, out, B, H, W, C);
-  FAMI_CHECK_LAUNCH("fami_shift_bilinear_fwd_f32");
+// ------------------------------------------------------------------ host side (templates over the storage type)
+template <typename T>
+static int shift_fwd_impl(const T* src, const float* t, T* out, int B, int H, int W, int C, hipStream_t s,
+                          const char* nm) {
+  FAMI_REQUIRE(src && t && out && B > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, nm, "bad argument");
+  hipLaunchKernelGGL(shift_fwd_kernel<T>, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, src, t, out, B, H, W, C);
+  FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
 
-// gsrc (=|+=) d/dsrc ; gt[B,2] (=|+=) d/d(tx,ty).  Either output may be null.
-int fami_shift_bilinear_bwd_f32(const float* gout, const float* src, const float* t, float* gsrc, float* gt, int B,
-                                int H, int W, int C, int acc_src, int acc_t, float* ws, hipStream_t s) {
-  FAMI_REQUIRE(gout && src && t && B > 0 && (C % 4) == 0, "fami_shift_bilinear_bwd_f32", "bad argument");
+template <typename T>
+static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, float* gt, int B, int H, int W, int C,
+                          int acc_src, int acc_t, float* ws, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(gout && src && t && B > 0 && (C % 4) == 0, nm, "bad argument");
   if (gsrc) {
-    hipLaunchKernelGGL(shift_bwd_src_kernel, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, gout, t, gsrc, B, H, W, C, acc_src);
-    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/src");
+    hipLaunchKernelGGL(shift_bwd_src_kernel<T>, dim3(fami_ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, s, gout, t, gsrc, B, H, W, C, acc_src);
+    FAMI_CHECK_LAUNCH(nm);
   }
   if (gt) {
-    FAMI_REQUIRE(ws, "fami_shift_bilinear_bwd_f32", "workspace required for gt");
+    FAMI_REQUIRE(ws, nm, "workspace required for gt");
     long g = ((long)H * W * (C / 4) + 255) / 256;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(shift_bwd_t_kernel, dim3((int)g, B), dim3(256), 0, s, gout, src, t, ws, H, W, C);
-    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/t");
+    hipLaunchKernelGGL(shift_bwd_t_kernel<T>, dim3((int)g, B), dim3(256), 0, s, gout, src, t, ws, H, W, C);
+    FAMI_CHECK_LAUNCH(nm);
     hipLaunchKernelGGL(shift_bwd_t_finalize_kernel, dim3(fami_cdiv(B * 2, 64)), dim3(64), 0, s, ws, (int)g, B, gt, acc_t);
-    FAMI_CHECK_LAUNCH("fami_shift_bilinear_bwd_f32/t_finalize");
+    FAMI_CHECK_LAUNCH(nm);
   }
   return FAMI_OK;
 }
 
-long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
-  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
+template <typename T, int NT>
+static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dcn_fwd_kernel<T, NT>), grid, dim3(256), lds, s, a);
 }
 
-int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
-  FAMI_REQUIRE(w_oihw && wp && G > 0 && C % G == 0 && ((C / G) % 4) == 0, "fami_dcn_pack_weight_f32", "channels per offset group must be a multiple of 4");
-  const int K = kh * kw, cg = C / G, KS16 = fami_cdiv((long)C * K, 16), NTt = fami_cdiv(Co, 16);
-  const long total = (long)KS16 * NTt * 256;
-  hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS16, NTt);
-  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
-  return FAMI_OK;
-}
-
-// y[B,Ho,Wo,Co] = deform_conv2d(x[B,H,W,C], off[B,Ho,Wo,2GK], msk[B,Ho,Wo,GK], W, bias)
-int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
-                     int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
-                     hipStream_t s) {
-  FAMI_REQUIRE(x && off && wp && y && B > 0 && G > 0 && C % G == 0, "fami_dcn_fwd_f32", "bad argument");
-  DcnArgs a;
+template <typename T>
+static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp, const float* bias, T* y, int B, int H,
+                        int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s,
+                        const char* nm) {
+  FAMI_REQUIRE(x && off && wp && y && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
+  DcnArgs<T> a;
   a.x = x; a.off = off; a.msk = msk; a.wp = wp; a.bias = bias; a.y = y;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
   a.stride = stride; a.pad = pad; a.dil = dil;
@@ -603,35 +597,29 @@ int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const f
   a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   a.cg = C / G;
   if ((a.cg % 4) != 0 || Co > 96) {
-    fami_set_error("fami_dcn_fwd_f32", "channels per offset group must be a multiple of 4 and Co <= 96");
+    fami_set_error(nm, "channels per offset group must be a multiple of 4 and Co <= 96");
     return FAMI_ESHAPE;
   }
   a.KS = fami_cdiv((long)C * kh * kw, 16);
   a.NTt = fami_cdiv(Co, 16);
   const long P = (long)B * a.Ho * a.Wo;
-  FAMI_REQUIRE(P < (1L << 31), "fami_dcn_fwd_f32", "size out of range");
+  FAMI_REQUIRE(P < (1L << 31), nm, "size out of range");
   a.P = (int)P;
   const dim3 grid(fami_cdiv(P, DCN_PIX));
   const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
   if (lds > 150 * 1024) {
-    fami_set_error("fami_dcn_fwd_f32", "C*kh*kw too large for the LDS column tile");
+    fami_set_error(nm, "C*kh*kw too large for the LDS column tile");
     return FAMI_ESHAPE;
   }
-#define FAMI_DCN_CASE(nt)                                                                              \
-  case nt: {                                                                                           \
-    static bool attr_set = false;                                                                      \
-    if (!attr_set) {                                                                                   \
-      (void)hipFuncSetAttribute((const void*)dcn_fwd_kernel<nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-      attr_set = true;                                                                                 \
-    }                                                                                                  \
-    hipLaunchKernelGGL(dcn_fwd_kernel<nt>, grid, dim3(256), lds, s, a);                                \
-  } break;
   switch (a.NTt) {
-    FAMI_DCN_CASE(1) FAMI_DCN_CASE(2) FAMI_DCN_CASE(3) FAMI_DCN_CASE(4) FAMI_DCN_CASE(5)
-    default: hipLaunchKernelGGL(dcn_fwd_kernel<6>, grid, dim3(256), lds, s, a); break;
+    case 1: dcn_fwd_launch<T, 1>(a, grid, lds, s); break;
+    case 2: dcn_fwd_launch<T, 2>(a, grid, lds, s); break;
+    case 3: dcn_fwd_launch<T, 3>(a, grid, lds, s); break;
+    case 4: dcn_fwd_launch<T, 4>(a, grid, lds, s); break;
+    case 5: dcn_fwd_launch<T, 5>(a, grid, lds, s); break;
+    default: dcn_fwd_launch<T, 6>(a, grid, lds, s); break;
   }
-#undef FAMI_DCN_CASE
-  FAMI_CHECK_LAUNCH("fami_dcn_fwd_f32");
+  FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
 
@@ -640,6 +628,75 @@ static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   for (int gc = 1; gc <= G; ++gc)
     if (G % gc == 0 && (gc * cg * K) % 16 == 0) return gc;
   return 0;
+}
+
+template <typename T, int KSO>
+static void dcn_bwd_launch(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<T, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dcn_bwd_kernel<T, KSO>), grid, dim3(256), lds, s, a);
+}
+
+template <typename T>
+static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, float* gx,
+                        T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
+                        int pad, int dil, int acc_off, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
+  DcnBwdArgs<T> a;
+  a.x = x; a.off = off; a.msk = msk; a.dy = dy; a.wpb = wpb; a.col = col; a.gx = gx; a.goff = goff; a.gmsk = gmsk;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
+  a.stride = stride; a.pad = pad; a.dil = dil; a.acc_off = acc_off;
+  a.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+  a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  a.cg = C / G;
+  const int K = kh * kw;
+  a.GC = (a.cg % 4 == 0) ? dcn_bwd_chunk_groups(G, a.cg, K) : 0;
+  a.KSo = fami_cdiv(Co, 16);
+  if (a.GC == 0 || a.KSo > 6) {
+    fami_set_error(nm, "unsupported channel grouping (need cg % 4 == 0, a 16-aligned group chunk, Co <= 96)");
+    return FAMI_ESHAPE;
+  }
+  a.NTc = a.GC * a.cg * K / 16;
+  a.tilesX = fami_cdiv(a.Wo, DCN_TILE); a.tilesY = fami_cdiv(a.Ho, DCN_TILE);
+  a.RH = (DCN_TILE - 1) * stride + (kh - 1) * dil + 2 + 2 * DCN_RO;
+  a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
+  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
+  if (lds > 150 * 1024) {
+    fami_set_error(nm, "tile does not fit LDS");
+    return FAMI_ESHAPE;
+  }
+  const dim3 grid(a.tilesX * a.tilesY * B, G / a.GC);
+  switch (a.KSo) {
+    case 1: dcn_bwd_launch<T, 1>(a, grid, lds, s); break;
+    case 2: dcn_bwd_launch<T, 2>(a, grid, lds, s); break;
+    case 3: dcn_bwd_launch<T, 3>(a, grid, lds, s); break;
+    case 4: dcn_bwd_launch<T, 4>(a, grid, lds, s); break;
+    case 5: dcn_bwd_launch<T, 5>(a, grid, lds, s); break;
+    default: dcn_bwd_launch<T, 6>(a, grid, lds, s); break;
+  }
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
+extern "C" {
+
+long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
+
+long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
+  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
+}
+
+// forward weight image (fp32 for both activation types: the contraction runs on the exact f32 MFMA)
+int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wp && G > 0 && C % G == 0 && ((C / G) % 4) == 0, "fami_dcn_pack_weight_f32", "channels per offset group must be a multiple of 4");
+  const int K = kh * kw, cg = C / G, KS16 = fami_cdiv((long)C * K, 16), NTt = fami_cdiv(Co, 16);
+  const long total = (long)KS16 * NTt * 256;
+  hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS16, NTt);
+  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
+  return FAMI_OK;
 }
 
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G) {
@@ -657,54 +714,33 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
   return FAMI_OK;
 }
 
-// Backward of fami_dcn_fwd_f32 wrt x, offsets and masks, plus the modulated-sample matrix `col` [P, C*K]
-// (column order (channel, tap) == weight.view(Co, C*K)) for the weight gradient:
-//   dW[co, kidx] = sum_p dy[p, co] * col[p, kidx].
-// gx is ACCUMULATED with atomics (zero it first unless accumulating); goff/gmsk (=|+=) per acc_off.
-// Any of col / gx / goff+gmsk may be null.  wpb from fami_dcn_pack_weight_bwd_f32.
-int fami_dcn_bwd_f32(const float* x, const float* off, const float* msk, const float* dy, const float* wpb,
-                     float* col, float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int Co, int G,
-                     int kh, int kw, int stride, int pad, int dil, int acc_off, hipStream_t s) {
-  FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, "fami_dcn_bwd_f32", "bad argument");
-  DcnBwdArgs a;
-  a.x = x; a.off = off; a.msk = msk; a.dy = dy; a.wpb = wpb; a.col = col; a.gx = gx; a.goff = goff; a.gmsk = gmsk;
-  a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
-  a.stride = stride; a.pad = pad; a.dil = dil; a.acc_off = acc_off;
-  a.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
-  a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
-  a.cg = C / G;
-  const int K = kh * kw;
-  a.GC = (a.cg % 4 == 0) ? dcn_bwd_chunk_groups(G, a.cg, K) : 0;
-  a.KSo = fami_cdiv(Co, 16);
-  if (a.GC == 0 || a.KSo > 6) {
-    fami_set_error("fami_dcn_bwd_f32", "unsupported channel grouping (need cg % 4 == 0, a 16-aligned group chunk, Co <= 96)");
-    return FAMI_ESHAPE;
+#define FAMI_ALIGN_ABI(sfx, T)                                                                                         \
+  /* out[b,y,x,:] = bilinear(src[b], y - t[b,1], x - t[b,0]) ; t device fp32 [B,2] = (tx,ty) */                        \
+  int fami_shift_bilinear_fwd_##sfx(const T* src, const float* t, T* out, int B, int H, int W, int C, hipStream_t s) { \
+    return shift_fwd_impl<T>(src, t, out, B, H, W, C, s, "fami_shift_bilinear_fwd_" #sfx);                             \
+  }                                                                                                                    \
+  /* gsrc (=|+=) d/dsrc ; gt[B,2] fp32 (=|+=) d/d(tx,ty).  Either output may be null. */                               \
+  int fami_shift_bilinear_bwd_##sfx(const T* gout, const T* src, const float* t, T* gsrc, float* gt, int B, int H,     \
+                                    int W, int C, int acc_src, int acc_t, float* ws, hipStream_t s) {                  \
+    return shift_bwd_impl<T>(gout, src, t, gsrc, gt, B, H, W, C, acc_src, acc_t, ws, s, "fami_shift_bilinear_bwd_" #sfx); \
+  }                                                                                                                    \
+  /* y[B,Ho,Wo,Co] = deform_conv2d(x[B,H,W,C], off[B,Ho,Wo,2GK], msk[B,Ho,Wo,GK], W, bias) */                          \
+  int fami_dcn_fwd_##sfx(const T* x, const T* off, const T* msk, const float* wp, const float* bias, T* y, int B,      \
+                         int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,             \
+                         hipStream_t s) {                                                                              \
+    return dcn_fwd_impl<T>(x, off, msk, wp, bias, y, B, H, W, C, Co, G, kh, kw, stride, pad, dil, s, "fami_dcn_fwd_" #sfx); \
+  }                                                                                                                    \
+  /* Backward of fami_dcn_fwd wrt x, offsets and masks, plus the modulated-sample matrix `col` [P, C*K] (column     */ \
+  /* order (channel, tap) == weight.view(Co, C*K)) for the weight gradient dW[co,k] = sum_p dy[p,co]*col[p,k].      */ \
+  /* gx is an FP32 buffer ACCUMULATED with atomics (zero it first); goff/gmsk (=|+=) per acc_off; each may be null. */ \
+  int fami_dcn_bwd_##sfx(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, float* gx,     \
+                         T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,      \
+                         int pad, int dil, int acc_off, hipStream_t s) {                                               \
+    return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, gx, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil,     \
+                           acc_off, s, "fami_dcn_bwd_" #sfx);                                                          \
   }
-  a.NTc = a.GC * a.cg * K / 16;
-  a.tilesX = fami_cdiv(a.Wo, DCN_TILE); a.tilesY = fami_cdiv(a.Ho, DCN_TILE);
-  a.RH = (DCN_TILE - 1) * stride + (kh - 1) * dil + 2 + 2 * DCN_RO;
-  a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
-  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
-  if (lds > 150 * 1024) {
-    fami_set_error("fami_dcn_bwd_f32", "tile does not fit LDS");
-    return FAMI_ESHAPE;
-  }
-  const dim3 grid(a.tilesX * a.tilesY * B, G / a.GC);
-#define FAMI_DCNB_CASE(kso)                                                                                   \
-  case kso: {                                                                                                 \
-    static bool attr_set = false;                                                                             \
-    if (!attr_set) {                                                                                          \
-      (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<kso>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
-      attr_set = true;                                                                                        \
-    }                                                                                                         \
-    hipLaunchKernelGGL(dcn_bwd_kernel<kso>, grid, dim3(256), lds, s, a);                                      \
-  } break;
-  switch (a.KSo) {
-    FAMI_DCNB_CASE(1) FAMI_DCNB_CASE(2) FAMI_DCNB_CASE(3) FAMI_DCNB_CASE(4) FAMI_DCNB_CASE(5) FAMI_DCNB_CASE(6)
-  }
-#undef FAMI_DCNB_CASE
-  FAMI_CHECK_LAUNCH("fami_dcn_bwd_f32");
-  return FAMI_OK;
-}
+FAMI_ALIGN_ABI(f32, float)
+FAMI_ALIGN_ABI(bf16, bf16_t)
+#undef FAMI_ALIGN_ABI
 
 }  // extern "C"

@@ -29,6 +29,39 @@ extern "C" void fami_set_error(const char* where, const char* what);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- storage types: activations are fp32 or bf16 (fp32 arithmetic either way) ----------------------------
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 4-element vector load/store with conversion to/from f32 (bf16: one 8-byte access, v_cvt_pk_bf16_f32 RNE)
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+  *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ f32x2 ld2(const bf16_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const bf16x2*>(p), f32x2);
+}
+__device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+__device__ __forceinline__ void st2(bf16_t* p, f32x2 v) {
+  *reinterpret_cast<bf16x2*>(p) = __builtin_convertvector(v, bf16x2);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+// stamps the two C-ABI instances of an entry point whose body is a template over the activation type
+#define FAMI_DTYPE_NAME_f32 float
+#define FAMI_DTYPE_NAME_bf16 bf16_t
+
 static inline int fami_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.

@@ -231,10 +231,247 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ bf16 implicit GEMM (fwd / dgrad)
+// bf16 activations and weights, fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Same mapping as the f32 kernel with
+// the operand roles swapped: the MFMA A operand is the weight fragment (rows = 16 output channels) and the B operand
+// the activation fragment (cols = 16 pixels), so a lane ends up with 4 CONSECUTIVE output channels of one pixel and
+// the epilogue is one 8-byte (bf16) or 16-byte (f32) store per tile instead of four scattered scalars.
+// K is walked tap-major in chunks of 32 channels; a lane's fragment is 8 consecutive channels = one 16-byte load.
+struct ConvArgsH {
+  const bf16_t* x;   // GEMM input activation  [N,Hi,Wi,Ci]
+  const bf16_t* wp;  // packed weights [taps][KC][NTt][64][8]
+  void* y;           // GEMM output activation [N,Ho,Wo,Co], bf16 or f32 (out_f32)
+  const float* bias; // [Co] or null
+  int N, Hi, Wi, Ci, Ho, Wo, Co;
+  int kh, kw, sh, pad, dil;
+  int KC, NTt, relu, accumulate, P, out_f32;
+  unsigned x_bytes, wp_bytes;
+};
+
+// packed[tap][kc][nt][lane][j] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
+__global__ void pack_w_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Co, int Ci, int taps,
+                                   int KC, int NTt, int mode) {
+  const long total = (long)taps * KC * NTt * 512;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long r = i >> 9;
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int kc = (int)(r % KC), tap = (int)(r / KC);
+    const int kidx = kc * 32 + (lane >> 4) * 8 + j, nidx = nt * 16 + (lane & 15);
+    const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
+    float v = 0.f;
+    if (co < Co && ci < Ci) v = w[((long)co * Ci + ci) * taps + tap];
+    wp[i] = (bf16_t)v;
+  }
+}
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int MT, int NT, int MODE, int VEC, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
+  __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int kpart = wave % KS, mgrp = wave / KS;
+  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
+  const bool active = m0 < p.P;  // wave-uniform
+  if (KS == 1 && !active) return;
+  const int ntg0 = blockIdx.y * NT;
+  const int HoWo = p.Ho * p.Wo;
+
+  int pn[MT], py[MT], px[MT];
+  bool pv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + col;
+    pv[mt] = m < p.P;
+    const int mm = pv[mt] ? m : 0;
+    const int n = mm / HoWo, r = mm - n * HoWo;
+    const int oy = r / p.Wo;
+    pn[mt] = n;
+    py[mt] = oy;
+    px[mt] = r - oy * p.Wo;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  unsigned aoff[MT];
+  const int taps = p.kh * p.kw;
+  int tap = 0, kc = kpart;
+  while (kc >= p.KC) {
+    kc -= p.KC;
+    ++tap;
+  }
+  unsigned boff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) boff[nt] = (unsigned)(min(ntg0 + nt, p.NTt - 1) * 512 + lane * 8) * 2u;
+
+  auto tap_setup = [&](int tp) {
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      bool v = pv[mt] && tp < taps;
+      int iy, ix;
+      if (MODE == 0) {
+        iy = (py[mt] << p.sh) - p.pad + ky * p.dil;
+        ix = (px[mt] << p.sh) - p.pad + kx * p.dil;
+        v = v && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      } else {
+        const int ty = py[mt] + p.pad - ky * p.dil, tx = px[mt] + p.pad - kx * p.dil;
+        iy = ty >> p.sh;
+        ix = tx >> p.sh;
+        v = v && ty >= 0 && tx >= 0 && (iy << p.sh) == ty && (ix << p.sh) == tx && iy < p.Hi && ix < p.Wi;
+      }
+      aoff[mt] = v ? (unsigned)((((pn[mt] * p.Hi + iy) * p.Wi + ix) * p.Ci + kq * 8) * 2) : FAMI_OOB;
+    }
+  };
+
+  auto load = [&](bf16x8(&a)[MT], bf16x8(&b)[NT]) {
+    const int cbase = kc * 32 + kq * 8;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (VEC) {
+        const unsigned o = cbase < p.Ci ? aoff[mt] + kc * 64 : FAMI_OOB;
+        a[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+      } else {
+        s16x8 t;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned o = cbase + q < p.Ci ? aoff[mt] + kc * 64 + q * 2 : FAMI_OOB;
+          t[q] = (short)__builtin_amdgcn_raw_buffer_load_b16(rx, o, 0, 0);
+        }
+        a[mt] = __builtin_bit_cast(bf16x8, t);
+      }
+    }
+    const unsigned wb = (unsigned)((tap * p.KC + kc) * p.NTt) * 1024u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wb + boff[nt], 0, 0));
+    kc += KS;
+    if (kc >= p.KC) {
+      do {
+        kc -= p.KC;
+        ++tap;
+      } while (kc >= p.KC);
+      tap_setup(tap);
+    }
+  };
+
+  auto mma = [&](const bf16x8(&a)[MT], const bf16x8(&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+  };
+
+  bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+  const int Tall = taps * p.KC;
+  const int T = active ? (Tall - kpart + KS - 1) / KS : 0;
+  if (T > 0) {
+    tap_setup(tap);
+    load(a0, b0);
+    for (int it = 0; it < T; it += 2) {
+      load(a1, b1);
+      mma(a0, b0);
+      load(a0, b0);
+      mma(a1, b1);
+    }
+  }
+
+  if (KS > 1) {
+    if (kpart > 0) {
+      float* dst = red + ((mgrp * (KS - 1)) + (kpart - 1)) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (kpart > 0 || !active) return;
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) {
+      const float* src = red + ((mgrp * (KS - 1)) + k) * (MT * NT * 256);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 4 + r) * 64 + lane];
+    }
+  }
+
+  // epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel): 4 consecutive channels per lane
+  const bool cvec = (p.Co & 3) == 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + mt * 16 + col;
+    if (m >= p.P) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      if (co0 >= p.Co) continue;
+      f32x4 v = acc[mt][nt];
+      const long idx = (long)m * p.Co + co0;
+      if (cvec) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.out_f32) {
+          float* yp = reinterpret_cast<float*>(p.y) + idx;
+          if (p.accumulate) v += ld4(yp);
+          st4(yp, v);
+        } else {
+          bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx;
+          if (p.accumulate) v += ld4(yp);
+          st4(yp, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (co0 + r >= p.Co) continue;
+          float u = v[r] + (p.bias ? p.bias[co0 + r] : 0.f);
+          if (p.relu) u = fmaxf(u, 0.f);
+          if (p.out_f32) {
+            float* yp = reinterpret_cast<float*>(p.y) + idx + r;
+            *yp = p.accumulate ? *yp + u : u;
+          } else {
+            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx + r;
+            st1(yp, p.accumulate ? ld1(yp) + u : u);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
+// one scalar through a buffer descriptor, converted to f32 (out-of-range offsets read 0)
+template <typename T>
+__device__ __forceinline__ float ldbuf(const __amdgpu_buffer_rsrc_t r, unsigned off);
+template <>
+__device__ __forceinline__ float ldbuf<float>(const __amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ float ldbuf<bf16_t>(const __amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+}
+
+template <typename T>
 struct WgradArgs {
-  const float* x;   // [N,H,W,Ci]
-  const float* dy;  // [N,Ho,Wo,Co]
+  const T* x;       // [N,H,W,Ci]
+  const T* dy;      // [N,Ho,Wo,Co]
   float* part;      // [psplit][Co][Ci][taps]
   int N, H, W, Ci, Ho, Wo, Co, kh, kw, sh, pad, dil;
   int P, chunk, ciBlocks, coBlocks;
@@ -242,8 +479,8 @@ struct WgradArgs {
 };
 
 // dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs<T> p) {
   __shared__ float red[4 * MT * NT * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, kq = lane >> 4;
@@ -270,12 +507,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int c = (cib * MT + mt) * 16 + c16;
-    cio[mt] = c < p.Ci ? (unsigned)c * 4u : FAMI_OOB;
+    cio[mt] = c < p.Ci ? (unsigned)c * (unsigned)sizeof(T) : FAMI_OOB;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c = (cob * NT + nt) * 16 + c16;
-    coo[nt] = c < p.Co ? (unsigned)c * 4u : FAMI_OOB;
+    coo[nt] = c < p.Co ? (unsigned)c * (unsigned)sizeof(T) : FAMI_OOB;
   }
 
   f32x4 acc[MT][NT];
@@ -301,14 +538,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
     const bool pvalid = pix < w_hi;
     const int iy = (oy << p.sh) - p.pad + ky * p.dil, ix = (ox << p.sh) - p.pad + kx * p.dil;
     const bool xin = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * 4u : FAMI_OOB;
-    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * 4u : FAMI_OOB;
+    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * (unsigned)sizeof(T) : FAMI_OOB;
+    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * (unsigned)sizeof(T) : FAMI_OOB;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      a[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff + cio[mt], 0, 0));
+      a[mt] = ldbuf<T>(rx, xoff + cio[mt]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + coo[nt], 0, 0));
+      b[nt] = ldbuf<T>(ry, yoff + coo[nt]);
     pix += 4;
     ox += 4;
     for (int k = 0; k < wrap_x; ++k) {
@@ -329,11 +566,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
   };
 
   // unconditional two-stage pipeline; steps past the wave's range load zeros (pvalid false)
-  const int T = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
+  const int Tn = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
   float a0[MT], b0[NT], a1[MT], b1[NT];
-  if (T > 0) {
+  if (Tn > 0) {
     load(a0, b0);
-    for (int it = 0; it < T; it += 2) {
+    for (int it = 0; it < Tn; it += 2) {
       load(a1, b1);
       mma(a0, b0);
       load(a0, b0);
@@ -365,8 +602,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs p) {
 // chunk, so dY and the shifted X rows are fetched from HBM/MALL once and served to the other taps by L1/L2
 // (the one-tap-per-workgroup layout above re-read both tensors kh*kw times: 478 MB per 48->48 conv).
 // Slab layout [psplit][tap][ci][co] (co contiguous => 64-byte stores); the reduce kernel transposes to OIHW.
-template <int MT, int NT>
-__global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs p) {
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
   const int lane = threadIdx.x & 63, tap = threadIdx.x >> 6;
   const int c16 = lane & 15, kq = lane >> 4;
   const int ps = blockIdx.x;
@@ -382,12 +619,12 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int c = (cib * MT + mt) * 16 + c16;
-    cio[mt] = c < p.Ci ? (unsigned)c * 4u : FAMI_OOB;
+    cio[mt] = c < p.Ci ? (unsigned)c * (unsigned)sizeof(T) : FAMI_OOB;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c = (cob * NT + nt) * 16 + c16;
-    coo[nt] = c < p.Co ? (unsigned)c * 4u : FAMI_OOB;
+    coo[nt] = c < p.Co ? (unsigned)c * (unsigned)sizeof(T) : FAMI_OOB;
   }
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -410,14 +647,14 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs p) {
     const bool pvalid = pix < w_hi;
     const int iy = (oy << p.sh) - p.pad + ky * p.dil, ix = (ox << p.sh) - p.pad + kx * p.dil;
     const bool xin = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * 4u : FAMI_OOB;
-    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * 4u : FAMI_OOB;
+    const unsigned xoff = xin ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.Ci) * (unsigned)sizeof(T) : FAMI_OOB;
+    const unsigned yoff = pvalid ? (unsigned)(pix * p.Co) * (unsigned)sizeof(T) : FAMI_OOB;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      a[mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff + cio[mt], 0, 0));
+      a[mt] = ldbuf<T>(rx, xoff + cio[mt]);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      b[nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, yoff + coo[nt], 0, 0));
+      b[nt] = ldbuf<T>(ry, yoff + coo[nt]);
     pix += 4;
     ox += 4;
     for (int k = 0; k < wrap_x; ++k) {
@@ -436,11 +673,11 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs p) {
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   };
-  const int T = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
+  const int Tn = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
   float a0[MT], b0[NT], a1[MT], b1[NT];
-  if (T > 0) {
+  if (Tn > 0) {
     load(a0, b0);
-    for (int it = 0; it < T; it += 2) {
+    for (int it = 0; it < Tn; it += 2) {
       load(a1, b1);
       mma(a0, b0);
       load(a0, b0);
@@ -703,27 +940,30 @@ long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, in
   return (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
 }
 
-// dw[Co,Ci,kh,kw] (=|+=) sum_pixels x (*) dy ; workspace from fami_conv2d_wgrad_workspace
-int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
-                          int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                          hipStream_t s) {
-  FAMI_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_wgrad_f32", "bad argument");
+}  // extern "C"
+
+// dw[Co,Ci,kh,kw] fp32 (=|+=) sum_pixels x (*) dy ; workspace from fami_conv2d_wgrad_workspace
+template <typename T>
+static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long ws_bytes, int N, int H, int W, int Ci,
+                      int Co, int kh, int kw, int stride, int pad, int dil, int accumulate, hipStream_t s,
+                      const char* nm) {
+  FAMI_REQUIRE(x && dy && dw && workspace && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
-    fami_set_error("fami_conv2d_wgrad_f32", "unsupported geometry");
+    fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
   const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
   const long need = (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
-  FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_f32", "workspace too small");
-  FAMI_REQUIRE(q.P < (1L << 31), "fami_conv2d_wgrad_f32", "size out of range");
-  WgradArgs a;
+  FAMI_REQUIRE(ws_bytes >= need, nm, "workspace too small");
+  FAMI_REQUIRE(q.P < (1L << 31), nm, "size out of range");
+  WgradArgs<T> a;
   a.x = x; a.dy = dy; a.part = workspace;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci;
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
   a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
-  const long xb = (long)N * H * W * Ci * 4, yb = q.P * Co * 4;
-  FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), "fami_conv2d_wgrad_f32", "tensor >= 2 GiB");
+  const long xb = (long)N * H * W * Ci * (long)sizeof(T), yb = q.P * Co * (long)sizeof(T);
+  FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), nm, "tensor >= 2 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
   const long n = (long)Co * Ci * kh * kw;
   if (q.pertap) {
@@ -731,7 +971,7 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
     bool ok = false;
 #define FAMI_TCASE(mt, nt)                                                                  \
   if (q.MT == mt && q.NT == nt) {                                                           \
-    hipLaunchKernelGGL((conv_wgrad_taps_f32<mt, nt>), grid, block, 0, s, a);                \
+    hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);             \
     ok = true;                                                                              \
   }
     FAMI_TCASE(1, 1) FAMI_TCASE(1, 2) FAMI_TCASE(1, 3) FAMI_TCASE(1, 4)
@@ -740,19 +980,19 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
     FAMI_TCASE(4, 1) FAMI_TCASE(4, 2) FAMI_TCASE(4, 3) FAMI_TCASE(4, 4)
 #undef FAMI_TCASE
     if (!ok) {
-      fami_set_error("fami_conv2d_wgrad_f32", "no kernel instance");
+      fami_set_error(nm, "no kernel instance");
       return FAMI_ESHAPE;
     }
-    FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/taps");
+    FAMI_CHECK_LAUNCH(nm);
     hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, workspace, dw, Co, Ci, kh * kw, q.psplit, accumulate);
-    FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce_taps");
+    FAMI_CHECK_LAUNCH(nm);
     return FAMI_OK;
   }
   const dim3 grid(q.psplit, kh * kw * q.ciBlocks * q.coBlocks);
   bool done = false;
 #define FAMI_WCASE(mt, nt)                                                                  \
   if (q.MT == mt && q.NT == nt) {                                                           \
-    hipLaunchKernelGGL((conv_wgrad_f32<mt, nt>), grid, dim3(256), 0, s, a);                 \
+    hipLaunchKernelGGL((conv_wgrad_f32<T, mt, nt>), grid, dim3(256), 0, s, a);              \
     done = true;                                                                            \
   }
   FAMI_WCASE(1, 1) FAMI_WCASE(1, 2) FAMI_WCASE(1, 3) FAMI_WCASE(1, 4)
@@ -761,13 +1001,141 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
   FAMI_WCASE(4, 1) FAMI_WCASE(4, 2) FAMI_WCASE(4, 3) FAMI_WCASE(4, 4)
 #undef FAMI_WCASE
   if (!done) {
-    fami_set_error("fami_conv2d_wgrad_f32", "no kernel instance");
+    fami_set_error(nm, "no kernel instance");
     return FAMI_ESHAPE;
   }
-  FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32");
+  FAMI_CHECK_LAUNCH(nm);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, workspace, dw, n, q.psplit, accumulate);
-  FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
+  FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
+}
+
+// ---- bf16 implicit GEMM launch
+template <int MODE, int VEC>
+static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, hipStream_t s) {
+  const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
+#define FAMI_CASE(mt, nt, ks)                                                                \
+  if (MT == mt && NT == nt && KS == ks) {                                                    \
+    hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks>), grid, dim3(256), 0, s, a);  \
+    return 0;                                                                                \
+  }
+  if constexpr (VEC) {
+#define FAMI_ROW(nt) FAMI_CASE(1, nt, 1) FAMI_CASE(1, nt, 2) FAMI_CASE(1, nt, 4) FAMI_CASE(2, nt, 1) FAMI_CASE(2, nt, 2) FAMI_CASE(2, nt, 4) FAMI_CASE(4, nt, 1)
+    FAMI_ROW(1) FAMI_ROW(2) FAMI_ROW(3) FAMI_ROW(4)
+#undef FAMI_ROW
+  } else {
+    FAMI_CASE(2, 1, 1) FAMI_CASE(2, 2, 1) FAMI_CASE(2, 3, 1) FAMI_CASE(2, 4, 1)
+  }
+#undef FAMI_CASE
+  return -1;
+}
+
+static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
+  const int vec = (a.Ci % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+  int NT = pick_nt(a.NTt);
+  if (NT == 6) NT = 3;
+  if (NT > 4) NT = 4;
+  int MT = 2, KS = 1;
+  if (vec) {
+    // the bf16 kernel is operand-fetch bound (an MFMA needs 2 KiB of fragments): larger register tiles raise the
+    // MFMAs per fetched KiB, split-K restores parallelism on the low-resolution branches
+    const long nblk = fami_cdiv(a.NTt, NT);
+    const long tiles = (long)fami_cdiv(a.P, 16) * nblk;
+    const long iters = (long)a.kh * a.kw * a.KC;
+    if (tiles >= 16384) MT = 4;
+    else if (tiles >= 4096) MT = 2;
+    else {
+      MT = 1;
+      if (iters >= 8) KS = tiles < 1024 ? 4 : 2;
+    }
+  }
+  if (vec && g_force_mt) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
+  int rc;
+  if (mode == 0)
+    rc = vec ? launch_igemm_h<0, 1>(a, MT, NT, KS, s) : launch_igemm_h<0, 0>(a, MT, NT, KS, s);
+  else
+    rc = vec ? launch_igemm_h<1, 1>(a, MT, NT, KS, s) : launch_igemm_h<1, 0>(a, MT, NT, KS, s);
+  if (rc != 0) {
+    fami_set_error(name, "no kernel instance for tile shape");
+    return FAMI_ESHAPE;
+  }
+  FAMI_CHECK_LAUNCH(name);
+  return FAMI_OK;
+}
+
+extern "C" {
+
+int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                          int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                          hipStream_t s) {
+  return wgrad_impl<float>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
+                           "fami_conv2d_wgrad_f32");
+}
+// bf16 activations / gradients, fp32 weight gradient (the f32 MFMA consumes the converted operands)
+int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                           hipStream_t s) {
+  return wgrad_impl<bf16_t>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
+                            "fami_conv2d_wgrad_bf16");
+}
+
+long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  return (long)kh * kw * fami_cdiv(kd, 32) * fami_cdiv(nd, 16) * 512;
+}
+
+int fami_pack_conv_weight_bf16(const float* w_oihw, bf16_t* wp, int Co, int Ci, int kh, int kw, int mode,
+                               hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wp && Co > 0 && Ci > 0 && (mode == 0 || mode == 1), "fami_pack_conv_weight_bf16", "bad argument");
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  const int KC = fami_cdiv(kd, 32), NTt = fami_cdiv(nd, 16);
+  const long total = (long)kh * kw * KC * NTt * 512;
+  hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, KC, NTt, mode);
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weight_bf16");
+  return FAMI_OK;
+}
+
+// y[N,Ho,Wo,Co] (bf16, or f32 when out_f32) (=|+=) relu?( conv(x[N,H,W,Ci] bf16) + bias ) ; wp packed with mode 0
+int fami_conv2d_fwd_bf16(const bf16_t* x, const bf16_t* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                         int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate, int out_f32,
+                         hipStream_t s) {
+  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_fwd_bf16", "bad argument");
+  if (!geom_ok(kh, kw, stride, pad, dil)) {
+    fami_set_error("fami_conv2d_fwd_bf16", "unsupported geometry");
+    return FAMI_ESHAPE;
+  }
+  ConvArgsH a;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias;
+  a.N = N; a.Hi = H; a.Wi = W; a.Ci = Ci;
+  a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
+  a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
+  a.KC = fami_cdiv(Ci, 32); a.NTt = fami_cdiv(Co, 16); a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  const long P = (long)N * a.Ho * a.Wo;
+  const long xb = (long)N * H * W * Ci * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_bf16", "tensor >= 2 GiB");
+  a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  return run_igemm_h(a, 0, s, "fami_conv2d_fwd_bf16");
+}
+
+// dx[N,H,W,Ci] bf16 (=|+=) conv_transpose(dy[N,Ho,Wo,Co] bf16) ; wp packed with mode 1
+int fami_conv2d_dgrad_bf16(const bf16_t* dy, const bf16_t* wp, bf16_t* dx, int N, int H, int W, int Ci, int Co, int kh,
+                           int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_dgrad_bf16", "bad argument");
+  if (!geom_ok(kh, kw, stride, pad, dil)) {
+    fami_set_error("fami_conv2d_dgrad_bf16", "unsupported geometry");
+    return FAMI_ESHAPE;
+  }
+  ConvArgsH a;
+  a.x = dy; a.wp = wp; a.y = dx; a.bias = nullptr;
+  a.N = N; a.Hi = out_dim(H, kh, stride, pad, dil); a.Wi = out_dim(W, kw, stride, pad, dil); a.Ci = Co;
+  a.Ho = H; a.Wo = W; a.Co = Ci;
+  a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
+  a.KC = fami_cdiv(Co, 32); a.NTt = fami_cdiv(Ci, 16); a.relu = 0; a.accumulate = accumulate; a.out_f32 = 0;
+  const long P = (long)N * H * W;
+  const long xb = (long)N * a.Hi * a.Wi * Co * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_bf16", "tensor >= 2 GiB");
+  a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  return run_igemm_h(a, 1, s, "fami_conv2d_dgrad_bf16");
 }
 
 }  // extern "C"

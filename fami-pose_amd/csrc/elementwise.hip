@@ -2,6 +2,7 @@
 // (the drop-in boundary is NCHW, the kernels run NHWC), channel concat / slice,
 // axpby, the HRNet cross-resolution fuse (BN-apply + nearest-upsample + sum +
 // ReLU in one pass), ReLU-masked gradient pooling, and the fused Adam step.
+// Every activation-touching kernel is a template over the storage type T (float | bf16); arithmetic is fp32.
 //
 // Replaces torch.cat / torch.chunk / `sup - kf` (Alignment_V15.py:117-125,132,139,143,160),
 // HighResolutionModule.forward's fuse loop (hrnet.py:159-168) with
@@ -9,19 +10,22 @@
 // (posetimation/optimizer/optimizer.py:66-68; lr 1e-3, betas (0.9,0.999), eps 1e-8).
 #include "common.h"
 
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H,
-                                    int W) {
+// boundary: NCHW fp32 (images, heatmap gradients) -> NHWC T
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W) {
   const long total = (long)N * C * H * W;
   const long HW = (long)H * W;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const long p = i / C;  // n*HW + hw
     const long n = p / HW, hw = p - n * HW;
-    dst[i] = src[(n * C + c) * HW + hw];
+    st1(dst + i, src[(n * C + c) * HW + hw]);
   }
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H,
-                                    int W, int accumulate) {
+// NHWC T -> NCHW fp32 (heatmaps, MI operands, nn.Flatten order)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                    int accumulate) {
   const long total = (long)N * C * H * W;
   const long HW = (long)H * W;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -29,14 +33,15 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
     const long nc = i / HW;
     const long n = nc / C;
     const int c = (int)(nc - n * C);
-    const float v = src[(n * HW + hw) * C + c];
+    const float v = ld1(src + (n * HW + hw) * C + c);
     dst[i] = accumulate ? dst[i] + v : v;
   }
 }
 
 // frames[(f*B + b), y, x, c] : f = 0 key frame, f >= 1 supporting frame f-1 (channels 3(f-1)..3(f-1)+2 of sup)
-__global__ void pack_frames_kernel(const float* __restrict__ kf, const float* __restrict__ sup,
-                                   float* __restrict__ out, int B, int S, int H, int W) {
+template <typename T>
+__global__ void pack_frames_kernel(const float* __restrict__ kf, const float* __restrict__ sup, T* __restrict__ out,
+                                   int B, int S, int H, int W) {
   const long HW = (long)H * W;
   const long total = (long)(1 + S) * B * HW * 3;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -49,34 +54,60 @@ __global__ void pack_frames_kernel(const float* __restrict__ kf, const float* __
       v = kf[((long)b * 3 + c) * HW + hw];
     else
       v = sup[((long)b * 3 * S + 3 * (f - 1) + c) * HW + hw];
-    out[i] = v;
+    st1(out + i, v);
   }
 }
 
-// dst[p][dst_off + c] (=|+=) src[p][src_off + c], c < Cc
-__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, long P, int Cs,
-                                     int src_off, int Cd, int dst_off, int Cc, int accumulate) {
-  const long total = P * Cc;
+// dst[p][dst_off + c] (=|+=) src[p][src_off + c], c < Cc ; 4 channels per thread when everything is 4-aligned
+template <typename T, int V>
+__global__ void copy_channels_kernel(const T* __restrict__ src, T* __restrict__ dst, long P, int Cs, int src_off,
+                                     int Cd, int dst_off, int Cc, int accumulate) {
+  const int CcV = Cc / V;
+  const long total = P * CcV;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cc);
-    const long p = i / Cc;
-    const float v = src[p * Cs + src_off + c];
-    float* d = dst + p * Cd + dst_off + c;
-    *d = accumulate ? *d + v : v;
+    const int c = (int)(i % CcV) * V;
+    const long p = i / CcV;
+    const T* sp = src + p * Cs + src_off + c;
+    T* d = dst + p * Cd + dst_off + c;
+    if (V == 4) {
+      f32x4 v = ld4(sp);
+      if (accumulate) v += ld4(d);
+      st4(d, v);
+    } else {
+      const float v = ld1(sp);
+      st1(d, accumulate ? ld1(d) + v : v);
+    }
   }
 }
 
 // out = alpha*a + beta*b (b may be null; out may alias a or b)
-__global__ void axpby_kernel(const float* a, const float* b, float* out, long n, float alpha, float beta) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float v = alpha * a[i];
-    if (b) v += beta * b[i];
-    out[i] = v;
+template <typename T>
+__global__ void axpby_kernel(const T* a, const T* b, T* out, long n, float alpha, float beta, int vec) {
+  const long n4 = vec ? n >> 2 : 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = ld4(a + i * 4) * alpha;
+    if (b) v += ld4(b + i * 4) * beta;
+    st4(out + i * 4, v);
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = alpha * ld1(a + i);
+    if (b) v += beta * ld1(b + i);
+    st1(out + i, v);
   }
 }
 
-__global__ void fill_kernel(float* out, long n, float v) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = v;
+// dst (=|+=) src : fp32 accumulation buffers folded into T gradients (DCN input gradient)
+template <typename T>
+__global__ void cast_add_kernel(const float* __restrict__ src, T* dst, long n, int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = src[i];
+    st1(dst + i, accumulate ? ld1(dst + i) + v : v);
+  }
+}
+
+template <typename T>
+__global__ void fill_kernel(T* out, long n, float v) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) st1(out + i, v);
 }
 
 __global__ void incr_i64_kernel(long long* v, long n) {
@@ -86,8 +117,9 @@ __global__ void add_i64_kernel(long long* v, const long long* inc, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v[i] += inc[i];
 }
 
+template <typename T>
 struct FuseArgs {
-  const float* x[4];
+  const T* x[4];
   const float* mean[4];
   const float* invstd[4];
   const float* gamma[4];
@@ -97,8 +129,9 @@ struct FuseArgs {
 };
 
 // y[n,h,w,c] = relu( sum_k term_k ), term_k = bn_k(x_k[n, h>>s_k, w>>s_k, c]) (bn_k optional)
-__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, float* __restrict__ y, int N, int H, int W,
-                                                       int C, int relu) {
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs<T> a, T* __restrict__ y, int N, int H, int W, int C,
+                                                       int relu) {
   const int CV = C >> 2;
   const long total = (long)N * H * W * CV;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -113,7 +146,7 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, float* __rest
       const int s = a.shift[k];
       const int Hk = H >> s, Wk = W >> s;
       const long o = ((n * Hk + (h >> s)) * Wk + (w >> s)) * C + cv * 4;
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.x[k] + o);
+      f32x4 v = ld4(a.x[k] + o);
       if (a.mean[k]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -128,26 +161,27 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, float* __rest
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = fmaxf(acc[t], 0.f);
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+    st4(y + i * 4, acc);
   }
 }
 
 // dx (=|+=) dy * (y > 0)
-__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* dx, long n4,
-                                int accumulate) {
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* dx, long n4, int accumulate) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 g = ld4(dy + i * 4);
+    const f32x4 yy = ld4(y + i * 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
-    if (accumulate) g += reinterpret_cast<const f32x4*>(dx)[i];
-    reinterpret_cast<f32x4*>(dx)[i] = g;
+    if (accumulate) g += ld4(dx + i * 4);
+    st4(dx + i * 4, g);
   }
 }
 
 // out[n,hl,wl,c] = sum_{window 2^s x 2^s} dy*(y>0) : gradient of nearest-upsample under the fuse ReLU
-__global__ void pool_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                     float* __restrict__ out, int N, int Hl, int Wl, int C, int s, int relu) {
+template <typename T>
+__global__ void pool_relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, int N,
+                                     int Hl, int Wl, int C, int s, int relu) {
   const int CV = C >> 2;
   const int f = 1 << s;
   const int H = Hl << s, W = Wl << s;
@@ -163,15 +197,15 @@ __global__ void pool_relu_bwd_kernel(const float* __restrict__ dy, const float* 
     for (int dh = 0; dh < f; ++dh)
       for (int dw = 0; dw < f; ++dw) {
         const long o = ((n * H + (hl * f + dh)) * W + (wl * f + dw)) * C + cv * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        f32x4 g = ld4(dy + o);
         if (relu) {
-          const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+          const f32x4 yy = ld4(y + o);
 #pragma unroll
           for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
         }
         acc += g;
       }
-    *reinterpret_cast<f32x4*>(out + i * 4) = acc;
+    st4(out + i * 4, acc);
   }
 }
 
@@ -201,47 +235,146 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+
+// ------------------------------------------------------------------ host side (templates over the storage type)
+template <typename T>
+static int nchw_to_nhwc_impl(const float* src, T* dst, int N, int C, int H, int W, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, nm, "bad argument");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(fami_ew_grid((long)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H, W);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int nhwc_to_nchw_impl(const T* src, float* dst, int N, int C, int H, int W, int accumulate, hipStream_t s,
+                             const char* nm) {
+  FAMI_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, nm, "bad argument");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(fami_ew_grid((long)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H, W, accumulate);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int pack_frames_impl(const float* kf, const float* sup, T* out, int B, int S, int H, int W, hipStream_t s,
+                            const char* nm) {
+  FAMI_REQUIRE(kf && out && B > 0 && S >= 0 && (S == 0 || sup), nm, "bad argument");
+  hipLaunchKernelGGL(pack_frames_kernel<T>, dim3(fami_ew_grid((long)(1 + S) * B * H * W * 3)), dim3(256), 0, s, kf, sup, out, B, S, H, W);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int copy_channels_impl(const T* src, T* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,
+                              int accumulate, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(src && dst && P > 0 && Cc > 0 && src_off >= 0 && dst_off >= 0 && src_off + Cc <= Cs && dst_off + Cc <= Cd, nm, "bad argument");
+  const bool v4 = ((Cs | src_off | Cd | dst_off | Cc) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL((copy_channels_kernel<T, 4>), dim3(fami_ew_grid(P * Cc / 4)), dim3(256), 0, s, src, dst, P, Cs, src_off, Cd, dst_off, Cc, accumulate);
+  else
+    hipLaunchKernelGGL((copy_channels_kernel<T, 1>), dim3(fami_ew_grid(P * Cc)), dim3(256), 0, s, src, dst, P, Cs, src_off, Cd, dst_off, Cc, accumulate);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int axpby_impl(const T* a, const T* b, T* out, long n, float alpha, float beta, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(a && out && n > 0, nm, "bad argument");
+  const int vec = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & (4 * sizeof(T) - 1)) == 0;
+  hipLaunchKernelGGL(axpby_kernel<T>, dim3(fami_ew_grid(vec ? (n + 3) / 4 : n)), dim3(256), 0, s, a, b, out, n, alpha, beta, vec);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int cast_add_impl(const float* src, T* dst, long n, int accumulate, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(src && dst && n > 0, nm, "bad argument");
+  hipLaunchKernelGGL(cast_add_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, src, dst, n, accumulate);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int fill_impl(T* out, long n, float v, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(out && n > 0, nm, "bad argument");
+  hipLaunchKernelGGL(fill_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, out, n, v);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int fuse_sum_impl(int nterms, const T* const* x, const float* const* mean, const float* const* invstd,
+                         const float* const* gamma, const float* const* beta, const int* shift, T* y, int N, int H,
+                         int W, int C, int relu, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(nterms >= 1 && nterms <= 4 && x && shift && y && (C % 4) == 0, nm, "bad argument");
+  FuseArgs<T> a;
+  a.nterms = nterms;
+  for (int k = 0; k < 4; ++k) {
+    const bool on = k < nterms;
+    a.x[k] = on ? x[k] : nullptr;
+    a.mean[k] = on && mean ? mean[k] : nullptr;
+    a.invstd[k] = on && invstd ? invstd[k] : nullptr;
+    a.gamma[k] = on && gamma ? gamma[k] : nullptr;
+    a.beta[k] = on && beta ? beta[k] : nullptr;
+    a.shift[k] = on ? shift[k] : 0;
+    if (on) {
+      FAMI_REQUIRE(a.x[k] && a.shift[k] >= 0 && (H % (1 << a.shift[k])) == 0 && (W % (1 << a.shift[k])) == 0, nm, "bad term");
+    }
+  }
+  hipLaunchKernelGGL(fuse_sum_kernel<T>, dim3(fami_ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, s, a, y, N, H, W, C, relu);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int relu_bwd_impl(const T* dy, const T* y, T* dx, long n, int accumulate, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(dy && y && dx && n > 0 && (n % 4) == 0, nm, "bad argument");
+  hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(fami_ew_grid(n / 4)), dim3(256), 0, s, dy, y, dx, n / 4, accumulate);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+template <typename T>
+static int pool_relu_bwd_impl(const T* dy, const T* y, T* out, int N, int Hl, int Wl, int C, int shift, int relu,
+                              hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(dy && out && (!relu || y) && (C % 4) == 0 && shift >= 0 && shift <= 4, nm, "bad argument");
+  hipLaunchKernelGGL(pool_relu_bwd_kernel<T>, dim3(fami_ew_grid((long)N * Hl * Wl * (C / 4))), dim3(256), 0, s, dy, y, out, N, Hl, Wl, C, shift, relu);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
 extern "C" {
 
-int fami_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s) {
-  FAMI_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "fami_nchw_to_nhwc_f32", "bad argument");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(fami_ew_grid((long)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H, W);
-  FAMI_CHECK_LAUNCH("fami_nchw_to_nhwc_f32");
-  return FAMI_OK;
-}
-int fami_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int accumulate, hipStream_t s) {
-  FAMI_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "fami_nhwc_to_nchw_f32", "bad argument");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(fami_ew_grid((long)N * C * H * W)), dim3(256), 0, s, src, dst, N, C, H, W, accumulate);
-  FAMI_CHECK_LAUNCH("fami_nhwc_to_nchw_f32");
-  return FAMI_OK;
-}
-// kf [B,3,H,W], sup [B,3S,H,W] (NCHW) -> frames [(1+S)*B, H, W, 3] (NHWC), frame-major
-int fami_pack_frames_f32(const float* kf, const float* sup, float* out, int B, int S, int H, int W, hipStream_t s) {
-  FAMI_REQUIRE(kf && out && B > 0 && S >= 0 && (S == 0 || sup), "fami_pack_frames_f32", "bad argument");
-  hipLaunchKernelGGL(pack_frames_kernel, dim3(fami_ew_grid((long)(1 + S) * B * H * W * 3)), dim3(256), 0, s, kf, sup, out, B, S, H, W);
-  FAMI_CHECK_LAUNCH("fami_pack_frames_f32");
-  return FAMI_OK;
-}
-int fami_copy_channels_f32(const float* src, float* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,
-                           int accumulate, hipStream_t s) {
-  FAMI_REQUIRE(src && dst && P > 0 && Cc > 0 && src_off >= 0 && dst_off >= 0 && src_off + Cc <= Cs && dst_off + Cc <= Cd,
-               "fami_copy_channels_f32", "bad argument");
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(fami_ew_grid(P * Cc)), dim3(256), 0, s, src, dst, P, Cs, src_off, Cd, dst_off, Cc, accumulate);
-  FAMI_CHECK_LAUNCH("fami_copy_channels_f32");
-  return FAMI_OK;
-}
-int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alpha, float beta, hipStream_t s) {
-  FAMI_REQUIRE(a && out && n > 0, "fami_axpby_f32", "bad argument");
-  hipLaunchKernelGGL(axpby_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, a, b, out, n, alpha, beta);
-  FAMI_CHECK_LAUNCH("fami_axpby_f32");
-  return FAMI_OK;
-}
-int fami_fill_f32(float* out, long n, float v, hipStream_t s) {
-  FAMI_REQUIRE(out && n > 0, "fami_fill_f32", "bad argument");
-  hipLaunchKernelGGL(fill_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, out, n, v);
-  FAMI_CHECK_LAUNCH("fami_fill_f32");
-  return FAMI_OK;
-}
+#define FAMI_EW_ABI(sfx, T)                                                                                            \
+  int fami_nchw_to_nhwc_##sfx(const float* src, T* dst, int N, int C, int H, int W, hipStream_t s) {                   \
+    return nchw_to_nhwc_impl<T>(src, dst, N, C, H, W, s, "fami_nchw_to_nhwc_" #sfx);                                   \
+  }                                                                                                                    \
+  int fami_nhwc_to_nchw_##sfx(const T* src, float* dst, int N, int C, int H, int W, int accumulate, hipStream_t s) {   \
+    return nhwc_to_nchw_impl<T>(src, dst, N, C, H, W, accumulate, s, "fami_nhwc_to_nchw_" #sfx);                       \
+  }                                                                                                                    \
+  /* kf [B,3,H,W], sup [B,3S,H,W] (NCHW fp32) -> frames [(1+S)*B, H, W, 3] (NHWC), frame-major */                      \
+  int fami_pack_frames_##sfx(const float* kf, const float* sup, T* out, int B, int S, int H, int W, hipStream_t s) {   \
+    return pack_frames_impl<T>(kf, sup, out, B, S, H, W, s, "fami_pack_frames_" #sfx);                                 \
+  }                                                                                                                    \
+  int fami_copy_channels_##sfx(const T* src, T* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,         \
+                               int accumulate, hipStream_t s) {                                                        \
+    return copy_channels_impl<T>(src, dst, P, Cs, src_off, Cd, dst_off, Cc, accumulate, s, "fami_copy_channels_" #sfx);\
+  }                                                                                                                    \
+  int fami_axpby_##sfx(const T* a, const T* b, T* out, long n, float alpha, float beta, hipStream_t s) {               \
+    return axpby_impl<T>(a, b, out, n, alpha, beta, s, "fami_axpby_" #sfx);                                            \
+  }                                                                                                                    \
+  int fami_cast_add_##sfx(const float* src, T* dst, long n, int accumulate, hipStream_t s) {                           \
+    return cast_add_impl<T>(src, dst, n, accumulate, s, "fami_cast_add_" #sfx);                                        \
+  }                                                                                                                    \
+  int fami_fill_##sfx(T* out, long n, float v, hipStream_t s) { return fill_impl<T>(out, n, v, s, "fami_fill_" #sfx); }\
+  /* term k: x[k] [N, H>>shift[k], W>>shift[k], C]; mean[k]==null => identity term.  Arrays of length nterms (<=4). */ \
+  int fami_fuse_sum_##sfx(int nterms, const T* const* x, const float* const* mean, const float* const* invstd,         \
+                          const float* const* gamma, const float* const* beta, const int* shift, T* y, int N, int H,   \
+                          int W, int C, int relu, hipStream_t s) {                                                     \
+    return fuse_sum_impl<T>(nterms, x, mean, invstd, gamma, beta, shift, y, N, H, W, C, relu, s, "fami_fuse_sum_" #sfx);\
+  }                                                                                                                    \
+  int fami_relu_bwd_##sfx(const T* dy, const T* y, T* dx, long n, int accumulate, hipStream_t s) {                     \
+    return relu_bwd_impl<T>(dy, y, dx, n, accumulate, s, "fami_relu_bwd_" #sfx);                                       \
+  }                                                                                                                    \
+  /* dy,y [N, Hl<<s, Wl<<s, C] -> out [N,Hl,Wl,C] */                                                                   \
+  int fami_pool_relu_bwd_##sfx(const T* dy, const T* y, T* out, int N, int Hl, int Wl, int C, int shift, int relu,     \
+                               hipStream_t s) {                                                                        \
+    return pool_relu_bwd_impl<T>(dy, y, out, N, Hl, Wl, C, shift, relu, s, "fami_pool_relu_bwd_" #sfx);                \
+  }
+FAMI_EW_ABI(f32, float)
+FAMI_EW_ABI(bf16, bf16_t)
+#undef FAMI_EW_ABI
+
 int fami_incr_i64(long long* v, long n, hipStream_t s) {
   FAMI_REQUIRE(v && n > 0, "fami_incr_i64", "bad argument");
   hipLaunchKernelGGL(incr_i64_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, v, n);
@@ -256,44 +389,6 @@ int fami_add_i64(long long* v, const long long* inc, long n, hipStream_t s) {
   return FAMI_OK;
 }
 
-// term k: x[k] [N, H>>shift[k], W>>shift[k], C]; mean[k]==null => identity term.  Arrays of length nterms (<=4).
-int fami_fuse_sum_f32(int nterms, const float* const* x, const float* const* mean, const float* const* invstd,
-                      const float* const* gamma, const float* const* beta, const int* shift, float* y, int N, int H,
-                      int W, int C, int relu, hipStream_t s) {
-  FAMI_REQUIRE(nterms >= 1 && nterms <= 4 && x && shift && y && (C % 4) == 0, "fami_fuse_sum_f32", "bad argument");
-  FuseArgs a;
-  a.nterms = nterms;
-  for (int k = 0; k < 4; ++k) {
-    const bool on = k < nterms;
-    a.x[k] = on ? x[k] : nullptr;
-    a.mean[k] = on && mean ? mean[k] : nullptr;
-    a.invstd[k] = on && invstd ? invstd[k] : nullptr;
-    a.gamma[k] = on && gamma ? gamma[k] : nullptr;
-    a.beta[k] = on && beta ? beta[k] : nullptr;
-    a.shift[k] = on ? shift[k] : 0;
-    if (on) {
-      FAMI_REQUIRE(a.x[k] && a.shift[k] >= 0 && (H % (1 << a.shift[k])) == 0 && (W % (1 << a.shift[k])) == 0,
-                   "fami_fuse_sum_f32", "bad term");
-    }
-  }
-  hipLaunchKernelGGL(fuse_sum_kernel, dim3(fami_ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, s, a, y, N, H, W, C, relu);
-  FAMI_CHECK_LAUNCH("fami_fuse_sum_f32");
-  return FAMI_OK;
-}
-int fami_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, int accumulate, hipStream_t s) {
-  FAMI_REQUIRE(dy && y && dx && n > 0 && (n % 4) == 0, "fami_relu_bwd_f32", "bad argument");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(fami_ew_grid(n / 4)), dim3(256), 0, s, dy, y, dx, n / 4, accumulate);
-  FAMI_CHECK_LAUNCH("fami_relu_bwd_f32");
-  return FAMI_OK;
-}
-// dy,y [N, Hl<<s, Wl<<s, C] -> out [N,Hl,Wl,C]
-int fami_pool_relu_bwd_f32(const float* dy, const float* y, float* out, int N, int Hl, int Wl, int C, int shift,
-                           int relu, hipStream_t s) {
-  FAMI_REQUIRE(dy && out && (!relu || y) && (C % 4) == 0 && shift >= 0 && shift <= 4, "fami_pool_relu_bwd_f32", "bad argument");
-  hipLaunchKernelGGL(pool_relu_bwd_kernel, dim3(fami_ew_grid((long)N * Hl * Wl * (C / 4))), dim3(256), 0, s, dy, y, out, N, Hl, Wl, C, shift, relu);
-  FAMI_CHECK_LAUNCH("fami_pool_relu_bwd_f32");
-  return FAMI_OK;
-}
 // state (device float[4]) = {step, lr, 1-beta1^step, 1-beta2^step}; prep increments step
 int fami_adam_prep_f32(float* state, float beta1, float beta2, hipStream_t s) {
   FAMI_REQUIRE(state, "fami_adam_prep_f32", "bad argument");

@@ -28,15 +28,19 @@ __device__ __forceinline__ ColMap col_map(int C) {
   return m;
 }
 
-// partial[g][0][c] = sum x, partial[g][1][c] = sum x^2 over this block's pixels
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+// partial[g][0][c] = sum (x - K), partial[g][1][c] = sum (x - K)^2 over this block's pixels, with the pivot
+// K[c] = x[0][c] (the first pixel): shifted sums keep E[d^2] - E[d]^2 free of the cancellation that the raw
+// moments suffer when |mean| >> std.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
                                                          long P, int C) {
   extern __shared__ float sm[];  // [rows][2][C]
   const ColMap m = col_map(C);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   if (m.active) {
+    const f32x4 piv = ld4(x + m.cv * 4);
     for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * C + m.cv * 4);
+      const f32x4 v = ld4(x + p * C + m.cv * 4) - piv;
       s += v;
       q += v * v;
     }
@@ -55,9 +59,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* mean,
-                                   float* invstd, float* running_mean, float* running_var, float momentum,
-                                   float eps) {
+template <typename T>
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, const T* __restrict__ x, int G, long P,
+                                   int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                                   float momentum, float eps) {
   const int c = blockIdx.x;  // one wave per channel
   double s = 0.0, q = 0.0;
   for (int g = threadIdx.x; g < G; g += 64) {
@@ -67,9 +72,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int G, lon
   s = wave_sum_d(s);
   q = wave_sum_d(q);
   if (threadIdx.x != 0) return;
-  const double mu = s / (double)P;
-  double var = q / (double)P - mu * mu;
+  const double dm = s / (double)P;              // mean of (x - pivot)
+  double var = q / (double)P - dm * dm;
   if (var < 0.0) var = 0.0;
+  const double mu = (double)ld1(x + c) + dm;
   mean[c] = (float)mu;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (running_mean) {
@@ -88,11 +94,12 @@ __global__ void bn_eval_stats_kernel(const float* running_mean, const float* run
 }
 
 // y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
-                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       const T* __restrict__ residual, T* __restrict__ y,
                                                        long P, int C, int relu) {
   const ColMap m = col_map(C);
   if (!m.active) return;
@@ -105,20 +112,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
   for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
     const long o = p * C + m.cv * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + o) * sc + sf;
-    if (residual) v += *reinterpret_cast<const f32x4*>(residual + o);
+    f32x4 v = ld4(x + o) * sc + sf;
+    if (residual) v += ld4(residual + o);
     if (relu) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
     }
-    *reinterpret_cast<f32x4*>(y + o) = v;
+    st4(y + o, v);
   }
 }
 
 // backward pass 1: partial[g][0][c] = sum dz, partial[g][1][c] = sum dz*xhat ; dz = relu ? dy*(y>0) : dy
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy,
-                                                             const float* __restrict__ x,
-                                                             const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ dy,
+                                                             const T* __restrict__ x,
+                                                             const T* __restrict__ y,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              float* __restrict__ partial, long P, int C, int relu) {
@@ -134,13 +142,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
     for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
       const long o = p * C + m.cv * 4;
-      f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+      f32x4 g = ld4(dy + o);
       if (relu) {
-        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+        const f32x4 yy = ld4(y + o);
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
       }
-      const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+      const f32x4 xh = (ld4(x + o) - mu) * is;
       s += g;
       q += g * xh;
     }
@@ -178,13 +186,14 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G,
 }
 
 // backward pass 2: dx = gamma*invstd*(dz - c1 - xhat*c2) ; dres (=|+=) dz
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long P, int C, int relu,
+                                                           const float* __restrict__ coef, T* __restrict__ dx,
+                                                           T* __restrict__ dres, long P, int C, int relu,
                                                            int acc_dx, int acc_dres) {
   const ColMap m = col_map(C);
   if (!m.active) return;
@@ -200,26 +209,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
     const long o = p * C + m.cv * 4;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+    f32x4 g = ld4(dy + o);
     if (relu) {
-      const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+      const f32x4 yy = ld4(y + o);
 #pragma unroll
       for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
     }
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * is;
+    const f32x4 xh = (ld4(x + o) - mu) * is;
     f32x4 d = gi * (g - c1 - xh * c2);
-    if (acc_dx) d += *reinterpret_cast<const f32x4*>(dx + o);
-    *reinterpret_cast<f32x4*>(dx + o) = d;
+    if (acc_dx) d += ld4(dx + o);
+    st4(dx + o, d);
     if (dres) {
       f32x4 r = g;
-      if (acc_dres) r += *reinterpret_cast<const f32x4*>(dres + o);
-      *reinterpret_cast<f32x4*>(dres + o) = r;
+      if (acc_dres) r += ld4(dres + o);
+      st4(dres + o, r);
     }
   }
 }
 
 // per-channel sum over pixels (bias gradients): partial then finalize
-__global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sum_partial_kernel(const T* __restrict__ x,
                                                                float* __restrict__ partial, long P, int C) {
   // scalar-channel version: works for any C (17, 2, ...)
   extern __shared__ float sm[];  // [rows][C]
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const float* __re
   const bool active = prow < rows && C <= 256;
   float s = 0.f;
   if (active) {
-    for (long p = (long)blockIdx.x * rows + prow; p < P; p += (long)gridDim.x * rows) s += x[p * C + c];
+    for (long p = (long)blockIdx.x * rows + prow; p < P; p += (long)gridDim.x * rows) s += ld1(x + p * C + c);
     sm[prow * C + c] = s;
   }
   __syncthreads();
@@ -257,27 +267,91 @@ static inline int bn_grid(long P, int C) {
 }
 static inline bool bn_shape_ok(long P, int C) { return P > 0 && C >= 4 && (C % 4) == 0 && C <= 1024; }
 
-extern "C" {
-
-long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
-
-// train-mode statistics: mean/invstd out, running stats updated in place (may be null)
-int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd, float* running_mean,
-                      float* running_var, float momentum, float eps, float* ws, hipStream_t s) {
-  FAMI_REQUIRE(x && mean && invstd && ws, "fami_bn_stats_f32", "null pointer");
+// ------------------------------------------------------------------ host side (templates over the storage type)
+template <typename T>
+static int bn_stats_impl(const T* x, long P, int C, float* mean, float* invstd, float* running_mean,
+                         float* running_var, float momentum, float eps, float* ws, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(x && mean && invstd && ws, nm, "null pointer");
   if (!bn_shape_ok(P, C)) {
-    fami_set_error("fami_bn_stats_f32", "C must be a multiple of 4, <= 1024");
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
     return FAMI_ESHAPE;
   }
   const int G = bn_grid(P, C);
   const int rows = 256 / (C >> 2);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x, ws, P, C);
-  FAMI_CHECK_LAUNCH("fami_bn_stats_f32/partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, ws, G, P, C, mean, invstd,
-                     running_mean, running_var, momentum, eps);
-  FAMI_CHECK_LAUNCH("fami_bn_stats_f32/finalize");
+  hipLaunchKernelGGL(bn_partial_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x, ws, P, C);
+  FAMI_CHECK_LAUNCH(nm);
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(C), dim3(64), 0, s, ws, x, G, P, C, mean, invstd, running_mean,
+                     running_var, momentum, eps);
+  FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
+
+template <typename T>
+static int bn_apply_impl(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         const T* residual, T* y, long P, int C, int relu, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(x && mean && invstd && gamma && beta && y, nm, "null pointer");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  const int rows = 256 / (C >> 2);
+  long g = (P + rows - 1) / rows;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((int)g), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, y, P,
+                     C, relu);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
+template <typename T>
+static int bn_bwd_impl(const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
+                       const float* gamma, T* dx, float* dgamma, float* dbeta, T* dres, long P, int C, int relu,
+                       int acc_dx, int acc_param, int acc_dres, float* ws, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(dy && x && mean && invstd && gamma && dx && ws, nm, "null pointer");
+  FAMI_REQUIRE(!relu || y, nm, "relu needs y");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  const int G = bn_grid(P, C);
+  const int rows = 256 / (C >> 2);
+  float* coef = ws + (long)BN_MAXG * 2 * C - 2 * C;  // tail of the workspace (G < BN_MAXG leaves it free)
+  const int Gp = G < BN_MAXG ? G : BN_MAXG - 1;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(Gp), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y,
+                     mean, invstd, ws, P, C, relu);
+  FAMI_CHECK_LAUNCH(nm);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma, dbeta, acc_param);
+  FAMI_CHECK_LAUNCH(nm);
+  long g = (P + rows - 1) / rows;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((int)g), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, dx,
+                     dres, P, C, relu, acc_dx, acc_dres);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
+template <typename T>
+static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s,
+                            const char* nm) {
+  FAMI_REQUIRE(x && out && ws && P > 0 && C > 0, nm, "bad argument");
+  if (C > 256) {
+    fami_set_error(nm, "C > 256 unsupported");
+    return FAMI_ESHAPE;
+  }
+  const int rows = 256 / C;
+  long g = (P + rows - 1) / rows;
+  if (g > BN_MAXG) g = BN_MAXG;
+  hipLaunchKernelGGL(chan_sum_partial_kernel<T>, dim3((int)g), dim3(256), (size_t)rows * C * sizeof(float), s, x, ws, P, C);
+  FAMI_CHECK_LAUNCH(nm);
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
+extern "C" {
+
+long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
+long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
 
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                            float eps, hipStream_t s) {
@@ -288,67 +362,29 @@ int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, 
   return FAMI_OK;
 }
 
-int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      const float* residual, float* y, long P, int C, int relu, hipStream_t s) {
-  FAMI_REQUIRE(x && mean && invstd && gamma && beta && y, "fami_bn_apply_f32", "null pointer");
-  if (!bn_shape_ok(P, C)) {
-    fami_set_error("fami_bn_apply_f32", "C must be a multiple of 4, <= 1024");
-    return FAMI_ESHAPE;
+#define FAMI_BN_ABI(sfx, T)                                                                                            \
+  /* train-mode statistics: mean/invstd out, running stats updated in place (may be null) */                          \
+  int fami_bn_stats_##sfx(const T* x, long P, int C, float* mean, float* invstd, float* running_mean,                  \
+                          float* running_var, float momentum, float eps, float* ws, hipStream_t s) {                   \
+    return bn_stats_impl<T>(x, P, C, mean, invstd, running_mean, running_var, momentum, eps, ws, s, "fami_bn_stats_" #sfx); \
+  }                                                                                                                    \
+  int fami_bn_apply_##sfx(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta,   \
+                          const T* residual, T* y, long P, int C, int relu, hipStream_t s) {                           \
+    return bn_apply_impl<T>(x, mean, invstd, gamma, beta, residual, y, P, C, relu, s, "fami_bn_apply_" #sfx);          \
+  }                                                                                                                    \
+  /* dz = relu ? dy*(y>0) : dy ; dx (=|+=) BN-backward(dz) ; dgamma/dbeta (=|+=) ; dres (=|+=) dz */                   \
+  int fami_bn_bwd_##sfx(const T* dy, const T* x, const T* y, const float* mean, const float* invstd,                   \
+                        const float* gamma, T* dx, float* dgamma, float* dbeta, T* dres, long P, int C, int relu,      \
+                        int acc_dx, int acc_param, int acc_dres, float* ws, hipStream_t s) {                           \
+    return bn_bwd_impl<T>(dy, x, y, mean, invstd, gamma, dx, dgamma, dbeta, dres, P, C, relu, acc_dx, acc_param,       \
+                          acc_dres, ws, s, "fami_bn_bwd_" #sfx);                                                       \
+  }                                                                                                                    \
+  /* out[c] (=|+=) sum_p x[p][c], any C <= 256 */                                                                      \
+  int fami_channel_sum_##sfx(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {        \
+    return channel_sum_impl<T>(x, P, C, out, accumulate, ws, s, "fami_channel_sum_" #sfx);                             \
   }
-  const int rows = 256 / (C >> 2);
-  long g = (P + rows - 1) / rows;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)g), dim3(256), 0, s, x, mean, invstd, gamma, beta, residual, y, P, C,
-                     relu);
-  FAMI_CHECK_LAUNCH("fami_bn_apply_f32");
-  return FAMI_OK;
-}
-
-// dz = relu ? dy*(y>0) : dy ; dx (=|+=) BN-backward(dz) ; dgamma/dbeta (=|+=) ; dres (=|+=) dz
-int fami_bn_bwd_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
-                    const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long P, int C, int relu,
-                    int acc_dx, int acc_param, int acc_dres, float* ws, hipStream_t s) {
-  FAMI_REQUIRE(dy && x && mean && invstd && gamma && dx && ws, "fami_bn_bwd_f32", "null pointer");
-  FAMI_REQUIRE(!relu || y, "fami_bn_bwd_f32", "relu needs y");
-  if (!bn_shape_ok(P, C)) {
-    fami_set_error("fami_bn_bwd_f32", "C must be a multiple of 4, <= 1024");
-    return FAMI_ESHAPE;
-  }
-  const int G = bn_grid(P, C);
-  const int rows = 256 / (C >> 2);
-  float* coef = ws + (long)BN_MAXG * 2 * C - 2 * C;  // tail of the workspace (G < BN_MAXG leaves it free)
-  const int Gp = G < BN_MAXG ? G : BN_MAXG - 1;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(Gp), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y,
-                     mean, invstd, ws, P, C, relu);
-  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma,
-                     dbeta, acc_param);
-  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/finalize");
-  long g = (P + rows - 1) / rows;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)g), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, coef, dx,
-                     dres, P, C, relu, acc_dx, acc_dres);
-  FAMI_CHECK_LAUNCH("fami_bn_bwd_f32/apply");
-  return FAMI_OK;
-}
-
-long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
-
-// out[c] (=|+=) sum_p x[p][c], any C <= 256
-int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {
-  FAMI_REQUIRE(x && out && ws && P > 0 && C > 0, "fami_channel_sum_f32", "bad argument");
-  if (C > 256) {
-    fami_set_error("fami_channel_sum_f32", "C > 256 unsupported");
-    return FAMI_ESHAPE;
-  }
-  const int rows = 256 / C;
-  long g = (P + rows - 1) / rows;
-  if (g > BN_MAXG) g = BN_MAXG;
-  hipLaunchKernelGGL(chan_sum_partial_kernel, dim3((int)g), dim3(256), (size_t)rows * C * sizeof(float), s, x, ws, P, C);
-  FAMI_CHECK_LAUNCH("fami_channel_sum_f32/partial");
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
-  FAMI_CHECK_LAUNCH("fami_channel_sum_f32/finalize");
-  return FAMI_OK;
-}
+FAMI_BN_ABI(f32, float)
+FAMI_BN_ABI(bf16, bf16_t)
+#undef FAMI_BN_ABI
 
 }  // extern "C"

@@ -6,8 +6,11 @@ the tape in reverse is the backward pass.  There is no tracing compiler and no
 torch compute op on this path: torch provides device memory (tensors), the
 stream and (optionally) hipGraph capture of the whole launch sequence.
 
-Activations are fp32 NHWC (`T.data` of shape [N,H,W,C]); small dense tensors
-(the translation regressor) are [M,K].
+Activations are NHWC (`T.data` of shape [N,H,W,C]) in the engine's activation dtype -- fp32 (parity
+configuration) or bf16 (BASELINE config 3: bf16 storage + bf16 MFMA convolutions, fp32 accumulation) -- and
+every activation-touching C-ABI entry point exists as a `_f32` / `_bf16` pair.  Heatmap-producing convolutions
+write fp32 in either mode; parameters, BatchNorm statistics, weight gradients, the translation regressor's
+dense layers ([M,K] tensors) and everything at the NCHW boundary are always fp32.
 """
 import ctypes
 
@@ -22,15 +25,21 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-class T:
-    """Engine tensor: NHWC (or 2-D) fp32 storage + lazily allocated gradient."""
-    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1')
+def _sfx(t):
+    return '_bf16' if t.dtype == torch.bfloat16 else '_f32'
 
-    def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0):
+
+class T:
+    """Engine tensor: NHWC (or 2-D) storage + lazily allocated gradient.  `f32grad`: the gradient is fp32
+    regardless of the activation dtype (dense [M,K] tensors of the translation regressor)."""
+    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad')
+
+    def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0, f32grad=False):
         self.data = data
         self.grad = None
         self.requires_grad = requires_grad
         self.parent, self.n0, self.n1 = parent, n0, n1
+        self.f32grad = f32grad
 
     @property
     def shape(self):
@@ -38,7 +47,10 @@ class T:
 
 
 class Engine:
-    def __init__(self, device, grad_views=None, record=True):
+    def __init__(self, device, grad_views=None, record=True, dtype=torch.float32):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.dt = dtype                # activation storage dtype
+        self.sfx = '_bf16' if dtype == torch.bfloat16 else '_f32'
         self.L = lib()
         self.record = record           # False: forward only (no tape, no gradient flags)
         self.dev = device
@@ -63,11 +75,22 @@ class Engine:
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.dev)
 
+    def act(self, *shape):
+        """Uninitialised activation-typed buffer."""
+        return torch.empty(shape, dtype=self.dt, device=self.dev)
+
+    def acall(self, name, *args):
+        """Call the activation-dtype instance of an entry point."""
+        self.L.call(name + self.sfx, *args, self.stream)
+
+    def new_grad(self, t):
+        return torch.empty(t.data.shape, dtype=torch.float32 if t.f32grad else self.dt, device=self.dev)
+
     def ws(self, nbytes):
         return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=self.dev)
 
     def fill(self, t, v=0.0):
-        self.call('fami_fill_f32', _p(t), t.numel(), float(v))
+        self.call('fami_fill' + _sfx(t), _p(t), t.numel(), float(v))
         return t
 
     def gbuf(self, t):
@@ -76,10 +99,10 @@ class Engine:
             if t.parent is not None:
                 par = t.parent
                 if par.grad is None:
-                    par.grad = self.fill(torch.empty_like(par.data))
+                    par.grad = self.fill(self.new_grad(par))
                 t.grad = par.grad[t.n0:t.n1]
                 return t.grad, 1
-            t.grad = torch.empty_like(t.data)
+            t.grad = self.new_grad(t)
             return t.grad, 0
         return t.grad, 1
 
@@ -100,14 +123,19 @@ class Engine:
 
     def packed(self, w, mode):
         Co, Ci, kh, kw = w.shape
-        key = (w.data_ptr(), mode, w.shape)
+        key = (w.data_ptr(), mode, w.shape, self.dt)
         if not w.requires_grad:
             hit = Engine._pack_cache.get(key)
             if hit is not None and hit[0] == w._version:
                 return hit[1]
-        n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
-        wp = self.empty(n)
-        self.call('fami_pack_conv_weight_f32', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
+        if self.dt == torch.bfloat16:
+            n = self.L.cdll.fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode)
+            wp = self.act(n)
+            self.call('fami_pack_conv_weight_bf16', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
+        else:
+            n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
+            wp = self.empty(n)
+            self.call('fami_pack_conv_weight_f32', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
         if not w.requires_grad:
             Engine._pack_cache[key] = (w._version, wp)
         return wp
@@ -117,22 +145,22 @@ class Engine:
         """Alignment_V15.py:115-119: key + S supporting frames stacked on the batch axis (frame-major)."""
         B, _, H, W = kf_x.shape
         S = 0 if sup_x is None else sup_x.shape[1] // 3
-        out = self.empty((1 + S) * B, H, W, 3)
-        self.call('fami_pack_frames_f32', _p(kf_x.contiguous()), _p(None if sup_x is None else sup_x.contiguous()),
+        out = self.act((1 + S) * B, H, W, 3)
+        self.acall('fami_pack_frames', _p(kf_x.contiguous()), _p(None if sup_x is None else sup_x.contiguous()),
                   _p(out), B, S, H, W)
         return T(out)
 
     def from_nchw(self, x, requires_grad=False):
         N, C, H, W = x.shape
-        out = self.empty(N, H, W, C)
-        self.call('fami_nchw_to_nhwc_f32', _p(x.contiguous()), _p(out), N, C, H, W)
+        out = self.act(N, H, W, C)
+        self.acall('fami_nchw_to_nhwc', _p(x.contiguous()), _p(out), N, C, H, W)
         return T(out, requires_grad)
 
     def to_nchw(self, x):
         """-> torch tensor [N,C,H,W]; gradient comes back through seed()."""
         N, H, W, C = x.shape
         out = self.empty(N, C, H, W)
-        self.call('fami_nhwc_to_nchw_f32', _p(x.data), _p(out), N, C, H, W, 0)
+        self.call('fami_nhwc_to_nchw' + _sfx(x.data), _p(x.data), _p(out), N, C, H, W, 0)
         return out
 
     def seed_nchw(self, x, g_nchw):
@@ -142,23 +170,29 @@ class Engine:
         N, H, W, C = x.shape
         g, acc = self.gbuf(x)
         if acc:
-            tmp = self.empty(N, H, W, C)
-            self.call('fami_nchw_to_nhwc_f32', _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
-            self.call('fami_axpby_f32', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
+            tmp = torch.empty_like(g)
+            self.call('fami_nchw_to_nhwc' + _sfx(g), _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
+            self.call('fami_axpby' + _sfx(g), _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
         else:
-            self.call('fami_nchw_to_nhwc_f32', _p(g_nchw.contiguous()), _p(g), N, C, H, W)
+            self.call('fami_nchw_to_nhwc' + _sfx(g), _p(g_nchw.contiguous()), _p(g), N, C, H, W)
 
     # ------------------------------------------------------------------ conv / bn
-    def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False):
+    def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False):
+        """nn.Conv2d.  out_f32: write fp32 even in bf16 mode (heatmap-producing layers)."""
         N, H, W, Ci = x.shape
         Co, Ci2, kh, kw = weight.shape
         assert Ci2 == Ci, (x.shape, weight.shape)
         Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
-        y = self.empty(N, Ho, Wo, Co)
         wp = self.packed(weight, 0)
-        self.call('fami_conv2d_fwd_f32', _p(x.data), _p(wp), _p(None if bias is None else bias.data), None, _p(y),
-                  N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0)
+        if self.dt == torch.bfloat16:
+            y = self.empty(N, Ho, Wo, Co) if out_f32 else self.act(N, Ho, Wo, Co)
+            self.call('fami_conv2d_fwd_bf16', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
+                      N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0, int(out_f32))
+        else:
+            y = self.empty(N, Ho, Wo, Co)
+            self.call('fami_conv2d_fwd_f32', _p(x.data), _p(wp), _p(None if bias is None else bias.data), None,
+                      _p(y), N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0)
         need_w = self.rq(weight) or self.rq(bias)
         out = T(y, x.requires_grad or need_w)
         if out.requires_grad:
@@ -173,15 +207,18 @@ class Engine:
                     g, acc = self.pgrad(weight)
                     nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
                     ws = self.ws(nb)
-                    self.call('fami_conv2d_wgrad_f32', _p(x.data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                    self.acall('fami_conv2d_wgrad', _p(x.data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
                 if self.rq(bias):
                     g, acc = self.pgrad(bias)
                     ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
-                    self.call('fami_channel_sum_f32', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
+                    self.acall('fami_channel_sum', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
                 if x.requires_grad:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
-                    self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
+                    if self.dt == torch.bfloat16:
+                        self.call('fami_conv2d_dgrad_bf16', _p(dy), _p(wpd), _p(gx), *geo, acc)
+                    else:
+                        self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
             self.tape.append((bwd, [weight, bias]))
         return out
 
@@ -194,14 +231,14 @@ class Engine:
         if bn.training:
             ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
-            self.call('fami_bn_stats_f32', _p(x.data), P, C, _p(mean), _p(invstd), _p(bn.running_mean),
-                      _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+            self.acall('fami_bn_stats', _p(x.data), P, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                       _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
             self.bn_trained.append(bn)
         else:
             self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd), C,
                       float(bn.eps))
         y = torch.empty_like(x.data)
-        self.call('fami_bn_apply_f32', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
+        self.acall('fami_bn_apply', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
                   _p(None if residual is None else residual.data), _p(y), P, C, int(relu))
         need_p = self.rq(bn.weight)
         rg = x.requires_grad or need_p or (residual is not None and residual.requires_grad)
@@ -214,7 +251,7 @@ class Engine:
                     return
                 if not training:
                     raise NotImplementedError("backward through eval-mode BatchNorm is outside the training hot path")
-                gx, accx = self.gbuf(x) if x.requires_grad else (self.empty(*shp), 0)
+                gx, accx = self.gbuf(x) if x.requires_grad else (self.act(*shp), 0)
                 gg = gb = None
                 accp = 0
                 if need_p:
@@ -224,9 +261,9 @@ class Engine:
                 if residual is not None and residual.requires_grad:
                     gr, accr = self.gbuf(residual)
                 ws = self.ws(self.L.cdll.fami_bn_workspace(C))
-                self.call('fami_bn_bwd_f32', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
-                          _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
-                          _p(ws))
+                self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
+                           _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
+                           _p(ws))
             self.tape.append((bwd, [bn.weight, bn.bias]))
         return out
 
@@ -247,8 +284,8 @@ class Engine:
             if bn.training:
                 ws = self.ws(self.L.cdll.fami_bn_workspace(C))
                 mom = 0.1 if bn.momentum is None else bn.momentum
-                self.call('fami_bn_stats_f32', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
-                          _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+                self.acall('fami_bn_stats', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                           _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
                 self.bn_trained.append(bn)
             else:
                 self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
@@ -261,8 +298,8 @@ class Engine:
         gam_a = PA(*[None if t[1] is None else _p(t[1].weight.data) for t in terms])
         bet_a = PA(*[None if t[1] is None else _p(t[1].bias.data) for t in terms])
         sh_a = (ctypes.c_int * k)(*[t[2] for t in terms])
-        y = self.empty(N, H, W, C)
-        self.call('fami_fuse_sum_f32', k, xs, mean_a, inv_a, gam_a, bet_a, sh_a, _p(y), N, H, W, C, 1)
+        y = self.act(N, H, W, C)
+        self.acall('fami_fuse_sum', k, xs, mean_a, inv_a, gam_a, bet_a, sh_a, _p(y), N, H, W, C, 1)
         rg = any(t[0].requires_grad or (t[1] is not None and self.rq(t[1].weight)) for t in terms)
         out = T(y, rg)
         if rg:
@@ -274,7 +311,7 @@ class Engine:
                     if bn is None:
                         if x.requires_grad:
                             g, acc = self.gbuf(x)
-                            self.call('fami_relu_bwd_f32', _p(dy), _p(y), _p(g), y.numel(), acc)
+                            self.acall('fami_relu_bwd', _p(dy), _p(y), _p(g), y.numel(), acc)
                         continue
                     if not bn.training:
                         raise NotImplementedError("backward through eval-mode BatchNorm")
@@ -290,13 +327,13 @@ class Engine:
                         gb, _ = self.pgrad(bn.bias)
                     ws = self.ws(self.L.cdll.fami_bn_workspace(C))
                     if s == 0:
-                        self.call('fami_bn_bwd_f32', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
-                                  _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
+                        self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
+                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
                     else:
                         low = torch.empty_like(x.data)
-                        self.call('fami_pool_relu_bwd_f32', _p(dy), _p(y), _p(low), N, H >> s, W >> s, C, s, 1)
-                        self.call('fami_bn_bwd_f32', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
-                                  _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
+                        self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> s, W >> s, C, s, 1)
+                        self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
+                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
             self.tape.append((bwd, [q for t in terms if t[1] is not None for q in (t[1].weight, t[1].bias)]))
         return out
 
@@ -307,7 +344,7 @@ class Engine:
 
     def sub(self, a, b):
         y = torch.empty_like(a.data)
-        self.call('fami_axpby_f32', _p(a.data), _p(b.data), _p(y), y.numel(), 1.0, -1.0)
+        self.acall('fami_axpby', _p(a.data), _p(b.data), _p(y), y.numel(), 1.0, -1.0)
         out = T(y, a.requires_grad or b.requires_grad)
         if out.requires_grad:
             def bwd():
@@ -316,7 +353,7 @@ class Engine:
                 for t, sgn in ((a, 1.0), (b, -1.0)):
                     if t.requires_grad:
                         g, acc = self.gbuf(t)
-                        self.call('fami_axpby_f32', _p(out.grad), _p(g) if acc else None, _p(g), g.numel(), sgn, 1.0)
+                        self.acall('fami_axpby', _p(out.grad), _p(g) if acc else None, _p(g), g.numel(), sgn, 1.0)
             self.tape.append((bwd, ()))
         return out
 
@@ -325,11 +362,11 @@ class Engine:
         N, H, W, _ = xs[0].shape
         Ct = sum(x.shape[3] for x in xs)
         P = N * H * W
-        y = self.empty(N, H, W, Ct)
+        y = self.act(N, H, W, Ct)
         off = 0
         for x in xs:
             c = x.shape[3]
-            self.call('fami_copy_channels_f32', _p(x.data), _p(y), P, c, 0, Ct, off, c, 0)
+            self.acall('fami_copy_channels', _p(x.data), _p(y), P, c, 0, Ct, off, c, 0)
             off += c
         out = T(y, any(x.requires_grad for x in xs))
         if out.requires_grad:
@@ -341,7 +378,7 @@ class Engine:
                     c = x.shape[3]
                     if x.requires_grad:
                         g, acc = self.gbuf(x)
-                        self.call('fami_copy_channels_f32', _p(out.grad), _p(g), P, Ct, o, c, 0, c, acc)
+                        self.acall('fami_copy_channels', _p(out.grad), _p(g), P, Ct, o, c, 0, c, acc)
                     o += c
             self.tape.append((bwd, ()))
         return out
@@ -350,8 +387,8 @@ class Engine:
         """nn.Flatten on an NCHW tensor: [N,H,W,C] -> [N, C*H*W] in (c,h,w) order (Alignment_V15.py:68)."""
         N, H, W, C = x.shape
         y = self.empty(N, C * H * W)
-        self.call('fami_nhwc_to_nchw_f32', _p(x.data), _p(y), N, C, H, W, 0)
-        out = T(y, x.requires_grad)
+        self.acall('fami_nhwc_to_nchw', _p(x.data), _p(y), N, C, H, W, 0)
+        out = T(y, x.requires_grad, f32grad=True)
         if out.requires_grad:
             def bwd():
                 if out.grad is None:
@@ -359,10 +396,10 @@ class Engine:
                 g, acc = self.gbuf(x)
                 if acc:
                     tmp = torch.empty_like(g)
-                    self.call('fami_nchw_to_nhwc_f32', _p(out.grad), _p(tmp), N, C, H, W)
-                    self.call('fami_axpby_f32', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
+                    self.acall('fami_nchw_to_nhwc', _p(out.grad), _p(tmp), N, C, H, W)
+                    self.acall('fami_axpby', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
                 else:
-                    self.call('fami_nchw_to_nhwc_f32', _p(out.grad), _p(g), N, C, H, W)
+                    self.acall('fami_nchw_to_nhwc', _p(out.grad), _p(g), N, C, H, W)
             self.tape.append((bwd, ()))
         return out
 
@@ -373,7 +410,7 @@ class Engine:
         self.call('fami_linear_fwd_f32', _p(x.data), _p(lin.weight.data), _p(None if lin.bias is None else lin.bias.data),
                   _p(y), M, K, Nn)
         need_p = self.rq(lin.weight)
-        out = T(y, x.requires_grad or need_p)
+        out = T(y, x.requires_grad or need_p, f32grad=True)
         if out.requires_grad:
             def bwd():
                 if out.grad is None:
@@ -396,7 +433,7 @@ class Engine:
         """kornia warp_affine with a pure translation t=[B,2]=(tx,ty) (Alignment_V15.py:133-135)."""
         B, H, W, C = x.shape
         y = torch.empty_like(x.data)
-        self.call('fami_shift_bilinear_fwd_f32', _p(x.data), _p(t.data), _p(y), B, H, W, C)
+        self.acall('fami_shift_bilinear_fwd', _p(x.data), _p(t.data), _p(y), B, H, W, C)
         out = T(y, x.requires_grad or t.requires_grad)
         if out.requires_grad:
             def bwd():
@@ -409,8 +446,8 @@ class Engine:
                 if t.requires_grad:
                     gt, acct = self.gbuf(t)
                 ws = self.ws(self.L.cdll.fami_shift_workspace(B))
-                self.call('fami_shift_bilinear_bwd_f32', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
-                          W, C, accs, acct, _p(ws))
+                self.acall('fami_shift_bilinear_bwd', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
+                           W, C, accs, acct, _p(ws))
             self.tape.append((bwd, ()))
         return out
 
@@ -422,9 +459,9 @@ class Engine:
         n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
         wp = self.empty(n)
         self.call('fami_dcn_pack_weight_f32', _p(weight.data), _p(wp), Co, C, kh, kw, G)
-        y = self.empty(B, H, W, Co)
-        self.call('fami_dcn_fwd_f32', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
-                  C, Co, G, kh, kw, 1, pad, dil)
+        y = self.act(B, H, W, Co)
+        self.acall('fami_dcn_fwd', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
+                   C, Co, G, kh, kw, 1, pad, dil)
         rg = x.requires_grad or off.requires_grad or msk.requires_grad or self.rq(weight)
         out = T(y, rg)
         if rg:
@@ -437,27 +474,33 @@ class Engine:
                 nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
                 wpb = self.empty(nwp)
                 self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
-                col = self.empty(P, CK) if self.rq(weight) else None
-                gx = goff = gmsk = None
-                acco = 0
+                col = self.act(P, CK) if self.rq(weight) else None
+                gx = gx32 = goff = gmsk = None
+                acco = accx = 0
                 if x.requires_grad:
                     gx, accx = self.gbuf(x)
-                    if not accx:
-                        self.fill(gx)
+                    if self.dt == torch.bfloat16:      # the scatter accumulates in an fp32 buffer (float atomics)
+                        gx32 = self.fill(self.empty(*gx.shape))
+                    else:
+                        gx32 = gx
+                        if not accx:
+                            self.fill(gx)
                 if off.requires_grad:
                     goff, acco = self.gbuf(off)
                     gmsk, accm = self.gbuf(msk)
                     assert acco == accm
-                self.call('fami_dcn_bwd_f32', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
-                          _p(gx), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
+                self.acall('fami_dcn_bwd', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                           _p(gx32), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
+                if gx is not None and gx32 is not gx:
+                    self.call('fami_cast_add_bf16', _p(gx32), _p(gx), gx.numel(), accx)
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)
                     ws = self.ws(self.L.cdll.fami_conv2d_wgrad_workspace(*geo))
-                    self.call('fami_conv2d_wgrad_f32', _p(col), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                    self.acall('fami_conv2d_wgrad', _p(col), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
-                    self.call('fami_channel_sum_f32', _p(dy), P, Co, _p(gb), accb, _p(ws2))
+                    self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
             self.tape.append((bwd, [weight, bias]))
         return out
 

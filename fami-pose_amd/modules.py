@@ -19,8 +19,8 @@ def _conv(cin, cout, k, stride=1, pad=0, dil=1, bias=False):
     return nn.Conv2d(cin, cout, k, stride, pad, dil, bias=bias)
 
 
-def run_conv(eng, conv, x):
-    return eng.conv(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0])
+def run_conv(eng, conv, x, out_f32=False):
+    return eng.conv(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], out_f32=out_f32)
 
 
 class conv_bn_relu(nn.Module):
@@ -246,5 +246,5 @@ class HRNetBody(nn.Module):
                     # branches (hrnet.py:156-157,323): HRNet.forward returns these branch outputs
                     stage4_in = list(ys)
                 ys = mod.run_fuse(eng, ys)
-        hm = run_conv(eng, self.final_layer, ys[0])
+        hm = run_conv(eng, self.final_layer, ys[0], out_f32=True)     # heatmaps are fp32 in every mode
         return hm, ys, stage4_in

@@ -14,7 +14,8 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, body, n_in, *tensors):
         inputs, params = tensors[:n_in], tensors[n_in:]
-        eng = Engine(inputs[0].device, grad_views=getattr(owner, '_grad_views', None), record=True)
+        eng = Engine(inputs[0].device, grad_views=getattr(owner, '_grad_views', None), record=True,
+                     dtype=owner.act_dtype)
         outs, seeds = body(eng, *inputs)
         owner._advance_bn_counters(eng)
         ctx.eng, ctx.seeds, ctx.params, ctx.n_in = eng, seeds, params, n_in
@@ -39,6 +40,16 @@ class EngineModule(nn.Module):
     _nbt_flat = None
     _nbt_index = None
     _nbt_inc = None
+    act_dtype = torch.float32      # activation storage / conv MFMA dtype of the HIP engine (fp32 | bf16)
+
+    def set_compute_dtype(self, dtype):
+        """'f32' (parity configuration: exact-f32 MFMA) or 'bf16' (bf16 activations + bf16 MFMA, fp32 accumulation,
+        fp32 master weights -- BASELINE config 3).  Parameters stay fp32 either way."""
+        dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}.get(dtype, dtype)
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('compute dtype must be f32 or bf16')
+        self.act_dtype = dtype
+        return self
 
     def _trainable(self):
         return [p for p in self.parameters() if p.requires_grad]
@@ -50,7 +61,7 @@ class EngineModule(nn.Module):
         inputs = tuple(t.float().contiguous() for t in inputs)
         params = self._trainable() if torch.is_grad_enabled() else []
         if not params:
-            eng = Engine(inputs[0].device, record=False)
+            eng = Engine(inputs[0].device, record=False, dtype=self.act_dtype)
             outs, _ = body(eng, *inputs)
             self._advance_bn_counters(eng)
             return tuple(outs)

@@ -172,7 +172,7 @@ class Trainer:
     # ------------------------------------------------------------------ the step (eager launch sequence)
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
         model = self.model
-        eng = Engine(self.dev, grad_views=self.views)
+        eng = Engine(self.dev, grad_views=self.views, dtype=getattr(model, 'act_dtype', torch.float32))
         if self.targets_from_joints:
             # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
             joints, vis = target, weight

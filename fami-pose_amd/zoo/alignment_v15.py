@@ -156,7 +156,7 @@ class Alignment_V15(EngineModule):
         al = self._dcn(eng, 3, comb, agg_sup)
         al = self._dcn(eng, 4, al, al)
         all_agg = self.init_feature_agg_block.run(eng, eng.concat([kf, al]))
-        final = run_conv(eng, self.agg_final_layer, all_agg)
+        final = run_conv(eng, self.agg_final_layer, all_agg, out_f32=True)
 
         outs = [eng.to_nchw(final), eng.to_nchw(kf_hm)]
         seeds = [lambda g: eng.seed_nchw(final, g), lambda g: eng.seed_nchw(kf_hm, g)]
@@ -167,7 +167,7 @@ class Alignment_V15(EngineModule):
 
             def label_mi(f):     # feat_label_mi_estimation: A = hrnet.final_layer(Feat).detach(), Bt = final_hm
                 a = eng.conv(_detached(f), fl.weight.detach(), None if fl.bias is None else fl.bias.detach(),
-                             fl.stride[0], fl.padding[0], fl.dilation[0])
+                             fl.stride[0], fl.padding[0], fl.dilation[0], out_f32=True)
                 return eng.softmax_kl(eng.to_nchw(a), final, MI_TEMPERATURE)
 
             def feat_mi(f1, f2):  # feat_feat_mi_estimation: A = F1.detach(), Bt = F2

@@ -89,6 +89,8 @@ int fami_copy_channels_f32(const float* src, float* dst, long P, int Cs, int src
 int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alpha, float beta,
                    fami_stream_t stream);
 int fami_fill_f32(float* out, long n, float v, fami_stream_t stream);
+/* dst (=|+=) src : fp32 accumulation buffer folded into an activation-typed gradient */
+int fami_cast_add_f32(const float* src, float* dst, long n, int accumulate, fami_stream_t stream);
 int fami_incr_i64(long long* v, long n, fami_stream_t stream);
 /* v[i] += inc[i] : BatchNorm num_batches_tracked counters, all layers in one launch */
 int fami_add_i64(long long* v, const long long* inc, long n, fami_stream_t stream);
@@ -153,6 +155,74 @@ int fami_softmax_kl_bwd_f32(const float* A, const float* Bt, const float* stats,
                             float temperature, float gscale, const float* gdev, int accumulate,
                             fami_stream_t stream);
 int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int L, fami_stream_t stream);
+
+
+/* ======================================================================================================
+ * bf16 activation storage (BASELINE config 3: bf16 compute, fp32 master weights / accumulation / losses).
+ * Every entry point above that touches an activation has a `_bf16` twin with identical semantics and argument
+ * order; only the activation pointers change type.  Parameters, BatchNorm statistics, workspaces, the
+ * translation (tx,ty), weight gradients, DCN input-gradient accumulators and everything at the NCHW boundary
+ * stay fp32.  Convolutions run on v_mfma_f32_16x16x32_bf16 with a bf16 packed weight image (KC = Cin/32).
+ * ====================================================================================================== */
+typedef unsigned short fami_bf16_t; /* IEEE bfloat16 bit pattern */
+
+long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode);
+int fami_pack_conv_weight_bf16(const float* w_oihw, fami_bf16_t* wp, int Co, int Ci, int kh, int kw, int mode,
+                               fami_stream_t stream);
+/* y is bf16, or fp32 when out_f32 (heatmap-producing layers) */
+int fami_conv2d_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const float* bias, void* y, int N, int H, int W,
+                         int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,
+                         int out_f32, fami_stream_t stream);
+int fami_conv2d_dgrad_bf16(const fami_bf16_t* dy, const fami_bf16_t* wp, fami_bf16_t* dx, int N, int H, int W, int Ci,
+                           int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                           fami_stream_t stream);
+int fami_conv2d_wgrad_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
+                           int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                           int accumulate, fami_stream_t stream);
+
+int fami_bn_stats_bf16(const fami_bf16_t* x, long P, int C, float* mean, float* invstd, float* running_mean,
+                       float* running_var, float momentum, float eps, float* ws, fami_stream_t stream);
+int fami_bn_apply_bf16(const fami_bf16_t* x, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, const fami_bf16_t* residual, fami_bf16_t* y, long P, int C, int relu,
+                       fami_stream_t stream);
+int fami_bn_bwd_bf16(const fami_bf16_t* dy, const fami_bf16_t* x, const fami_bf16_t* y, const float* mean,
+                     const float* invstd, const float* gamma, fami_bf16_t* dx, float* dgamma, float* dbeta,
+                     fami_bf16_t* dres, long P, int C, int relu, int acc_dx, int acc_param, int acc_dres, float* ws,
+                     fami_stream_t stream);
+int fami_channel_sum_bf16(const fami_bf16_t* x, long P, int C, float* out, int accumulate, float* ws,
+                          fami_stream_t stream);
+
+int fami_nchw_to_nhwc_bf16(const float* src, fami_bf16_t* dst, int N, int C, int H, int W, fami_stream_t stream);
+int fami_nhwc_to_nchw_bf16(const fami_bf16_t* src, float* dst, int N, int C, int H, int W, int accumulate,
+                           fami_stream_t stream);
+int fami_pack_frames_bf16(const float* kf_nchw, const float* sup_nchw, fami_bf16_t* frames_nhwc, int B, int S, int H,
+                          int W, fami_stream_t stream);
+int fami_copy_channels_bf16(const fami_bf16_t* src, fami_bf16_t* dst, long P, int Cs, int src_off, int Cd,
+                            int dst_off, int Cc, int accumulate, fami_stream_t stream);
+int fami_axpby_bf16(const fami_bf16_t* a, const fami_bf16_t* b, fami_bf16_t* out, long n, float alpha, float beta,
+                    fami_stream_t stream);
+int fami_cast_add_bf16(const float* src, fami_bf16_t* dst, long n, int accumulate, fami_stream_t stream);
+int fami_fill_bf16(fami_bf16_t* out, long n, float v, fami_stream_t stream);
+int fami_fuse_sum_bf16(int nterms, const fami_bf16_t* const* x, const float* const* mean, const float* const* invstd,
+                       const float* const* gamma, const float* const* beta, const int* shift, fami_bf16_t* y, int N,
+                       int H, int W, int C, int relu, fami_stream_t stream);
+int fami_relu_bwd_bf16(const fami_bf16_t* dy, const fami_bf16_t* y, fami_bf16_t* dx, long n, int accumulate,
+                       fami_stream_t stream);
+int fami_pool_relu_bwd_bf16(const fami_bf16_t* dy, const fami_bf16_t* y, fami_bf16_t* out, int N, int Hl, int Wl,
+                            int C, int shift, int relu, fami_stream_t stream);
+
+int fami_shift_bilinear_fwd_bf16(const fami_bf16_t* src, const float* t, fami_bf16_t* out, int B, int H, int W, int C,
+                                 fami_stream_t stream);
+int fami_shift_bilinear_bwd_bf16(const fami_bf16_t* gout, const fami_bf16_t* src, const float* t, fami_bf16_t* gsrc,
+                                 float* gt, int B, int H, int W, int C, int acc_src, int acc_t, float* ws,
+                                 fami_stream_t stream);
+int fami_dcn_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_bf16_t* msk, const float* wp,
+                      const float* bias, fami_bf16_t* y, int B, int H, int W, int C, int Co, int G, int kh, int kw,
+                      int stride, int pad, int dil, fami_stream_t stream);
+int fami_dcn_bwd_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_bf16_t* msk, const fami_bf16_t* dy,
+                      const float* wpb, fami_bf16_t* col, float* gx, fami_bf16_t* goff, fami_bf16_t* gmsk, int B,
+                      int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_off,
+                      fami_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,160 @@
+"""bf16 activation mode (BASELINE config 3) of the HIP kernels, through the C ABI, against torch fp32 evaluated on
+the SAME bf16-rounded operands.  What separates the two is then only (a) the bf16 rounding of each kernel's
+output (relative 2^-9 = 2e-3 per element) and (b) fp32 summation order, so the tolerance is 1e-2 of the tensor's
+max magnitude for activations / activation gradients and 2e-3 for fp32 results (weight / BN-parameter gradients,
+statistics)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+ACT_TOL, F32_TOL = 1e-2, 2e-3
+
+
+def _eng(dev):
+    from fami_pose_amd.engine import Engine
+    return Engine(dev, dtype=BF)
+
+
+def rb(x):
+    """round to bf16, keep fp32 storage (the reference operand)"""
+    return x.to(BF).float()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, dil, bias
+    (2, 24, 18, 48, 48, 3, 1, 1, 1, False),
+    (2, 12, 9, 96, 96, 3, 1, 1, 1, False),
+    (1, 12, 9, 192, 192, 3, 1, 1, 1, False),
+    (2, 6, 5, 384, 384, 3, 1, 1, 1, False),      # split-K path
+    (2, 32, 24, 3, 64, 3, 2, 1, 1, False),       # stem (Ci = 3: scalar operand fetch)
+    (2, 16, 12, 64, 64, 3, 2, 1, 1, False),
+    (2, 16, 12, 64, 256, 1, 1, 0, 1, False),
+    (2, 16, 12, 256, 48, 3, 1, 1, 1, False),
+    (2, 13, 9, 96, 192, 3, 2, 1, 1, False),      # odd sizes, stride 2
+    (2, 24, 18, 48, 216, 3, 1, 3, 3, True),      # DCN offset predictor (dilation 3)
+    (2, 24, 18, 48, 17, 1, 1, 0, 1, True),       # heatmap head (Co = 17, fp32 output)
+    (3, 7, 5, 16, 16, 3, 2, 1, 1, True),
+    (1, 5, 7, 20, 36, 3, 1, 1, 1, True),         # channel tails
+    (20, 96, 72, 48, 48, 3, 1, 1, 1, False),     # the dominant shape at full size (MT = 4 tiles)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16(dev, case):
+    N, H, W, Ci, Co, k, s, p, d, has_bias = case
+    torch.manual_seed(hash(case) % 1000)
+    conv = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias)
+    with torch.no_grad():
+        conv.weight.copy_(rb(conv.weight))
+    x = rb(torch.randn(N, Ci, H, W)).requires_grad_(True)
+    y = conv(x)
+    gy = rb(torch.randn_like(y))
+    y.backward(gy)
+
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    cd = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias).to(dev)
+    cd.load_state_dict(conv.state_dict())
+    out_f32 = Co == 17
+    xt = T(nhwc(x.detach()).to(dev).to(BF), True)
+    yt = eng.conv(xt, cd.weight, cd.bias, s, p, d, out_f32=out_f32)
+    assert yt.data.dtype == (torch.float32 if out_f32 else BF)
+    assert relerr(nchw(yt.data), y) < (F32_TOL if out_f32 else ACT_TOL)
+    yt.grad = nhwc(gy).to(dev).to(BF)
+    eng.backward()
+    assert xt.grad.dtype == BF and relerr(nchw(xt.grad), x.grad) < ACT_TOL
+    assert relerr(eng.param_grads[id(cd.weight)], conv.weight.grad) < F32_TOL
+    if has_bias:
+        assert relerr(eng.param_grads[id(cd.bias)], conv.bias.grad) < F32_TOL
+
+
+@pytest.mark.parametrize("C,relu,res", [(48, True, True), (96, False, False), (384, True, True)])
+def test_bn_bf16(dev, C, relu, res):
+    torch.manual_seed(C)
+    N, H, W = 3, 10, 7
+    bn = nn.BatchNorm2d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    bd = nn.BatchNorm2d(C, momentum=0.1).to(dev)
+    bd.load_state_dict(bn.state_dict())
+    x = rb(torch.randn(N, C, H, W) * 2 + 0.7).requires_grad_(True)
+    r = rb(torch.randn(N, C, H, W)).requires_grad_(True) if res else None
+    y = bn(x)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = rb(torch.randn_like(y))
+    y.backward(gy)
+    from fami_pose_amd.engine import T
+    eng = _eng(dev)
+    xt = T(nhwc(x.detach()).to(dev).to(BF), True)
+    rt = T(nhwc(r.detach()).to(dev).to(BF), True) if res else None
+    yt = eng.bn(xt, bd, relu=relu, residual=rt)
+    assert yt.data.dtype == BF and relerr(nchw(yt.data), y) < ACT_TOL
+    assert relerr(bd.running_mean, bn.running_mean) < 1e-5 and relerr(bd.running_var, bn.running_var) < 1e-5
+    yt.grad = nhwc(gy).to(dev).to(BF)
+    eng.backward()
+    # the HIP backward sees the bf16-rounded y for the ReLU mask; elements with |y| below rounding may flip
+    assert relerr(nchw(xt.grad), x.grad) < 2 * ACT_TOL
+    assert relerr(eng.param_grads[id(bd.weight)], bn.weight.grad) < 5 * F32_TOL
+    assert relerr(eng.param_grads[id(bd.bias)], bn.bias.grad) < 5 * F32_TOL
+
+
+def test_fuse_concat_shift_dcn_bf16(dev):
+    from oracle import ops as O
+    from fami_pose_amd.engine import T
+    torch.manual_seed(3)
+    eng = _eng(dev)
+    # shift
+    x = rb(torch.randn(2, 48, 24, 18)).requires_grad_(True)
+    t = torch.tensor([[0.3, -1.7], [4.25, 2.5]], requires_grad=True)
+    y = O.warp_translate(x, t)
+    g = rb(torch.randn_like(y))
+    y.backward(g)
+    xt = T(nhwc(x.detach()).to(dev).to(BF), True)
+    tt = T(t.detach().to(dev), True, f32grad=True)
+    yt = eng.shift(xt, tt)
+    assert relerr(nchw(yt.data), y) < ACT_TOL
+    yt.grad = nhwc(g).to(dev).to(BF)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < ACT_TOL and relerr(tt.grad, t.grad) < F32_TOL
+    # dcn
+    B, C, G, H, W = 2, 48, 12, 12, 9
+    x = rb(torch.randn(B, C, H, W)).requires_grad_(True)
+    off = rb(torch.randn(B, 18 * G, H, W) * 2.0).requires_grad_(True)
+    msk = rb(torch.randn(B, 9 * G, H, W)).requires_grad_(True)
+    w = (torch.randn(C, C, 3, 3) * 0.1).requires_grad_(True)
+    b = torch.randn(C, requires_grad=True)
+    y = O.deform_conv2d(x, off, msk, w, b, 1, 3, 3)
+    g = rb(torch.randn_like(y))
+    y.backward(g)
+    eng = _eng(dev)
+    wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(b.detach().to(dev))
+    xt, ot, mt = (T(nhwc(v.detach()).to(dev).to(BF), True) for v in (x, off, msk))
+    yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+    assert yt.data.dtype == BF and relerr(nchw(yt.data), y) < ACT_TOL
+    yt.grad = nhwc(g).to(dev).to(BF)
+    eng.backward()
+    assert relerr(nchw(xt.grad), x.grad) < ACT_TOL
+    assert relerr(nchw(ot.grad), off.grad) < ACT_TOL and relerr(nchw(mt.grad), msk.grad) < ACT_TOL
+    # col (the weight-gradient operand) is stored in bf16: one extra rounding of the modulated samples
+    assert relerr(eng.param_grads[id(wd)], w.grad) < 3 * F32_TOL
+    assert relerr(eng.param_grads[id(bd)], b.grad) < F32_TOL

@@ -27,6 +27,10 @@ f0.retain_grad()
 l0 = oops.total_loss(f0, tgt, w, mi0 if USE_MI else [])
 l0.backward()
 
+tune = os.environ.get("TUNE")
+if tune:
+    eng_l = __import__("fami_pose_amd._lib", fromlist=["lib"]).lib()
+    eng_l.cdll.fami_conv_tune(*[int(v) for v in tune.split(",")])
 eng = Engine(dev, record=True)
 outs, seeds = model._body(eng, kf.to(dev), sup.to(dev))
 from fami_pose_amd.loss import JointMSELoss
@@ -91,3 +95,19 @@ ref64 = dict(orc64.named_parameters())
 for n in ['init_feature_agg_block.layers.2.conv2.weight', 'init_feature_agg_block.layers.0.conv1.weight', 'dcn_4.weight', 'dcn_offset_2.conv.weight',
           'sup_agg_block.layers.0.conv1.weight', 'feat_global_offset_layers.2.conv.weight', 'hrnet.stage3.0.branches.1.0.conv1.weight', 'hrnet.conv1.weight']:
     cmp3(n, eng.param_grads[id(mp[n])], ref[n].grad, ref64[n].grad)
+
+# ---- ranking of parameters by (hip error) / (cpu error), both vs fp64
+rows = []
+for n, p64 in ref64.items():
+    if p64.grad is None or n not in mp or eng.param_grads.get(id(mp[n])) is None:
+        continue
+    g64 = p64.grad; s64 = g64.abs().max().item()
+    if s64 < 1e-9: continue
+    e_cpu = (ref[n].grad.double() - g64).abs().max().item() / s64
+    e_hip = (eng.param_grads[id(mp[n])].cpu().double() - g64).abs().max().item() / s64
+    rows.append((e_hip / (e_cpu + 1e-6), e_hip, e_cpu, n))
+rows.sort(reverse=True)
+import numpy as np
+print('\nmedian e_hip %.3e  median e_cpu %.3e' % (np.median([r[1] for r in rows]), np.median([r[2] for r in rows])))
+for r in rows[:25]:
+    print('ratio %6.1f  hip %.3e cpu %.3e  %s' % r)
