@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -46,25 +47,36 @@ def build(args, dev):
     torch.manual_seed(19970808)
     model = fp.build_model(cfg, 'train')
     om.realistic_init_(model, seed=19970808)
+    model.set_compute_dtype(args.dtype)
     return model.to(dev)
 
 
-def conv_roofline(dev, N, reps=30):
+def conv_roofline(dev, N, dtype, reps=30):
     """Live HIP-event timing of the dominant kernel: the 48->48 3x3 branch conv at 96x72 (26 % of the
     step's conv FLOPs, 64 forward launches per step) on the stream it is launched on."""
     from fami_pose_amd._lib import lib
     L = lib()
     H, W, C = 96, 72, 48
-    x = torch.randn(N, H, W, C, device=dev)
+    bf = dtype == 'bf16'
+    tdt = torch.bfloat16 if bf else torch.float32
+    x = torch.randn(N, H, W, C, device=dev).to(tdt)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
-    y = torch.empty(N, H, W, C, device=dev)
-    wp = torch.empty(L.cdll.fami_packed_weight_elems(C, C, 3, 3, 0), device=dev)
+    y = torch.empty(N, H, W, C, device=dev, dtype=tdt)
     s = torch.cuda.current_stream(dev)
-    L.call('fami_pack_conv_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+    if bf:
+        wp = torch.empty(L.cdll.fami_packed_weight_elems_bf16(C, C, 3, 3, 0), device=dev, dtype=tdt)
+        L.call('fami_pack_conv_weight_bf16', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
 
-    def launch():
-        L.call('fami_conv2d_fwd_f32', x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 3, 3, 1,
-               1, 1, 0, 0, s.cuda_stream)
+        def launch():
+            L.call('fami_conv2d_fwd_bf16', x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), N, H, W, C, C, 3, 3, 1, 1, 1,
+                   0, 0, 0, s.cuda_stream)
+    else:
+        wp = torch.empty(L.cdll.fami_packed_weight_elems(C, C, 3, 3, 0), device=dev)
+        L.call('fami_pack_conv_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+
+        def launch():
+            L.call('fami_conv2d_fwd_f32', x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 3, 3, 1,
+                   1, 1, 0, 0, s.cuda_stream)
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -76,28 +88,31 @@ def conv_roofline(dev, N, reps=30):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * N * H * W * C * 9 * C
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_f32 (48->48 3x3 @96x72, N=%d frames)" % N,
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
+    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
+    return {"bound": "mfma", "kernel": "conv_igemm_%s (48->48 3x3 @96x72, N=%d frames)" % (dtype, N),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
 
 
-def dcn_roofline(dev, B, reps=30):
+def dcn_roofline(dev, B, dtype, reps=30):
     """Secondary roofline: the fused DCNv2 gather+contraction (HBM-bound; SURVEY.md 8d algorithmic bytes)."""
     from fami_pose_amd._lib import lib
     L = lib()
     H, W, C, G = 96, 72, 48, 12
-    x = torch.randn(B, H, W, C, device=dev)
-    off = torch.randn(B, H, W, 18 * G, device=dev)
-    msk = torch.randn(B, H, W, 9 * G, device=dev)
+    bf = dtype == 'bf16'
+    tdt = torch.bfloat16 if bf else torch.float32
+    x = torch.randn(B, H, W, C, device=dev).to(tdt)
+    off = torch.randn(B, H, W, 18 * G, device=dev).to(tdt)
+    msk = torch.randn(B, H, W, 9 * G, device=dev).to(tdt)
     w = torch.randn(C, C, 3, 3, device=dev) * 0.05
     bias = torch.zeros(C, device=dev)
-    y = torch.empty(B, H, W, C, device=dev)
+    y = torch.empty(B, H, W, C, device=dev, dtype=tdt)
     wp = torch.empty(L.cdll.fami_dcn_packed_weight_elems(C, C, 3, 3, G), device=dev)
     s = torch.cuda.current_stream(dev)
     L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
 
     def launch():
-        L.call('fami_dcn_fwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),
+        L.call('fami_dcn_fwd_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),
                y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream)
     for _ in range(5):
         launch()
@@ -108,11 +123,11 @@ def dcn_roofline(dev, B, reps=30):
     e1.record(s)
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    nbytes = (C + 3 * G * 9 + C) * H * W * 4.0 * B
+    nbytes = (C + 3 * G * 9 + C) * H * W * (2.0 if bf else 4.0) * B
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "dcn_fwd_kernel (48ch, 12 groups, 96x72, B=%d)" % B, "achieved": round(ach, 1),
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-            "avg_launch_us": round(ms * 1e3, 2)}
+    return {"bound": "hbm", "kernel": "dcn_fwd_kernel (48ch, 12 groups, 96x72, B=%d, %s)" % (B, dtype),
+            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def cpu_baseline_worker(args):
@@ -179,12 +194,18 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bucket-mb', type=int, default=32)
+    ap.add_argument('--also', choices=['f32', 'bf16', 'none'], default='bf16',
+                    help='additionally time this dtype (fewer steps) and report it as an extra "also_<dtype>" object')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='activation storage / conv MFMA type (accumulation, master weights, losses are fp32 either way)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=32, help='host threads for the CPU baseline (capped at the core count)')
     ap.add_argument('--cpu-timeout', type=int, default=240)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         return cpu_baseline_worker(args)
+    if args.also == 'none':
+        args.also = None
 
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -198,39 +219,54 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from fami_pose_amd.train import Trainer
-    model = build(args, dev)
-    # N>1: the eager launch sequence with RCCL all-reduces overlapped on RCCL's stream is the default; the
-    # per-bucket hipGraph plan (train.py) is opt-in until it has been exercised on a multi-GPU node.
-    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH') == '1')
-    trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=use_graph, targets_from_joints=True,
-                      bucket_mb=args.bucket_mb)
-    kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 1)):
-        trainer.step(kf, sup, joints, vis)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(kf, sup, joints, vis)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    loss = trainer.loss_value()
+    # N>1: the eager launch sequence with RCCL all-reduces overlapped on RCCL's stream is the default; the
+    # per-bucket hipGraph plan (train.py) is opt-in until it has been exercised on a multi-GPU node.
+    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH') == '1')
+    kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
+
+    def timed_run(dtype, steps, warmup):
+        args.dtype = dtype
+        model = build(args, dev)
+        trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=use_graph, targets_from_joints=True,
+                          bucket_mb=args.bucket_mb)
+        for _ in range(max(warmup, 1)):
+            trainer.step(kf, sup, joints, vis)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(kf, sup, joints, vis)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        loss = trainer.loss_value()
+        del trainer, model
+        torch.cuda.empty_cache()
+        return dt, loss
+
+    primary = args.dtype
+    dt, loss = timed_run(primary, args.steps, args.warmup)
+    other = None
+    if args.also and args.also != primary:
+        o_steps = max(3, min(args.steps, 10))
+        o_dt, o_loss = timed_run(args.also, o_steps, max(2, min(args.warmup, 3)))
+        other = (args.also, o_dt, o_loss, o_steps)
+    args.dtype = primary
 
     if rank == 0:
         clips = args.batch * world * args.steps
         out = {
             "metric": "train clips/sec (5-frame 384x288 HRNet-W48)", "value": round(clips / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "HRNet-W%d %dx%d, %d-frame clips + MI loss, batch %d/GPU, backbone %s, Adam, "
                                    "on-device Gaussian targets" % (args.width, args.img_h, args.img_w, args.sup + 1,
                                                                    args.batch, "frozen" if args.freeze_backbone else "unfrozen"),
@@ -238,8 +274,18 @@ def main():
                        "hipgraph": use_graph},
             "loss": round(loss, 6),
         }
-        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1))
-        out["roofline_dcn"] = dcn_roofline(dev, args.batch)
+        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype)
+        out["roofline_dcn"] = dcn_roofline(dev, args.batch, args.dtype)
+        if other is not None:
+            o_dtype, o_dt, o_loss, o_steps = other
+            out["also_" + o_dtype] = {
+                "note": "same workload with %s activation storage / conv MFMA (fp32 accumulation, master weights, "
+                        "losses); not the parity-gated configuration" % o_dtype if o_dtype == 'bf16' else
+                        "same workload in the fp32 parity configuration",
+                "value": round(args.batch * world * o_steps / o_dt, 3), "unit": "clips/s", "steps": o_steps,
+                "ms_per_step": round(o_dt / o_steps * 1e3, 3), "loss": round(o_loss, 6),
+                "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype),
+                "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -56,7 +56,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // KS = number of K partitions among the 4 waves of a workgroup (split-K for the low-resolution
 // branches, whose pixel count alone cannot fill 1024 SIMDs); partial accumulators meet in LDS.
-template <int MT, int NT, int MODE, int VEC, int KS>
+template <int MT, int NT, int MODE, int VEC, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -162,19 +162,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
   };
 
-  f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+  f32x4 af[ST][MT], bf[ST][NT];
   const int Tall = taps * p.KC;
   const int T = active ? (Tall - kpart + KS - 1) / KS : 0;  // iterations owned by this wave
-  // two-stage register pipeline with an unconditional body: loads issued past the last iteration carry
-  // out-of-range offsets (zeros), so an odd T costs one MFMA group on zeros instead of a branch in the loop
+  // ST-stage register pipeline (ST-1 operand sets in flight: the loop is bound by memory latency x concurrency, not
+  // by MFMA issue) with an unconditional body: loads issued past the last iteration carry out-of-range offsets
+  // (zeros), so a T that is not a multiple of ST costs MFMA groups on zeros instead of branches in the loop
   if (T > 0) {
     tap_setup(tap);
-    load(a0, b0);
-    for (int it = 0; it < T; it += 2) {
-      load(a1, b1);
-      mma(a0, b0);
-      load(a0, b0);
-      mma(a1, b1);
+#pragma unroll
+    for (int st = 0; st < ST - 1; ++st) load(af[st], bf[st]);
+    for (int it = 0; it < T; it += ST) {
+#pragma unroll
+      for (int st = 0; st < ST; ++st) {
+        load(af[(st + ST - 1) % ST], bf[(st + ST - 1) % ST]);
+        mma(af[st], bf[st]);
+      }
     }
   }
 
@@ -268,7 +271,7 @@ __global__ void pack_w_bf16_kernel(const float* __restrict__ w, bf16_t* __restri
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int NT, int MODE, int VEC, int KS>
+template <int MT, int NT, int MODE, int VEC, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -371,17 +374,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
   };
 
-  bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+  bf16x8 af[ST][MT], bf[ST][NT];
   const int Tall = taps * p.KC;
   const int T = active ? (Tall - kpart + KS - 1) / KS : 0;
   if (T > 0) {
     tap_setup(tap);
-    load(a0, b0);
-    for (int it = 0; it < T; it += 2) {
-      load(a1, b1);
-      mma(a0, b0);
-      load(a0, b0);
-      mma(a1, b1);
+#pragma unroll
+    for (int st = 0; st < ST - 1; ++st) load(af[st], bf[st]);
+    for (int it = 0; it < T; it += ST) {
+#pragma unroll
+      for (int st = 0; st < ST; ++st) {
+        load(af[(st + ST - 1) % ST], bf[(st + ST - 1) % ST]);
+        mma(af[st], bf[st]);
+      }
     }
   }
 
@@ -781,12 +786,14 @@ static int pick_small(int tiles) {  // wgrad tile counts in {4,3,2,1}
 }
 
 template <int MODE, int VEC>
-static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, hipStream_t s) {
+static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipStream_t s) {
   const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
-#define FAMI_CASE(mt, nt, ks)                                                                \
-  if (MT == mt && NT == nt && KS == ks) {                                                    \
-    hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks>), grid, dim3(256), 0, s, a);   \
-    return 0;                                                                                \
+#define FAMI_CASE(mt, nt, ks)                                                                       \
+  if (MT == mt && NT == nt && KS == ks) {                                                           \
+    if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
+    else if (ST == 4 && mt == 1) hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks, 4>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks, 2>), grid, dim3(256), 0, s, a);   \
+    return 0;                                                                                       \
   }
   if constexpr (VEC) {
 #define FAMI_ROW(nt) FAMI_CASE(1, nt, 1) FAMI_CASE(1, nt, 2) FAMI_CASE(1, nt, 4) FAMI_CASE(2, nt, 1) FAMI_CASE(2, nt, 2) FAMI_CASE(2, nt, 4)
@@ -801,6 +808,7 @@ static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, hipStream_t s
 }
 
 static int g_force_mt = 0, g_force_nt = 0, g_force_ks = 0;  // tuning overrides (fami_conv_tune)
+static int g_stages = 0;                                     // pipeline depth override (fami_conv_tune_stages)
 
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
@@ -823,11 +831,12 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
     }
   }
   if (vec && g_force_mt) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
+  const int ST = g_stages ? g_stages : 2;
   int rc;
   if (mode == 0)
-    rc = vec ? launch_igemm<0, 1>(a, MT, NT, KS, s) : launch_igemm<0, 0>(a, MT, NT, KS, s);
+    rc = vec ? launch_igemm<0, 1>(a, MT, NT, KS, ST, s) : launch_igemm<0, 0>(a, MT, NT, KS, 2, s);
   else
-    rc = vec ? launch_igemm<1, 1>(a, MT, NT, KS, s) : launch_igemm<1, 0>(a, MT, NT, KS, s);
+    rc = vec ? launch_igemm<1, 1>(a, MT, NT, KS, ST, s) : launch_igemm<1, 0>(a, MT, NT, KS, 2, s);
   if (rc != 0) {
     fami_set_error(name, "no kernel instance for tile shape");
     return FAMI_ESHAPE;
@@ -848,6 +857,11 @@ extern "C" {
 // tuning hook (benchmarks only): force the implicit-GEMM tile (0 = heuristic)
 int fami_conv_tune(int mt, int nt, int ks) {
   g_force_mt = mt; g_force_nt = nt; g_force_ks = ks;
+  return FAMI_OK;
+}
+// tuning hook (benchmarks only): register-pipeline depth of the implicit GEMM (2..4; 0 = default)
+int fami_conv_tune_stages(int stages) {
+  g_stages = (stages >= 2 && stages <= 4) ? stages : 0;
   return FAMI_OK;
 }
 
@@ -1012,12 +1026,14 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
 
 // ---- bf16 implicit GEMM launch
 template <int MODE, int VEC>
-static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, hipStream_t s) {
+static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hipStream_t s) {
   const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
-#define FAMI_CASE(mt, nt, ks)                                                                \
-  if (MT == mt && NT == nt && KS == ks) {                                                    \
-    hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks>), grid, dim3(256), 0, s, a);  \
-    return 0;                                                                                \
+#define FAMI_CASE(mt, nt, ks)                                                                        \
+  if (MT == mt && NT == nt && KS == ks) {                                                            \
+    if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
+    else if (ST == 4 && mt <= 2) hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 4>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 2>), grid, dim3(256), 0, s, a);   \
+    return 0;                                                                                        \
   }
   if constexpr (VEC) {
 #define FAMI_ROW(nt) FAMI_CASE(1, nt, 1) FAMI_CASE(1, nt, 2) FAMI_CASE(1, nt, 4) FAMI_CASE(2, nt, 1) FAMI_CASE(2, nt, 2) FAMI_CASE(2, nt, 4) FAMI_CASE(4, nt, 1)
@@ -1050,11 +1066,12 @@ static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
     }
   }
   if (vec && g_force_mt) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
+  const int ST = g_stages ? g_stages : 2;
   int rc;
   if (mode == 0)
-    rc = vec ? launch_igemm_h<0, 1>(a, MT, NT, KS, s) : launch_igemm_h<0, 0>(a, MT, NT, KS, s);
+    rc = vec ? launch_igemm_h<0, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<0, 0>(a, MT, NT, KS, 2, s);
   else
-    rc = vec ? launch_igemm_h<1, 1>(a, MT, NT, KS, s) : launch_igemm_h<1, 0>(a, MT, NT, KS, s);
+    rc = vec ? launch_igemm_h<1, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<1, 0>(a, MT, NT, KS, 2, s);
   if (rc != 0) {
     fami_set_error(name, "no kernel instance for tile shape");
     return FAMI_ESHAPE;

@@ -118,15 +118,16 @@ class Engine:
         self.param_grads[id(p)] = g
         return g, 0
 
-    # packed weights: frozen parameters are packed once, trainable ones every forward
-    _pack_cache = {}
-
+    # packed weights: frozen nn.Parameters are packed once (cache lives ON the parameter object, keyed by mode /
+    # dtype / version counter, so it can never outlive or be confused with another model's weights); trainable
+    # parameters and ad-hoc tensors are packed every forward
     def packed(self, w, mode):
         Co, Ci, kh, kw = w.shape
-        key = (w.data_ptr(), mode, w.shape, self.dt)
-        if not w.requires_grad:
-            hit = Engine._pack_cache.get(key)
-            if hit is not None and hit[0] == w._version:
+        cacheable = isinstance(w, torch.nn.Parameter) and not w.requires_grad
+        key = (mode, self.dt)
+        if cacheable:
+            hit = getattr(w, '_fami_packed', {}).get(key)
+            if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
                 return hit[1]
         if self.dt == torch.bfloat16:
             n = self.L.cdll.fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode)
@@ -136,8 +137,10 @@ class Engine:
             n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
             wp = self.empty(n)
             self.call('fami_pack_conv_weight_f32', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
-        if not w.requires_grad:
-            Engine._pack_cache[key] = (w._version, wp)
+        if cacheable:
+            if not hasattr(w, '_fami_packed'):
+                w._fami_packed = {}
+            w._fami_packed[key] = (w._version, wp, w.data_ptr())
         return wp
 
     # ------------------------------------------------------------------ inputs / boundary

@@ -16,17 +16,22 @@ orc = om.AlignmentOracle(om.make_cfg(48), True, S, (H, W))
 om.realistic_init_(orc, 1, offset_std=float(os.environ.get("OFFSTD", 1.0)))
 model.load_state_dict(orc.state_dict())
 model = model.to(dev)
+model.set_compute_dtype(os.environ.get('DTYPE', 'f32'))
 kf, sup = torch.randn(B, 3, H, W), torch.randn(B, 3 * S, H, W)
 f0, k0, mi0, aux0 = orc(kf, sup, return_aux=True)
-eng = Engine(dev, record=False)
+eng = Engine(dev, record=False, dtype=model.act_dtype)
 outs, _ = model._body(eng, kf.to(dev), sup.to(dev))
 a = eng.aux
 def cmp(name, t, ref):
     x = t.data if hasattr(t, 'data') and not torch.is_tensor(t) else t
     if x.dim() == 4 and x.shape != ref.shape:
         x = x.permute(0, 3, 1, 2)
-    d = (x.cpu() - ref).abs().max().item()
+    d = (x.float().cpu() - ref).abs().max().item()
     print('%-10s max|ref| %.3e  maxabs diff %.3e  rel %.3e' % (name, ref.abs().max().item(), d, d / ref.abs().max().item()))
+import torch.nn.functional as Fn
+fr = torch.cat([kf] + list(torch.chunk(sup, S, 1)), 0)
+with torch.no_grad():
+    st1 = Fn.relu(orc.hrnet.bn1(orc.hrnet.conv1(fr)))
 cmp('kf_feat', a['kf_feat'], aux0['kf_feat'])
 for i, (t, r) in enumerate(zip(a['shifts'], aux0['shifts'])):
     cmp('shift%d' % i, t, r)
