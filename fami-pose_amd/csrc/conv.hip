@@ -460,6 +460,244 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
   }
 }
 
+// ------------------------------------------------------------------ LDS-staged 3x3 (stride 1, pad 1, dilation 1)
+// The HRNet branch convolutions (90 % of the FLOPs).  The direct kernels above re-fetch every activation 9 times and
+// every weight fragment once per wave from L2 and are bound by L2 requests (TCC busy 85 %, profiles/r01_pmc_conv_f32).
+// Here a workgroup owns a band of R full output rows of one frame (R*W <= 144 pixels = up to 9 row tiles) and
+//   * stages the input band + one halo row above and below, one channel chunk at a time, ONCE into LDS
+//     (contiguous copy; no halo columns: out-of-image taps are masked to zero per lane at fragment-read time);
+//   * stages the weight fragments of one (chunk, tap) into a double-buffered LDS slot shared by the 4 waves,
+//     prefetching the next tap's fragments into registers while the current tap is multiplied;
+//   * distributes the (row tile, channel tile) pairs round-robin over the 4 waves; both MFMA operands are 16-byte
+//     LDS reads (activation fragment = 4 f32 / 8 bf16 channels of one pixel, tap shift = a wave-uniform LDS offset).
+// MFMA A = weights (rows = output channels), B = activations (cols = pixels): a lane ends with 4 consecutive output
+// channels of one pixel -> one 16-byte (f32) / 8-byte (bf16) store.  dgrad = the same kernel with the tap shift
+// negated and the mode-1 weight image.
+struct ConvLdsArgs {
+  const void* x;      // [N,H,W,Ci]
+  const void* wp;     // packed weights (pack_w_kernel / pack_w_bf16_kernel layout)
+  void* y;            // [N,H,W,Co]
+  const float* bias;  // [Co] or null
+  int N, H, W, Ci, Co;
+  int R, bands;       // rows per band, bands per frame
+  int CH, CHP;        // real / LDS-padded channels per chunk
+  int PSTRIDE;        // LDS bytes per pixel (odd multiple of 16)
+  int KC, NTt;        // packed-weight geometry: K groups over all of Ci, channel tiles over all of Co
+  int sgn;            // +1 forward, -1 dgrad
+  int relu, accumulate, out_f32;
+  int patch_bytes;
+};
+
+template <typename T> struct LdsTraits;
+template <> struct LdsTraits<float> {
+  typedef f32x4 frag;
+  static constexpr int KSTEP = 16;
+  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[t], acc, 0, 0, 0);
+    return acc;
+  }
+  __device__ static __forceinline__ frag zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct LdsTraits<bf16_t> {
+  typedef bf16x8 frag;
+  static constexpr int KSTEP = 32;
+  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ frag zero() { return __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); }
+};
+
+template <typename T, int NT, int KSC>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef LdsTraits<T> TR;
+  typedef typename TR::frag frag;
+  constexpr int SZ = (int)sizeof(T);
+  // taps per weight slab: one barrier per slab.  bf16 MFMAs are 8x shorter, so a slab carries a whole tap row there.
+  constexpr int TPS = SZ == 2 ? 3 : 1;
+  constexpr int NSLAB = 9 / TPS;
+  constexpr int WSLAB = TPS * KSC * NT * 1024;             // bytes of one slab
+  constexpr int WPIECES = WSLAB / 16;                      // 16-byte pieces of one slab
+  constexpr int WR = (WPIECES + 255) / 256;                // prefetch registers (u32x4) per thread
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int img = blockIdx.x / p.bands, bnd = blockIdx.x - img * p.bands;
+  const int y0 = bnd * p.R;
+  const int rows = min(p.R, p.H - y0);
+  const int npix = rows * p.W;
+  const int ntile = (npix + 15) >> 4;
+  const int ntg0 = blockIdx.y * NT;
+  char* patch = smem;
+  char* wbuf = smem + p.patch_bytes;
+
+  // Row-tile slots of this wave: slots 0/1 = tiles wave, wave+4 with all NT channel tiles; slot 2 = the ninth
+  // tile, whose NT channel tiles are dealt to waves 0..NT-1 one each (7+7+7+6 MFMA groups: balanced).
+  int base[3], vmask[3];
+  const int nt2 = wave < NT ? wave : 0;
+  const bool has2 = ntile > 8 && wave < NT;
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    const int mt = sl < 2 ? wave + 4 * sl : 8;
+    const int j = mt * 16 + col;
+    base[sl] = 0;
+    vmask[sl] = 0;
+    if (mt < ntile && j < npix && (sl < 2 || has2)) {
+      const int ry = j / p.W, rx = j - ry * p.W;
+      base[sl] = ((ry + 1) * p.W + rx) * p.PSTRIDE + kq * 16;
+      int m = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y0 + ry + p.sgn * (t / 3 - 1), xx = rx + p.sgn * (t % 3 - 1);
+        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) m |= 1 << t;
+      }
+      vmask[sl] = m;
+    }
+  }
+  f32x4 acc[2][NT], acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[sl][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const char* xg = reinterpret_cast<const char*>(p.x);
+  const char* wg = reinterpret_cast<const char*>(p.wp);
+  const int pcs_real = p.CH * SZ / 16, pcs_all = p.CHP * SZ / 16;  // 16-byte pieces per pixel (real / padded)
+  const int npx_patch = (p.R + 2) * p.W;
+  const int nchunk = p.Ci / p.CH;
+
+  // global byte offset of 16-byte piece i of the weight slab holding taps tp0 .. tp0+TPS-1 of chunk kc0
+  auto wsrc = [&](int i, int tp0, int kc0) -> long {
+    const int blk = i >> 6, l = i & 63;        // blk = (tt*KSC + ks)*NT + nt
+    const int nt = blk % NT, r = blk / NT;
+    const int ks = r % KSC, tt = r / KSC;
+    return ((long)(((tp0 + tt) * p.KC + kc0 + ks) * p.NTt + ntg0 + nt)) * 1024 + l * 16;
+  };
+
+  for (int c = 0; c < nchunk; ++c) {
+    if (c > 0) __syncthreads();  // the previous chunk's last slab has been consumed
+    {                            // ---- stage the activation patch of this chunk
+      const long img_base = (long)img * p.H * p.W * p.Ci * SZ + (long)c * p.CH * SZ;
+      const int total = npx_patch * pcs_all;
+      for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+        u32x4 v[4];
+        int dsto[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256;
+          v[u] = u32x4{0u, 0u, 0u, 0u};
+          dsto[u] = -1;
+          if (i < total) {
+            const int px = i / pcs_all, pc = i - px * pcs_all;
+            const int pr = px / p.W, xc = px - pr * p.W;
+            const int yy = y0 - 1 + pr;
+            dsto[u] = px * p.PSTRIDE + pc * 16;
+            if ((unsigned)yy < (unsigned)p.H && pc < pcs_real)
+              v[u] = *reinterpret_cast<const u32x4*>(xg + img_base + ((long)yy * p.W + xc) * p.Ci * SZ + pc * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (dsto[u] >= 0) *reinterpret_cast<u32x4*>(patch + dsto[u]) = v[u];
+      }
+    }
+    const int kc0 = c * KSC;
+#pragma unroll
+    for (int u = 0; u < WR; ++u) {  // slab 0 straight into buffer 0
+      const int i = tid + u * 256;
+      if (i < WPIECES) *reinterpret_cast<u32x4*>(wbuf + i * 16) = *reinterpret_cast<const u32x4*>(wg + wsrc(i, 0, kc0));
+    }
+    __syncthreads();
+
+    for (int g = 0; g < NSLAB; ++g) {
+      u32x4 wr[WR];  // next slab -> registers while this one is multiplied
+      if (g + 1 < NSLAB) {
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+          const int i = tid + u * 256;
+          wr[u] = u32x4{0u, 0u, 0u, 0u};
+          if (i < WPIECES) wr[u] = *reinterpret_cast<const u32x4*>(wg + wsrc(i, (g + 1) * TPS, kc0));
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int t = g * TPS + tt;
+        const char* wb = wbuf + (g & 1) * WSLAB + tt * (KSC * NT * 1024) + lane * 16;
+        const int toff = p.sgn * ((t / 3 - 1) * p.W + (t % 3 - 1)) * p.PSTRIDE;
+        frag a[KSC][3], w[KSC][NT], wx[KSC];
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {  // every fragment of the tap is requested before the first MFMA
+#pragma unroll
+          for (int sl = 0; sl < 3; ++sl) {
+            a[ks][sl] = TR::zero();
+            if ((vmask[sl] >> t) & 1) a[ks][sl] = *reinterpret_cast<const frag*>(patch + base[sl] + toff + ks * 64);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) w[ks][nt] = *reinterpret_cast<const frag*>(wb + (ks * NT + nt) * 1024);
+          wx[ks] = *reinterpret_cast<const frag*>(wb + (ks * NT + nt2) * 1024);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+          if constexpr (SZ == 4) {  // element-major order: consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+              for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[sl][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks][nt][e], a[ks][sl][e], acc[sl][nt], 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[ks][e], a[ks][2][e], acc2, 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[sl][nt] = TR::mma(w[ks][nt], a[ks][sl], acc[sl][nt]);
+            acc2 = TR::mma(wx[ks], a[ks][2], acc2);
+          }
+        }
+      }
+      if (g + 1 < NSLAB) {
+        char* wn = wbuf + ((g + 1) & 1) * WSLAB;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+          const int i = tid + u * 256;
+          if (i < WPIECES) *reinterpret_cast<u32x4*>(wn + i * 16) = wr[u];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
+  const long pix0 = ((long)img * p.H + y0) * p.W;
+  auto store = [&](int mt, int nt, f32x4 v) {
+    const int j = mt * 16 + col;
+    if (mt >= ntile || j >= npix) return;
+    const int co0 = (ntg0 + nt) * 16 + kq * 4;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+    if (p.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    const long idx = (pix0 + j) * p.Co + co0;
+    if (p.out_f32 || SZ == 4) {
+      float* yp = reinterpret_cast<float*>(p.y) + idx;
+      if (p.accumulate) v += ld4(yp);
+      st4(yp, v);
+    } else {
+      bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx;
+      if (p.accumulate) v += ld4(yp);
+      st4(yp, v);
+    }
+  };
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) store(wave + 4 * sl, nt, acc[sl][nt]);
+  if (has2) store(8, nt2, acc2);
+}
+
 // ------------------------------------------------------------------ wgrad
 // one scalar through a buffer descriptor, converted to f32 (out-of-range offsets read 0)
 template <typename T>
@@ -845,6 +1083,71 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   return FAMI_OK;
 }
 
+// The LDS-staged 3x3 kernel cuts L2 requests ~5x but, measured on MI355X (tools/bench_dvfs.py), does not beat the
+// direct kernels on the HRNet shapes (f32 48ch: 75 vs 67 us; bf16: 24.7 vs 21.5 us): both sit at 62-84 % of the
+// register-only MFMA rate of this part (138 TF f32, tools/probes/mfma_peak.hip).  It is therefore opt-in
+// (fami_conv_tune_lds(1)); tests exercise it explicitly.
+static int g_use_lds = 0;
+
+// LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
+template <typename T>
+static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
+                           int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                           const char* name) {
+  constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
+  if (!g_use_lds || W > 144 || (Ci * SZ) % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  int NT = 0;
+  if (Co % 48 == 0) NT = 3;
+  else if (Co % 64 == 0) NT = 4;
+  if (!NT) return 0;
+  // channel chunk staged per pass
+  int CH = 0;
+  const int cand_f32[4] = {48, 64, 32, 16}, cand_bf16[3] = {96, 64, 32};
+  if (SZ == 4) { for (int i = 0; i < 4 && !CH; ++i) if (Ci % cand_f32[i] == 0) CH = cand_f32[i]; }
+  else { for (int i = 0; i < 3 && !CH; ++i) if (Ci % cand_bf16[i] == 0) CH = cand_bf16[i]; }
+  if (!CH && Ci <= (SZ == 4 ? 64 : 96)) CH = Ci;  // single chunk, padded to a whole K group in LDS
+  if (!CH) return 0;
+  ConvLdsArgs a;
+  a.CH = CH;
+  a.CHP = ((CH + KSTEP - 1) / KSTEP) * KSTEP;
+  if (a.CHP / KSTEP > 4) return 0;
+  a.PSTRIDE = a.CHP * SZ;
+  if (((a.PSTRIDE / 16) & 1) == 0) a.PSTRIDE += 16;
+  a.R = 144 / W;
+  if (a.R < 1) a.R = 1;
+  if (a.R > H) a.R = H;
+  a.bands = fami_cdiv(H, a.R);
+  a.patch_bytes = (a.R + 2) * W * a.PSTRIDE;
+  const size_t lds = (size_t)a.patch_bytes + 2 * (size_t)(SZ == 2 ? 3 : 1) * (a.CHP / KSTEP) * NT * 1024;
+  if (lds > 156 * 1024) return 0;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt; a.sgn = sgn;
+  a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  const dim3 grid(N * a.bands, Co / (16 * NT));
+  const int KSC = a.CHP / KSTEP;
+  bool launched = false;
+#define FAMI_LDS_CASE(nt, ksc)                                                                                     \
+  if (NT == nt && KSC == ksc) {                                                                                    \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<T, nt, ksc>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv3x3_lds_kernel<T, nt, ksc>), grid, dim3(256), lds, s, a);                              \
+    launched = true;                                                                                               \
+  }
+  FAMI_LDS_CASE(3, 1) FAMI_LDS_CASE(3, 2) FAMI_LDS_CASE(3, 3) FAMI_LDS_CASE(3, 4)
+  FAMI_LDS_CASE(4, 1) FAMI_LDS_CASE(4, 2) FAMI_LDS_CASE(4, 3) FAMI_LDS_CASE(4, 4)
+#undef FAMI_LDS_CASE
+  if (!launched) return 0;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fami_set_error(name, hipGetErrorString(e));
+    return FAMI_EHIP;
+  }
+  return 1;
+}
+
 static bool geom_ok(int kh, int kw, int stride, int pad, int dil) {
   return kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7 && (stride == 1 || stride == 2) && pad >= 0 && dil >= 1;
 }
@@ -857,6 +1160,11 @@ extern "C" {
 // tuning hook (benchmarks only): force the implicit-GEMM tile (0 = heuristic)
 int fami_conv_tune(int mt, int nt, int ks) {
   g_force_mt = mt; g_force_nt = nt; g_force_ks = ks;
+  return FAMI_OK;
+}
+// 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 (default) through the direct kernels
+int fami_conv_tune_lds(int on) {
+  g_use_lds = on ? 1 : 0;
   return FAMI_OK;
 }
 // tuning hook (benchmarks only): register-pipeline depth of the implicit GEMM (2..4; 0 = default)
@@ -900,6 +1208,10 @@ int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, cons
   const long xb = (long)N * H * W * Ci * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_f32", "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
+    const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, "fami_conv2d_fwd_f32");
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   return run_igemm(a, 0, s, "fami_conv2d_fwd_f32");
 }
 
@@ -922,6 +1234,11 @@ int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend,
   const long xb = (long)N * a.Hi * a.Wi * Co * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_f32", "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
+    // dgrad of a stride-1 "same" conv is the same conv on dy with the taps mirrored: GEMM K = Co, N = Ci
+    const int rc = try_conv3x3_lds<float>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 1, s, "fami_conv2d_dgrad_f32");
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
 }
 
@@ -1131,6 +1448,10 @@ int fami_conv2d_fwd_bf16(const bf16_t* x, const bf16_t* wp, const float* bias, v
   const long xb = (long)N * H * W * Ci * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_bf16", "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
+    const int rc = try_conv3x3_lds<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, "fami_conv2d_fwd_bf16");
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   return run_igemm_h(a, 0, s, "fami_conv2d_fwd_bf16");
 }
 
@@ -1152,6 +1473,10 @@ int fami_conv2d_dgrad_bf16(const bf16_t* dy, const bf16_t* wp, bf16_t* dx, int N
   const long xb = (long)N * a.Hi * a.Wi * Co * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_bf16", "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
+    const int rc = try_conv3x3_lds<bf16_t>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, "fami_conv2d_dgrad_bf16");
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   return run_igemm_h(a, 1, s, "fami_conv2d_dgrad_bf16");
 }
 

@@ -9,6 +9,15 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=['direct', 'lds'])
+def lds_mode(request):
+    """Run the convolution cases on the direct kernels and with the LDS-staged 3x3 kernel enabled."""
+    from fami_pose_amd._lib import lib
+    lib().cdll.fami_conv_tune_lds(request.param)
+    yield request.param
+    lib().cdll.fami_conv_tune_lds(0)
+
+
 def _eng(dev):
     from fami_pose_amd.engine import Engine
     return Engine(dev)
@@ -51,7 +60,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_fwd_bwd(dev, case):
+def test_conv_fwd_bwd(dev, case, lds_mode):
     N, H, W, Ci, Co, k, s, p, d, has_bias = case
     torch.manual_seed(hash(case) % 1000)
     conv = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias)
