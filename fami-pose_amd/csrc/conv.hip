@@ -992,6 +992,164 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ bf16 wgrad on the bf16 matrix core
+// dW[tap][ci][co] = sum_p X[p + tap][ci] * dY[p][co]: the reduction runs over PIXELS, but NHWC keeps channels, not
+// pixels, contiguous -- both MFMA operands need a transpose.  gfx950's ds_read_b64_tr_b16 does it on the way out of
+// LDS: the 16 lanes of a group hand in 16 row pieces (4 pixels x 16 channels) and each lane receives its channel's
+// 4 pixel values.  A workgroup stages a run of pixels ONCE (X with a +-(W+1)-pixel halo so all 9 taps are LDS address
+// shifts, dY without), every (channel tile, tap) pair is an accumulator group in registers (fp32), out-of-image taps
+// are redirected per pixel to a zero row, and the 32-pixel K steps feed v_mfma_f32_16x16x32_bf16.
+// 3x3, stride 1, pad 1, dilation 1; everything else takes the scalar-operand kernels above.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct WgradLdsArgs {
+  const bf16_t* x;   // [N,H,W,Ci]
+  const bf16_t* dy;  // [N,H,W,Co]
+  float* part;       // [G][9][Ci][Co]
+  int N, H, W, Ci, Co, P;
+  int chunk;         // pixels per staged sub-chunk (multiple of 32)
+  int nsub;          // sub-chunks walked by one workgroup (accumulators persist, LDS is restaged)
+  int ciBlocks, coBlocks;
+  int CiB, CoB;      // channels per block (16 * CIT, 16 * COT)
+  int xrow, yrow;    // LDS bytes per pixel of the X / dY tiles
+  int xbytes;        // size of the X tile
+};
+
+template <int CIT, int COT>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPW = (CIT * 9 + 3) / 4;  // (ci tile, tap) pairs per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int rsel = l16 >> 2, piece = l16 & 3;  // this lane feeds pixel row `rsel` (of 4), channels piece*4..+3
+  const int g = blockIdx.x;
+  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  const int halo = p.W + 1;
+  char* xt = smem;                             // [(chunk + 2*halo)][xrow]
+  char* yt = smem + p.xbytes;                  // [chunk][yrow]
+  char* zrow = yt + p.chunk * p.yrow;          // 32 zero bytes
+
+  // pairs of this wave: q = wave + 4*i -> (ci tile, tap)
+  int pci[NPW], ptap[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = wave + 4 * i;
+    const bool ok = q < CIT * 9;
+    pci[i] = ok ? q / 9 : 0;
+    ptap[i] = ok ? q % 9 : -1;
+  }
+  f32x4 acc[NPW][COT];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int HW = p.H * p.W;
+
+  for (int sub = 0; sub < p.nsub; ++sub) {
+  const int p0 = (g * p.nsub + sub) * p.chunk;
+  if (p0 >= p.P) break;
+  const int M = min(p.chunk, p.P - p0);       // pixels of this sub-chunk
+  if (sub > 0) __syncthreads();               // the previous sub-chunk has been consumed
+  // ---- stage X (pixels p0-halo .. p0+chunk+halo) and dY (p0 .. p0+chunk); out-of-tensor pixels are zero-filled
+  {
+    const int xpcs = p.CiB / 8, ypcs = p.CoB / 8;  // 16-byte pieces per pixel
+    const int nx = (p.chunk + 2 * halo) * xpcs, ny = p.chunk * ypcs;
+    const char* xg = reinterpret_cast<const char*>(p.x) + (long)cib * p.CiB * 2;
+    const char* yg = reinterpret_cast<const char*>(p.dy) + (long)cob * p.CoB * 2;
+    for (int i0 = tid; i0 < nx + ny; i0 += 256 * 4) {
+      u32x4 v[4];
+      int dsto[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        dsto[u] = -1;
+        if (i < nx) {
+          const int px = i / xpcs, pc = i - px * xpcs;
+          const long pg = (long)p0 - halo + px;
+          dsto[u] = px * p.xrow + pc * 16;
+          if (pg >= 0 && pg < p.P) v[u] = *reinterpret_cast<const u32x4*>(xg + pg * p.Ci * 2 + pc * 16);
+        } else if (i < nx + ny) {
+          const int k = i - nx;
+          const int px = k / ypcs, pc = k - px * ypcs;
+          const long pg = (long)p0 + px;
+          dsto[u] = p.xbytes + px * p.yrow + pc * 16;
+          if (pg < p.P) v[u] = *reinterpret_cast<const u32x4*>(yg + pg * p.Co * 2 + pc * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dsto[u] >= 0) *reinterpret_cast<u32x4*>(smem + dsto[u]) = v[u];
+    }
+    if (tid < 2) *reinterpret_cast<u32x4*>(zrow + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+
+  const int ksteps = (M + 31) >> 5;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    // the two pixels (of the 8 this lane-group covers) whose rows THIS lane hands to the transposing reads
+    int pl[2], py[2], pxx[2];
+    bool pin[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      pl[h] = ks * 32 + kq * 8 + h * 4 + rsel;  // local pixel index
+      const int pg = p0 + pl[h];
+      pin[h] = pl[h] < M;
+      const int r = pg % HW;
+      py[h] = r / p.W;
+      pxx[h] = r - py[h] * p.W;
+    }
+    // B operand (dY): 8 pixels x 16 output channels per tile
+    bf16x8 bfr[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4*)(pin[0] ? yt + pl[0] * p.yrow + c * 32 + piece * 8 : zrow + piece * 8));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4*)(pin[1] ? yt + pl[1] * p.yrow + c * 32 + piece * 8 : zrow + piece * 8));
+      s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      bfr[c] = __builtin_bit_cast(bf16x8, t);
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int tap = ptap[i];
+      if (tap < 0) continue;  // wave-uniform
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const char* a0 = zrow + piece * 8;
+      const char* a1 = zrow + piece * 8;
+      if (pin[0] && (unsigned)(py[0] + dy) < (unsigned)p.H && (unsigned)(pxx[0] + dx) < (unsigned)p.W)
+        a0 = xt + (pl[0] + halo + dy * p.W + dx) * p.xrow + pci[i] * 32 + piece * 8;
+      if (pin[1] && (unsigned)(py[1] + dy) < (unsigned)p.H && (unsigned)(pxx[1] + dx) < (unsigned)p.W)
+        a1 = xt + (pl[1] + halo + dy * p.W + dx) * p.xrow + pci[i] * 32 + piece * 8;
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+      s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const bf16x8 afr = __builtin_bit_cast(bf16x8, t);
+#pragma unroll
+      for (int c = 0; c < COT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[c], acc[i][c], 0, 0, 0);
+    }
+  }
+
+  }  // sub-chunks
+
+  // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [g][tap][ci][co]
+  float* slab = p.part + (long)g * 9 * p.Ci * p.Co;
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    if (ptap[i] < 0) continue;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int co = cob * p.CoB + c * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = cib * p.CiB + pci[i] * 16 + kq * 4 + r;
+        slab[((long)ptap[i] * p.Ci + ci) * p.Co + co] = acc[i][c][r];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ host side
 static int pick_nt(int tiles) {
   const int cand[5] = {6, 4, 3, 2, 1};
@@ -1088,6 +1246,8 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // register-only MFMA rate of this part (138 TF f32, tools/probes/mfma_peak.hip).  It is therefore opt-in
 // (fami_conv_tune_lds(1)); tests exercise it explicitly.
 static int g_use_lds = 0;
+static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
+static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
 
 // LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
 template <typename T>
@@ -1165,6 +1325,12 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 (default) through the direct kernels
 int fami_conv_tune_lds(int on) {
   g_use_lds = on ? 1 : 0;
+  return FAMI_OK;
+}
+// 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
+int fami_conv_tune_wgrad_lds(int on) {
+  g_wgrad_lds = on ? 1 : 0;
+  if (on > 1) g_wgrad_nsub = on - 1;  // benchmarks: on = 1 + sub-chunks per workgroup
   return FAMI_OK;
 }
 // tuning hook (benchmarks only): register-pipeline depth of the implicit GEMM (2..4; 0 = default)
@@ -1265,10 +1431,46 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   return q;
 }
 
+// bf16 transposing-LDS wgrad plan (3x3 stride-1 pad-1): pixel groups G, chunk pixels, channel blocks
+struct WgradLdsPlan { int ok, CIT, COT, ciBlocks, coBlocks, G, chunk, nsub; size_t lds; int xrow, yrow, xbytes; };
+static WgradLdsPlan wgrad_lds_plan(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  WgradLdsPlan q;
+  q.ok = 0;
+  if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) || (Ci % 16) || (Co % 16) || W > 160) return q;
+  q.CIT = Ci % 48 == 0 ? 3 : (Ci % 32 == 0 ? 2 : 1);
+  q.COT = Co % 48 == 0 ? 3 : (Co % 32 == 0 ? 2 : 1);
+  q.ciBlocks = Ci / (16 * q.CIT);
+  q.coBlocks = Co / (16 * q.COT);
+  const long P = (long)N * H * W;
+  const long blocks = (long)q.ciBlocks * q.coBlocks;
+  long G = (512 + blocks - 1) / blocks;
+  long chunk = (P + G - 1) / G;
+  chunk = ((chunk + 31) / 32) * 32;
+  if (chunk < 32) chunk = 32;
+  if (chunk > 320) chunk = 320;
+  q.nsub = g_wgrad_nsub;
+  G = (P + chunk * q.nsub - 1) / (chunk * q.nsub);
+  q.G = (int)G;
+  q.chunk = (int)chunk;
+  // LDS rows: an odd number of 16-byte units per pixel keeps the 8-byte row pieces of the transposing reads apart
+  q.xrow = 32 * q.CIT + (((2 * q.CIT) & 1) ? 0 : 16);
+  q.yrow = 32 * q.COT + (((2 * q.COT) & 1) ? 0 : 16);
+  q.xbytes = (q.chunk + 2 * (W + 1)) * q.xrow;
+  q.lds = (size_t)q.xbytes + (size_t)q.chunk * q.yrow + 32;
+  q.ok = q.lds <= 150 * 1024 && P < (1L << 31) && G < 65536;
+  return q;
+}
+
 long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
   if (!geom_ok(kh, kw, stride, pad, dil)) return -1;
   const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
-  return (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
+  long need = (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
+  const WgradLdsPlan l = wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
+  if (l.ok) {
+    const long nl = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
+    if (nl > need) need = nl;
+  }
+  return need;
 }
 
 }  // extern "C"
@@ -1409,6 +1611,38 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
 int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
                            int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                            hipStream_t s) {
+  const WgradLdsPlan l = g_wgrad_lds ? wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
+  if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    const long need = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
+    FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_bf16", "workspace too small");
+    WgradLdsArgs a;
+    a.x = x; a.dy = dy; a.part = workspace;
+    a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.P = N * H * W;
+    a.chunk = l.chunk; a.nsub = l.nsub; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks;
+    a.CiB = 16 * l.CIT; a.CoB = 16 * l.COT; a.xrow = l.xrow; a.yrow = l.yrow; a.xbytes = l.xbytes;
+    const dim3 grid(l.G, l.ciBlocks * l.coBlocks);
+    bool ok = false;
+#define FAMI_WL_CASE(cit, cot)                                                                                     \
+  if (l.CIT == cit && l.COT == cot) {                                                                              \
+    static bool attr = false;                                                                                      \
+    if (!attr) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      attr = true;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<cit, cot>), grid, dim3(256), l.lds, s, a);                          \
+    ok = true;                                                                                                     \
+  }
+    FAMI_WL_CASE(1, 1) FAMI_WL_CASE(1, 2) FAMI_WL_CASE(1, 3) FAMI_WL_CASE(2, 1) FAMI_WL_CASE(2, 2) FAMI_WL_CASE(2, 3)
+    FAMI_WL_CASE(3, 1) FAMI_WL_CASE(3, 2) FAMI_WL_CASE(3, 3)
+#undef FAMI_WL_CASE
+    if (ok) {
+      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/lds");
+      const long n = (long)Co * Ci * 9;
+      hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, workspace, dw, Co, Ci, 9, l.G, accumulate);
+      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/reduce");
+      return FAMI_OK;
+    }
+  }
   return wgrad_impl<bf16_t>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
                             "fami_conv2d_wgrad_bf16");
 }
