@@ -51,6 +51,16 @@ def build(args, dev):
     return model.to(dev)
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch measured with rocprofv3 --pmc (profiles/pmc_traffic.json; separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 wide-read correction applied) for the SAME launch the roofline times; None if not on record."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))[key]
+        return rec['read_bytes_corrected'] + rec['write_bytes']
+    except Exception:
+        return None
+
+
 def conv_roofline(dev, N, dtype, reps=30):
     """Live HIP-event timing of the dominant kernel: the 48->48 3x3 branch conv at 96x72 (26 % of the
     step's conv FLOPs, 64 forward launches per step) on the stream it is launched on."""
@@ -91,7 +101,8 @@ def conv_roofline(dev, N, dtype, reps=30):
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "kernel": "conv_igemm_%s (48->48 3x3 @96x72, N=%d frames)" % (dtype, N),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic('conv_igemm_' + dtype) if N == 20 else None,
+            "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def dcn_roofline(dev, B, dtype, reps=30):
@@ -127,7 +138,7 @@ def dcn_roofline(dev, B, dtype, reps=30):
     ach = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "dcn_fwd_kernel (48ch, 12 groups, 96x72, B=%d, %s)" % (B, dtype),
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-            "traffic": None, "avg_launch_us": round(ms * 1e3, 2)}
+            "traffic": pmc_traffic('dcn_fwd_' + dtype) if B == 4 else None, "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def cpu_baseline_worker(args):

@@ -269,6 +269,34 @@ __global__ void pack_w_bf16_kernel(const float* __restrict__ w, bf16_t* __restri
   }
 }
 
+// All weight images of a step in ONE launch: descriptor i = {src element offset (fp32 parameter arena), dst element
+// offset (packed arena), Co, Ci, taps, mode}; blockIdx.y walks the descriptors.  Replaces ~600 pack launches per step.
+struct PackDesc { long src, dst; int Co, Ci, taps, mode; };
+template <typename T>
+__global__ void pack_w_batch_kernel(const float* __restrict__ params, T* __restrict__ packed,
+                                    const PackDesc* __restrict__ desc) {
+  const PackDesc d = desc[blockIdx.y];
+  const float* w = params + d.src;
+  T* wp = packed + d.dst;
+  constexpr int KG = sizeof(T) == 2 ? 32 : 16;   // channels per K group
+  constexpr int FR = sizeof(T) == 2 ? 8 : 4;     // elements per lane fragment
+  const int kd = d.mode == 0 ? d.Ci : d.Co, nd = d.mode == 0 ? d.Co : d.Ci;
+  const int KC = (kd + KG - 1) / KG, NTt = (nd + 15) / 16;
+  const long total = (long)d.taps * KC * NTt * 64 * FR;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % FR), lane = (int)((i / FR) & 63);
+    long r = i / (FR * 64);
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int kc = (int)(r % KC), tap = (int)(r / KC);
+    const int kidx = kc * KG + (lane >> 4) * FR + j, nidx = nt * 16 + (lane & 15);
+    const int co = d.mode == 0 ? nidx : kidx, ci = d.mode == 0 ? kidx : nidx;
+    float v = 0.f;
+    if (co < d.Co && ci < d.Ci) v = w[((long)co * d.Ci + ci) * d.taps + tap];
+    st1(wp + i, v);
+  }
+}
+
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int MT, int NT, int MODE, int VEC, int KS, int ST>
@@ -1452,9 +1480,10 @@ static WgradLdsPlan wgrad_lds_plan(int N, int H, int W, int Ci, int Co, int kh, 
   G = (P + chunk * q.nsub - 1) / (chunk * q.nsub);
   q.G = (int)G;
   q.chunk = (int)chunk;
-  // LDS rows: an odd number of 16-byte units per pixel keeps the 8-byte row pieces of the transposing reads apart
-  q.xrow = 32 * q.CIT + (((2 * q.CIT) & 1) ? 0 : 16);
-  q.yrow = 32 * q.COT + (((2 * q.COT) & 1) ? 0 : 16);
+  // LDS rows are unpadded: the 4 pixel rows a 16-lane group hands to one transposing read are 32/64/96 bytes apart
+  // (distinct bank groups); padding would only separate the kq groups and costs the second resident workgroup
+  q.xrow = 32 * q.CIT;
+  q.yrow = 32 * q.COT;
   q.xbytes = (q.chunk + 2 * (W + 1)) * q.xrow;
   q.lds = (size_t)q.xbytes + (size_t)q.chunk * q.yrow + 32;
   q.ok = q.lds <= 150 * 1024 && P < (1L << 31) && G < 65536;
@@ -1645,6 +1674,21 @@ int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* 
   }
   return wgrad_impl<bf16_t>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
                             "fami_conv2d_wgrad_bf16");
+}
+
+// every weight image of a step in one launch.  desc: device array of n records {long src_elem_off, long dst_elem_off,
+// int Co, int Ci, int taps, int mode} (32 bytes each); params = fp32 parameter arena, packed = destination arena.
+int fami_pack_conv_weights_batch_f32(const float* params, float* packed, const void* desc, int n, hipStream_t s) {
+  FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_f32", "bad argument");
+  hipLaunchKernelGGL(pack_w_batch_kernel<float>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_f32");
+  return FAMI_OK;
+}
+int fami_pack_conv_weights_batch_bf16(const float* params, bf16_t* packed, const void* desc, int n, hipStream_t s) {
+  FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_bf16", "bad argument");
+  hipLaunchKernelGGL(pack_w_batch_kernel<bf16_t>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_bf16");
+  return FAMI_OK;
 }
 
 long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode) {

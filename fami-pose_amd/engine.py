@@ -60,6 +60,7 @@ class Engine:
         self.stream = None
         self.aux = {}                  # handles a model body leaves for the trainer (final T, MI seeds, ...)
         self.bn_trained = []           # BatchNorm modules that consumed a training batch this forward
+        self.prepacked = None          # optional {(id(param), mode): packed weight image} filled by the Trainer
         self.sync_stream()
 
     # ------------------------------------------------------------------ plumbing
@@ -122,6 +123,10 @@ class Engine:
     # dtype / version counter, so it can never outlive or be confused with another model's weights); trainable
     # parameters and ad-hoc tensors are packed every forward
     def packed(self, w, mode):
+        if self.prepacked is not None:
+            hit = self.prepacked.get((id(w), mode))
+            if hit is not None:
+                return hit
         Co, Ci, kh, kw = w.shape
         cacheable = isinstance(w, torch.nn.Parameter) and not w.requires_grad
         key = (mode, self.dt)

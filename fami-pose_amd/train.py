@@ -68,6 +68,42 @@ def flatten_parameters(model):
     return flat, table
 
 
+class WeightPacker:
+    """MFMA-fragment images of every trainable nn.Conv2d weight (forward and dgrad orientation), rebuilt from the
+    flat fp32 parameter arena in ONE launch per step (fami_pack_conv_weights_batch_*) instead of ~600."""
+
+    def __init__(self, model, flat, table, dtype):
+        import numpy as np
+        L = lib().cdll
+        bf = dtype == torch.bfloat16
+        elems = L.fami_packed_weight_elems_bf16 if bf else L.fami_packed_weight_elems
+        convs = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Conv2d)}
+        recs, self.views, off = [], {}, 0
+        spans = []
+        for prm, src, _ in table:
+            if id(prm) not in convs:
+                continue
+            Co, Ci, kh, kw = prm.shape
+            for mode in (0, 1):
+                n = elems(Co, Ci, kh, kw, mode)
+                recs.append((src, off, Co, Ci, kh * kw, mode))
+                spans.append((id(prm), mode, off, n))
+                off += n
+        self.n = len(recs)
+        self.flat = flat
+        self.arena = torch.empty(max(off, 1), dtype=dtype, device=flat.device)
+        desc = np.array(recs, dtype=[('src', '<i8'), ('dst', '<i8'), ('Co', '<i4'), ('Ci', '<i4'), ('taps', '<i4'),
+                                     ('mode', '<i4')])
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(flat.device)
+        for pid, mode, o, n in spans:
+            self.views[(pid, mode)] = self.arena[o:o + n]
+        self.fn = 'fami_pack_conv_weights_batch_bf16' if bf else 'fami_pack_conv_weights_batch_f32'
+
+    def run(self, stream):
+        if self.n:
+            lib().call(self.fn, _p(self.flat), _p(self.arena), _p(self.desc), self.n, stream)
+
+
 class BucketReducer:
     """Data-parallel gradient exchange over one flat gradient arena (pure host logic + torch.distributed;
     no HIP dependency, so the N>1 path is covered by gloo tests on CPU).
@@ -139,7 +175,7 @@ class Trainer:
     """One optimisation step per call: forward, loss, backward, (all-reduce), Adam -- all HIP kernels."""
 
     def __init__(self, model, lr=1e-3, mse_weight=1.0, alpha=0.5, beta=0.1, use_mi=True, bucket_mb=32,
-                 process_group=None, use_graph=True, targets_from_joints=False, sigma=3):
+                 process_group=None, use_graph=True, targets_from_joints=False, sigma=3, force_ddp=False):
         self.model = model
         self.targets_from_joints, self.sigma = targets_from_joints, sigma
         self.dev = next(model.parameters()).device
@@ -154,12 +190,17 @@ class Trainer:
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         if self.world > 1 and process_group is None:
             self.pg = dist.group.WORLD
+        # force_ddp: run the bucketed all-reduce path even with one rank (exercises the hooks / RCCL stream ordering
+        # on a single GPU; an all-reduce over one rank is the identity)
+        self.ddp = self.world > 1 or (force_ddp and dist.is_initialized())
         self.reducer = BucketReducer(self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg)
-        self.use_graph = use_graph
+        self.packer = WeightPacker(model, self.flat, self.table, getattr(model, 'act_dtype', torch.float32))
+        # the per-bucket hipGraph plan of the data-parallel path (_capture) is experimental: opt in with FAMI_DDP_GRAPH=1
+        self.use_graph = use_graph and (not self.ddp or os.environ.get('FAMI_DDP_GRAPH') == '1')
         self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
         self._graphs = None
         self._static = None
-        if self.world > 1:
+        if self.ddp:
             self.broadcast_parameters()
 
     # ------------------------------------------------------------------ data parallel
@@ -173,6 +214,8 @@ class Trainer:
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=getattr(model, 'act_dtype', torch.float32))
+        self.packer.run(eng.stream)             # every conv weight image of this step, one launch
+        eng.prepacked = self.packer.views
         if self.targets_from_joints:
             # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
             joints, vis = target, weight
@@ -209,7 +252,7 @@ class Trainer:
         return outs
 
     def _eager_step(self, kf_x, sup_x, target, weight):
-        if self.world > 1:
+        if self.ddp:
             outs = self._forward_backward(kf_x, sup_x, target, weight, on_bucket=self.reducer.allreduce)
             self.reducer.wait()
             lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world, 0.0,
@@ -229,7 +272,7 @@ class Trainer:
                 self._eager_step(st['kf'], st['sup'], st['target'], st['weight'])
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        if self.world == 1:
+        if not self.ddp:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])

@@ -47,6 +47,9 @@ int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline dep
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);
+/* all weight images of a step in one launch: desc = device array of n 32-byte records
+ * {long src_elem_off (in params), long dst_elem_off (in packed), int Co, int Ci, int taps, int mode} */
+int fami_pack_conv_weights_batch_f32(const float* params, float* packed, const void* desc, int n, fami_stream_t stream);
 /* y[N,Ho,Wo,Co] (=|+=) relu?( conv(x[N,H,W,Ci]) + bias + addend ) ; bias/addend may be NULL */
 int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* addend, float* y, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
@@ -172,6 +175,8 @@ typedef unsigned short fami_bf16_t; /* IEEE bfloat16 bit pattern */
 long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_bf16(const float* w_oihw, fami_bf16_t* wp, int Co, int Ci, int kh, int kw, int mode,
                                fami_stream_t stream);
+int fami_pack_conv_weights_batch_bf16(const float* params, fami_bf16_t* packed, const void* desc, int n,
+                                      fami_stream_t stream);
 /* y is bf16, or fp32 when out_f32 (heatmap-producing layers) */
 int fami_conv2d_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const float* bias, void* y, int N, int H, int W,
                          int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,

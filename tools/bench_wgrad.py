@@ -10,7 +10,7 @@ for (H, W, C) in ((96, 72, 48), (48, 36, 96), (24, 18, 192), (12, 9, 384)):
     dw = torch.empty(C, C, 3, 3, device=dev)
     ref = None
     out = []
-    for mode in (0, 2, 3, 5, 9):      # 0 = scalar-operand kernels; k = 1 + sub-chunks
+    for mode in (0, 2):      # 0 = scalar-operand kernels; 2 = LDS transposing kernel
         L.cdll.fami_conv_tune_wgrad_lds(mode)
         nb = L.cdll.fami_conv2d_wgrad_workspace(N, H, W, C, C, 3, 3, 1, 1, 1)
         ws = torch.empty(nb // 4, device=dev)
