@@ -198,6 +198,32 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   }
 }
 
+// get_final_preds (datasets/process/heatmaps_process.py:47-73): per (b, j) the argmax coordinate (zeroed when the
+// maximum is <= 0), the quarter-pixel shift toward the higher neighbour, and transform_preds' inverse affine for
+// rot = 0 (affine_transform.py:13-43: uniform scale s = 200*scale[0]/W about (W/2, H/2) -> image centre).
+__global__ void final_preds_kernel(const float* __restrict__ hm, const long long* __restrict__ idx,
+                                   const float* __restrict__ maxval, const float* __restrict__ center,
+                                   const float* __restrict__ scale, float* __restrict__ preds, int B, int J, int H,
+                                   int W) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B * J) return;
+  const int b = r / J;
+  const int i = (int)idx[r];
+  float x = (float)(i % W), y = floorf((float)i / (float)W);
+  if (!(maxval[r] > 0.f)) x = y = 0.f;
+  const int px = (int)floorf(x + 0.5f), py = (int)floorf(y + 0.5f);
+  if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+    const float* m = hm + (long)r * H * W;
+    const float dx = m[py * W + px + 1] - m[py * W + px - 1];
+    const float dy = m[(py + 1) * W + px] - m[(py - 1) * W + px];
+    x += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
+    y += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+  }
+  const float s = scale[b * 2] * 200.f / (float)W;
+  preds[r * 2 + 0] = center[b * 2 + 0] + (x - 0.5f * (float)W) * s;
+  preds[r * 2 + 1] = center[b * 2 + 1] + (y - 0.5f * (float)H) * s;
+}
+
 extern "C" {
 
 // joints [B,J,2] px, vis [B,J] -> target [B,J,Hh,Wh] (NCHW), weight [B,J]
@@ -256,6 +282,19 @@ int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int
   FAMI_REQUIRE(hm && idx && R > 0 && L > 0, "fami_argmax2d_f32", "bad argument");
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(R), dim3(256), 0, s, hm, idx, maxval, L);
   FAMI_CHECK_LAUNCH("fami_argmax2d_f32");
+  return FAMI_OK;
+}
+
+// hm [B,J,H,W] NCHW, center/scale [B,2] -> preds [B,J,2] image coordinates, maxvals [B,J]; idx_ws: B*J int64 scratch
+int fami_final_preds_f32(const float* hm, const float* center, const float* scale, float* preds, float* maxvals,
+                         long long* idx_ws, int B, int J, int H, int W, hipStream_t s) {
+  FAMI_REQUIRE(hm && center && scale && preds && maxvals && idx_ws && B > 0 && J > 0 && H > 2 && W > 2,
+               "fami_final_preds_f32", "bad argument");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(B * J), dim3(256), 0, s, hm, idx_ws, maxvals, H * W);
+  FAMI_CHECK_LAUNCH("fami_final_preds_f32/argmax");
+  hipLaunchKernelGGL(final_preds_kernel, dim3(fami_cdiv(B * J, 64)), dim3(64), 0, s, hm, idx_ws, maxvals, center, scale,
+                     preds, B, J, H, W);
+  FAMI_CHECK_LAUNCH("fami_final_preds_f32");
   return FAMI_OK;
 }
 

@@ -99,6 +99,22 @@ def get_max_preds(hm):
     return preds, mx.unsqueeze(-1)
 
 
+def get_final_preds(batch_heatmaps, center, scale):
+    """On-device get_final_preds (datasets/process/heatmaps_process.py:47-73): heatmaps [B,J,H,W] (device),
+    center / scale [B,2] -> (preds [B,J,2] image coordinates, maxvals [B,J,1]) as device tensors."""
+    _need_cuda(batch_heatmaps)
+    B, J, H, W = batch_heatmaps.shape
+    dev = batch_heatmaps.device
+    c = torch.as_tensor(center, dtype=torch.float32, device=dev).reshape(B, 2).contiguous()
+    sc = torch.as_tensor(scale, dtype=torch.float32, device=dev).reshape(B, 2).contiguous()
+    preds = torch.empty(B, J, 2, device=dev)
+    mx = torch.empty(B, J, device=dev)
+    ws = torch.empty(B * J, dtype=torch.int64, device=dev)
+    lib().call('fami_final_preds_f32', _p(batch_heatmaps.float().contiguous()), _p(c), _p(sc), _p(preds), _p(mx), _p(ws),
+               B, J, H, W, _stream(batch_heatmaps))
+    return preds, mx.unsqueeze(-1)
+
+
 def accuracy(output, target, thr=0.5):
     """PCK on heatmap argmax (evaluate.py:39-75).  -> (acc[J+1], avg_acc, cnt, pred[B,J,2] ndarray)."""
     pred, _ = get_max_preds(output)

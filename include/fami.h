@@ -161,6 +161,11 @@ int fami_softmax_kl_bwd_f32(const float* A, const float* Bt, const float* stats,
                             float temperature, float gscale, const float* gdev, int accumulate,
                             fami_stream_t stream);
 int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int L, fami_stream_t stream);
+/* get_final_preds (datasets/process/heatmaps_process.py:47-73 + transform_preds, affine_transform.py:13-43, rot 0):
+ * argmax, quarter-pixel shift, inverse affine to image coordinates.  hm [B,J,H,W]; center, scale [B,2];
+ * preds [B,J,2]; maxvals [B,J]; idx_ws: B*J int64 scratch */
+int fami_final_preds_f32(const float* hm, const float* center, const float* scale, float* preds, float* maxvals,
+                         long long* idx_ws, int B, int J, int H, int W, fami_stream_t stream);
 
 
 /* ======================================================================================================

@@ -241,6 +241,31 @@ def g7_decode(ns):
           cnt=np.array(cnt), pred=pred)
 
 
+def g12_final_preds(ns):
+    """get_final_preds.  cv2 is absent: the reference runs with oracle.ops.cv2_get_affine_transform
+    injected as cv2.getAffineTransform (ref_harness), so this pins everything but that one third-party call."""
+    rng = np.random.RandomState(12)
+    B, J, H, W = 3, 17, 96, 72
+    hm = rng.randn(B, J, H, W).astype(np.float32) * 0.1
+    for b in range(B):
+        for j in range(J):
+            y, x = rng.randint(0, H), rng.randint(0, W)
+            hm[b, j, y, x] += 1.0 + rng.rand()
+            if 0 < x < W - 1:
+                hm[b, j, y, x + 1] += 0.5 * rng.rand()
+    hm[0, 0] = -np.abs(hm[0, 0])                    # no positive maximum -> coordinates zeroed before the transform
+    hm[0, 1] = 0.0
+    hm[0, 1, 0, 5] = 1.0                            # border maxima: no quarter-pixel shift
+    hm[0, 2] = 0.0
+    hm[0, 2, 40, 71] = 1.0
+    hm[0, 3] = 0.0
+    hm[0, 3, 50, 30] = 1.0                          # symmetric neighbours: sign(0) = 0
+    center = np.array([[150.5, 200.25], [512.0, 300.0], [80.0, 1000.5]], np.float32)
+    scale = np.array([[1.2, 1.6], [2.5, 3.3333], [0.45, 0.6]], np.float32)
+    preds, maxvals = ns.get_final_preds(hm.copy(), center, scale)
+    _save('g12_final_preds.npz', hm=hm, center=center, scale=scale, preds=preds, maxvals=maxvals)
+
+
 # ------------------------------------------------------------------ G8 MI / G9 whole model / G10 keys / G11 init stats
 def g9_alignment(ns):
     cfg = rh.ref_cfg(48)
@@ -334,6 +359,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ns = rh.load()
+    if len(sys.argv) > 1:                 # regenerate selected fixtures only: python -m oracle.gen_golden g12_final_preds
+        for name in sys.argv[1:]:
+            globals()[name](ns)
+        return
+    g12_final_preds(ns)
     g1_blocks(ns)
     g2_hrmodule(ns)
     g3_hrnet_w32(ns)

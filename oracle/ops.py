@@ -273,6 +273,71 @@ def accuracy(output, target, thr=0.5):
     return acc, avg, cnt, pred
 
 
+def cv2_get_affine_transform(src, dst):
+    """cv2.getAffineTransform(src, dst): the 2x3 matrix M with M @ [x, y, 1] = dst for three point pairs.  cv2 is a
+    third-party package absent from this image; this restates its documented definition (exact 6x6 linear solve in
+    float64).  Used by the oracle AND injected as the reference's `cv2.getAffineTransform` when golden vectors are
+    generated (oracle/ref_harness.py), so get_final_preds is pinned up to this one call."""
+    src = np.asarray(src, np.float64)
+    dst = np.asarray(dst, np.float64)
+    A = np.zeros((6, 6))
+    bvec = np.zeros(6)
+    for i in range(3):
+        A[2 * i, 0:3] = (src[i, 0], src[i, 1], 1.0)
+        A[2 * i + 1, 3:6] = (src[i, 0], src[i, 1], 1.0)
+        bvec[2 * i], bvec[2 * i + 1] = dst[i, 0], dst[i, 1]
+    return np.linalg.solve(A, bvec).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size, inv=0):
+    """datasets/process/affine_transform.py:13-43 (shift = 0)."""
+    scale = np.asarray(scale, np.float64)
+    scale_tmp = scale * 200.0
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rad = np.pi * rot / 180
+    sn, cs = np.sin(rad), np.cos(rad)
+    pt = (0.0, src_w * -0.5)
+    src_dir = np.array([pt[0] * cs - pt[1] * sn, pt[0] * sn + pt[1] * cs])
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0, :] = center
+    src[1, :] = np.asarray(center) + src_dir
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
+
+    def third(a, b):
+        d = a - b
+        return b + np.array([-d[1], d[0]], np.float32)
+    src[2, :] = third(src[0], src[1])
+    dst[2, :] = third(dst[0], dst[1])
+    return cv2_get_affine_transform(dst, src) if inv else cv2_get_affine_transform(src, dst)
+
+
+def get_final_preds(batch_heatmaps, center, scale):
+    """datasets/process/heatmaps_process.py:47-73: argmax, quarter-pixel shift toward the higher neighbour,
+    transform_preds (inverse affine, rot 0) to image coordinates."""
+    coords, maxvals = get_max_preds(batch_heatmaps)
+    H, W = batch_heatmaps.shape[2], batch_heatmaps.shape[3]
+    for n in range(coords.shape[0]):
+        for p in range(coords.shape[1]):
+            hm = batch_heatmaps[n][p]
+            px = int(math.floor(coords[n][p][0] + 0.5))
+            py = int(math.floor(coords[n][p][1] + 0.5))
+            if 1 < px < W - 1 and 1 < py < H - 1:
+                diff = np.array([hm[py][px + 1] - hm[py][px - 1], hm[py + 1][px] - hm[py - 1][px]])
+                coords[n][p] += np.sign(diff) * .25
+    preds = coords.copy()
+    for i in range(coords.shape[0]):
+        trans = get_affine_transform(center[i], scale[i], 0, [W, H], inv=1)
+        out = np.zeros(coords[i].shape)
+        for p in range(coords.shape[1]):
+            out[p, 0:2] = trans @ np.array([coords[i][p, 0], coords[i][p, 1], 1.0])
+        preds[i] = out
+    return preds, maxvals
+
+
 def total_loss(final_hm, target, weight, mi_list, mse_weight=1.0, alpha=0.5, beta=0.1):
     """Loss assembly of engine/core/functions/alignment_mi_function_term6_1.py:108-148
     (local_warped_sup_hm_list is empty for Alignment_V15, SURVEY.md 2.3 #3)."""

@@ -85,7 +85,9 @@ def load():
     # shadows the unrelated HuggingFace `datasets` in site-packages
     _pkg('datasets', os.path.join(REF, 'datasets'))
     _pkg('datasets.process', os.path.join(REF, 'datasets', 'process'))
-    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    cv2 = sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    # the one cv2 function the post-processing calls (affine_transform.py:38-41); cv2 itself is absent here
+    cv2.getAffineTransform = oops.cv2_get_affine_transform
 
     class DeformConv2d(nn.Module):
         def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, bias=True):
@@ -122,6 +124,7 @@ def load():
     ns.BasicBlock, ns.Bottleneck = layers.BasicBlock, layers.Bottleneck
     ns.ChainOfBasicBlocks, ns.conv_bn_relu = layers.ChainOfBasicBlocks, layers.conv_bn_relu
     ns.generate_heatmaps, ns.get_max_preds = hp.generate_heatmaps, hp.get_max_preds
+    ns.get_final_preds = hp.get_final_preds
     ns.JointMSELoss = _load_by_path('ref_mse_loss', 'posetimation/loss/mse_loss.py').JointMSELoss
     ns.accuracy = _load_by_path('ref_evaluate', 'engine/core/utils/evaluate.py').accuracy
     ns.Alignment_V15 = _load_by_path('ref_alignment_v15', 'posetimation/zoo/Alignment/Alignment_V15.py').Alignment_V15

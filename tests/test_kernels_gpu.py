@@ -363,3 +363,14 @@ def test_adam_matches_torch(dev):
         ad.grad.copy_(g.to(dev))
         ad.step()
     assert relerr(flat, ref.data) < 1e-6
+
+
+def test_final_preds_golden(dev):
+    """On-device get_final_preds against the reference-generated golden (tests/golden/g12): fp32 arithmetic vs the
+    reference's float64 affine -> 1e-3 image pixels on coordinates up to ~1e3."""
+    import os
+    from fami_pose_amd import loss as FL
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g12_final_preds.npz'))
+    preds, maxvals = FL.get_final_preds(torch.from_numpy(g['hm']).to(dev), g['center'], g['scale'])
+    assert np.array_equal(maxvals.cpu().numpy(), g['maxvals'])
+    assert np.abs(preds.cpu().numpy().astype(np.float64) - g['preds']).max() < 1e-3

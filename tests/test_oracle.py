@@ -265,3 +265,16 @@ def test_warp_translate_vs_gridsample_and_integer_shift():
     assert torch.equal(out[:, :, 1:, 2:], src[:, :, :-1, :-2]) and out[:, :, 0].abs().max() == 0
     M = torch.tensor([[[1.0, 0.0, 2.0], [0.0, 1.0, 1.0]]]).repeat(3, 1, 1)
     assert torch.equal(oops.warp_affine_like(src, M, (12, 9)), out)
+
+
+def test_g12_final_preds():
+    """get_final_preds: argmax + quarter-pixel shift + inverse affine (heatmaps_process.py:47-73)."""
+    g = gold('g12_final_preds.npz')
+    preds, maxvals = oops.get_final_preds(g['hm'].copy(), g['center'], g['scale'])
+    assert np.array_equal(maxvals, g['maxvals'])
+    assert np.abs(preds - g['preds']).max() < 1e-9
+    # closed form of the rot-0 inverse affine: uniform scale 200*scale[0]/W about the heatmap centre
+    c, s = g['center'][0], g['scale'][0]
+    want = c + (np.array([5.0, 0.0]) - np.array([36.0, 48.0])) * (200.0 * s[0] / 72)
+    assert np.abs(preds[0, 1] - want).max() < 1e-4
+    assert np.abs(preds[0, 0] - (c - np.array([36.0, 48.0]) * (200.0 * s[0] / 72))).max() < 1e-4
