@@ -1275,6 +1275,7 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // (fami_conv_tune_lds(1)); tests exercise it explicitly.
 static int g_use_lds = 0;
 static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
+static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
 static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
 
 // LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
@@ -1357,6 +1358,10 @@ int fami_conv_tune_lds(int on) {
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
 int fami_conv_tune_wgrad_lds(int on) {
+  if (on >= 100) {  // benchmarks: 100 + mt caps the input-channel tiles per workgroup of the f32 kernels
+    g_wgrad_mt = on - 100;
+    return FAMI_OK;
+  }
   g_wgrad_lds = on ? 1 : 0;
   if (on > 1) g_wgrad_nsub = on - 1;  // benchmarks: on = 1 + sub-chunks per workgroup
   return FAMI_OK;
@@ -1443,6 +1448,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   q.P = (long)N * Ho * Wo;
   q.MT = pick_small(fami_cdiv(Ci, 16));
   q.NT = pick_small(fami_cdiv(Co, 16));
+  if (g_wgrad_mt > 0 && g_wgrad_mt <= q.MT) q.MT = g_wgrad_mt;  // benchmarks: fewer input-channel tiles per workgroup
   q.ciBlocks = fami_cdiv(fami_cdiv(Ci, 16), q.MT);
   q.coBlocks = fami_cdiv(fami_cdiv(Co, 16), q.NT);
   q.pertap = (kh * kw > 1 && kh * kw <= 9) ? 1 : 0;   // one wave per tap (3x3): workgroups of kh*kw waves

@@ -227,15 +227,160 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- small-tensor BatchNorm: statistics + apply (forward) / both reductions + apply (backward) in ONE launch.
+// One workgroup per 4-channel column: the tensor of a low-resolution HRNet branch (P <= BN_SMALL_P pixels) is
+// L2-resident, so the second pass re-reads it from cache and the three launches of the general path collapse
+// into one (these layers are launch-latency bound, not bandwidth bound).  Same arithmetic: shifted moments,
+// fp64 finalize, biased variance for normalisation / unbiased for running_var.
+#define BN_SMALL_P 16384
+// one workgroup per 4 channels is serial over pixels: measured slower than the three-launch path for everything but
+// tiny tensors (the translation regressor's 16-channel maps below 24x18), where launch count is all that matters
+static inline bool bn_small_ok(long P, int C) { return P * C <= 32768; }
+
+__device__ __forceinline__ f32x4 block_sum4(f32x4 v, float* sm) {  // sm: 4 * 4 floats
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = wave_sum(v[t]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sm[wave * 4 + t] = v[t];
+  }
+  __syncthreads();
+  f32x4 r;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) r[t] = (sm[t] + sm[4 + t]) + (sm[8 + t] + sm[12 + t]);
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ residual,
+                                                           T* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* running_mean,
+                                                           float* running_var, long P, int C, int relu,
+                                                           float momentum, float eps) {
+  __shared__ float sm[16];
+  const int c0 = blockIdx.x * 4;
+  const f32x4 piv = ld4(x + c0);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const f32x4 v = ld4(x + p * C + c0) - piv;
+    s += v;
+    q += v * v;
+  }
+  s = block_sum4(s, sm);
+  q = block_sum4(q, sm);
+  f32x4 mu, is, sc, sf;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double dm = (double)s[t] / (double)P;
+    double var = (double)q[t] / (double)P - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double m = (double)piv[t] + dm;
+    mu[t] = (float)m;
+    is[t] = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+      mean[c0 + t] = mu[t];
+      invstd[c0 + t] = is[t];
+      if (running_mean) {
+        const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+        running_mean[c0 + t] = (float)((1.0 - momentum) * running_mean[c0 + t] + momentum * m);
+        running_var[c0 + t] = (float)((1.0 - momentum) * running_var[c0 + t] + momentum * unb);
+      }
+    }
+    sc[t] = is[t] * gamma[c0 + t];
+    sf[t] = beta[c0 + t] - mu[t] * sc[t];
+  }
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const long o = p * C + c0;
+    f32x4 v = ld4(x + o) * sc + sf;
+    if (residual) v += ld4(residual + o);
+    if (relu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+    }
+    st4(y + o, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, T* __restrict__ dx,
+                                                           float* dgamma, float* dbeta, T* __restrict__ dres, long P,
+                                                           int C, int relu, int acc_dx, int acc_param, int acc_dres) {
+  __shared__ float sm[16];
+  const int c0 = blockIdx.x * 4;
+  f32x4 mu, is, gi;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    mu[t] = mean[c0 + t];
+    is[t] = invstd[c0 + t];
+    gi[t] = gamma[c0 + t] * is[t];
+  }
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const long o = p * C + c0;
+    f32x4 g = ld4(dy + o);
+    if (relu) {
+      const f32x4 yy = ld4(y + o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
+    }
+    s += g;
+    q += g * ((ld4(x + o) - mu) * is);
+  }
+  s = block_sum4(s, sm);
+  q = block_sum4(q, sm);
+  f32x4 c1, c2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    c1[t] = (float)((double)s[t] / (double)P);
+    c2[t] = (float)((double)q[t] / (double)P);
+    if (threadIdx.x == 0) {
+      if (dgamma) dgamma[c0 + t] = acc_param ? dgamma[c0 + t] + q[t] : q[t];
+      if (dbeta) dbeta[c0 + t] = acc_param ? dbeta[c0 + t] + s[t] : s[t];
+    }
+  }
+  for (long p = threadIdx.x; p < P; p += 256) {
+    const long o = p * C + c0;
+    f32x4 g = ld4(dy + o);
+    if (relu) {
+      const f32x4 yy = ld4(y + o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
+    }
+    const f32x4 xh = (ld4(x + o) - mu) * is;
+    f32x4 d = gi * (g - c1 - xh * c2);
+    if (acc_dx) d += ld4(dx + o);
+    st4(dx + o, d);
+    if (dres) {
+      f32x4 r = g;
+      if (acc_dres) r += ld4(dres + o);
+      st4(dres + o, r);
+    }
+  }
+}
+
 // per-channel sum over pixels (bias gradients): partial then finalize
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const T* __restrict__ x,
                                                                float* __restrict__ partial, long P, int C) {
-  // scalar-channel version: works for any C (17, 2, ...)
+  // scalar-channel version: works for any C (17, 2, 288, ...); C > 256 walks the channels in strides of 256
   extern __shared__ float sm[];  // [rows][C]
+  if (C > 256) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      for (long p = blockIdx.x; p < P; p += gridDim.x) s += ld1(x + p * C + c);
+      partial[(long)blockIdx.x * C + c] = s;
+    }
+    return;
+  }
   const int rows = max(1, 256 / C);
   const int c = threadIdx.x % C, prow = threadIdx.x / C;
-  const bool active = prow < rows && C <= 256;
+  const bool active = prow < rows;
   float s = 0.f;
   if (active) {
     for (long p = (long)blockIdx.x * rows + prow; p < P; p += (long)gridDim.x * rows) s += ld1(x + p * C + c);
@@ -313,6 +458,12 @@ static int bn_bwd_impl(const T* dy, const T* x, const T* y, const float* mean, c
     fami_set_error(nm, "C must be a multiple of 4, <= 1024");
     return FAMI_ESHAPE;
   }
+  if (bn_small_ok(P, C)) {  // low-resolution branches: one launch (see bn_small_bwd_kernel)
+    hipLaunchKernelGGL(bn_small_bwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, dx, dgamma,
+                       dbeta, dres, P, C, relu, acc_dx, acc_param, acc_dres);
+    FAMI_CHECK_LAUNCH(nm);
+    return FAMI_OK;
+  }
   const int G = bn_grid(P, C);
   const int rows = 256 / (C >> 2);
   float* coef = ws + (long)BN_MAXG * 2 * C - 2 * C;  // tail of the workspace (G < BN_MAXG leaves it free)
@@ -330,18 +481,37 @@ static int bn_bwd_impl(const T* dy, const T* x, const T* y, const float* mean, c
   return FAMI_OK;
 }
 
+// train-mode BatchNorm forward in one call: statistics (+ running-stat update) and apply (+ residual, + ReLU).
+// Small tensors take the single-launch kernel, large ones the three-launch path.
+template <typename T>
+static int bn_train_fwd_impl(const T* x, const T* residual, T* y, const float* gamma, const float* beta, float* mean,
+                             float* invstd, float* running_mean, float* running_var, long P, int C, int relu,
+                             float momentum, float eps, float* ws, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(x && y && gamma && beta && mean && invstd && ws, nm, "null pointer");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  if (bn_small_ok(P, C)) {
+    hipLaunchKernelGGL(bn_small_fwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, x, residual, y, gamma, beta, mean, invstd,
+                       running_mean, running_var, P, C, relu, momentum, eps);
+    FAMI_CHECK_LAUNCH(nm);
+    return FAMI_OK;
+  }
+  int rc = bn_stats_impl<T>(x, P, C, mean, invstd, running_mean, running_var, momentum, eps, ws, s, nm);
+  if (rc != FAMI_OK) return rc;
+  return bn_apply_impl<T>(x, mean, invstd, gamma, beta, residual, y, P, C, relu, s, nm);
+}
+
 template <typename T>
 static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s,
                             const char* nm) {
   FAMI_REQUIRE(x && out && ws && P > 0 && C > 0, nm, "bad argument");
-  if (C > 256) {
-    fami_set_error(nm, "C > 256 unsupported");
-    return FAMI_ESHAPE;
-  }
-  const int rows = 256 / C;
+  FAMI_REQUIRE(C <= 4096, nm, "C > 4096 unsupported");
+  const int rows = C > 256 ? 1 : 256 / C;
   long g = (P + rows - 1) / rows;
   if (g > BN_MAXG) g = BN_MAXG;
-  hipLaunchKernelGGL(chan_sum_partial_kernel<T>, dim3((int)g), dim3(256), (size_t)rows * C * sizeof(float), s, x, ws, P, C);
+  hipLaunchKernelGGL(chan_sum_partial_kernel<T>, dim3((int)g), dim3(256), C > 256 ? 0 : (size_t)rows * C * sizeof(float), s, x, ws, P, C);
   FAMI_CHECK_LAUNCH(nm);
   hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
   FAMI_CHECK_LAUNCH(nm);
@@ -379,7 +549,14 @@ int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, 
     return bn_bwd_impl<T>(dy, x, y, mean, invstd, gamma, dx, dgamma, dbeta, dres, P, C, relu, acc_dx, acc_param,       \
                           acc_dres, ws, s, "fami_bn_bwd_" #sfx);                                                       \
   }                                                                                                                    \
-  /* out[c] (=|+=) sum_p x[p][c], any C <= 256 */                                                                      \
+  /* train-mode forward, statistics + apply in one call (one launch for P <= 16384 pixels) */                         \
+  int fami_bn_train_fwd_##sfx(const T* x, const T* residual, T* y, const float* gamma, const float* beta,              \
+                              float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,      \
+                              int relu, float momentum, float eps, float* ws, hipStream_t s) {                         \
+    return bn_train_fwd_impl<T>(x, residual, y, gamma, beta, mean, invstd, running_mean, running_var, P, C, relu,      \
+                                momentum, eps, ws, s, "fami_bn_train_fwd_" #sfx);                                      \
+  }                                                                                                                    \
+  /* out[c] (=|+=) sum_p x[p][c] */                                                                      \
   int fami_channel_sum_##sfx(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {        \
     return channel_sum_impl<T>(x, P, C, out, accumulate, ws, s, "fami_channel_sum_" #sfx);                             \
   }

@@ -236,18 +236,19 @@ class Engine:
         C = shp[-1]
         P = x.data.numel() // C
         mean, invstd = self.empty(C), self.empty(C)
+        y = torch.empty_like(x.data)
         if bn.training:
             ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
-            self.acall('fami_bn_stats', _p(x.data), P, C, _p(mean), _p(invstd), _p(bn.running_mean),
-                       _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+            self.acall('fami_bn_train_fwd', _p(x.data), _p(None if residual is None else residual.data), _p(y),
+                       _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd), _p(bn.running_mean),
+                       _p(bn.running_var), P, C, int(relu), float(mom), float(bn.eps), _p(ws))
             self.bn_trained.append(bn)
         else:
             self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd), C,
                       float(bn.eps))
-        y = torch.empty_like(x.data)
-        self.acall('fami_bn_apply', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
-                  _p(None if residual is None else residual.data), _p(y), P, C, int(relu))
+            self.acall('fami_bn_apply', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
+                       _p(None if residual is None else residual.data), _p(y), P, C, int(relu))
         need_p = self.rq(bn.weight)
         rg = x.requires_grad or need_p or (residual is not None and residual.requires_grad)
         out = T(y, rg)

@@ -70,6 +70,11 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
 long fami_bn_workspace(int C);
 int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd, float* running_mean,
                       float* running_var, float momentum, float eps, float* ws, fami_stream_t stream);
+/* train-mode forward in one call: batch statistics (+ running-stat update) and apply (+ residual, + ReLU);
+ * tensors of <= 16384 pixels (the low-resolution branches) run as ONE launch */
+int fami_bn_train_fwd_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
+                          float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
+                          int relu, float momentum, float eps, float* ws, fami_stream_t stream);
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                            float eps, fami_stream_t stream);
 int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -195,6 +200,9 @@ int fami_conv2d_wgrad_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, float* d
 
 int fami_bn_stats_bf16(const fami_bf16_t* x, long P, int C, float* mean, float* invstd, float* running_mean,
                        float* running_var, float momentum, float eps, float* ws, fami_stream_t stream);
+int fami_bn_train_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* residual, fami_bf16_t* y, const float* gamma,
+                           const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
+                           long P, int C, int relu, float momentum, float eps, float* ws, fami_stream_t stream);
 int fami_bn_apply_bf16(const fami_bf16_t* x, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, const fami_bf16_t* residual, fami_bf16_t* y, long P, int C, int relu,
                        fami_stream_t stream);

@@ -164,6 +164,35 @@ def test_model_vs_oracle(dev, S, hw, B):
     assert np.percentile(e_hips, 90) <= 3 * np.percentile(e_cpus, 90) + 1e-4, (np.percentile(e_hips, 90), np.percentile(e_cpus, 90))
 
 
+@pytest.mark.parametrize('width,S,hw,B', [(48, 7, (512, 384), 1), (64, 4, (128, 96), 2), (32, 2, (128, 96), 2)])
+def test_baseline_configs_4_5_forward(dev, width, S, hw, B):
+    """BASELINE configs[3] (W48, 512x384, 7 supporting frames: 128x96 feature maps, 336-channel sup_agg input) and the
+    widths of configs[0]/[4] (W32: 8 DCN offset groups, W64: 16) -- forward + loss parity against the oracle with the
+    generalised head."""
+    H, W = hw
+    G = 12 if width % 48 == 0 else width // 4
+    orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(width), True, S, (H, W), dcn_groups=G), 40 + width)
+    model = fp.build_model(fp.default_cfg(width, image_size=(W, H), num_sup=S), 'train')
+    assert model.G == G
+    model.load_state_dict(orc.state_dict())
+    model = model.to(dev)
+    gen = torch.Generator().manual_seed(60 + width)
+    kf, sup = torch.randn(B, 3, H, W, generator=gen), torch.randn(B, 3 * S, H, W, generator=gen)
+    tgt = torch.rand(B, 17, H // 4, W // 4, generator=gen)
+    w = (torch.rand(B, 17, 1, generator=gen) < 0.8).float()
+    with torch.no_grad():
+        f0, k0, mi0 = orc(kf, sup)
+        l0 = oops.total_loss(f0, tgt, w, mi0)
+    f1, k1, mi1 = model(kf.to(dev), sup.to(dev))
+    assert (f1.cpu() - f0).abs().max().item() < HM_TOL and (k1.cpu() - k0).abs().max().item() < HM_TOL
+    assert np.array_equal(_argmax(f1), _argmax(f0)) and np.array_equal(_argmax(k1), _argmax(k0))
+    from fami_pose_amd.loss import JointMSELoss
+    l1 = JointMSELoss()(f1, tgt.to(dev), w.to(dev)) + 0.5 * (-0.1 * mi1[0] + 0.1 * mi1[1] + mi1[2] - mi1[3] + mi1[4] - mi1[5])
+    assert l1.item() == pytest.approx(l0.item(), rel=1e-4)
+    l1.backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+
+
 def test_full_size_properties(dev):
     """BASELINE's full per-GPU batch (4 five-frame 384x288 clips): properties that need no CPU reference."""
     model, _ = _pair(48, 4, (384, 288), fp.VAL_PHASE, 21)
