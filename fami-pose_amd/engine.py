@@ -13,6 +13,7 @@ write fp32 in either mode; parameters, BatchNorm statistics, weight gradients, t
 dense layers ([M,K] tensors) and everything at the NCHW boundary are always fp32.
 """
 import ctypes
+import os
 
 import torch
 
@@ -61,6 +62,14 @@ class Engine:
         self.aux = {}                  # handles a model body leaves for the trainer (final T, MI seeds, ...)
         self.bn_trained = []           # BatchNorm modules that consumed a training batch this forward
         self.prepacked = None          # optional {(id(param), mode): packed weight image} filled by the Trainer
+        # stream lanes: independent sub-graphs (the parallel HRNet branches) run on side streams between fork()/join()
+        self.use_lanes = os.environ.get('FAMI_LANES', '1') != '0'
+        self.lane = 0
+        self._main = None              # torch stream object of lane 0
+        self._side = []                # torch side streams (lanes 1..)
+        self._forked = 0               # lanes currently forked (backward bookkeeping for deferred bucket hooks)
+        self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
+                                       # the caching allocator must not recycle a block across lanes within a step
         self.sync_stream()
 
     # ------------------------------------------------------------------ plumbing
@@ -68,27 +77,91 @@ class Engine:
         return self.record and p is not None and p.requires_grad
 
     def sync_stream(self):
-        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self._main = torch.cuda.current_stream(self.dev)
+        self.stream = self._main.cuda_stream
+        self.lane = 0
+
+    # ------------------------------------------------------------------ stream lanes
+    _side_pool = {}
+
+    def _lanes(self, n):
+        pool = Engine._side_pool.setdefault(self.dev, [])
+        while len(pool) < n - 1:
+            pool.append(torch.cuda.Stream(self.dev))
+        self._side = pool
+        return pool
+
+    def set_lane(self, i):
+        self.lane = i
+        self.stream = self._main.cuda_stream if i == 0 else self._side[i - 1].cuda_stream
+
+    def _do_fork(self, n):
+        side = self._lanes(n)
+        ev = torch.cuda.Event()
+        ev.record(self._main)
+        for i in range(n - 1):
+            side[i].wait_event(ev)
+        self._forked = n
+
+    def _do_join(self, n):
+        side = self._lanes(n)
+        for i in range(n - 1):
+            ev = torch.cuda.Event()
+            ev.record(side[i])
+            self._main.wait_event(ev)
+        self.set_lane(0)
+        self._forked = 0
+
+    def fork(self, n):
+        """Lanes 1..n-1 start after everything enqueued on lane 0 so far; the backward of a fork is a join."""
+        if not self.use_lanes or n < 2:
+            return False
+        self._do_fork(n)
+        if self.record:
+            self.tape.append((lambda: self._do_join(n), (), 0))
+        return True
+
+    def join(self, n):
+        """Lane 0 continues after lanes 1..n-1; the backward of a join is a fork."""
+        self._do_join(n)
+        if self.record:
+            self.tape.append((lambda: self._do_fork(n), (), 0))
+
+    def record_bwd(self, fn, params):
+        self.tape.append((fn, params, self.lane))
 
     def call(self, name, *args):
         self.L.call(name, *args, self.stream)
 
     def empty(self, *shape, dtype=torch.float32):
-        return torch.empty(shape, dtype=dtype, device=self.dev)
+        t = torch.empty(shape, dtype=dtype, device=self.dev)
+        self._keep.append(t)
+        return t
 
     def act(self, *shape):
         """Uninitialised activation-typed buffer."""
-        return torch.empty(shape, dtype=self.dt, device=self.dev)
+        t = torch.empty(shape, dtype=self.dt, device=self.dev)
+        self._keep.append(t)
+        return t
 
     def acall(self, name, *args):
         """Call the activation-dtype instance of an entry point."""
         self.L.call(name + self.sfx, *args, self.stream)
 
     def new_grad(self, t):
-        return torch.empty(t.data.shape, dtype=torch.float32 if t.f32grad else self.dt, device=self.dev)
+        g = torch.empty(t.data.shape, dtype=torch.float32 if t.f32grad else self.dt, device=self.dev)
+        self._keep.append(g)
+        return g
+
+    def like(self, t):
+        r = torch.empty_like(t)
+        self._keep.append(r)
+        return r
 
     def ws(self, nbytes):
-        return torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=self.dev)
+        t = torch.empty((max(int(nbytes), 4) + 3) // 4, dtype=torch.float32, device=self.dev)
+        self._keep.append(t)
+        return t
 
     def fill(self, t, v=0.0):
         self.call('fami_fill' + _sfx(t), _p(t), t.numel(), float(v))
@@ -115,7 +188,7 @@ class Engine:
         if self.grad_views is not None:
             g = self.grad_views[id(p)]
         else:
-            g = torch.empty_like(p.data)
+            g = self.like(p.data)
         self.param_grads[id(p)] = g
         return g, 0
 
@@ -178,7 +251,7 @@ class Engine:
         N, H, W, C = x.shape
         g, acc = self.gbuf(x)
         if acc:
-            tmp = torch.empty_like(g)
+            tmp = self.like(g)
             self.call('fami_nchw_to_nhwc' + _sfx(g), _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
             self.call('fami_axpby' + _sfx(g), _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
         else:
@@ -227,7 +300,7 @@ class Engine:
                         self.call('fami_conv2d_dgrad_bf16', _p(dy), _p(wpd), _p(gx), *geo, acc)
                     else:
                         self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
-            self.tape.append((bwd, [weight, bias]))
+            self.record_bwd(bwd, [weight, bias])
         return out
 
     def bn(self, x, bn, relu=False, residual=None):
@@ -236,7 +309,7 @@ class Engine:
         C = shp[-1]
         P = x.data.numel() // C
         mean, invstd = self.empty(C), self.empty(C)
-        y = torch.empty_like(x.data)
+        y = self.like(x.data)
         if bn.training:
             ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
@@ -273,7 +346,7 @@ class Engine:
                 self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
                            _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
                            _p(ws))
-            self.tape.append((bwd, [bn.weight, bn.bias]))
+            self.record_bwd(bwd, [bn.weight, bn.bias])
         return out
 
     # ------------------------------------------------------------------ fuse (hrnet.py:159-168)
@@ -328,7 +401,7 @@ class Engine:
                     if not (x.requires_grad or need_p):
                         continue
                     Pk = x.data.numel() // C
-                    gx, accx = self.gbuf(x) if x.requires_grad else (torch.empty_like(x.data), 0)
+                    gx, accx = self.gbuf(x) if x.requires_grad else (self.like(x.data), 0)
                     gg = gb = None
                     accp = 0
                     if need_p:
@@ -339,11 +412,11 @@ class Engine:
                         self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
                                    _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
                     else:
-                        low = torch.empty_like(x.data)
+                        low = self.like(x.data)
                         self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> s, W >> s, C, s, 1)
                         self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
                                    _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
-            self.tape.append((bwd, [q for t in terms if t[1] is not None for q in (t[1].weight, t[1].bias)]))
+            self.record_bwd(bwd, [q for t in terms if t[1] is not None for q in (t[1].weight, t[1].bias)])
         return out
 
     # ------------------------------------------------------------------ glue ops
@@ -352,7 +425,7 @@ class Engine:
         return T(x.data[n0:n1], x.requires_grad, parent=x, n0=n0, n1=n1)
 
     def sub(self, a, b):
-        y = torch.empty_like(a.data)
+        y = self.like(a.data)
         self.acall('fami_axpby', _p(a.data), _p(b.data), _p(y), y.numel(), 1.0, -1.0)
         out = T(y, a.requires_grad or b.requires_grad)
         if out.requires_grad:
@@ -363,7 +436,7 @@ class Engine:
                     if t.requires_grad:
                         g, acc = self.gbuf(t)
                         self.acall('fami_axpby', _p(out.grad), _p(g) if acc else None, _p(g), g.numel(), sgn, 1.0)
-            self.tape.append((bwd, ()))
+            self.record_bwd(bwd, ())
         return out
 
     def concat(self, xs):
@@ -389,7 +462,7 @@ class Engine:
                         g, acc = self.gbuf(x)
                         self.acall('fami_copy_channels', _p(out.grad), _p(g), P, Ct, o, c, 0, c, acc)
                     o += c
-            self.tape.append((bwd, ()))
+            self.record_bwd(bwd, ())
         return out
 
     def flatten_chw(self, x):
@@ -404,12 +477,12 @@ class Engine:
                     return
                 g, acc = self.gbuf(x)
                 if acc:
-                    tmp = torch.empty_like(g)
+                    tmp = self.like(g)
                     self.acall('fami_nchw_to_nhwc', _p(out.grad), _p(tmp), N, C, H, W)
                     self.acall('fami_axpby', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
                 else:
                     self.acall('fami_nchw_to_nhwc', _p(out.grad), _p(g), N, C, H, W)
-            self.tape.append((bwd, ()))
+            self.record_bwd(bwd, ())
         return out
 
     def linear(self, x, lin):
@@ -434,14 +507,14 @@ class Engine:
                         gb, _ = self.pgrad(lin.bias)
                 self.call('fami_linear_bwd_f32', _p(out.grad), _p(x.data), _p(lin.weight.data), _p(gx), _p(gw),
                           _p(gb), M, K, Nn, accx, accp)
-            self.tape.append((bwd, [lin.weight, lin.bias]))
+            self.record_bwd(bwd, [lin.weight, lin.bias])
         return out
 
     # ------------------------------------------------------------------ alignment ops
     def shift(self, x, t):
         """kornia warp_affine with a pure translation t=[B,2]=(tx,ty) (Alignment_V15.py:133-135)."""
         B, H, W, C = x.shape
-        y = torch.empty_like(x.data)
+        y = self.like(x.data)
         self.acall('fami_shift_bilinear_fwd', _p(x.data), _p(t.data), _p(y), B, H, W, C)
         out = T(y, x.requires_grad or t.requires_grad)
         if out.requires_grad:
@@ -457,7 +530,7 @@ class Engine:
                 ws = self.ws(self.L.cdll.fami_shift_workspace(B))
                 self.acall('fami_shift_bilinear_bwd', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
                            W, C, accs, acct, _p(ws))
-            self.tape.append((bwd, ()))
+            self.record_bwd(bwd, ())
         return out
 
     def dcn(self, x, off, msk, weight, bias, G, pad=3, dil=3):
@@ -510,7 +583,7 @@ class Engine:
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
-            self.tape.append((bwd, [weight, bias]))
+            self.record_bwd(bwd, [weight, bias])
         return out
 
     # ------------------------------------------------------------------ MI estimators (Alignment_V15.py:250-277)
@@ -542,19 +615,27 @@ class Engine:
         remaining = None
         if on_params_done is not None:
             remaining = {}
-            for _, ps in self.tape:
+            for _, ps, _lane in self.tape:
                 for p in ps:
                     if p is not None and p.requires_grad:
                         remaining[id(p)] = remaining.get(id(p), 0) + 1
-        for fn, ps in reversed(self.tape):
+        pending = []
+        for fn, ps, lane in reversed(self.tape):
+            if lane != self.lane:
+                self.set_lane(lane)
             fn()
             if remaining is not None and ps:
-                done = []
                 for p in ps:
                     if p is not None and p.requires_grad:
                         remaining[id(p)] -= 1
                         if remaining[id(p)] == 0:
-                            done.append(p)
-                if done:
-                    on_params_done(done)
+                            pending.append(p)
+            # bucket hooks only fire from lane 0 outside a forked region: by then every lane's gradient
+            # kernels are ordered before whatever the hook enqueues on the main stream
+            if pending and on_params_done is not None and self._forked == 0 and self.lane == 0:
+                on_params_done(pending)
+                pending = []
+        self.set_lane(0)
+        if pending and on_params_done is not None:
+            on_params_done(pending)
         self.tape = []

@@ -136,12 +136,18 @@ class HighResolutionModule(nn.Module):
             self.fuse_layers = nn.ModuleList(rows)
 
     def run_branches(self, eng, xs):
+        """The parallel branches are independent until the fuse: each runs on its own stream lane."""
         ys = []
+        forked = eng.fork(self.num_branches)
         for b in range(self.num_branches):
+            if forked:
+                eng.set_lane(b)
             y = xs[b]
             for blk in self.branches[b]:
                 y = blk.run(eng, y)
             ys.append(y)
+        if forked:
+            eng.join(self.num_branches)
         return ys
 
     def run_fuse(self, eng, ys):
