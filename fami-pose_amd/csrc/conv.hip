@@ -59,7 +59,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int MT, int NT, int MODE, int VEC, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
   const int row = lane & 15, kq = lane >> 4;
   const int kpart = wave % KS, mgrp = wave / KS;
   const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
@@ -302,7 +303,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 template <int MT, int NT, int MODE, int VEC, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
   const int col = lane & 15, kq = lane >> 4;
   const int kpart = wave % KS, mgrp = wave / KS;
   const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
@@ -548,7 +550,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
   constexpr int WSLAB = TPS * KSC * NT * 1024;             // bytes of one slab
   constexpr int WPIECES = WSLAB / 16;                      // 16-byte pieces of one slab
   constexpr int WR = (WPIECES + 255) / 256;                // prefetch registers (u32x4) per thread
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
   const int img = blockIdx.x / p.bands, bnd = blockIdx.x - img * p.bands;
   const int y0 = bnd * p.R;
@@ -753,7 +756,8 @@ struct WgradArgs {
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs<T> p) {
   __shared__ float red[4 * MT * NT * 256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
   const int c16 = lane & 15, kq = lane >> 4;
   const int ps = blockIdx.x;
   int by = blockIdx.y;
@@ -875,7 +879,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs<T> p) {
 // Slab layout [psplit][tap][ci][co] (co contiguous => 64-byte stores); the reduce kernel transposes to OIHW.
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
-  const int lane = threadIdx.x & 63, tap = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int tap = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, kq = lane >> 4;
   const int ps = blockIdx.x;
   const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
@@ -1048,7 +1053,8 @@ template <int CIT, int COT>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPW = (CIT * 9 + 3) / 4;  // (ci tile, tap) pairs per wave
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, kq = lane >> 4;
   const int rsel = l16 >> 2, piece = l16 & 3;  // this lane feeds pixel row `rsel` (of 4), channels piece*4..+3
   const int g = blockIdx.x;
