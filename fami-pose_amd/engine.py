@@ -68,6 +68,8 @@ class Engine:
         self._main = None              # torch stream object of lane 0
         self._side = []                # torch side streams (lanes 1..)
         self._forked = 0               # lanes currently forked (backward bookkeeping for deferred bucket hooks)
+        self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
+                                       # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
                                        # the caching allocator must not recycle a block across lanes within a step
         self.sync_stream()
@@ -422,6 +424,8 @@ class Engine:
     # ------------------------------------------------------------------ glue ops
     def batch_slice(self, x, n0, n1):
         """torch.chunk on the batch axis (Alignment_V15.py:121-125): a view; gradients land in the parent slice."""
+        if x.requires_grad and all(x is not p for p in self._sliced):
+            self._sliced.append(x)
         return T(x.data[n0:n1], x.requires_grad, parent=x, n0=n0, n1=n1)
 
     def sub(self, a, b):
@@ -619,6 +623,9 @@ class Engine:
                 for p in ps:
                     if p is not None and p.requires_grad:
                         remaining[id(p)] = remaining.get(id(p), 0) + 1
+        for par in self._sliced:
+            if par.grad is None:
+                par.grad = self.fill(self.new_grad(par))
         pending = []
         for fn, ps, lane in reversed(self.tape):
             if lane != self.lane:
