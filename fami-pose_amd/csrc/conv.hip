@@ -1281,6 +1281,7 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // (fami_conv_tune_lds(1)); tests exercise it explicitly.
 static int g_use_lds = 0;
 static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
+static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
 static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
 
@@ -1364,6 +1365,10 @@ int fami_conv_tune_lds(int on) {
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
 int fami_conv_tune_wgrad_lds(int on) {
+  if (on >= 1000) {
+    g_wgrad_ps = on - 1000;
+    return FAMI_OK;
+  }
   if (on >= 100) {  // benchmarks: 100 + mt caps the input-channel tiles per workgroup of the f32 kernels
     g_wgrad_mt = on - 100;
     return FAMI_OK;
@@ -1459,7 +1464,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   q.coBlocks = fami_cdiv(fami_cdiv(Co, 16), q.NT);
   q.pertap = (kh * kw > 1 && kh * kw <= 9) ? 1 : 0;   // one wave per tap (3x3): workgroups of kh*kw waves
   const long by = q.pertap ? (long)q.ciBlocks * q.coBlocks : (long)kh * kw * q.ciBlocks * q.coBlocks;
-  long ps = ((q.pertap ? 512 : 1024) + by - 1) / by;
+  long ps = ((q.pertap ? (g_wgrad_ps ? g_wgrad_ps : 512) : 1024) + by - 1) / by;
   const long maxps = q.pertap ? (q.P + 63) / 64 : (q.P + 255) / 256;
   if (ps > maxps) ps = maxps;
   if (ps < 1) ps = 1;

@@ -370,3 +370,24 @@ def test_ddp_path_single_rank_rccl(dev):
         assert ld == pytest.approx(l4, rel=0.05) and ld < l0
     finally:
         dist.destroy_process_group()
+
+
+def test_predict_end_to_end(dev):
+    """Inference step (val-phase forward + on-device get_final_preds) against oracle forward + oracle decode."""
+    from fami_pose_amd.evaluate import predict
+    S, H, W, B = 4, 384, 288, 2
+    model, orc = _pair(48, S, (H, W), fp.VAL_PHASE, 77)
+    model = model.to(dev)
+    orc.eval()
+    gen = torch.Generator().manual_seed(78)
+    kf, sup = torch.randn(B, 3, H, W, generator=gen), torch.randn(B, 3 * S, H, W, generator=gen)
+    center = np.array([[320.0, 240.5], [100.25, 400.0]], np.float32)
+    scale = np.array([[1.5, 2.0], [0.9, 1.2]], np.float32)
+    with torch.no_grad():
+        f0, _ = orc(kf, sup)
+    p0, m0 = oops.get_final_preds(f0.numpy().copy(), center, scale)
+    preds, maxvals, hm = predict(model, kf.to(dev), sup.to(dev), center, scale)
+    assert (hm.cpu() - f0).abs().max().item() < HM_TOL
+    assert np.abs(maxvals.cpu().numpy() - m0).max() < HM_TOL
+    # same argmax and same quarter-pixel decision on every joint -> image coordinates agree to fp32 rounding
+    assert np.abs(preds.cpu().numpy().astype(np.float64) - p0).max() < 1e-2

@@ -9,8 +9,8 @@ for (H, W, C) in ((96, 72, 48), (48, 36, 96), (24, 18, 192), (12, 9, 384)):
     x = torch.randn(N, H, W, C, device=dev); dy = torch.randn(N, H, W, C, device=dev)
     dw = torch.empty(C, C, 3, 3, device=dev)
     out = []
-    for mt in (0, 1, 2):
-        L.cdll.fami_conv_tune_wgrad_lds(100 + mt)
+    for mt in (0, 128, 256, 384, 768):
+        L.cdll.fami_conv_tune_wgrad_lds(1000 + mt)
         nb = L.cdll.fami_conv2d_wgrad_workspace(N, H, W, C, C, 3, 3, 1, 1, 1)
         ws = torch.empty(nb // 4, device=dev)
         fn = lambda: L.call('fami_conv2d_wgrad_f32', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, C, C, 3, 3, 1, 1, 1, 0, st)
@@ -19,6 +19,6 @@ for (H, W, C) in ((96, 72, 48), (48, 36, 96), (24, 18, 192), (12, 9, 384)):
         e0.record(s)
         for _ in range(20): fn()
         e1.record(s); e1.synchronize()
-        out.append('mt%d %.1fus ws %.0fMB' % (mt, e0.elapsed_time(e1) / 20 * 1e3, nb / 1e6))
-    L.cdll.fami_conv_tune_wgrad_lds(100)
+        out.append('ps%d %.1fus ws %.0fMB' % (mt, e0.elapsed_time(e1) / 20 * 1e3, nb / 1e6))
+    L.cdll.fami_conv_tune_wgrad_lds(1000)
     print('%3dx%-3d C=%-3d ' % (H, W, C) + '  '.join(out))
