@@ -271,7 +271,7 @@ def main():
     primary = args.dtype
     dt, loss = timed_run(primary, args.steps, args.warmup)
     other = None
-    if args.also and args.also != primary:
+    if args.also and args.also != primary and world == 1:      # the extra dtype line is a single-GPU report
         o_steps = max(3, min(args.steps, 10))
         o_dt, o_loss = timed_run(args.also, o_steps, max(2, min(args.warmup, 3)))
         other = (args.also, o_dt, o_loss, o_steps)

@@ -28,6 +28,16 @@ __device__ __forceinline__ ColMap col_map(int C) {
   return m;
 }
 
+// sum of one double per thread over a 256-thread block (result valid in thread 0)
+__device__ __forceinline__ double block_sum_d(double v, double* sm4) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm4[wave] = v;
+  __syncthreads();
+  return (sm4[0] + sm4[1]) + (sm4[2] + sm4[3]);
+}
+
 // partial[g][0][c] = sum (x - K), partial[g][1][c] = sum (x - K)^2 over this block's pixels, with the pivot
 // K[c] = x[0][c] (the first pixel): shifted sums keep E[d^2] - E[d]^2 free of the cancellation that the raw
 // moments suffer when |mean| >> std.
@@ -63,14 +73,15 @@ template <typename T>
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, const T* __restrict__ x, int G, long P,
                                    int C, float* mean, float* invstd, float* running_mean, float* running_var,
                                    float momentum, float eps) {
-  const int c = blockIdx.x;  // one wave per channel
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;  // one 256-thread block per channel: G <= 512 partials are two loads per thread
   double s = 0.0, q = 0.0;
-  for (int g = threadIdx.x; g < G; g += 64) {
+  for (int g = threadIdx.x; g < G; g += 256) {
     s += (double)partial[(long)g * 2 * C + c];
     q += (double)partial[(long)g * 2 * C + C + c];
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
+  s = block_sum_d(s, sm4);
+  q = block_sum_d(q, sm4);
   if (threadIdx.x != 0) return;
   const double dm = s / (double)P;              // mean of (x - pivot)
   double var = q / (double)P - dm * dm;
@@ -170,14 +181,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
 // coef[0][c] = mean(dz), coef[1][c] = mean(dz*xhat); dgamma/dbeta optional
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, long P, int C, float* coef,
                                        float* dgamma, float* dbeta, int accumulate) {
-  const int c = blockIdx.x;  // one wave per channel
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;  // one 256-thread block per channel
   double s = 0.0, q = 0.0;
-  for (int g = threadIdx.x; g < G; g += 64) {
+  for (int g = threadIdx.x; g < G; g += 256) {
     s += (double)partial[(long)g * 2 * C + c];
     q += (double)partial[(long)g * 2 * C + C + c];
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
+  s = block_sum_d(s, sm4);
+  q = block_sum_d(q, sm4);
   if (threadIdx.x != 0) return;
   coef[c] = (float)(s / (double)P);
   coef[C + c] = (float)(q / (double)P);
@@ -395,10 +407,11 @@ __global__ __launch_bounds__(256) void chan_sum_partial_kernel(const T* __restri
 }
 __global__ void chan_sum_finalize_kernel(const float* __restrict__ partial, int G, int C, float* out,
                                          int accumulate) {
-  const int c = blockIdx.x;  // one wave per channel
+  __shared__ double sm4[4];
+  const int c = blockIdx.x;  // one 256-thread block per channel
   double s = 0.0;
-  for (int g = threadIdx.x; g < G; g += 64) s += (double)partial[(long)g * C + c];
-  s = wave_sum_d(s);
+  for (int g = threadIdx.x; g < G; g += 256) s += (double)partial[(long)g * C + c];
+  s = block_sum_d(s, sm4);
   if (threadIdx.x != 0) return;
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
@@ -425,7 +438,7 @@ static int bn_stats_impl(const T* x, long P, int C, float* mean, float* invstd, 
   const int rows = 256 / (C >> 2);
   hipLaunchKernelGGL(bn_partial_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x, ws, P, C);
   FAMI_CHECK_LAUNCH(nm);
-  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(C), dim3(64), 0, s, ws, x, G, P, C, mean, invstd, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(C), dim3(256), 0, s, ws, x, G, P, C, mean, invstd, running_mean,
                      running_var, momentum, eps);
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
@@ -471,7 +484,7 @@ static int bn_bwd_impl(const T* dy, const T* x, const T* y, const float* mean, c
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(Gp), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y,
                      mean, invstd, ws, P, C, relu);
   FAMI_CHECK_LAUNCH(nm);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, Gp, P, C, coef, dgamma, dbeta, acc_param);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, ws, Gp, P, C, coef, dgamma, dbeta, acc_param);
   FAMI_CHECK_LAUNCH(nm);
   long g = (P + rows - 1) / rows;
   if (g > 2048) g = 2048;
@@ -513,7 +526,7 @@ static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulat
   if (g > BN_MAXG) g = BN_MAXG;
   hipLaunchKernelGGL(chan_sum_partial_kernel<T>, dim3((int)g), dim3(256), C > 256 ? 0 : (size_t)rows * C * sizeof(float), s, x, ws, P, C);
   FAMI_CHECK_LAUNCH(nm);
-  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, s, ws, (int)g, C, out, accumulate);
+  hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(256), 0, s, ws, (int)g, C, out, accumulate);
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
