@@ -147,3 +147,16 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_product_init_matches_oracle_init():
+    """bench.py initialises with fami_pose_amd.init.realistic_init_ (the product may not import the oracle); the parity
+    tests use the oracle's copy.  Same seed -> same weights, on the same module tree."""
+    from fami_pose_amd.init import realistic_init_
+    from oracle import model as om
+    a = fp.build_model(fp.default_cfg(32, image_size=(96, 128), num_sup=2), fp.TRAIN_PHASE)
+    b = fp.build_model(fp.default_cfg(32, image_size=(96, 128), num_sup=2), fp.TRAIN_PHASE)
+    realistic_init_(a, 11)
+    om.realistic_init_(b, 11)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
