@@ -33,22 +33,52 @@ struct ConvArgs {
   unsigned x_bytes, wp_bytes;  // buffer-descriptor extents (out-of-range lanes read 0)
 };
 
-// packed[tap][kc][nt][lane][t] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
-__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int taps,
-                              int KC, int NTt, int mode) {
-  const long total = (long)taps * KC * NTt * 256;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+// f32 weight image = [16x16-tile image][32x32-tile image]:
+//   first  packed[tap][kc16][nt16][lane][t] : K index kc16*16 + (lane>>4)*4 + t, N index nt16*16 + (lane&15)
+//   second packed[tap][kc8 ][nt32][lane][t] : K index kc8*8   + (lane>>5)*4 + t, N index nt32*32 + (lane&31)
+//          (operand layout of v_mfma_f32_32x32x2_f32; present for 1x1 convs with N >= 64 and K % 4 == 0 -- the only
+//          shapes where the 32x32 tile measured faster than the 16x16 one, tools/bench_c32.py)
+// mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin.
+__host__ __device__ static inline long pack16_elems(int kd, int nd, int taps) {
+  return (long)taps * ((kd + 15) / 16) * ((nd + 15) / 16) * 256;
+}
+__host__ __device__ static inline long pack32_elems(int kd, int nd, int taps) {
+  return (taps == 1 && nd >= 64 && kd % 4 == 0) ? (long)taps * ((kd + 7) / 8) * ((nd + 31) / 32) * 256 : 0;
+}
+__device__ __forceinline__ float pack_f32_elem(const float* __restrict__ w, long i, int Co, int Ci, int taps, int mode) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  const long n16 = pack16_elems(kd, nd, taps);
+  int kidx, nidx, tap;
+  if (i < n16) {
+    const int KC = (kd + 15) / 16, NTt = (nd + 15) / 16;
     const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
     long r = i >> 8;
     const int nt = (int)(r % NTt);
     r /= NTt;
-    const int kc = (int)(r % KC), tap = (int)(r / KC);
-    const int kidx = kc * 16 + (lane >> 4) * 4 + t, nidx = nt * 16 + (lane & 15);
-    const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
-    float v = 0.f;
-    if (co < Co && ci < Ci) v = w[((long)co * Ci + ci) * taps + tap];
-    wp[i] = v;
+    const int kc = (int)(r % KC);
+    tap = (int)(r / KC);
+    kidx = kc * 16 + (lane >> 4) * 4 + t;
+    nidx = nt * 16 + (lane & 15);
+  } else {
+    const long j = i - n16;
+    const int KC = (kd + 7) / 8, NTt = (nd + 31) / 32;
+    const int t = (int)(j & 3), lane = (int)((j >> 2) & 63);
+    long r = j >> 8;
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int kc = (int)(r % KC);
+    tap = (int)(r / KC);
+    kidx = kc * 8 + (lane >> 5) * 4 + t;
+    nidx = nt * 32 + (lane & 31);
   }
+  const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
+  return (co < Co && ci < Ci) ? w[((long)co * Ci + ci) * taps + tap] : 0.f;
+}
+__global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int taps, int mode) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  const long total = pack16_elems(kd, nd, taps) + pack32_elems(kd, nd, taps);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    wp[i] = pack_f32_elem(w, i, Co, Ci, taps, mode);
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -235,6 +265,156 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ f32 implicit GEMM on 32x32 tiles
+// Same direct (global -> register) scheme on v_mfma_f32_32x32x2_f32: measured on this part the 32x32x2 form issues at
+// 99 % of the 157 TFLOP/s f32 MFMA peak from a single wave, the 16x16x4 form at 60-90 % depending on occupancy
+// (tools/probes/mfma_peak2.hip), and a 32x32 tile needs half the operand bytes per FLOP.  A wave owns 32 pixels x NT
+// 32-channel tiles; MFMA A = weights (rows = output channels), B = activations (cols = pixels), so a lane ends with
+// groups of 4 consecutive output channels of one pixel (16-byte stores).  A lane's fragment is 4 consecutive channels
+// (one 16-byte load): lanes 0-31 carry channels kc*8+0..3, lanes 32-63 channels kc*8+4..7 of the 8-channel K step.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT, int MODE, int KS>
+__global__ __launch_bounds__(256) void conv_igemm32_f32(ConvArgs p) {
+  __shared__ float red[KS > 1 ? (4 - 4 / KS) * NT * 1024 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, kh2 = lane >> 5;
+  const int kpart = wave % KS, mgrp = wave / KS;
+  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * 32;
+  const bool active = m0 < p.P;  // wave-uniform
+  if (KS == 1 && !active) return;
+  const int ntg0 = blockIdx.y * NT;
+  const int HoWo = p.Ho * p.Wo;
+  const int m = m0 + col;
+  const bool pv = m < p.P;
+  const int mm = pv ? m : 0;
+  const int pn = mm / HoWo, rr = mm - pn * HoWo;
+  const int py = rr / p.Wo, px = rr - py * p.Wo;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, (int)p.wp_bytes, 0x00020000);
+  const int taps = p.kh * p.kw;
+  int tap = 0, kc = kpart;  // p.KC = 8-channel K steps, p.NTt = 32-channel tiles (set by the host for this kernel)
+  while (kc >= p.KC) {
+    kc -= p.KC;
+    ++tap;
+  }
+  unsigned boff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) boff[nt] = (unsigned)(min(ntg0 + nt, p.NTt - 1) * 256 + lane * 4) * 4u;
+  unsigned aoff = FAMI_OOB;
+  auto tap_setup = [&](int tp) {
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+    bool v = pv && tp < taps;
+    int iy, ix;
+    if (MODE == 0) {
+      iy = (py << p.sh) - p.pad + ky * p.dil;
+      ix = (px << p.sh) - p.pad + kx * p.dil;
+      v = v && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    } else {
+      const int ty = py + p.pad - ky * p.dil, tx = px + p.pad - kx * p.dil;
+      iy = ty >> p.sh;
+      ix = tx >> p.sh;
+      v = v && ty >= 0 && tx >= 0 && (iy << p.sh) == ty && (ix << p.sh) == tx && iy < p.Hi && ix < p.Wi;
+    }
+    aoff = v ? (unsigned)((((pn * p.Hi + iy) * p.Wi + ix) * p.Ci + kh2 * 4) * 4) : FAMI_OOB;
+  };
+  auto load = [&](f32x4& a, f32x4(&b)[NT]) {
+    const unsigned o = (kc * 8 + kh2 * 4) < p.Ci ? aoff + kc * 32 : FAMI_OOB;
+    a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+    const unsigned wb = (unsigned)((tap * p.KC + kc) * p.NTt) * 1024u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wb + boff[nt], 0, 0));
+    kc += KS;
+    if (kc >= p.KC) {
+      do {
+        kc -= p.KC;
+        ++tap;
+      } while (kc >= p.KC);
+      tap_setup(tap);
+    }
+  };
+  auto mma = [&](const f32x4& a, const f32x4(&b)[NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][t], a[t], acc[nt], 0, 0, 0);
+  };
+  f32x4 a0, a1, b0[NT], b1[NT];
+  const int Tall = taps * p.KC;
+  const int T = active ? (Tall - kpart + KS - 1) / KS : 0;
+  if (T > 0) {
+    tap_setup(tap);
+    load(a0, b0);
+    for (int it = 0; it < T; it += 2) {
+      load(a1, b1);
+      mma(a0, b0);
+      load(a0, b0);
+      mma(a1, b1);
+    }
+  }
+  if (KS > 1) {
+    if (kpart > 0) {
+      float* dst = red + ((mgrp * (KS - 1)) + (kpart - 1)) * (NT * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(nt * 16 + r) * 64 + lane] = acc[nt][r];
+    }
+    __syncthreads();
+    if (kpart > 0 || !active) return;
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k) {
+      const float* src = red + ((mgrp * (KS - 1)) + k) * (NT * 1024);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] += src[(nt * 16 + r) * 64 + lane];
+    }
+  }
+  // D row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31 (pixel)
+  if (!pv) return;
+  const bool cvec = (p.Co & 3) == 0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co0 = (ntg0 + nt) * 32 + 8 * q + 4 * kh2;
+      if (co0 >= p.Co) continue;
+      f32x4 v = {acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]};
+      const long idx = (long)m * p.Co + co0;
+      if (cvec) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+        if (p.addend) v += *reinterpret_cast<const f32x4*>(p.addend + idx);
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(p.y + idx);
+        *reinterpret_cast<f32x4*>(p.y + idx) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (co0 + r >= p.Co) continue;
+          float u = v[r] + (p.bias ? p.bias[co0 + r] : 0.f);
+          if (p.addend) u += p.addend[idx + r];
+          if (p.relu) u = fmaxf(u, 0.f);
+          if (p.accumulate) u += p.y[idx + r];
+          p.y[idx + r] = u;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ bf16 implicit GEMM (fwd / dgrad)
 // bf16 activations and weights, fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Same mapping as the f32 kernel with
 // the operand roles swapped: the MFMA A operand is the weight fragment (rows = 16 output channels) and the B operand
@@ -279,22 +459,27 @@ __global__ void pack_w_batch_kernel(const float* __restrict__ params, T* __restr
   const PackDesc d = desc[blockIdx.y];
   const float* w = params + d.src;
   T* wp = packed + d.dst;
-  constexpr int KG = sizeof(T) == 2 ? 32 : 16;   // channels per K group
-  constexpr int FR = sizeof(T) == 2 ? 8 : 4;     // elements per lane fragment
   const int kd = d.mode == 0 ? d.Ci : d.Co, nd = d.mode == 0 ? d.Co : d.Ci;
-  const int KC = (kd + KG - 1) / KG, NTt = (nd + 15) / 16;
-  const long total = (long)d.taps * KC * NTt * 64 * FR;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i % FR), lane = (int)((i / FR) & 63);
-    long r = i / (FR * 64);
-    const int nt = (int)(r % NTt);
-    r /= NTt;
-    const int kc = (int)(r % KC), tap = (int)(r / KC);
-    const int kidx = kc * KG + (lane >> 4) * FR + j, nidx = nt * 16 + (lane & 15);
-    const int co = d.mode == 0 ? nidx : kidx, ci = d.mode == 0 ? kidx : nidx;
-    float v = 0.f;
-    if (co < d.Co && ci < d.Ci) v = w[((long)co * d.Ci + ci) * d.taps + tap];
-    st1(wp + i, v);
+  if constexpr (sizeof(T) == 4) {
+    const long total = pack16_elems(kd, nd, d.taps) + pack32_elems(kd, nd, d.taps);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+      st1(wp + i, pack_f32_elem(w, i, d.Co, d.Ci, d.taps, d.mode));
+  } else {
+    constexpr int KG = 32, FR = 8;  // channels per K group / elements per lane fragment (bf16 16x16x32)
+    const int KC = (kd + KG - 1) / KG, NTt = (nd + 15) / 16;
+    const long total = (long)d.taps * KC * NTt * 64 * FR;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int j = (int)(i % FR), lane = (int)((i / FR) & 63);
+      long r = i / (FR * 64);
+      const int nt = (int)(r % NTt);
+      r /= NTt;
+      const int kc = (int)(r % KC), tap = (int)(r / KC);
+      const int kidx = kc * KG + (lane >> 4) * FR + j, nidx = nt * 16 + (lane & 15);
+      const int co = d.mode == 0 ? nidx : kidx, ci = d.mode == 0 ? kidx : nidx;
+      float v = 0.f;
+      if (co < d.Co && ci < d.Ci) v = w[((long)co * d.Ci + ci) * d.taps + tap];
+      st1(wp + i, v);
+    }
   }
 }
 
@@ -1008,6 +1193,49 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __
   }
 }
 
+// same reduction with 16-byte loads: a thread owns 4 consecutive output channels of one (tap, ci), 2^sg slab groups per
+// block walk the slab axis with four independent partial sums (Co % 4 == 0; summation order is fixed)
+__global__ __launch_bounds__(256) void wgrad_reduce_taps4_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int Co, int Ci, int taps, int psplit, int accumulate,
+                                                                 int sg) {
+  __shared__ f32x4 sm[256];
+  const int SG = 1 << sg, cols = 256 >> sg;
+  const int o = threadIdx.x & (cols - 1), g = threadIdx.x >> (8 - sg);
+  const long n4 = (long)taps * Ci * Co / 4;
+  const long i = (long)blockIdx.x * cols + o;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s0 = z, s1 = z, s2 = z, s3 = z;
+  if (i < n4) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + i;
+    int k = g;
+    for (; k + 3 * SG < psplit; k += 4 * SG) {
+      s0 += p4[(long)k * n4];
+      s1 += p4[(long)(k + SG) * n4];
+      s2 += p4[(long)(k + 2 * SG) * n4];
+      s3 += p4[(long)(k + 3 * SG) * n4];
+    }
+    for (; k < psplit; k += SG) s0 += p4[(long)k * n4];
+  }
+  sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    f32x4 t = sm[o];
+    for (int q = 1; q < SG; ++q) t += sm[q * cols + o];
+    const long e = i * 4;
+    const int co = (int)(e % Co);
+    const long r = e / Co;
+    const int ci = (int)(r % Ci), tap = (int)(r / Ci);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float* d = dw + ((long)(co + u) * Ci + ci) * taps + tap;
+      *d = accumulate ? *d + t[u] : t[u];
+    }
+  }
+}
+
+static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
+                               hipStream_t s);
+
 // dw[i] (=|+=) sum_k part[k][i]; 64 outputs x 4 slab groups per block so the serial chain is psplit/4 long
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            long n, int psplit, int accumulate) {
@@ -1184,6 +1412,153 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ f32 wgrad staged through LDS
+// Same decomposition as the bf16 kernel above, on the exact f32 MFMA (16x16x4: K = 4 pixels).  f32 fragments need no
+// transposing read: lane (channel l&15, pixel l>>4) reads one float; rows are padded so the 4 pixel rows of a read land
+// in distinct bank groups.  A workgroup of 8 waves stages X (+-(W+1)-pixel halo) and dY of a pixel run once; the
+// (input-channel tile, tap) pairs are dealt round-robin to the waves, each pair holding COT accumulator tiles.
+struct WgradLdsArgsF {
+  const float* x;   // [N,H,W,Ci]
+  const float* dy;  // [N,H,W,Co]
+  float* part;      // [G][9][Ci][Co]
+  int N, H, W, Ci, Co, P;
+  int chunk;        // pixels per workgroup (multiple of 8)
+  int ciBlocks, coBlocks;
+  int CiB, CoB;     // channels per block (16 * CIT, 16 * COT)
+  int xrow, yrow;   // LDS floats per pixel of the X / dY tiles (padded)
+  int xfloats;      // size of the X tile in floats
+};
+
+template <int CIT, int COT>
+__global__ __launch_bounds__(512) void conv_wgrad_lds_f32_kernel(WgradLdsArgsF p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPW = (CIT * 9 + 7) / 8;  // (ci tile, tap) pairs per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, kq = lane >> 4;
+  const int g = blockIdx.x;
+  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  const int halo = p.W + 1;
+  float* xt = reinterpret_cast<float*>(smem);  // [(chunk + 2*halo)][xrow]
+  float* yt = xt + p.xfloats;                  // [chunk][yrow]
+  const int zoff = p.xfloats + p.chunk * p.yrow;  // 16 zero floats
+
+  const int p0 = g * p.chunk;
+  const int M = min(p.chunk, p.P - p0);
+  // ---- stage X (pixels p0-halo .. p0+chunk+halo) and dY (p0 .. p0+chunk); pixels outside the tensor are zero
+  {
+    const int xpcs = p.CiB / 4, ypcs = p.CoB / 4;  // 16-byte pieces per pixel
+    const int nx = (p.chunk + 2 * halo) * xpcs, ny = p.chunk * ypcs;
+    const float* xg = p.x + (long)cib * p.CiB;
+    const float* yg = p.dy + (long)cob * p.CoB;
+    for (int i0 = tid; i0 < nx + ny; i0 += 512 * 4) {
+      f32x4 v[4];
+      int dsto[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 512;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dsto[u] = -1;
+        if (i < nx) {
+          const int px = i / xpcs, pc = i - px * xpcs;
+          const long pg = (long)p0 - halo + px;
+          dsto[u] = px * p.xrow + pc * 4;
+          if (pg >= 0 && pg < p.P) v[u] = *reinterpret_cast<const f32x4*>(xg + pg * p.Ci + pc * 4);
+        } else if (i < nx + ny) {
+          const int k = i - nx;
+          const int px = k / ypcs, pc = k - px * ypcs;
+          const long pg = (long)p0 + px;
+          dsto[u] = p.xfloats + px * p.yrow + pc * 4;
+          if (pg < p.P) v[u] = *reinterpret_cast<const f32x4*>(yg + pg * p.Co + pc * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dsto[u] >= 0) *reinterpret_cast<f32x4*>(xt + dsto[u]) = v[u];
+    }
+    if (tid < 4) *reinterpret_cast<f32x4*>(xt + zoff + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // pairs of this wave: q = wave + 8*i -> (ci tile, tap); per-pair LDS shift of the tap
+  int pci[NPW], pdy[NPW], pdx[NPW], psh[NPW];
+  bool pok[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = wave + 8 * i;
+    pok[i] = q < CIT * 9;
+    const int qq = pok[i] ? q : 0;
+    pci[i] = qq / 9;
+    const int tap = qq - pci[i] * 9;
+    pdy[i] = tap / 3 - 1;
+    pdx[i] = tap - (tap / 3) * 3 - 1;
+    psh[i] = (halo + pdy[i] * p.W + pdx[i]) * p.xrow + pci[i] * 16 + c16;
+  }
+  f32x4 acc[NPW][COT];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // image coordinates of this lane's pixel of the current K step (pixel p0 + ks*4 + kq)
+  int oy, ox;
+  {
+    const int r = (p0 + kq) % (p.H * p.W);
+    oy = r / p.W;
+    ox = r - oy * p.W;
+  }
+  __syncthreads();
+
+  const int ksteps = (M + 3) >> 2;
+  int pl = kq;
+  auto step = [&]() {
+    float bfr[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) bfr[c] = yt[pl * p.yrow + c * 16 + c16];
+    const int xb = pl * p.xrow;
+    float afr[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const bool in = (unsigned)(oy + pdy[i]) < (unsigned)p.H && (unsigned)(ox + pdx[i]) < (unsigned)p.W;
+      afr[i] = xt[in ? xb + psh[i] : zoff + c16];
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      if (!pok[i]) continue;  // wave-uniform
+#pragma unroll
+      for (int c = 0; c < COT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[i], bfr[c], acc[i][c], 0, 0, 0);
+    }
+    pl += 4;
+    ox += 4;
+    const bool w = ox >= p.W;  // W >= 4 (plan): at most one row wrap per step
+    ox -= w ? p.W : 0;
+    oy += w ? 1 : 0;
+    oy -= oy >= p.H ? p.H : 0;
+  };
+  int ks = 0;
+  for (; ks + 2 <= ksteps; ks += 2) {
+    step();
+    step();
+  }
+  if (ks < ksteps) step();
+
+  // D row = kq*4 + r (ci), col = c16 (co)  ->  slab [g][tap][ci][co]
+  float* slab = p.part + (long)g * 9 * p.Ci * p.Co;
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    if (!pok[i]) continue;
+    const int tap = (pdy[i] + 1) * 3 + pdx[i] + 1;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int co = cob * p.CoB + c * 16 + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = cib * p.CiB + pci[i] * 16 + kq * 4 + r;
+        slab[((long)tap * p.Ci + ci) * p.Co + co] = acc[i][c][r];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ host side
 static int pick_nt(int tiles) {
   const int cand[5] = {6, 4, 3, 2, 1};
@@ -1215,6 +1590,19 @@ static int pick_small(int tiles) {  // wgrad tile counts in {4,3,2,1}
   return best;
 }
 
+static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
+                               hipStream_t s) {
+  const long n = (long)Co * Ci * taps;
+  if (Co % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
+    int sg = 0;
+    while (sg < 4 && (8 << sg) <= psplit) ++sg;  // up to 16 slab groups, each at least 4 slabs deep
+    const int cols = 256 >> sg;
+    hipLaunchKernelGGL(wgrad_reduce_taps4_kernel, dim3(fami_cdiv(n / 4, cols)), dim3(256), 0, s, part, dw, Co, Ci, taps, psplit, accumulate, sg);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, part, dw, Co, Ci, taps, psplit, accumulate);
+  }
+}
+
 template <int MODE, int VEC>
 static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipStream_t s) {
   const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
@@ -1240,8 +1628,52 @@ static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipSt
 static int g_force_mt = 0, g_force_nt = 0, g_force_ks = 0;  // tuning overrides (fami_conv_tune)
 static int g_stages = 0;                                     // pipeline depth override (fami_conv_tune_stages)
 
+static int g_use32 = 1;  // fami_conv_tune(-1, ...) disables the 32x32-tile f32 kernel (benchmarks / tests)
+
+// 32x32x2 path: eligible when the weight image carries the 32-tile section (N >= 32, K % 4 == 0)
+static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
+  const long n16 = pack16_elems(a.Ci, a.Co, a.kh * a.kw);
+  a.wp = a.wp + n16;
+  a.KC = fami_cdiv(a.Ci, 8);
+  a.NTt = fami_cdiv(a.Co, 32);
+  a.wp_bytes = (unsigned)((long)a.kh * a.kw * a.KC * a.NTt * 1024);
+  // tile choice: up to 3 channel tiles per wave (48 accumulator registers); fewer tiles / split-K when the pixel
+  // count alone cannot fill the 1024 SIMDs
+  int NT = a.NTt >= 3 && a.NTt % 3 == 0 ? 3 : (a.NTt % 2 == 0 ? 2 : (a.NTt >= 3 ? 3 : a.NTt));
+  const long mt = fami_cdiv(a.P, 32);
+  int KS = 1;
+  const long iters = (long)a.kh * a.kw * a.KC;
+  if (mt * fami_cdiv(a.NTt, NT) < 2048 && NT > 1) NT = a.NTt % 2 == 0 && NT == 3 ? 2 : 1;
+  if (mt * fami_cdiv(a.NTt, NT) < 2048 && NT > 1) NT = 1;
+  const long waves = mt * fami_cdiv(a.NTt, NT);
+  if (iters >= 16) {
+    if (waves < 1536) KS = 4;
+    else if (waves < 3072) KS = 2;
+  }
+  if (g_force_nt > 0 && g_force_mt == 32) { NT = g_force_nt; KS = g_force_ks ? g_force_ks : 1; }
+  const dim3 grid(fami_cdiv(a.P, (4 / KS) * 32), fami_cdiv(a.NTt, NT));
+  bool ok = false;
+#define FAMI_C32(nt, ks)                                                                          \
+  if (NT == nt && KS == ks) {                                                                     \
+    if (mode == 0) hipLaunchKernelGGL((conv_igemm32_f32<nt, 0, ks>), grid, dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((conv_igemm32_f32<nt, 1, ks>), grid, dim3(256), 0, s, a);             \
+    ok = true;                                                                                    \
+  }
+  FAMI_C32(1, 1) FAMI_C32(1, 2) FAMI_C32(1, 4) FAMI_C32(2, 1) FAMI_C32(2, 2) FAMI_C32(2, 4) FAMI_C32(3, 1) FAMI_C32(3, 2) FAMI_C32(3, 4)
+#undef FAMI_C32
+  if (!ok) {
+    fami_set_error(name, "no 32x32 kernel instance");
+    return FAMI_ESHAPE;
+  }
+  FAMI_CHECK_LAUNCH(name);
+  return FAMI_OK;
+}
+
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
+  if (vec && g_use32 && (g_force_mt == 0 || g_force_mt == 32) && pack32_elems(a.Ci, a.Co, a.kh * a.kw) > 0 &&
+      (long)a.kh * a.kw * fami_cdiv(a.Ci, 8) * fami_cdiv(a.Co, 32) * 1024 < (1L << 31))
+    return run_igemm32(a, mode, s, name);
   int NT = pick_nt(a.NTt);
   int MT, KS = 1;
   if (!vec) {
@@ -1260,7 +1692,7 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
       else if (waves < 6000) KS = 2;
     }
   }
-  if (vec && g_force_mt) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
+  if (vec && g_force_mt && g_force_mt != 16) { MT = g_force_mt; NT = g_force_nt ? g_force_nt : NT; KS = g_force_ks ? g_force_ks : 1; }
   const int ST = g_stages ? g_stages : 2;
   int rc;
   if (mode == 0)
@@ -1284,6 +1716,7 @@ static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (
 static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
 static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
+static int g_wgrad_lds_f32 = 2;  // f32 LDS weight gradient: 0 never, 1 whenever eligible, 2 only where it measured faster
 
 // LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
 template <typename T>
@@ -1355,6 +1788,8 @@ extern "C" {
 
 // tuning hook (benchmarks only): force the implicit-GEMM tile (0 = heuristic)
 int fami_conv_tune(int mt, int nt, int ks) {
+  // mt = 16: force the 16x16-tile f32 kernel with its heuristics (nt = ks = 0) ; mt = 32: force (nt, ks) of the 32x32-tile
+  // kernel ; other mt > 0: force the (mt, nt, ks) tile of the 16x16 kernels ; 0: heuristics
   g_force_mt = mt; g_force_nt = nt; g_force_ks = ks;
   return FAMI_OK;
 }
@@ -1373,7 +1808,14 @@ int fami_conv_tune_wgrad_lds(int on) {
     g_wgrad_mt = on - 100;
     return FAMI_OK;
   }
+  if (on < 0) {  // defaults
+    g_wgrad_lds = 1;
+    g_wgrad_lds_f32 = 2;
+    g_wgrad_nsub = 1;
+    return FAMI_OK;
+  }
   g_wgrad_lds = on ? 1 : 0;
+  g_wgrad_lds_f32 = on ? 1 : 0;
   if (on > 1) g_wgrad_nsub = on - 1;  // benchmarks: on = 1 + sub-chunks per workgroup
   return FAMI_OK;
 }
@@ -1385,16 +1827,15 @@ int fami_conv_tune_stages(int stages) {
 
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
-  return (long)kh * kw * fami_cdiv(kd, 16) * fami_cdiv(nd, 16) * 256;
+  return pack16_elems(kd, nd, kh * kw) + pack32_elems(kd, nd, kh * kw);
 }
 
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               hipStream_t s) {
   FAMI_REQUIRE(w_oihw && wp && Co > 0 && Ci > 0 && (mode == 0 || mode == 1), "fami_pack_conv_weight_f32", "bad argument");
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
-  const int KC = fami_cdiv(kd, 16), NTt = fami_cdiv(nd, 16);
-  const long total = (long)kh * kw * KC * NTt * 256;
-  hipLaunchKernelGGL(pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, KC, NTt, mode);
+  const long total = pack16_elems(kd, nd, kh * kw) + pack32_elems(kd, nd, kh * kw);
+  hipLaunchKernelGGL(pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, mode);
   FAMI_CHECK_LAUNCH("fami_pack_conv_weight_f32");
   return FAMI_OK;
 }
@@ -1507,6 +1948,42 @@ static WgradLdsPlan wgrad_lds_plan(int N, int H, int W, int Ci, int Co, int kh, 
   return q;
 }
 
+// f32 LDS wgrad plan (3x3 stride-1 pad-1): one 8-wave workgroup per CU (the tile takes most of the 160 KB), about two
+// workgroups per CU in total so the partial-slab traffic stays at ~512 slabs
+static int lds_row_floats(int cb) {  // row stride with (stride mod 64) in {16, 48}: conflict-free 4-row reads
+  const int m = cb % 64;
+  return (m == 16 || m == 48) ? cb : cb + 16;  // cb is a multiple of 16: m in {0, 32} -> +16
+}
+static WgradLdsPlan wgrad_lds_plan_f32(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  WgradLdsPlan q;
+  q.ok = 0;
+  if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) || (Ci % 16) || (Co % 16) || W < 4) return q;
+  q.CIT = Ci % 48 == 0 ? 3 : (Ci % 64 == 0 ? 4 : (Ci % 32 == 0 ? 2 : 1));
+  q.COT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : (Co % 32 == 0 ? 2 : 1));
+  q.ciBlocks = Ci / (16 * q.CIT);
+  q.coBlocks = Co / (16 * q.COT);
+  q.nsub = 1;
+  q.xrow = lds_row_floats(16 * q.CIT);
+  q.yrow = lds_row_floats(16 * q.COT);
+  const long P = (long)N * H * W;
+  const long blocks = (long)q.ciBlocks * q.coBlocks;
+  const long budget = 156 * 1024 / 4 - 16 - 2L * (W + 1) * q.xrow;  // floats left for the chunk rows
+  if (budget < 8L * (q.xrow + q.yrow)) return q;
+  long cmax = budget / (q.xrow + q.yrow);
+  cmax -= cmax % 8;
+  long G = (512 + blocks - 1) / blocks;
+  long chunk = (P + G - 1) / G;
+  chunk = ((chunk + 7) / 8) * 8;
+  if (chunk > cmax) chunk = cmax;
+  G = (P + chunk - 1) / chunk;
+  q.G = (int)G;
+  q.chunk = (int)chunk;
+  q.xbytes = (int)((chunk + 2 * (W + 1)) * q.xrow);  // floats
+  q.lds = ((size_t)q.xbytes + (size_t)chunk * q.yrow + 16) * 4;
+  q.ok = P < (1L << 31) && G < 65536;
+  return q;
+}
+
 long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
   if (!geom_ok(kh, kw, stride, pad, dil)) return -1;
   const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
@@ -1514,6 +1991,11 @@ long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, in
   const WgradLdsPlan l = wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
   if (l.ok) {
     const long nl = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
+    if (nl > need) need = nl;
+  }
+  const WgradLdsPlan f = wgrad_lds_plan_f32(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
+  if (f.ok) {
+    const long nl = (long)f.G * Co * Ci * 9 * (long)sizeof(float);
     if (nl > need) need = nl;
   }
   return need;
@@ -1563,7 +2045,7 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
       return FAMI_ESHAPE;
     }
     FAMI_CHECK_LAUNCH(nm);
-    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, workspace, dw, Co, Ci, kh * kw, q.psplit, accumulate);
+    launch_reduce_taps(workspace, dw, Co, Ci, kh * kw, q.psplit, accumulate, s);
     FAMI_CHECK_LAUNCH(nm);
     return FAMI_OK;
   }
@@ -1650,6 +2132,41 @@ extern "C" {
 int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                           hipStream_t s) {
+  WgradLdsPlan l = g_wgrad_lds_f32 ? wgrad_lds_plan_f32(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
+  // measured (tools/bench_wgrad.py f32): the staged kernel wins once the channel blocks alone give >= 64 workgroup
+  // columns (384 channels: 136 vs 151 us); below that the per-tap scalar-operand kernel is faster (85 vs 105 us)
+  if (g_wgrad_lds_f32 == 2 && l.ok && l.ciBlocks * l.coBlocks < 64) l.ok = 0;
+  if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    const long need = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
+    FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_f32", "workspace too small");
+    WgradLdsArgsF a;
+    a.x = x; a.dy = dy; a.part = workspace;
+    a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.P = N * H * W;
+    a.chunk = l.chunk; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks;
+    a.CiB = 16 * l.CIT; a.CoB = 16 * l.COT; a.xrow = l.xrow; a.yrow = l.yrow; a.xfloats = l.xbytes;
+    const dim3 grid(l.G, l.ciBlocks * l.coBlocks);
+    bool ok = false;
+#define FAMI_WF_CASE(cit, cot)                                                                                        \
+  if (l.CIT == cit && l.COT == cot) {                                                                                 \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_lds_f32_kernel<cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((conv_wgrad_lds_f32_kernel<cit, cot>), grid, dim3(512), l.lds, s, a);                          \
+    ok = true;                                                                                                        \
+  }
+    FAMI_WF_CASE(1, 1) FAMI_WF_CASE(1, 2) FAMI_WF_CASE(1, 3) FAMI_WF_CASE(1, 4) FAMI_WF_CASE(2, 1) FAMI_WF_CASE(2, 2)
+    FAMI_WF_CASE(2, 3) FAMI_WF_CASE(2, 4) FAMI_WF_CASE(3, 1) FAMI_WF_CASE(3, 2) FAMI_WF_CASE(3, 3) FAMI_WF_CASE(3, 4)
+    FAMI_WF_CASE(4, 1) FAMI_WF_CASE(4, 2) FAMI_WF_CASE(4, 3) FAMI_WF_CASE(4, 4)
+#undef FAMI_WF_CASE
+    if (ok) {
+      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/lds");
+      launch_reduce_taps(workspace, dw, Co, Ci, 9, l.G, accumulate, s);
+      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
+      return FAMI_OK;
+    }
+  }
   return wgrad_impl<float>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
                            "fami_conv2d_wgrad_f32");
 }
@@ -1683,8 +2200,7 @@ int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* 
 #undef FAMI_WL_CASE
     if (ok) {
       FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/lds");
-      const long n = (long)Co * Ci * 9;
-      hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, workspace, dw, Co, Ci, 9, l.G, accumulate);
+      launch_reduce_taps(workspace, dw, Co, Ci, 9, l.G, accumulate, s);
       FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/reduce");
       return FAMI_OK;
     }

@@ -68,6 +68,12 @@ class Engine:
         self._main = None              # torch stream object of lane 0
         self._side = []                # torch side streams (lanes 1..)
         self._forked = 0               # lanes currently forked (backward bookkeeping for deferred bucket hooks)
+        # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
+        # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
+        # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
+        self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
+        self._wstream = None
+        self._wdirty = False
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
@@ -96,6 +102,33 @@ class Engine:
     def set_lane(self, i):
         self.lane = i
         self.stream = self._main.cuda_stream if i == 0 else self._side[i - 1].cuda_stream
+
+    _wgrad_pool = {}
+
+    def _lane_stream(self):
+        return self._main if self.lane == 0 else self._side[self.lane - 1]
+
+    def _enter_wlane(self):
+        """Route the following calls to the weight-gradient stream, ordered after the current lane's work so far."""
+        if self._wstream is None:
+            if self.dev not in Engine._wgrad_pool:
+                Engine._wgrad_pool[self.dev] = torch.cuda.Stream(self.dev)
+            self._wstream = Engine._wgrad_pool[self.dev]
+        ev = torch.cuda.Event()
+        ev.record(self._lane_stream())
+        self._wstream.wait_event(ev)
+        saved = self.stream
+        self.stream = self._wstream.cuda_stream
+        self._wdirty = True
+        return saved
+
+    def sync_wgrad_lane(self):
+        """Lane 0 continues after every weight-gradient kernel enqueued so far (before an all-reduce / the optimizer)."""
+        if self._wdirty:
+            ev = torch.cuda.Event()
+            ev.record(self._wstream)
+            self._main.wait_event(ev)
+            self._wdirty = False
 
     def _do_fork(self, n):
         side = self._lanes(n)
@@ -286,6 +319,7 @@ class Engine:
                 if out.grad is None:
                     return
                 dy = out.grad
+                saved = self._enter_wlane() if (self.use_wlane and need_w) else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
@@ -295,6 +329,8 @@ class Engine:
                     g, acc = self.pgrad(bias)
                     ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
+                if saved is not None:
+                    self.stream = saved
                 if x.requires_grad:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
@@ -643,6 +679,7 @@ class Engine:
                 on_params_done(pending)
                 pending = []
         self.set_lane(0)
+        self.sync_wgrad_lane()
         if pending and on_params_done is not None:
             on_params_done(pending)
         self.tape = []

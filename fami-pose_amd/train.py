@@ -245,7 +245,12 @@ class Trainer:
             for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
                 eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
                 seed(c)
-        hook = self.reducer.begin(on_bucket) if on_bucket is not None else None
+        hook = None
+        if on_bucket is not None:
+            def bucket_ready(lo, hi):
+                eng.sync_wgrad_lane()       # the slice's weight gradients live on the engine's wgrad stream
+                return on_bucket(lo, hi)
+            hook = self.reducer.begin(bucket_ready)
         eng.backward(on_params_done=hook)
         if on_bucket is not None:
             self.reducer.flush()

@@ -42,7 +42,8 @@ int fami_device_info(int device, int* info, char* name, int name_len);
 /* benchmarks only: force the implicit-GEMM tile (MT x NT 16x16 tiles per wave, KS-way split-K); 0 = heuristic */
 int fami_conv_tune(int mt, int nt, int ks);
 int fami_conv_tune_lds(int on);          /* 1 = route eligible 3x3 stride-1 convs through the LDS-staged kernel (default 0) */
-int fami_conv_tune_wgrad_lds(int on);    /* 0 = bf16 weight gradients on the scalar-operand kernels (default 1) */
+int fami_conv_tune_wgrad_lds(int on);    /* 0 = weight gradients on the scalar-operand kernels, 1 = LDS-staged kernels wherever eligible,
+                                          * -1 = defaults (bf16: staged; f32: staged only where it measured faster) */
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default */
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,

@@ -37,6 +37,7 @@ def test_host_only_entry_points():
     from fami_pose_amd._lib import lib, FamiError
     L = lib()
     assert L.cdll.fami_packed_weight_elems(48, 48, 3, 3, 0) == 9 * 3 * 3 * 256
+    assert L.cdll.fami_packed_weight_elems(256, 64, 1, 1, 0) == 4 * 16 * 256 + 8 * 8 * 256      # 16- and 32-tile images
     assert L.cdll.fami_packed_weight_elems(17, 48, 1, 1, 0) == 3 * 2 * 256
     assert L.cdll.fami_conv2d_wgrad_workspace(20, 96, 72, 48, 48, 3, 3, 1, 1, 1) > 0
     assert L.cdll.fami_conv2d_wgrad_workspace(1, 8, 8, 8, 8, 3, 3, 3, 1, 1) == -1      # stride 3 unsupported

@@ -14,8 +14,10 @@ def lds_mode(request):
     """Run the convolution cases on the direct kernels and with the LDS-staged 3x3 kernel enabled."""
     from fami_pose_amd._lib import lib
     lib().cdll.fami_conv_tune_lds(request.param)
+    lib().cdll.fami_conv_tune_wgrad_lds(request.param)      # 'direct' also takes the scalar-operand weight-gradient kernels
     yield request.param
     lib().cdll.fami_conv_tune_lds(0)
+    lib().cdll.fami_conv_tune_wgrad_lds(-1)
 
 
 def _eng(dev):
@@ -56,6 +58,9 @@ CONV_CASES = [
     (3, 7, 5, 16, 16, 3, 2, 1, 1, True),
     (2, 24, 18, 192, 48, 3, 1, 1, 1, False),
     (1, 5, 7, 20, 36, 3, 1, 1, 1, True),        # channel tails (Ci % 16 != 0)
+    (1, 9, 7, 36, 72, 1, 1, 0, 1, True),        # 1x1 on the 32x32-tile kernel with K and N tails
+    (3, 7, 5, 32, 64, 3, 1, 1, 1, True),        # LDS weight gradient: odd map, 2 / 4 channel tiles
+    (2, 5, 3, 16, 16, 3, 1, 1, 1, False),       # map narrower than one K step
 ]
 
 

@@ -1,20 +1,22 @@
-"""bf16 LDS wgrad: sub-chunks-per-workgroup sweep (GPU box)."""
+"""LDS-staged vs scalar-operand weight-gradient kernels (GPU box).  usage: python tools/bench_wgrad.py [f32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fami_pose_amd._lib import lib
 L = lib(); dev = torch.device('cuda:0'); s = torch.cuda.current_stream(dev); st = s.cuda_stream
 N = 20
+DT = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+cast = (lambda t: t.bfloat16()) if DT == 'bf16' else (lambda t: t)
 for (H, W, C) in ((96, 72, 48), (48, 36, 96), (24, 18, 192), (12, 9, 384)):
-    x = torch.randn(N, H, W, C, device=dev).bfloat16(); dy = torch.randn(N, H, W, C, device=dev).bfloat16()
+    x = cast(torch.randn(N, H, W, C, device=dev)); dy = cast(torch.randn(N, H, W, C, device=dev))
     dw = torch.empty(C, C, 3, 3, device=dev)
     ref = None
     out = []
-    for mode in (0, 2):      # 0 = scalar-operand kernels; 2 = LDS transposing kernel
+    for mode in (0, 1):      # 0 = scalar-operand kernels; 1 = LDS-staged kernel
         L.cdll.fami_conv_tune_wgrad_lds(mode)
         nb = L.cdll.fami_conv2d_wgrad_workspace(N, H, W, C, C, 3, 3, 1, 1, 1)
         ws = torch.empty(nb // 4, device=dev)
-        fn = lambda: L.call('fami_conv2d_wgrad_bf16', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, C, C, 3, 3, 1, 1, 1, 0, st)
+        fn = lambda: L.call('fami_conv2d_wgrad_' + DT, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, C, C, 3, 3, 1, 1, 1, 0, st)
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
