@@ -241,9 +241,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # N>1: the eager launch sequence with RCCL all-reduces overlapped on RCCL's stream is the default; the
-    # per-bucket hipGraph plan (train.py) is opt-in until it has been exercised on a multi-GPU node.
-    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH') == '1')
+    # N>1: hipGraph(forward + backward) -> bucketed RCCL all-reduce of the gradient arena -> hipGraph(scale + Adam);
+    # FAMI_DDP_GRAPH=0 (or --no-graph) selects the eager sequence with the all-reduce overlapped bucket by bucket.
+    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH', '1') != '0')
     kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
 
     def timed_run(dtype, steps, warmup):

@@ -68,6 +68,8 @@ class Engine:
         self._main = None              # torch stream object of lane 0
         self._side = []                # torch side streams (lanes 1..)
         self._forked = 0               # lanes currently forked (backward bookkeeping for deferred bucket hooks)
+        self._epoch = 0                # id of the current forked region (see _lane_guard)
+        self._lane_owner = {}
         # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
@@ -137,6 +139,7 @@ class Engine:
         for i in range(n - 1):
             side[i].wait_event(ev)
         self._forked = n
+        self._epoch += 1
 
     def _do_join(self, n):
         side = self._lanes(n)
@@ -217,6 +220,7 @@ class Engine:
 
     def pgrad(self, p):
         """-> (gradient buffer of parameter p, accumulate flag) for this step."""
+        self._lane_guard(('grad', id(p)))
         g = self.param_grads.get(id(p))
         if g is not None:
             return g, 1
@@ -226,6 +230,17 @@ class Engine:
             g = self.like(p.data)
         self.param_grads[id(p)] = g
         return g, 0
+
+    def _lane_guard(self, key):
+        """Shared mutable state (a parameter's gradient accumulator, a BatchNorm's running statistics) may be touched by
+        ONE lane per forked region: a module applied on two concurrent lanes would race.  Fails loudly instead."""
+        if not self._forked:
+            return
+        seen = self._lane_owner.get(key)
+        if seen is not None and seen[0] == self._epoch and seen[1] != self.lane:
+            raise RuntimeError('engine: %s used on stream lanes %d and %d inside one forked region -- modules that share '
+                               'parameters must run on one lane' % (key[0], seen[1], self.lane))
+        self._lane_owner[key] = (self._epoch, self.lane)
 
     # packed weights: frozen nn.Parameters are packed once (cache lives ON the parameter object, keyed by mode /
     # dtype / version counter, so it can never outlive or be confused with another model's weights); trainable
@@ -349,6 +364,7 @@ class Engine:
         mean, invstd = self.empty(C), self.empty(C)
         y = self.like(x.data)
         if bn.training:
+            self._lane_guard(('running statistics', id(bn)))
             ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
             self.acall('fami_bn_train_fwd', _p(x.data), _p(None if residual is None else residual.data), _p(y),

@@ -195,8 +195,8 @@ class Trainer:
         self.ddp = self.world > 1 or (force_ddp and dist.is_initialized())
         self.reducer = BucketReducer(self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg)
         self.packer = WeightPacker(model, self.flat, self.table, getattr(model, 'act_dtype', torch.float32))
-        # the per-bucket hipGraph plan of the data-parallel path (_capture) is experimental: opt in with FAMI_DDP_GRAPH=1
-        self.use_graph = use_graph and (not self.ddp or os.environ.get('FAMI_DDP_GRAPH') == '1')
+        # FAMI_DDP_GRAPH=0 forces the eager, hook-overlapped launch sequence on the data-parallel path
+        self.use_graph = use_graph and (not self.ddp or os.environ.get('FAMI_DDP_GRAPH', '1') != '0')
         self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
         self._graphs = None
         self._static = None
@@ -270,12 +270,22 @@ class Trainer:
     # ------------------------------------------------------------------ hipGraph capture / replay
     def _capture(self, kf_x, sup_x, target, weight):
         st = {'kf': kf_x.clone(), 'sup': sup_x.clone(), 'target': target.clone(), 'weight': weight.clone()}
+        # warm-up on a side stream (allocator + pack caches).  The warm-up steps must not count as training steps: the
+        # parameters, Adam state and module buffers (BN running statistics) are restored afterwards, so the first
+        # step() of a graph-mode Trainer is exactly one optimisation step, like the eager one.
+        snap = [t.clone() for t in (self.flat, self.opt.m, self.opt.v, self.opt.state)]
+        bufs = [(b, b.clone()) for b in self.model.buffers()]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(side):                     # warm-up on a side stream (allocator + pack caches)
+        with torch.cuda.stream(side):
             for _ in range(2):
                 self._eager_step(st['kf'], st['sup'], st['target'], st['weight'])
         torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        for dst, src in zip((self.flat, self.opt.m, self.opt.v, self.opt.state), snap):
+            dst.copy_(src)
+        for b, src in bufs:
+            b.copy_(src)
         torch.cuda.synchronize(self.dev)
         if not self.ddp:
             g = torch.cuda.CUDAGraph()
@@ -284,28 +294,16 @@ class Trainer:
                 self.opt.step()
             self._graphs = [('graph', g)]
         else:
-            # one graph per bucket boundary; collectives run between graph launches
+            # data parallel: graph 1 = forward + backward, then the bucketed all-reduce of the flat gradient arena
+            # (RCCL, outside any graph), then graph 2 = 1/world scale + Adam.  The exchange is ~260 MB of fp32 per
+            # step, ~2 ms on 8 xGMI-linked GPUs against a ~75 ms step, so it is not overlapped with backward here; the
+            # eager path (use_graph=False) overlaps it bucket by bucket through the Engine.backward hooks.
             pool = torch.cuda.graph_pool_handle()
-            plan = []
-            cur = {'g': None, 'ctx': None}
-
-            def begin():
-                cur['g'] = torch.cuda.CUDAGraph()
-                cur['ctx'] = torch.cuda.graph(cur['g'], pool=pool)
-                cur['ctx'].__enter__()
-
-            def end():
-                cur['ctx'].__exit__(None, None, None)
-                plan.append(('graph', cur['g']))
-
-            def on_bucket(lo, hi):
-                end()
-                plan.append(('allreduce', (lo, hi)))
-                begin()
-
-            begin()
-            outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], on_bucket=on_bucket)
-            end()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, pool=pool):
+                outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
+            plan = [('graph', g1)]
+            plan += [('allreduce', r) for r in self.reducer.ranges()]
             plan.append(('wait', None))
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=pool):

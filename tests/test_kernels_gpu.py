@@ -91,9 +91,11 @@ def test_conv_fwd_bwd(dev, case, lds_mode):
 
 @pytest.mark.parametrize("C,relu,res", [(48, True, True), (48, True, False), (96, False, False), (16, True, False),
                                         (384, True, True), (256, False, True)])
-def test_bn_train_fwd_bwd(dev, C, relu, res):
+@pytest.mark.parametrize("size", [(3, 10, 7), (4, 30, 23)], ids=['small', 'large'])
+def test_bn_train_fwd_bwd(dev, C, relu, res, size):
+    """(3,10,7): single-launch small-tensor kernels for C <= 96; (4,30,23): the statistics / finalize / apply path."""
     torch.manual_seed(C)
-    N, H, W = 3, 10, 7
+    N, H, W = size
     bn = nn.BatchNorm2d(C, momentum=0.1)
     with torch.no_grad():
         bn.weight.uniform_(0.5, 1.5)
@@ -255,7 +257,7 @@ def test_shift_bilinear(dev, shape):
     assert relerr(tt.grad, t.grad) < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [(2, 48, 12, 12, 9), (1, 32, 8, 10, 7), (1, 96, 12, 6, 5)])
+@pytest.mark.parametrize("cfg", [(2, 48, 12, 12, 9), (1, 32, 8, 10, 7), (1, 96, 12, 6, 5), (3, 48, 12, 13, 11)])
 def test_dcn_fwd_bwd(dev, cfg):
     """DeformConv2d(C,C,3,padding=3,dilation=3) with G offset groups vs oracle.deform_conv2d."""
     from oracle import ops as O
@@ -379,3 +381,36 @@ def test_final_preds_golden(dev):
     preds, maxvals = FL.get_final_preds(torch.from_numpy(g['hm']).to(dev), g['center'], g['scale'])
     assert np.array_equal(maxvals.cpu().numpy(), g['maxvals'])
     assert np.abs(preds.cpu().numpy().astype(np.float64) - g['preds']).max() < 1e-3
+
+
+def test_lane_guard_rejects_shared_module_on_two_lanes(dev):
+    """A module applied on two concurrent stream lanes would race on its weight-gradient accumulator (and a train-mode
+    BatchNorm on its running statistics): the engine refuses instead of producing run-dependent gradients."""
+    from fami_pose_amd.engine import Engine, T
+    torch.manual_seed(0)
+    conv = nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(dev)
+    bn = nn.BatchNorm2d(16).to(dev).train()
+    xs = [T(torch.randn(1, 8, 8, 16, device=dev), True) for _ in range(2)]
+    eng = Engine(dev)
+    if not eng.use_lanes:
+        pytest.skip('stream lanes disabled')
+    assert eng.fork(2)
+    ys = []
+    for i in range(2):
+        eng.set_lane(i)
+        ys.append(eng.conv(xs[i], conv.weight))
+    eng.join(2)
+    for y in ys:
+        y.grad = torch.ones_like(y.data)
+    with pytest.raises(RuntimeError, match='one lane'):
+        eng.backward()
+    torch.cuda.synchronize(dev)
+    eng = Engine(dev)
+    eng.fork(2)
+    eng.set_lane(0)
+    eng.bn(xs[0], bn)
+    eng.set_lane(1)
+    with pytest.raises(RuntimeError, match='running statistics'):
+        eng.bn(xs[1], bn)
+    eng.join(2)
+    torch.cuda.synchronize(dev)
