@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
   float* col = smem;                       // [DCN_PIX][stride]
   float* red = smem + DCN_PIX * stride;    // [4][NT*256]
   __shared__ int pcoord[DCN_PIX][4];       // b, oy*stride-pad, ox*stride-pad, valid
-  const int m0 = blockIdx.x * DCN_PIX;
+  int bxl, byl;
+  xcd_tile(1, bxl, byl);  // neighbouring pixel tiles gather from the same input rows: keep them on one XCD's L2
+  const int m0 = bxl * DCN_PIX;
   if (tid < DCN_PIX) {
     const int m = m0 + tid;
     const bool v = m < p.P;

@@ -87,3 +87,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own 4 MB L2:
+// with the natural order, neighbouring pixel tiles -- which share their 3x3 halo rows -- sit in 8 different L2s and
+// every input row is fetched from the fabric by several of them.  This remap hands XCD x the x-th contiguous eighth
+// of the tile sequence (all output-channel blocks of a pixel tile adjacent), so halo re-fetch happens only at the
+// 7 chunk borders.  bx/by: the logical (pixel tile, channel block) of this workgroup.
+__device__ __forceinline__ void xcd_tile(int on, int& bx, int& by) {
+  if (!on) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    return;
+  }
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int n = gx * gy;
+  const int lin = blockIdx.y * gx + blockIdx.x;
+  const int q = n >> 3, r = n & 7;
+  const int x = lin & 7, l = lin >> 3;
+  const int t = x * q + (x < r ? x : r) + l;  // position in the XCD-contiguous order
+  bx = t / gy;
+  by = t - bx * gy;
+}
+

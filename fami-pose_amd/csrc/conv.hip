@@ -31,6 +31,7 @@ struct ConvArgs {
   int kh, kw, sh, pad, dil;  // sh = log2(stride)
   int KC, NTt, relu, accumulate, P;
   unsigned x_bytes, wp_bytes;  // buffer-descriptor extents (out-of-range lanes read 0)
+  int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
 };
 
 // f32 weight image = [16x16-tile image][32x32-tile image]:
@@ -93,10 +94,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
   const int row = lane & 15, kq = lane >> 4;
   const int kpart = wave % KS, mgrp = wave / KS;
-  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
+  int bx, by;
+  xcd_tile(p.xcd, bx, by);
+  const int m0 = (bx * (4 / KS) + mgrp) * (MT * 16);
   const bool active = m0 < p.P;  // wave-uniform
   if (KS == 1 && !active) return;
-  const int ntg0 = blockIdx.y * NT;
+  const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
 
   int pn[MT], py[MT], px[MT];
@@ -281,10 +284,12 @@ __global__ __launch_bounds__(256) void conv_igemm32_f32(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, kh2 = lane >> 5;
   const int kpart = wave % KS, mgrp = wave / KS;
-  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * 32;
+  int bx, by;
+  xcd_tile(p.xcd, bx, by);
+  const int m0 = (bx * (4 / KS) + mgrp) * 32;
   const bool active = m0 < p.P;  // wave-uniform
   if (KS == 1 && !active) return;
-  const int ntg0 = blockIdx.y * NT;
+  const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
   const int m = m0 + col;
   const bool pv = m < p.P;
@@ -430,6 +435,7 @@ struct ConvArgsH {
   int kh, kw, sh, pad, dil;
   int KC, NTt, relu, accumulate, P, out_f32;
   unsigned x_bytes, wp_bytes;
+  int xcd;
 };
 
 // packed[tap][kc][nt][lane][j] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
@@ -492,10 +498,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
   const int col = lane & 15, kq = lane >> 4;
   const int kpart = wave % KS, mgrp = wave / KS;
-  const int m0 = (blockIdx.x * (4 / KS) + mgrp) * (MT * 16);
+  int bx, by;
+  xcd_tile(p.xcd, bx, by);
+  const int m0 = (bx * (4 / KS) + mgrp) * (MT * 16);
   const bool active = m0 < p.P;  // wave-uniform
   if (KS == 1 && !active) return;
-  const int ntg0 = blockIdx.y * NT;
+  const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
 
   int pn[MT], py[MT], px[MT];
@@ -738,12 +746,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
-  const int img = blockIdx.x / p.bands, bnd = blockIdx.x - img * p.bands;
+  int bxl, byl;
+  xcd_tile(1, bxl, byl);  // neighbouring row bands (shared halo rows) on one XCD's L2
+  const int img = bxl / p.bands, bnd = bxl - img * p.bands;
   const int y0 = bnd * p.R;
   const int rows = min(p.R, p.H - y0);
   const int npix = rows * p.W;
   const int ntile = (npix + 15) >> 4;
-  const int ntg0 = blockIdx.y * NT;
+  const int ntg0 = byl * NT;
   char* patch = smem;
   char* wbuf = smem + p.patch_bytes;
 
@@ -935,6 +945,7 @@ struct WgradArgs {
   int N, H, W, Ci, Ho, Wo, Co, kh, kw, sh, pad, dil;
   int P, chunk, ciBlocks, coBlocks;
   unsigned x_bytes, dy_bytes;
+  int xcd;
 };
 
 // dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
@@ -1067,8 +1078,9 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
   const int lane = threadIdx.x & 63;
   const int tap = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, kq = lane >> 4;
-  const int ps = blockIdx.x;
-  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  int ps, byl;
+  xcd_tile(p.xcd, ps, byl);  // neighbouring pixel chunks (shared halo rows) on one XCD's L2
+  const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
   const int taps = p.kh * p.kw;
   const int w_lo = ps * p.chunk;
@@ -1275,6 +1287,7 @@ struct WgradLdsArgs {
   int CiB, CoB;      // channels per block (16 * CIT, 16 * COT)
   int xrow, yrow;    // LDS bytes per pixel of the X / dY tiles
   int xbytes;        // size of the X tile
+  int xcd;
 };
 
 template <int CIT, int COT>
@@ -1285,8 +1298,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, kq = lane >> 4;
   const int rsel = l16 >> 2, piece = l16 & 3;  // this lane feeds pixel row `rsel` (of 4), channels piece*4..+3
-  const int g = blockIdx.x;
-  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  int g, byl;
+  xcd_tile(p.xcd, g, byl);
+  const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
   const int halo = p.W + 1;
   char* xt = smem;                             // [(chunk + 2*halo)][xrow]
   char* yt = smem + p.xbytes;                  // [chunk][yrow]
@@ -1427,6 +1441,7 @@ struct WgradLdsArgsF {
   int CiB, CoB;     // channels per block (16 * CIT, 16 * COT)
   int xrow, yrow;   // LDS floats per pixel of the X / dY tiles (padded)
   int xfloats;      // size of the X tile in floats
+  int xcd;
 };
 
 template <int CIT, int COT>
@@ -1436,8 +1451,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_lds_f32_kernel(WgradLdsArgsF p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, kq = lane >> 4;
-  const int g = blockIdx.x;
-  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  int g, byl;
+  xcd_tile(p.xcd, g, byl);
+  const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
   const int halo = p.W + 1;
   float* xt = reinterpret_cast<float*>(smem);  // [(chunk + 2*halo)][xrow]
   float* yt = xt + p.xfloats;                  // [chunk][yrow]
@@ -1631,7 +1647,12 @@ static int g_stages = 0;                                     // pipeline depth o
 static int g_use32 = 1;  // fami_conv_tune(-1, ...) disables the 32x32-tile f32 kernel (benchmarks / tests)
 
 // 32x32x2 path: eligible when the weight image carries the 32-tile section (N >= 32, K % 4 == 0)
+static int g_xcd_w = 1;  // same switch for the weight-gradient kernels (fami_conv_tune_xcd bit 1)
+static int g_xcd = -1;  // fami_conv_tune_xcd: 0 natural tile order, 1 XCD-contiguous, -1 default (= 1: PMC FETCH_SIZE of the
+                        // 48->48 3x3 @96x72 N=20 launch drops from 46.6 MB to 13.7 MB, time -1..-2 %; tools/bench_xcd.py)
+
 static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
+  a.xcd = g_xcd < 0 ? 1 : g_xcd;
   const long n16 = pack16_elems(a.Ci, a.Co, a.kh * a.kw);
   a.wp = a.wp + n16;
   a.KC = fami_cdiv(a.Ci, 8);
@@ -1670,6 +1691,7 @@ static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
 }
 
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
+  a.xcd = g_xcd < 0 ? 1 : g_xcd;
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   if (vec && g_use32 && (g_force_mt == 0 || g_force_mt == 32) && pack32_elems(a.Ci, a.Co, a.kh * a.kw) > 0 &&
       (long)a.kh * a.kw * fami_cdiv(a.Ci, 8) * fami_cdiv(a.Co, 32) * 1024 < (1L << 31))
@@ -1707,11 +1729,12 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   return FAMI_OK;
 }
 
-// The LDS-staged 3x3 kernel cuts L2 requests ~5x but, measured on MI355X (tools/bench_dvfs.py), does not beat the
-// direct kernels on the HRNet shapes (f32 48ch: 75 vs 67 us; bf16: 24.7 vs 21.5 us): both sit at 62-84 % of the
-// register-only MFMA rate of this part (138 TF f32, tools/probes/mfma_peak.hip).  It is therefore opt-in
-// (fami_conv_tune_lds(1)); tests exercise it explicitly.
-static int g_use_lds = 0;
+// The LDS-staged 3x3 kernel cuts L2 requests ~5x.  Measured on MI355X: launch by launch it does not beat the direct
+// kernels on the HRNet shapes (f32 48ch: 75 vs 67 us; bf16: 24.7 vs 21.5 us, tools/bench_dvfs.py), but inside the
+// training step -- where the branch lanes run several convs at once and share the L2s -- the bf16 step is 4 % faster
+// with it (42.3 -> 40.6 ms) and the f32 step 4 % slower (77.3 -> 80.7 ms; interleaved A/B, tools/ab_step.py).
+// Default (-1): bf16 staged, f32 direct.  fami_conv_tune_lds(0/1) forces one path for both (tests exercise both).
+static int g_use_lds = -1;
 static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
 static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
@@ -1724,7 +1747,8 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                            const char* name) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
-  if (!g_use_lds || W > 144 || (Ci * SZ) % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  const int use = g_use_lds < 0 ? (SZ == 2 ? 1 : 0) : g_use_lds;
+  if (!use || W > 144 || (Ci * SZ) % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
   int NT = 0;
   if (Co % 48 == 0) NT = 3;
   else if (Co % 64 == 0) NT = 4;
@@ -1793,9 +1817,10 @@ int fami_conv_tune(int mt, int nt, int ks) {
   g_force_mt = mt; g_force_nt = nt; g_force_ks = ks;
   return FAMI_OK;
 }
-// 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 (default) through the direct kernels
+// 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
+// -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
-  g_use_lds = on ? 1 : 0;
+  g_use_lds = on < 0 ? -1 : (on ? 1 : 0);
   return FAMI_OK;
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
@@ -1820,6 +1845,11 @@ int fami_conv_tune_wgrad_lds(int on) {
   return FAMI_OK;
 }
 // tuning hook (benchmarks only): register-pipeline depth of the implicit GEMM (2..4; 0 = default)
+int fami_conv_tune_xcd(int mode) {
+  g_xcd = mode < 0 ? -1 : (mode & 1);
+  g_xcd_w = mode < 0 ? 1 : ((mode >> 1) & 1);
+  return FAMI_OK;
+}
 int fami_conv_tune_stages(int stages) {
   g_stages = (stages >= 2 && stages <= 4) ? stages : 0;
   return FAMI_OK;
@@ -2022,7 +2052,7 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
   a.N = N; a.H = H; a.W = W; a.Ci = Ci;
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
-  a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
+  a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks; a.xcd = g_xcd_w;
   const long xb = (long)N * H * W * Ci * (long)sizeof(T), yb = q.P * Co * (long)sizeof(T);
   FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), nm, "tensor >= 2 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
@@ -2094,6 +2124,7 @@ static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hi
 }
 
 static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
+  a.xcd = g_xcd < 0 ? 1 : g_xcd;
   const int vec = (a.Ci % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   int NT = pick_nt(a.NTt);
   if (NT == 6) NT = 3;
@@ -2142,7 +2173,7 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
     WgradLdsArgsF a;
     a.x = x; a.dy = dy; a.part = workspace;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.P = N * H * W;
-    a.chunk = l.chunk; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks;
+    a.chunk = l.chunk; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks; a.xcd = g_xcd_w;
     a.CiB = 16 * l.CIT; a.CoB = 16 * l.COT; a.xrow = l.xrow; a.yrow = l.yrow; a.xfloats = l.xbytes;
     const dim3 grid(l.G, l.ciBlocks * l.coBlocks);
     bool ok = false;
@@ -2181,7 +2212,7 @@ int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* 
     WgradLdsArgs a;
     a.x = x; a.dy = dy; a.part = workspace;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.P = N * H * W;
-    a.chunk = l.chunk; a.nsub = l.nsub; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks;
+    a.chunk = l.chunk; a.nsub = l.nsub; a.ciBlocks = l.ciBlocks; a.coBlocks = l.coBlocks; a.xcd = g_xcd_w;
     a.CiB = 16 * l.CIT; a.CoB = 16 * l.COT; a.xrow = l.xrow; a.yrow = l.yrow; a.xbytes = l.xbytes;
     const dim3 grid(l.G, l.ciBlocks * l.coBlocks);
     bool ok = false;

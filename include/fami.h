@@ -41,9 +41,12 @@ int fami_device_info(int device, int* info, char* name, int name_len);
  * Weights are consumed in a fragment-packed image (mode 0 = forward, 1 = dgrad). */
 /* benchmarks only: force the implicit-GEMM tile (MT x NT 16x16 tiles per wave, KS-way split-K); 0 = heuristic */
 int fami_conv_tune(int mt, int nt, int ks);
-int fami_conv_tune_lds(int on);          /* 1 = route eligible 3x3 stride-1 convs through the LDS-staged kernel (default 0) */
+int fami_conv_tune_lds(int on);          /* 1 / 0 = route eligible 3x3 stride-1 convs through the LDS-staged / direct kernel,
+                                          * -1 = default (bf16 staged, f32 direct: measured per dtype inside the step) */
 int fami_conv_tune_wgrad_lds(int on);    /* 0 = weight gradients on the scalar-operand kernels, 1 = LDS-staged kernels wherever eligible,
                                           * -1 = defaults (bf16: staged; f32: staged only where it measured faster) */
+int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous workgroup->tile order in the implicit-GEMM kernels,
+                                        * bit 1 = in the weight-gradient kernels; -1 = default (both on) */
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default */
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,

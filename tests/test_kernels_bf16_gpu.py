@@ -17,7 +17,7 @@ def lds_mode(request):
     from fami_pose_amd._lib import lib
     lib().cdll.fami_conv_tune_lds(request.param)
     yield request.param
-    lib().cdll.fami_conv_tune_lds(0)
+    lib().cdll.fami_conv_tune_lds(-1)
 BF = torch.bfloat16
 ACT_TOL, F32_TOL = 1e-2, 2e-3
 

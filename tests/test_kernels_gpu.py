@@ -16,7 +16,7 @@ def lds_mode(request):
     lib().cdll.fami_conv_tune_lds(request.param)
     lib().cdll.fami_conv_tune_wgrad_lds(request.param)      # 'direct' also takes the scalar-operand weight-gradient kernels
     yield request.param
-    lib().cdll.fami_conv_tune_lds(0)
+    lib().cdll.fami_conv_tune_lds(-1)
     lib().cdll.fami_conv_tune_wgrad_lds(-1)
 
 

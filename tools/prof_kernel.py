@@ -13,6 +13,8 @@ N, H, W, C = int(os.environ.get('N', 20)), int(os.environ.get('H', 96)), int(os.
 kind, dt = what.rsplit('_', 1)
 tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
 st = s.cuda_stream
+if os.environ.get('XCD'):
+    L.cdll.fami_conv_tune_xcd(int(os.environ['XCD']))
 if kind in ('conv', 'dgrad', 'wgrad'):
     x = torch.randn(N, H, W, C, device=dev).to(tdt)
     y = torch.randn(N, H, W, C, device=dev).to(tdt)
