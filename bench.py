@@ -99,9 +99,11 @@ def conv_roofline(dev, N, dtype, reps=30):
     flops = 2.0 * N * H * W * C * 9 * C
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
-    return {"bound": "mfma", "kernel": "conv_igemm_%s (48->48 3x3 @96x72, N=%d frames)" % (dtype, N),
+    # the library's default route for this shape: direct implicit GEMM in f32, LDS-staged 3x3 kernel in bf16
+    kname = 'conv3x3_lds_bf16' if bf else 'conv_igemm_f32'
+    return {"bound": "mfma", "kernel": "%s (48->48 3x3 @96x72, N=%d frames)" % (kname, N),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic('conv_igemm_' + dtype) if N == 20 else None,
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic(kname) if N == 20 else None,
             "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
 
 

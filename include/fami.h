@@ -176,6 +176,18 @@ int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int
 int fami_final_preds_f32(const float* hm, const float* center, const float* scale, float* preds, float* maxvals,
                          long long* idx_ws, int B, int J, int H, int W, fami_stream_t stream);
 
+/* ---- input pipeline on the device -------------------------------------------------------------
+ * cv2.warpAffine(frame, trans, (Wd, Hd), flags=INTER_LINEAR) on the F 8-bit HWC frames of one clip (one transform
+ * for key + supporting frames, datasets/zoo/posetrack/PoseTrack_Alignment.py:421-427; flip = source mirrored in x
+ * first, :409-413; swap_rb = cv2.cvtColor(BGR2RGB), :299-300), then transforms.ToTensor + Normalize
+ * (datasets/transforms/build.py:12-23): out[f][c][y][x] = ((crop / 255) - mean[c]) / std[c], NCHW fp32.
+ * m00..m12: the INVERSE map (dst -> src) cv2 derives from `trans` (fami_pose_amd.data.invert_affine).  Coordinates and
+ * interpolation follow OpenCV's generic fixed-point path bit for bit (see csrc/preproc.hip). */
+int fami_warp_normalize_u8(const unsigned char* src, float* out, int F, int Hs, int Ws, long src_stride, int Hd, int Wd,
+                           long out_stride, double m00, double m01, double m02, double m10, double m11, double m12,
+                           int flip, int swap_rb, float mean0, float mean1, float mean2, float std0, float std1,
+                           float std2, fami_stream_t stream);
+
 
 /* ======================================================================================================
  * bf16 activation storage (BASELINE config 3: bf16 compute, fp32 master weights / accumulation / losses).

@@ -266,6 +266,37 @@ def g12_final_preds(ns):
     _save('g12_final_preds.npz', hm=hm, center=center, scale=scale, preds=preds, maxvals=maxvals)
 
 
+def g13_input_pipeline(ns):
+    """Crop transform, joint transform and flip bookkeeping of the training pipeline, from the
+    reference's own datasets/process/affine_transform.py and pose_process.py (cv2.getAffineTransform injected as for
+    g12).  The image resampling itself (cv2.warpAffine) is third-party and stays unpinned."""
+    import importlib
+    at = importlib.import_module('datasets.process.affine_transform')
+    pp = importlib.import_module('datasets.process.pose_process')
+    rng = np.random.RandomState(13)
+    image_size = np.array([288, 384])
+    centers = np.array([[640.5, 360.25], [100.0, 80.0], [1200.75, 700.0], [333.0, 512.5]], np.float64)
+    scales = np.array([[1.8, 2.4], [0.6, 0.8], [2.7, 3.6], [1.2375, 1.65]], np.float64)
+    rots = np.array([0.0, 27.5, -44.0, 90.0])
+    trans = np.stack([at.dark_get_affine_transform(c.copy(), s.copy(), r, image_size) for c, s, r in zip(centers, scales, rots)])
+    trans_inv = np.stack([at.dark_get_affine_transform(c.copy(), s.copy(), r, image_size, inv=1)
+                          for c, s, r in zip(centers, scales, rots)])
+    joints = np.zeros((4, 17, 3), np.float32)
+    joints[:, :, 0] = rng.uniform(0, 1280, (4, 17))
+    joints[:, :, 1] = rng.uniform(0, 720, (4, 17))
+    vis = np.zeros((4, 17, 3), np.float32)
+    vis[:, :, :2] = (rng.rand(4, 17, 1) < 0.8).astype(np.float32)
+    pts = np.stack([np.stack([at.exec_affine_transform(joints[b, j, 0:2], trans[b]) for j in range(17)]) for b in range(4)])
+    flip_pairs = [[3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    fj, fv = [], []
+    for b in range(4):
+        a, v = pp.fliplr_joints(joints[b].copy(), vis[b].copy(), 1280, flip_pairs)
+        fj.append(a)
+        fv.append(v)
+    _save('g13_input_pipeline.npz', image_size=image_size, centers=centers, scales=scales, rots=rots, trans=trans,
+          trans_inv=trans_inv, joints=joints, vis=vis, pts=pts, flip_joints=np.stack(fj), flip_vis=np.stack(fv))
+
+
 # ------------------------------------------------------------------ G8 MI / G9 whole model / G10 keys / G11 init stats
 def g9_alignment(ns):
     cfg = rh.ref_cfg(48)
@@ -364,6 +395,7 @@ def main():
             globals()[name](ns)
         return
     g12_final_preds(ns)
+    g13_input_pipeline(ns)
     g1_blocks(ns)
     g2_hrmodule(ns)
     g3_hrnet_w32(ns)

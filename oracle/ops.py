@@ -346,3 +346,106 @@ def total_loss(final_hm, target, weight, mi_list, mse_weight=1.0, alpha=0.5, bet
         m1, m2, m3, m4, m5, m6 = mi_list
         loss = loss + alpha * (-beta * m1 + beta * m2 + m3 - m4 + m5 - m6)
     return loss
+
+
+# ------------------------------------------------------------------ input pipeline
+def dark_get_affine_transform(center, scale, rot, output_size, inv=0):
+    """datasets/process/affine_transform.py:45-77 (shift = 0): the crop transform of the training pipeline
+    (PoseTrack_Alignment.py:420), anchored on (w-1)/2 pixel centres."""
+    scale = np.asarray(scale, np.float64)
+    scale_tmp = scale * 200.0
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rad = np.pi * rot / 180
+    sn, cs = np.sin(rad), np.cos(rad)
+    pt = (0.0, (src_w - 1) * -0.5)
+    src_dir = np.array([pt[0] * cs - pt[1] * sn, pt[0] * sn + pt[1] * cs])
+    dst_dir = np.array([0, (dst_w - 1) * -0.5], np.float32)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0, :] = center
+    src[1, :] = np.asarray(center) + src_dir
+    dst[0, :] = [(dst_w - 1) * 0.5, (dst_h - 1) * 0.5]
+    dst[1, :] = np.array([(dst_w - 1) * 0.5, (dst_h - 1) * 0.5]) + dst_dir
+
+    def third(a, b):
+        d = a - b
+        return b + np.array([-d[1], d[0]], np.float32)
+    src[2, :] = third(src[0], src[1])
+    dst[2, :] = third(dst[0], dst[1])
+    return cv2_get_affine_transform(dst, src) if inv else cv2_get_affine_transform(src, dst)
+
+
+def exec_affine_transform(pt, t):
+    """affine_transform.py:79-82."""
+    return np.dot(t, np.array([pt[0], pt[1], 1.0]).T)[:2]
+
+
+def fliplr_joints(joints, joints_vis, width, matched_parts):
+    """datasets/process/pose_process.py:12-26 (operates on copies)."""
+    joints, joints_vis = joints.copy(), joints_vis.copy()
+    joints[:, 0] = width - joints[:, 0] - 1
+    for a, b in matched_parts:
+        joints[a, :], joints[b, :] = joints[b, :], joints[a, :].copy()
+        joints_vis[a, :], joints_vis[b, :] = joints_vis[b, :], joints_vis[a, :].copy()
+    return joints * joints_vis, joints_vis
+
+
+def cv2_invert_affine(M):
+    """The inverse map cv2.warpAffine derives from the forward 2x3 matrix (float64, its own operation order)."""
+    M = np.asarray(M, np.float64).copy().reshape(6)
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[4] * D, M[0] * D
+    M[0] = A11
+    M[1] *= -D
+    M[3] *= -D
+    M[4] = A22
+    b1 = -M[0] * M[2] - M[1] * M[5]
+    b2 = -M[3] * M[2] - M[4] * M[5]
+    M[2], M[5] = b1, b2
+    return M.reshape(2, 3)
+
+
+def cv2_warp_affine_u8(src, M, dsize, flip=False):
+    """cv2.warpAffine(src, M, dsize, flags=cv2.INTER_LINEAR) for 8-bit HWC images, borderMode=BORDER_CONSTANT(0)
+    (PoseTrack_Alignment.py:421-427).  PARITY UNPINNED: cv2 is a third-party package absent from this image and the
+    reference pins no version; this restates OpenCV's published generic (non-IPP) algorithm: inverse map in float64,
+    source coordinates in fixed point with 10 fractional bits rounded to 1/32 pixel (AB_BITS 10, INTER_BITS 5), bilinear
+    weights (32-fy)(32-fx)*32 ... summing to 2^15, result (sum + 2^14) >> 15, taps outside the image read 0.
+    flip: the source is mirrored in x first (`data_numpy[:, ::-1, :]`, :409)."""
+    src = np.asarray(src)
+    if flip:
+        src = src[:, ::-1, :]
+    Hs, Ws = src.shape[:2]
+    Wd, Hd = int(dsize[0]), int(dsize[1])
+    Mi = cv2_invert_affine(M)
+    x = np.arange(Wd, dtype=np.float64)
+    y = np.arange(Hd, dtype=np.float64)
+    rnd = lambda v: np.clip(np.rint(v), -2147483648.0, 2147483647.0).astype(np.int64)     # saturate_cast<int>
+    adelta = rnd(Mi[0, 0] * x * 1024.0)
+    bdelta = rnd(Mi[1, 0] * x * 1024.0)
+    X0 = rnd((Mi[0, 1] * y + Mi[0, 2]) * 1024.0) + 16
+    Y0 = rnd((Mi[1, 1] * y + Mi[1, 2]) * 1024.0) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx = np.clip(X >> 5, -32768, 32767)
+    sy = np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    w = [(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32]
+    out = np.zeros((Hd, Wd, src.shape[2]), np.int64)
+    for k, (dy, dx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < Hs) & (xx >= 0) & (xx < Ws)
+        tap = src[np.clip(yy, 0, Hs - 1), np.clip(xx, 0, Ws - 1)].astype(np.int64) * ok[..., None]
+        out += tap * w[k][..., None]
+    return ((out + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def to_tensor_normalize(img_u8, mean, std):
+    """transforms.ToTensor + transforms.Normalize (datasets/transforms/build.py:12-23): HWC uint8 -> CHW fp32,
+    ((v / 255) - mean) / std evaluated in fp32 in this order."""
+    t = torch.from_numpy(np.ascontiguousarray(img_u8.transpose(2, 0, 1))).float().div(255)
+    m = torch.tensor(mean, dtype=torch.float32)[:, None, None]
+    s = torch.tensor(std, dtype=torch.float32)[:, None, None]
+    return t.sub_(m).div_(s)

@@ -161,3 +161,28 @@ def test_product_init_matches_oracle_init():
     om.realistic_init_(b, 11)
     sa, sb = a.state_dict(), b.state_dict()
     assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
+def test_input_pipeline_host_logic_matches_reference_golden():
+    """fami_pose_amd.data (crop transform, its inverse, joint transform, flip bookkeeping, visibility rule) against the
+    vectors the reference's datasets/process modules produced (tests/golden/g13_input_pipeline.npz)."""
+    from fami_pose_amd import data as D
+    g = np.load(os.path.join(GOLD, 'g13_input_pipeline.npz'))
+    for b in range(4):
+        t = D.dark_get_affine_transform(g['centers'][b], g['scales'][b], float(g['rots'][b]), g['image_size'])
+        assert np.array_equal(t, g['trans'][b])
+        assert np.array_equal(D.dark_get_affine_transform(g['centers'][b], g['scales'][b], float(g['rots'][b]), g['image_size'], inv=1),
+                              g['trans_inv'][b])
+        mi = D.invert_affine(t)
+        assert np.allclose(mi @ np.append(t @ np.array([7.0, 9.0, 1.0]), 1.0), [7.0, 9.0], atol=1e-8)
+        fj, fv = D.fliplr_joints(g['joints'][b], g['vis'][b], 1280)
+        assert np.array_equal(fj, g['flip_joints'][b]) and np.array_equal(fv, g['flip_vis'][b])
+        j2, v2 = D.transform_joints(g['joints'][b], g['vis'][b], t, g['image_size'])
+        for j in range(17):
+            if g['vis'][b, j, 0] > 0:
+                assert np.array_equal(j2[j, 0:2].astype(np.float32), g['pts'][b, j].astype(np.float32))
+            x, y = j2[j, 0], j2[j, 1]
+            outside = x < 0 or y < 0 or x > 288 or y > 384
+            assert (v2[j] == 0).all() if outside else np.array_equal(v2[j], g['vis'][b, j])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        D.crop_clip(torch.zeros(2, 8, 8, 3, dtype=torch.uint8), [4, 4], [0.1, 0.1], 0, (8, 8))

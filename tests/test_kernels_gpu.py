@@ -414,3 +414,55 @@ def test_lane_guard_rejects_shared_module_on_two_lanes(dev):
         eng.bn(xs[1], bn)
     eng.join(2)
     torch.cuda.synchronize(dev)
+
+
+@pytest.mark.parametrize("flip,bgr,rot", [(False, False, 0.0), (True, False, 31.0), (False, True, -44.0), (True, True, 90.0)])
+def test_warp_normalize_bit_exact_vs_oracle(dev, flip, bgr, rot):
+    """fami_warp_normalize_u8 (cv2.warpAffine INTER_LINEAR + ToTensor + Normalize, one transform for all frames of a
+    clip) against the CPU restatement: the 8-bit crop arithmetic is integer, the float conversion follows torch's
+    operation order -> bit-exact, including borders that leave the source image."""
+    from oracle import ops as O
+    from fami_pose_amd import data as D
+    rng = np.random.RandomState(7)
+    F, Hs, Ws = 3, 180, 260
+    frames = (rng.rand(F, Hs, Ws, 3) * 255).astype(np.uint8)
+    center, scale, size = np.array([140.5, 80.25]), np.array([0.9, 1.2]), (96, 128)     # crop reaches outside the image
+    key, sup, trans = D.crop_clip(torch.from_numpy(frames).to(dev), center, scale, rot, size, flip=flip, bgr=bgr)
+    assert np.array_equal(trans, O.dark_get_affine_transform(center, scale, rot, size))
+    got = torch.cat([key, sup], 0).cpu().reshape(F, 3, size[1], size[0])
+    for f in range(F):
+        img = frames[f][:, :, ::-1] if bgr else frames[f]
+        want = O.to_tensor_normalize(O.cv2_warp_affine_u8(np.ascontiguousarray(img), trans, size, flip=flip), D.MEAN, D.STD)
+        assert torch.equal(got[f], want), (f, (got[f] - want).abs().max().item())
+    assert (got == torch.tensor([-m / s for m, s in zip(D.MEAN, D.STD)]).view(1, 3, 1, 1)).any()   # zero border present
+
+
+def test_prepare_clip_writes_batch_slices(dev):
+    """prepare_clip: flip bookkeeping + crop of every frame straight into the [B,3,H,W] / [B,3S,H,W] batch tensors the
+    model consumes, joints through the same transform."""
+    from oracle import ops as O
+    from fami_pose_amd import data as D
+    rng = np.random.RandomState(8)
+    S, Hs, Ws, size = 2, 120, 160, (48, 64)
+    kf = torch.zeros(2, 3, size[1], size[0], device=dev)
+    sup = torch.zeros(2, 3 * S, size[1], size[0], device=dev)
+    frames = (rng.rand(1 + S, Hs, Ws, 3) * 255).astype(np.uint8)
+    joints = np.zeros((17, 3), np.float32)
+    joints[:, 0], joints[:, 1] = rng.uniform(0, Ws, 17), rng.uniform(0, Hs, 17)
+    vis = np.ones((17, 3), np.float32)
+    vis[:, 2] = 0
+    vis[5] = 0
+    center, scale = np.array([80.0, 60.0]), np.array([0.5, 0.6667])
+    k, s_, j2, v2 = D.prepare_clip(torch.from_numpy(frames).to(dev), joints, vis, center, scale, 12.0, size, flip=True,
+                                   out_key=kf[1], out_sup=sup[1])
+    assert k.data_ptr() == kf[1].data_ptr() and float(kf[0].abs().max()) == 0.0
+    c2 = center.copy()
+    c2[0] = Ws - c2[0] - 1
+    trans = O.dark_get_affine_transform(c2, scale, 12.0, size)
+    want = O.to_tensor_normalize(O.cv2_warp_affine_u8(frames[2], trans, size, flip=True), D.MEAN, D.STD)
+    assert torch.equal(sup[1, 3:6].cpu(), want)
+    fj, fv = O.fliplr_joints(joints, vis, Ws, D.FLIP_PAIRS)
+    for j in range(17):
+        if fv[j, 0] > 0:
+            assert np.allclose(j2[j, :2], O.exec_affine_transform(fj[j, :2], trans), atol=1e-4)
+    assert (v2[5] == 0).all() or (fv[5] != 0).any()

@@ -278,3 +278,60 @@ def test_g12_final_preds():
     want = c + (np.array([5.0, 0.0]) - np.array([36.0, 48.0])) * (200.0 * s[0] / 72)
     assert np.abs(preds[0, 1] - want).max() < 1e-4
     assert np.abs(preds[0, 0] - (c - np.array([36.0, 48.0]) * (200.0 * s[0] / 72))).max() < 1e-4
+
+
+# ------------------------------------------------------------------ input pipeline
+def test_input_pipeline_transforms_match_reference_golden():
+    """dark_get_affine_transform / exec_affine_transform / fliplr_joints against vectors produced by the reference's own
+    datasets/process modules (oracle/gen_golden.py::g13_input_pipeline)."""
+    from oracle import ops as O
+    g = np.load(os.path.join(GOLD, 'g13_input_pipeline.npz'))
+    for b in range(4):
+        t = O.dark_get_affine_transform(g['centers'][b], g['scales'][b], float(g['rots'][b]), g['image_size'])
+        ti = O.dark_get_affine_transform(g['centers'][b], g['scales'][b], float(g['rots'][b]), g['image_size'], inv=1)
+        assert np.array_equal(t, g['trans'][b]) and np.array_equal(ti, g['trans_inv'][b])
+        for j in range(17):
+            assert np.array_equal(O.exec_affine_transform(g['joints'][b, j, 0:2], t), g['pts'][b, j])
+        fj, fv = O.fliplr_joints(g['joints'][b], g['vis'][b], 1280, [[3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]])
+        assert np.array_equal(fj, g['flip_joints'][b]) and np.array_equal(fv, g['flip_vis'][b])
+        # the inverse transform really inverts (cv2_invert_affine is what warpAffine applies)
+        mi = O.cv2_invert_affine(t)
+        p = np.array([100.0, 50.0, 1.0])
+        assert np.allclose(mi @ np.append(t @ p, 1.0), p[:2], atol=1e-8)
+
+
+def test_warp_affine_restatement_vs_float_bilinear():
+    """PARITY UNPINNED for cv2.warpAffine (third-party, absent): the fixed-point restatement is held against an
+    independent float64 bilinear resampling of the same inverse map -- sub-pixel positions are quantised to 1/32 pixel
+    and the result is rounded to 8 bits, so the two agree within a few grey levels everywhere (max |d| bounded by the
+    local gradient x 1/32 px + 0.5) and exactly for an integer translation."""
+    from oracle import ops as O
+    rng = np.random.RandomState(3)
+    src = (rng.rand(60, 80, 3) * 255).astype(np.uint8)
+    src = np.round(np.stack([np.convolve(np.convolve(src[..., c].astype(np.float64).ravel(), np.ones(5) / 5, 'same')
+                                         .reshape(60, 80).T.ravel(), np.ones(5) / 5, 'same').reshape(80, 60).T for c in range(3)], -1)).astype(np.uint8)
+    M = O.dark_get_affine_transform([40.0, 30.0], [0.3, 0.4], 20.0, [48, 64])
+    out = O.cv2_warp_affine_u8(src, M, (48, 64))
+    Mi = O.cv2_invert_affine(M)
+    ys, xs = np.mgrid[0:64, 0:48].astype(np.float64)
+    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
+    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = sx - x0, sy - y0
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < 60) & (xx >= 0) & (xx < 80)
+        return src[np.clip(yy, 0, 59), np.clip(xx, 0, 79)].astype(np.float64) * ok[..., None]
+    ref = (tap(y0, x0) * ((1 - fy) * (1 - fx))[..., None] + tap(y0, x0 + 1) * ((1 - fy) * fx)[..., None] +
+           tap(y0 + 1, x0) * (fy * (1 - fx))[..., None] + tap(y0 + 1, x0 + 1) * (fy * fx)[..., None])
+    d = np.abs(out.astype(np.float64) - ref)
+    assert d.max() < 6.0 and d.mean() < 0.6, (d.max(), d.mean())
+    # integer translation: pure copy with zero border
+    T = np.array([[1.0, 0.0, 3.0], [0.0, 1.0, -2.0]])
+    o2 = O.cv2_warp_affine_u8(src, T, (80, 60))
+    assert np.array_equal(o2[0:58, 3:80], src[2:60, 0:77]) and o2[58:].max() == 0 and o2[:, :3].max() == 0
+    # flip = warp of the mirrored image
+    assert np.array_equal(O.cv2_warp_affine_u8(src, M, (48, 64), flip=True), O.cv2_warp_affine_u8(src[:, ::-1].copy(), M, (48, 64)))
+    t = O.to_tensor_normalize(out, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    assert t.shape == (3, 64, 48) and t.dtype == torch.float32
+    assert float(t[0, 5, 7]) == pytest.approx((out[5, 7, 0] / 255.0 - 0.485) / 0.229, rel=1e-6)
