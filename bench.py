@@ -230,11 +230,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    # FAMI_DIST_BACKEND=gloo: validation mode for boxes with fewer GPUs than ranks (ranks share devices round-robin and
+    # exchange gradients through gloo); the measured configuration is one rank per GPU over RCCL ('nccl')
+    backend = os.environ.get('FAMI_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from fami_pose_amd.train import Trainer
 
@@ -289,7 +297,7 @@ def main():
                                    "on-device Gaussian targets" % (args.width, args.img_h, args.img_w, args.sup + 1,
                                                                    args.batch, "frozen" if args.freeze_backbone else "unfrozen"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hipgraph": use_graph},
+                       "hipgraph": use_graph, **({} if backend == 'nccl' or world == 1 else {"dist_backend": backend})},
             "loss": round(loss, 6),
         }
         out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype)
