@@ -1747,7 +1747,9 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                            const char* name) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
-  const int use = g_use_lds < 0 ? (SZ == 2 ? 1 : 0) : g_use_lds;
+  // default: bf16 from 96 input channels up (per launch: 192 ch 18.8 vs 30.3 us, 384 ch 27.8 vs 32.4, 96 ch equal,
+  // 48 ch 23.9 vs 21.8 -> direct; tools/bench_xcd.py with KNOB=lds), f32 never (slower on every shape)
+  const int use = g_use_lds < 0 ? (SZ == 2 && Ci >= 96 ? 1 : 0) : g_use_lds;
   if (!use || W > 144 || (Ci * SZ) % 16 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
   int NT = 0;
   if (Co % 48 == 0) NT = 3;
