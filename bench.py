@@ -209,6 +209,7 @@ def main():
     ap.add_argument('--img-h', type=int, default=384)
     ap.add_argument('--img-w', type=int, default=288)
     ap.add_argument('--freeze-backbone', action='store_true')
+    ap.add_argument('--no-frozen', action='store_true', help='skip the extra frozen-backbone measurement')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bucket-mb', type=int, default=32)
@@ -286,6 +287,15 @@ def main():
         o_dt, o_loss = timed_run(args.also, o_steps, max(2, min(args.warmup, 3)))
         other = (args.also, o_dt, o_loss, o_steps)
     args.dtype = primary
+    frozen = None
+    if world == 1 and not args.freeze_backbone and not args.no_frozen:
+        # the reference default freezes the backbone (Base_PoseTrack17.yaml:28); reported beside the
+        # unfrozen headline (backbone forward only + the head's forward/backward/Adam)
+        args.freeze_backbone = True
+        f_steps = max(3, min(args.steps, 10))
+        f_dt, f_loss = timed_run(primary, f_steps, max(2, min(args.warmup, 3)))
+        args.freeze_backbone = False
+        frozen = (f_dt, f_loss, f_steps)
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -312,6 +322,13 @@ def main():
                 "ms_per_step": round(o_dt / o_steps * 1e3, 3), "loss": round(o_loss, 6),
                 "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype),
                 "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype)}
+        if frozen is not None:
+            f_dt, f_loss, f_steps = frozen
+            out["also_frozen_backbone"] = {
+                "note": "same workload and dtype with MODEL.FREEZE_HRNET_WEIGHTS (the reference's default config): no "
+                        "backbone backward / weight gradients, head trained",
+                "value": round(args.batch * world * f_steps / f_dt, 3), "unit": "clips/s", "steps": f_steps,
+                "ms_per_step": round(f_dt / f_steps * 1e3, 3), "loss": round(f_loss, 6)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -19,6 +19,8 @@ for st in states:
     for k, v in st.items():
         if k.isupper():
             os.environ[k] = v
+        elif k == 'tile':                     # tile=mt:nt:ks -> fami_conv_tune(mt, nt, ks)
+            L.fami_conv_tune(*[int(t) for t in v.split(':')])
         else:
             getattr(L, 'fami_conv_tune_' + k)(int(v))
     tr = Trainer(bench.build(args, dev), lr=1e-3, use_mi=True, use_graph=True, targets_from_joints=True)
