@@ -300,13 +300,14 @@ class Trainer:
             # eager path (use_graph=False) overlaps it bucket by bucket through the Engine.backward hooks.
             pool = torch.cuda.graph_pool_handle()
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=pool):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g1, pool=pool, capture_error_mode='thread_local'):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
             plan = [('graph', g1)]
             plan += [('allreduce', r) for r in self.reducer.ranges()]
             plan.append(('wait', None))
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=pool):
+            with torch.cuda.graph(g2, pool=pool, capture_error_mode='thread_local'):
                 lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world,
                            0.0, _stream(self.dev))
                 self.opt.step()
