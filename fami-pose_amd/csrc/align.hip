@@ -386,11 +386,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   const int CKc = p.NTc * 16, gstride = CKc + 4, Cc = p.GC * p.cg, CK = p.C * K;
   float* gcol = smem;                   // [16][gstride]
   float* region = smem + 16 * gstride;  // [RH][RW][Cc]
-  int t = blockIdx.x;
+  int t, chunk;
+  xcd_tile(1, t, chunk);  // neighbouring tiles (overlapping halo / gather regions, all group chunks of a tile) on one XCD
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY, b = t / p.tilesY;
-  const int chunk = blockIdx.y;
   const int oy0 = ty * DCN_TILE, ox0 = tx * DCN_TILE;
   const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
   const int rsize = p.RH * p.RW * Cc;
