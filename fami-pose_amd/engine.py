@@ -73,6 +73,7 @@ class Engine:
         # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
+        self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
         self._wdirty = False
@@ -404,20 +405,17 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ fuse (hrnet.py:159-168)
-    def fuse(self, terms):
-        """terms: list of (T x_k, bn_k or None, shift_k); returns relu(sum_k up_{2^shift}(bn_k(x_k)))."""
-        k = len(terms)
-        assert 1 <= k <= 4
-        big = [t for t in terms if t[2] == 0][0][0]
-        N, H, W, C = big.shape
-        stats = []
-        for (x, bn, s) in terms:
-            if bn is None:
-                stats.append(None)
-                continue
+    def fuse_term(self, x, bn, shift):
+        """One term of a HighResolutionModule fuse sum (hrnet.py:151-172): its BatchNorm statistics now, its backward as
+        its own tape entry on the CURRENT lane -- all terms fed by branch j run on lane j, so the gradient of x_j is
+        accumulated by one stream.  -> handle for Engine.fuse."""
+        C = x.shape[-1]
+        h = {'x': x, 'bn': bn, 'shift': shift, 'stats': None, 'out': None}
+        if bn is not None:
             Pk = x.data.numel() // C
             mean, invstd = self.empty(C), self.empty(C)
             if bn.training:
+                self._lane_guard(('running statistics', id(bn)))
                 ws = self.ws(self.L.cdll.fami_bn_workspace(C))
                 mom = 0.1 if bn.momentum is None else bn.momentum
                 self.acall('fami_bn_stats', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
@@ -426,51 +424,61 @@ class Engine:
             else:
                 self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
                           C, float(bn.eps))
-            stats.append((mean, invstd))
+            h['stats'] = (mean, invstd)
+        need_p = bn is not None and self.rq(bn.weight)
+        if self.record and (x.requires_grad or need_p):
+            def bwd():
+                out = h['out']
+                if out is None or out.grad is None:
+                    return
+                dy, y = out.grad, out.data
+                N, H, W, _ = out.shape
+                if bn is None:
+                    if x.requires_grad:
+                        g, acc = self.gbuf(x)
+                        self.acall('fami_relu_bwd', _p(dy), _p(y), _p(g), y.numel(), acc)
+                    return
+                if not bn.training:
+                    raise NotImplementedError("backward through eval-mode BatchNorm")
+                Pk = x.data.numel() // C
+                gx, accx = self.gbuf(x) if x.requires_grad else (self.like(x.data), 0)
+                gg = gb = None
+                accp = 0
+                if need_p:
+                    gg, accp = self.pgrad(bn.weight)
+                    gb, _ = self.pgrad(bn.bias)
+                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                st = h['stats']
+                if shift == 0:
+                    self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
+                               _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
+                else:
+                    low = self.like(x.data)
+                    self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> shift, W >> shift, C, shift, 1)
+                    self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
+                               _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
+            self.record_bwd(bwd, [bn.weight, bn.bias] if bn is not None else [])
+        return h
+
+    def fuse(self, handles):
+        """handles from fuse_term (k <= 4): returns relu(sum_k up_{2^shift}(bn_k(x_k))).  The terms own the backward."""
+        k = len(handles)
+        assert 1 <= k <= 4
+        big = [h for h in handles if h['shift'] == 0][0]['x']
+        N, H, W, C = big.shape
         PA = ctypes.c_void_p * k
-        xs = PA(*[_p(t[0].data) for t in terms])
-        mean_a = PA(*[None if s is None else _p(s[0]) for s in stats])
-        inv_a = PA(*[None if s is None else _p(s[1]) for s in stats])
-        gam_a = PA(*[None if t[1] is None else _p(t[1].weight.data) for t in terms])
-        bet_a = PA(*[None if t[1] is None else _p(t[1].bias.data) for t in terms])
-        sh_a = (ctypes.c_int * k)(*[t[2] for t in terms])
+        xs = PA(*[_p(h['x'].data) for h in handles])
+        mean_a = PA(*[None if h['stats'] is None else _p(h['stats'][0]) for h in handles])
+        inv_a = PA(*[None if h['stats'] is None else _p(h['stats'][1]) for h in handles])
+        gam_a = PA(*[None if h['bn'] is None else _p(h['bn'].weight.data) for h in handles])
+        bet_a = PA(*[None if h['bn'] is None else _p(h['bn'].bias.data) for h in handles])
+        sh_a = (ctypes.c_int * k)(*[h['shift'] for h in handles])
         y = self.act(N, H, W, C)
         self.acall('fami_fuse_sum', k, xs, mean_a, inv_a, gam_a, bet_a, sh_a, _p(y), N, H, W, C, 1)
-        rg = any(t[0].requires_grad or (t[1] is not None and self.rq(t[1].weight)) for t in terms)
+        rg = self.record and any(h['x'].requires_grad or (h['bn'] is not None and self.rq(h['bn'].weight)) for h in handles)
         out = T(y, rg)
-        if rg:
-            def bwd():
-                if out.grad is None:
-                    return
-                dy = out.grad
-                for (x, bn, s), st in zip(terms, stats):
-                    if bn is None:
-                        if x.requires_grad:
-                            g, acc = self.gbuf(x)
-                            self.acall('fami_relu_bwd', _p(dy), _p(y), _p(g), y.numel(), acc)
-                        continue
-                    if not bn.training:
-                        raise NotImplementedError("backward through eval-mode BatchNorm")
-                    need_p = self.rq(bn.weight)
-                    if not (x.requires_grad or need_p):
-                        continue
-                    Pk = x.data.numel() // C
-                    gx, accx = self.gbuf(x) if x.requires_grad else (self.like(x.data), 0)
-                    gg = gb = None
-                    accp = 0
-                    if need_p:
-                        gg, accp = self.pgrad(bn.weight)
-                        gb, _ = self.pgrad(bn.bias)
-                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
-                    if s == 0:
-                        self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
-                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
-                    else:
-                        low = self.like(x.data)
-                        self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> s, W >> s, C, s, 1)
-                        self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
-                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
-            self.record_bwd(bwd, [q for t in terms if t[1] is not None for q in (t[1].weight, t[1].bias)])
+        for h in handles:
+            h['out'] = out
         return out
 
     # ------------------------------------------------------------------ glue ops

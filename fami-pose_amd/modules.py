@@ -151,25 +151,30 @@ class HighResolutionModule(nn.Module):
         return ys
 
     def run_fuse(self, eng, ys):
+        """out_i = relu(sum_j f_ij(x_j)).  Every f_ij -- conv chain, BatchNorm statistics, and in backward the gradient
+        into x_j -- depends on branch j only, so the terms run on stream lane j; the sums follow the join."""
         nb = self.num_branches
         if nb == 1:
             return ys
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
-            terms = []
-            for j in range(nb):
+        handles = [[None] * nb for _ in self.fuse_layers]
+        forked = eng.fork(nb) if eng.fuse_lanes else False
+        for j in range(nb):
+            if forked:
+                eng.set_lane(j)
+            for i, row in enumerate(self.fuse_layers):
                 if j == i:
-                    terms.append((ys[j], None, 0))
+                    handles[i][j] = eng.fuse_term(ys[j], None, 0)
                 elif j > i:
-                    terms.append((run_conv(eng, row[j][0], ys[j]), row[j][1], j - i))
+                    handles[i][j] = eng.fuse_term(run_conv(eng, row[j][0], ys[j]), row[j][1], j - i)
                 else:
                     z = ys[j]
                     chain = row[j]
                     for k in range(len(chain) - 1):
                         z = run_cbr(eng, chain[k], z)
-                    terms.append((run_conv(eng, chain[-1][0], z), chain[-1][1], 0))
-            outs.append(eng.fuse(terms))
-        return outs
+                    handles[i][j] = eng.fuse_term(run_conv(eng, chain[-1][0], z), chain[-1][1], 0)
+        if forked:
+            eng.join(nb)
+        return [eng.fuse(hs) for hs in handles]
 
     def run(self, eng, xs):
         return self.run_fuse(eng, self.run_branches(eng, xs))

@@ -174,7 +174,7 @@ def test_fuse_sum_fwd_bwd(dev):
         d.load_state_dict(b.state_dict())
         bd.append(d)
     ts = [T(nhwc(t.detach()).to(dev), True) for t in (x0, z1, z2, z3)]
-    yt = eng.fuse([(ts[0], None, 0), (ts[1], bd[0], 1), (ts[2], bd[1], 2), (ts[3], bd[2], 0)])
+    yt = eng.fuse([eng.fuse_term(*t) for t in ((ts[0], None, 0), (ts[1], bd[0], 1), (ts[2], bd[1], 2), (ts[3], bd[2], 0))])
     assert relerr(nchw(yt.data), y) < 1e-5
     yt.grad = nhwc(gy).to(dev)
     eng.backward()
