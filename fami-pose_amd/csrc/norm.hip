@@ -96,6 +96,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, const T* _
   }
 }
 
+// running statistics from an already finalised (mean, invstd): lets BatchNorm calls that SHARE a module run concurrently
+// on several streams without touching the running buffers, and applies their updates afterwards in call order
+// (Alignment_V15.py:125-135 applies one regressor to every supporting frame, updating frame by frame).
+__global__ void bn_running_update_kernel(float* running_mean, float* running_var, const float* __restrict__ mean,
+                                         const float* __restrict__ invstd, int C, long P, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = (double)mean[c], is = (double)invstd[c];
+  double var = 1.0 / (is * is) - (double)eps;
+  if (var < 0.0) var = 0.0;
+  const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+  running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+  running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+}
+
 __global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* mean, float* invstd,
                                      int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,6 +557,15 @@ int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, 
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var, mean,
                      invstd, C, eps);
   FAMI_CHECK_LAUNCH("fami_bn_eval_stats_f32");
+  return FAMI_OK;
+}
+
+int fami_bn_running_update_f32(float* running_mean, float* running_var, const float* mean, const float* invstd, int C,
+                               long P, float momentum, float eps, hipStream_t s) {
+  FAMI_REQUIRE(running_mean && running_var && mean && invstd && C > 0 && P > 0, "fami_bn_running_update_f32", "bad argument");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var, mean,
+                     invstd, C, P, momentum, eps);
+  FAMI_CHECK_LAUNCH("fami_bn_running_update_f32");
   return FAMI_OK;
 }
 

@@ -70,9 +70,13 @@ class Engine:
         self._forked = 0               # lanes currently forked (backward bookkeeping for deferred bucket hooks)
         self._epoch = 0                # id of the current forked region (see _lane_guard)
         self._lane_owner = {}
+        self._lane_priv = {}           # (id(param), lane) -> private gradient buffer inside the current forked region
+        self._merge = []               # [(id(param), private buffer)] folded into the owner's buffer at the join
+        self.defer_bn = None           # list while BatchNorm running-stat updates are deferred (shared modules on lanes)
         # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
+        self.regressor_lanes = os.environ.get('FAMI_REGRESSOR_LANES', '1') != '0'   # shared-weight regressors on lanes
         self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
@@ -150,6 +154,12 @@ class Engine:
             self._main.wait_event(ev)
         self.set_lane(0)
         self._forked = 0
+        # parameters used on several lanes of the region: fold the lane-private gradients into the owner's buffer
+        for key, buf in self._merge:
+            g = self.param_grads[key]
+            self.call('fami_axpby_f32', _p(buf), _p(g), _p(g), g.numel(), 1.0, 1.0)
+        self._merge = []
+        self._lane_priv = {}
 
     def fork(self, n):
         """Lanes 1..n-1 start after everything enqueued on lane 0 so far; the backward of a fork is a join."""
@@ -221,7 +231,21 @@ class Engine:
 
     def pgrad(self, p):
         """-> (gradient buffer of parameter p, accumulate flag) for this step."""
-        self._lane_guard(('grad', id(p)))
+        key = id(p)
+        if self._forked:
+            # a module applied on several lanes of one forked region (the translation regressor: one set of weights for
+            # every supporting frame): the first lane owns the gradient buffer, the others accumulate privately and
+            # are folded in at the join, in lane order
+            owner = self._lane_owner.get(('grad', key))
+            if owner is not None and owner[0] == self._epoch and owner[1] != self.lane:
+                buf = self._lane_priv.get((key, self.lane))
+                if buf is not None:
+                    return buf, 1
+                buf = self.like(p.data)
+                self._lane_priv[(key, self.lane)] = buf
+                self._merge.append((key, buf))
+                return buf, 0
+            self._lane_owner[('grad', key)] = (self._epoch, self.lane)
         g = self.param_grads.get(id(p))
         if g is not None:
             return g, 1
@@ -231,6 +255,13 @@ class Engine:
             g = self.like(p.data)
         self.param_grads[id(p)] = g
         return g, 0
+
+    def apply_deferred_bn(self):
+        """Running-statistics updates of the BatchNorm calls made while `defer_bn` was a list, in call order (lane 0)."""
+        items, self.defer_bn = self.defer_bn, None
+        for bn, mean, invstd, P, mom in items or ():
+            self.call('fami_bn_running_update_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
+                      mean.numel(), P, mom, float(bn.eps))
 
     def _lane_guard(self, key):
         """Shared mutable state (a parameter's gradient accumulator, a BatchNorm's running statistics) may be touched by
@@ -365,12 +396,17 @@ class Engine:
         mean, invstd = self.empty(C), self.empty(C)
         y = self.like(x.data)
         if bn.training:
-            self._lane_guard(('running statistics', id(bn)))
+            deferred = self.defer_bn is not None and bn.running_mean is not None
+            if not deferred:
+                self._lane_guard(('running statistics', id(bn)))
             ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
             self.acall('fami_bn_train_fwd', _p(x.data), _p(None if residual is None else residual.data), _p(y),
-                       _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd), _p(bn.running_mean),
-                       _p(bn.running_var), P, C, int(relu), float(mom), float(bn.eps), _p(ws))
+                       _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
+                       _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
+                       int(relu), float(mom), float(bn.eps), _p(ws))
+            if deferred:
+                self.defer_bn.append((bn, mean, invstd, P, float(mom)))
             self.bn_trained.append(bn)
         else:
             self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd), C,

@@ -144,16 +144,27 @@ class Alignment_V15(EngineModule):
         kf_hm = eng.batch_slice(hm, 0, B)
         kf = eng.batch_slice(feat, 0, B)
         # The S translation regressors SHARE their weights and BatchNorm modules (Alignment_V15.py:125-135 applies the same
-        # feat_global_offset_layers to every supporting frame), so they stay on one stream in frame order: concurrent
-        # lanes would race on the shared weight-gradient accumulators in backward and on the BN running statistics in
-        # forward (and the reference updates those statistics frame by frame, in this order).
+        # feat_global_offset_layers to every supporting frame) and are chains of ~40 tiny kernels each: they run on
+        # separate stream lanes.  What they share is kept race-free by the engine: weight gradients accumulate in
+        # lane-private buffers folded at the join (Engine.pgrad), and the BatchNorm running statistics are not touched
+        # inside the lanes but updated afterwards frame by frame, the order the reference updates them in
+        # (Engine.defer_bn / apply_deferred_bn).  `sup - kf` stays on lane 0: all S differences send gradient into the
+        # same key-frame slice.
         sups = [eng.batch_slice(feat, (1 + i) * B, (2 + i) * B) for i in range(S)]
         diffs = [eng.sub(sup, kf) for sup in sups]
         aligned, shifts = [], []
+        forked = eng.fork(min(S, 4)) if eng.regressor_lanes else False
+        if forked:
+            eng.defer_bn = []
         for i in range(S):
+            if forked:
+                eng.set_lane(i % 4)
             t = self._translation(eng, diffs[i])
             shifts.append(t)
             aligned.append(eng.shift(sups[i], t))
+        if forked:
+            eng.join(min(S, 4))
+            eng.apply_deferred_bn()
         agg_sup = self.sup_agg_block.run(eng, eng.concat(aligned))
         comb = self.combined_feat_layers.run(eng, eng.concat([agg_sup, kf]))
         comb = self._dcn(eng, 1, comb, comb)

@@ -79,6 +79,11 @@ int fami_bn_stats_f32(const float* x, long P, int C, float* mean, float* invstd,
 int fami_bn_train_fwd_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
                           float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
                           int relu, float momentum, float eps, float* ws, fami_stream_t stream);
+/* running_mean / running_var update from a finished (mean, invstd) of a train-mode call that was run with NULL running
+ * pointers: shared BatchNorm modules can then run concurrently on several streams and be updated afterwards in call
+ * order (var = 1/invstd^2 - eps, unbiased for running_var as nn.BatchNorm2d) */
+int fami_bn_running_update_f32(float* running_mean, float* running_var, const float* mean, const float* invstd, int C,
+                               long P, float momentum, float eps, fami_stream_t stream);
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                            float eps, fami_stream_t stream);
 int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -383,37 +383,67 @@ def test_final_preds_golden(dev):
     assert np.abs(preds.cpu().numpy().astype(np.float64) - g['preds']).max() < 1e-3
 
 
-def test_lane_guard_rejects_shared_module_on_two_lanes(dev):
-    """A module applied on two concurrent stream lanes would race on its weight-gradient accumulator (and a train-mode
-    BatchNorm on its running statistics): the engine refuses instead of producing run-dependent gradients."""
+def test_shared_module_on_two_lanes(dev):
+    """A module applied on two concurrent stream lanes (the translation regressor): weight gradients accumulate in
+    lane-private buffers folded at the join -- same result as the sequential application; a train-mode BatchNorm must
+    either defer its running-statistics update (Engine.defer_bn: applied afterwards in call order) or the engine refuses."""
     from fami_pose_amd.engine import Engine, T
     torch.manual_seed(0)
-    conv = nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(dev)
-    bn = nn.BatchNorm2d(16).to(dev).train()
-    xs = [T(torch.randn(1, 8, 8, 16, device=dev), True) for _ in range(2)]
-    eng = Engine(dev)
-    if not eng.use_lanes:
-        pytest.skip('stream lanes disabled')
-    assert eng.fork(2)
-    ys = []
-    for i in range(2):
-        eng.set_lane(i)
-        ys.append(eng.conv(xs[i], conv.weight))
-    eng.join(2)
-    for y in ys:
-        y.grad = torch.ones_like(y.data)
-    with pytest.raises(RuntimeError, match='one lane'):
+    conv = nn.Conv2d(16, 16, 3, 1, 1, bias=True).to(dev)
+    xs = [torch.randn(2, 12, 10, 16, device=dev) for _ in range(2)]
+    gs = [torch.randn(2, 12, 10, 16, device=dev) for _ in range(2)]
+
+    def run(lanes):
+        eng = Engine(dev)
+        ts = [T(x.clone(), True) for x in xs]
+        forked = eng.fork(2) if lanes else False
+        ys = []
+        for i in range(2):
+            if forked:
+                eng.set_lane(i)
+            ys.append(eng.conv(ts[i], conv.weight, conv.bias, 1, 1, 1))
+        if forked:
+            eng.join(2)
+        for y, g in zip(ys, gs):
+            y.grad = g.clone()
         eng.backward()
-    torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)
+        return eng.param_grads[id(conv.weight)].clone(), eng.param_grads[id(conv.bias)].clone(), [t.grad.clone() for t in ts]
+    if not Engine(dev).use_lanes:
+        pytest.skip('stream lanes disabled')
+    w0, b0, g0 = run(False)
+    w1, b1, g1 = run(True)
+    assert relerr(w1, w0) < 1e-6 and relerr(b1, b0) < 1e-6
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+    bn = nn.BatchNorm2d(16).to(dev).train()
+    ref = nn.BatchNorm2d(16).to(dev).train()
+    ref.load_state_dict(bn.state_dict())
     eng = Engine(dev)
     eng.fork(2)
     eng.set_lane(0)
-    eng.bn(xs[0], bn)
+    eng.bn(T(xs[0]), bn)
     eng.set_lane(1)
     with pytest.raises(RuntimeError, match='running statistics'):
-        eng.bn(xs[1], bn)
+        eng.bn(T(xs[1]), bn)
     eng.join(2)
     torch.cuda.synchronize(dev)
+    # deferred: both lanes normalise with their own batch statistics, the running buffers advance afterwards in call order
+    bn.load_state_dict(ref.state_dict())
+    eng = Engine(dev)
+    eng.fork(2)
+    eng.defer_bn = []
+    outs = []
+    for i in range(2):
+        eng.set_lane(i)
+        outs.append(eng.bn(T(xs[i]), bn))
+    eng.join(2)
+    eng.apply_deferred_bn()
+    torch.cuda.synchronize(dev)
+    for i in range(2):
+        want = ref(xs[i].permute(0, 3, 1, 2))                       # sequential torch calls: frame 0 then frame 1
+        assert relerr(outs[i].data.permute(0, 3, 1, 2), want) < 1e-5
+    assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
 
 
 @pytest.mark.parametrize("flip,bgr,rot", [(False, False, 0.0), (True, False, 31.0), (False, True, -44.0), (True, True, 90.0)])
