@@ -23,7 +23,7 @@ for st in states:
             L.fami_conv_tune(*[int(t) for t in v.split(':')])
         else:
             getattr(L, 'fami_conv_tune_' + k)(int(v))
-    tr = Trainer(bench.build(args, dev), lr=1e-3, use_mi=True, use_graph=True, targets_from_joints=True)
+    tr = Trainer(bench.build(args, dev), lr=1e-3, use_mi=os.environ.get('AB_NO_MI') != '1', use_graph=True, targets_from_joints=True)
     for _ in range(3):
         tr.step(kf, sup, joints, vis)
     trainers.append(tr)
