@@ -8,6 +8,12 @@ temporal-alignment training hot path, behind the reference's model-registry API.
 Compute runs exclusively in libfami_hip.so (hand-written HIP); importing the
 package does not need a GPU, running a model does.
 """
+import os as _os
+
+# ROCm runtime: kernel arguments in device memory (lower launch latency; -4..5 % step time with ~4000 launches per step).
+# Only effective when this package is imported before the HIP runtime initialises; harmless otherwise.
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 from .config import CfgNode, default_cfg
 from .zoo import (MODEL_REGISTRY, CORE_FUNCTION_REGISTRY, DATASET_REGISTRY, TRAIN_PHASE, VAL_PHASE, TEST_PHASE,
                   build_model, get_model_hyperparameter, Alignment_V15, HRNet, HRNetPlus)

@@ -1,5 +1,8 @@
 import os
 import sys
+# ROCm runtime: kernel arguments in device memory -- 2-3 us less launch latency per kernel; with ~4000 dependent launches
+# per training step that is -4 % (f32) / -5 % (bf16) step time on MI355X.  Must be set before the HIP runtime initialises.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 import pytest
 
