@@ -170,14 +170,19 @@ struct DcnArgs {
   int cg, KS, NTt, P;  // KS = ceil(C*K / 16): 16-wide k groups of the contraction
 };
 
-// Column index of the contraction: kidx = (g*K + tap)*cg + cc  (channel c = g*cg + cc), KS16 = ceil(C*K / 16).
+// Column index of the contraction, TAP-major: kidx = ((tap*G + g)*q4 + q)*4 + c4  (channel c = g*cg + q*4 + c4,
+// q4 = cg/4), KS16 = ceil(C*K / 16).  Tap-major so that the 16 sample blocks a workgroup gathers at a time are the
+// G groups of one or two taps: together they consume whole NHWC pixels (all C channels of each touched pixel, i.e.
+// whole cache lines) at positions that neighbouring output pixels share, instead of a 16-byte slice of every pixel
+// of the window per step -- with the group-major order the window (~30 KB per workgroup in f32) was re-fetched from
+// L2 on every step.
 // packed[((ks16*NTt + nt)*64 + lane)*4 + t] = W[co = nt*16 + (lane&15)][kidx = (ks16*4 + (lane>>4))*4 + t]:
-// lane (row, kq) of the A operand reads ONE float4 = kidx (ks16*4 + kq)*4 .. +3 of its pixel from the LDS column
-// tile and feeds it to 4 consecutive MFMAs; the weight image carries the same K permutation.
+// lane (row, kq) of the A operand holds ONE float4 = kidx (ks16*4 + kq)*4 .. +3 of its pixel and feeds it to 4
+// consecutive MFMAs; the weight image carries the same K permutation.
 __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int C, int K, int cg,
                                   int KS16, int NTt) {
   const long total = (long)KS16 * NTt * 256;
-  const int CK = C * K;
+  const int CK = C * K, G = C / cg, q4 = cg >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
     const long r = i >> 8;
@@ -186,15 +191,65 @@ __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict
     const int co = nt * 16 + (lane & 15);
     float v = 0.f;
     if (kidx < CK && co < Co) {
-      const int cc = kidx % cg, gt = kidx / cg;
-      const int tap = gt % K, g = gt / K;
-      v = w[((long)co * C + g * cg + cc) * K + tap];
+      const int item = kidx >> 2, q = item % q4, tg = item / q4;
+      const int g = tg % G, tap = tg / G;
+      v = w[((long)co * C + g * cg + q * 4 + t) * K + tap];
     }
     wp[i] = v;
   }
 }
 
 #define DCN_PIX 16  // output pixels per workgroup (= one MFMA row tile)
+
+// a wave-uniform float kept in an SGPR (the scalar unit has no int->float conversion)
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Tail shared by the two forward kernels: the 4 waves hold partial [16, Co] tiles over their K slices; they meet in
+// LDS, bias is added and the block is stored as one contiguous run.
+template <typename T, int NT>
+__device__ __forceinline__ void dcn_reduce_store(const DcnArgs<T>& p, const f32x4 (&acc)[NT], float* red, int m0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // D row = kq*4 + r (pixel), col = lane & 15 (channel of tile nt)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * (NT * 256) + (nt * 4 + r) * 64 + lane] = acc[nt][r];
+  __syncthreads();
+  for (int e = tid; e < DCN_PIX * NT * 16; e += 256) {
+    const int co = e % (NT * 16), pix = e / (NT * 16);
+    const int nt = co >> 4, c16 = co & 15;
+    const int idx = (nt * 4 + (pix & 3)) * 64 + (pix >> 2) * 16 + c16;
+    if (co < p.Co && m0 + pix < p.P) {
+      float v = (red[idx] + red[NT * 256 + idx]) + (red[2 * NT * 256 + idx] + red[3 * NT * 256 + idx]);
+      if (p.bias) v += p.bias[co];
+      st1(p.y + (long)(m0 + pix) * p.Co + co, v);
+    }
+  }
+}
+
+// Contraction phase of dcn_fwd_kernel: y[16, Co] = col[16, C*K] x W^T + bias; the 4 waves split K.
+template <typename T, int NT>
+__device__ __forceinline__ void dcn_contract(const DcnArgs<T>& p, const float* col, float* red, int m0, int stride,
+                                             int KS16) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ks = wave; ks < KS16; ks += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(col + row * stride + (ks * 4 + kq) * 4);
+    f32x4 bw[NT];
+    const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bw[nt][t], acc[nt], 0, 0, 0);
+  }
+  dcn_reduce_store<T, NT>(p, acc, red, m0);
+}
 
 // Forward, two phases per workgroup of DCN_PIX consecutive output pixels:
 //  1. gather: one work item per (pixel, group*tap, 4-channel block).  Consecutive lanes walk consecutive
@@ -207,7 +262,7 @@ __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
   extern __shared__ float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2;
   const int KS16 = p.KS, stride = KS16 * 16 + 4;
   float* col = smem;                       // [DCN_PIX][stride]
@@ -256,7 +311,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
       mv[u] = 1.f;
       if (okv[u]) {
         const long m = m0 + pixv[u];
-        const int gt = rv[u] / q4;
+        const int tg = rv[u] / q4, tap = tg / p.G;
+        const int gt = (tg - tap * p.G) * K + tap;  // tap-major item -> (group, tap) index of the offset tensor
         ov[u] = ld2(p.off + (m * GK + gt) * 2);
         if (p.msk) mv[u] = ld1(p.msk + m * GK + gt);
       }
@@ -265,8 +321,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
     float wgt[DCN_U][4];
 #pragma unroll
     for (int u = 0; u < DCN_U; ++u) {
-      const int gt = rv[u] / q4, q = rv[u] - gt * q4;
-      const int g = gt / K, tap = gt - g * K;
+      const int tg = rv[u] / q4, q = rv[u] - tg * q4;
+      const int tap = tg / p.G, g = tg - tap * p.G;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
       const float py = (float)(pcoord[pixv[u]][1] + ky * p.dil) + ov[u].x;
       const float px = (float)(pcoord[pixv[u]][2] + kx * p.dil) + ov[u].y;
@@ -296,38 +352,142 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
   }
   __syncthreads();
 
+  dcn_contract<T, NT>(p, col, red, m0, stride, KS16);
+}
+
+// Forward, register-fed form (default; dcn_fwd_kernel above stays as the fallback for tensors of 4 GiB and more and
+// as the A/B partner, fami_dcn_tune).  Ablations of dcn_fwd_kernel on the MI355X (tools/bench_dcn.py history: offset
+// stream + arithmetic 12.6 us, + corner loads 15.5 us, + contraction 13.8 us = the 38-40 us of the whole kernel) show
+// that its phases do not overlap: every workgroup of a CU gathers, meets at the barrier, then contracts, so the
+// L1-bound gather and the MFMA-bound contraction are paid one after the other; neither cutting the gather's VALU work
+// 3x nor prefetching the weight fragments moved the total.  Here the lane that gathers a sample is the lane that
+// feeds it to the matrix core:
+//  * v_mfma_f32_16x16x4_f32 takes A[row][k] from lane k*16 + row.  Lane (row, kq) of wave w therefore gathers, for
+//    k group ks = w, w+4, .., the 4-channel sample block kidx = (ks*4 + kq)*4 .. +3 of pixel `row` -- exactly the
+//    f32x4 the old kernel wrote to and re-read from the LDS column tile -- and issues the 4 MFMAs on it directly.
+//    No column tile, no barrier between gather and contraction: the 16 waves of a CU run free, one wave's MFMAs
+//    cover another wave's load latency.
+//  * offsets and masks (77 % of the bytes) are still streamed fully coalesced: the tile's rows are one contiguous
+//    run in HBM and are copied to LDS with 16-byte accesses before the waves read them in (row, tap) order.
+//  * the (group, tap) decode is a per-workgroup LDS table; out-of-map corners zero the 1-D bilinear weight and clamp
+//    the address (unconditional 16-byte loads, SGPR base + 32-bit byte offset); PF k groups per wave are in flight.
+template <typename T, int NT, int PF>
+__global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2, CK = p.C * K;
+  const int KS16 = p.KS;
+  const int nitem = KS16 * 4;  // 4-channel sample blocks per pixel, padded to whole k groups
+  T* soff = reinterpret_cast<T*>(smem);                                  // [DCN_PIX][GK*2]
+  T* smsk = soff + DCN_PIX * GK * 2;                                     // [DCN_PIX][GK]
+  const int staged = (DCN_PIX * GK * 3 * (int)sizeof(T) + 15) & ~15;     // bytes
+  int4* tapt = reinterpret_cast<int4*>(reinterpret_cast<char*>(smem) + staged);  // [nitem]
+  float* red = reinterpret_cast<float*>(tapt + nitem);                   // [4][NT*256]
+  int bxl, byl;
+  xcd_tile(1, bxl, byl);
+  const int m0 = bxl * DCN_PIX;
+  const int rows = min(DCN_PIX, p.P - m0);
+
+  {  // offsets / masks of the tile: contiguous runs, 16-byte copies
+    const int nb = rows * GK * 2 * (int)sizeof(T);
+    const char* src = reinterpret_cast<const char*>(p.off + (long)m0 * GK * 2);
+    char* dst = reinterpret_cast<char*>(soff);
+    for (int i = tid * 16; i + 16 <= nb; i += 256 * 16) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+    for (int i = (nb & ~15) + tid * (int)sizeof(T); i < nb; i += 256 * (int)sizeof(T))
+      *reinterpret_cast<T*>(dst + i) = *reinterpret_cast<const T*>(src + i);
+  }
+  if (p.msk) {
+    const int nb = rows * GK * (int)sizeof(T);
+    const char* src = reinterpret_cast<const char*>(p.msk + (long)m0 * GK);
+    char* dst = reinterpret_cast<char*>(smsk);
+    for (int i = tid * 16; i + 16 <= nb; i += 256 * 16) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+    for (int i = (nb & ~15) + tid * (int)sizeof(T); i < nb; i += 256 * (int)sizeof(T))
+      *reinterpret_cast<T*>(dst + i) = *reinterpret_cast<const T*>(src + i);
+  }
+  for (int it = tid; it < nitem; it += 256) {
+    int4 e = {0, 0, 0, 0};
+    if (it * 4 < CK) {
+      const int tg = it / q4, q = it - tg * q4;
+      const int tap = tg / p.G, g = tg - tap * p.G;  // tap-major column order (dcn_pack_w_kernel)
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      e = int4{(g * p.cg + q * 4) * (int)sizeof(T), ky * p.dil, kx * p.dil, g * K + tap};
+    }
+    tapt[it] = e;
+  }
+  // this lane's pixel
   const int row = lane & 15, kq = lane >> 4;
+  const bool valid = row < rows;
+  int oy0, ox0;
+  unsigned xoff;  // byte offset of the pixel's sample in x
+  {
+    const int mm = valid ? m0 + row : 0;
+    const int HoWo = p.Ho * p.Wo;
+    const int b = mm / HoWo, r = mm - b * HoWo;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    oy0 = oy * p.stride - p.pad;
+    ox0 = ox * p.stride - p.pad;
+    xoff = (unsigned)b * (unsigned)(p.H * p.W * p.C) * (unsigned)sizeof(T);
+  }
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  const unsigned WCb = p.W * p.C * (unsigned)sizeof(T), Cb = p.C * (unsigned)sizeof(T);
+  const int Hm1 = p.H - 1, Wm1 = p.W - 1;
+  const float Hf1 = sgpr_f((float)(p.H + 1)), Wf1 = sgpr_f((float)(p.W + 1));
+  const T* myoff = soff + row * GK * 2;
+  const T* mymsk = smsk + row * GK;
+  __syncthreads();
+
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int ks = wave; ks < KS16; ks += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(col + row * stride + (ks * 4 + kq) * 4);
-    f32x4 bw[NT];
-    const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
+  for (int ks0 = wave; ks0 < KS16; ks0 += 4 * PF) {
+    f32x4 bw[PF][NT];
+    f32x4 a[PF][4];
+    float w1[PF][4];  // mask*wy0, mask*wy1, wx0, wx1 (validity folded in)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
+    for (int i = 0; i < PF; ++i) {
+      const int ks = ks0 + 4 * i;
+      if (ks < KS16) {
+        const int4 te = tapt[ks * 4 + kq];
+        const bool ok = valid && (ks * 4 + kq) * 4 < CK;
+        const f32x2 ov = ld2(myoff + te.w * 2);
+        const float mv = p.msk ? ld1(mymsk + te.w) : 1.f;
+        const float py = (float)(oy0 + te.y) + ov.x;
+        const float px = (float)(ox0 + te.z) + ov.y;
+        const float fy = floorf(py), fx = floorf(px);
+        const float ly = py - fy, lx = px - fx;
+        const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, Hf1), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, Wf1);
+        const int y1 = y0 + 1, x1 = x0 + 1;
+        w1[i][0] = (ok && (unsigned)y0 <= (unsigned)Hm1) ? (1.f - ly) * mv : 0.f;  // modulation folded into the row weights
+        w1[i][1] = (ok && (unsigned)y1 <= (unsigned)Hm1) ? ly * mv : 0.f;
+        w1[i][2] = (unsigned)x0 <= (unsigned)Wm1 ? 1.f - lx : 0.f;
+        w1[i][3] = (unsigned)x1 <= (unsigned)Wm1 ? lx : 0.f;
+        const unsigned r0 = xoff + __umul24(min(max(y0, 0), Hm1), WCb), r1 = xoff + __umul24(min(max(y1, 0), Hm1), WCb);
+        const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)te.x, c1 = __umul24(min(max(x1, 0), Wm1), Cb) + (unsigned)te.x;
+        a[i][0] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0)));
+        a[i][1] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
+        a[i][2] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0)));
+        a[i][3] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
+        const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int nt = 0; nt < NT; ++nt) bw[i][nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
+      }
+    }
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bw[nt][t], acc[nt], 0, 0, 0);
-  }
-  // D row = kq*4 + r (pixel), col = row (channel of tile nt)
+    for (int i = 0; i < PF; ++i) {
+      if (ks0 + 4 * i < KS16) {
+        // corner order of the oracle's sum
+        const f32x4 v = ((a[i][0] * (w1[i][0] * w1[i][2]) + a[i][1] * (w1[i][0] * w1[i][3])) + a[i][2] * (w1[i][1] * w1[i][2])) +
+                        a[i][3] * (w1[i][1] * w1[i][3]);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * (NT * 256) + (nt * 4 + r) * 64 + lane] = acc[nt][r];
-  __syncthreads();
-  for (int e = tid; e < DCN_PIX * NT * 16; e += 256) {
-    const int co = e % (NT * 16), pix = e / (NT * 16);
-    const int nt = co >> 4, c16 = co & 15;
-    const int idx = (nt * 4 + (pix & 3)) * 64 + (pix >> 2) * 16 + c16;
-    if (co < p.Co && m0 + pix < p.P) {
-      float v = (red[idx] + red[NT * 256 + idx]) + (red[2 * NT * 256 + idx] + red[3 * NT * 256 + idx]);
-      if (p.bias) v += p.bias[co];
-      st1(p.y + (long)(m0 + pix) * p.Co + co, v);
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], bw[i][nt][t], acc[nt], 0, 0, 0);
+      }
     }
   }
+  dcn_reduce_store<T, NT>(p, acc, red, m0);
 }
 
 // ------------------------------------------------------------------ DCN backward (fused)
@@ -576,14 +736,27 @@ static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, 
   return FAMI_OK;
 }
 
+static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, -1 default (= 1)
+static int g_dcn_pf = 0;       // fami_dcn_tune(16 + pf): k groups in flight per wave of the direct kernel (benchmarks)
+
 template <typename T, int NT>
-static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, size_t lds_direct, bool direct, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dcn_fwd_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_fwd_kernel<T, NT>), grid, dim3(256), lds, s, a);
+  if (!direct)
+    hipLaunchKernelGGL((dcn_fwd_kernel<T, NT>), grid, dim3(256), lds, s, a);
+  else if (NT > 3 || g_dcn_pf == 1)  // wide outputs: the weight fragments of one k group already take 4*NT registers
+    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 1>), grid, dim3(256), lds_direct, s, a);
+  else if (g_dcn_pf == 3)
+    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 3>), grid, dim3(256), lds_direct, s, a);
+  else
+    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 2>), grid, dim3(256), lds_direct, s, a);
 }
 
 template <typename T>
@@ -608,18 +781,23 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   FAMI_REQUIRE(P < (1L << 31), nm, "size out of range");
   a.P = (int)P;
   const dim3 grid(fami_cdiv(P, DCN_PIX));
+  // the direct kernel addresses x with 32-bit byte offsets (24-bit row / column products)
   const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
-  if (lds > 150 * 1024) {
+  const size_t lds_direct = (((size_t)DCN_PIX * G * kh * kw * 3 * sizeof(T) + 15) & ~(size_t)15) + (size_t)a.KS * 4 * sizeof(int4) +
+                            4 * (size_t)a.NTt * 256 * sizeof(float);
+  const bool direct = g_dcn_gather != 0 && (long)B * H * W * C * sizeof(T) < (1L << 32) &&
+                      (long)H * W * C * sizeof(T) < (1L << 24) && lds_direct <= 150 * 1024;
+  if (!direct && lds > 150 * 1024) {
     fami_set_error(nm, "C*kh*kw too large for the LDS column tile");
     return FAMI_ESHAPE;
   }
   switch (a.NTt) {
-    case 1: dcn_fwd_launch<T, 1>(a, grid, lds, s); break;
-    case 2: dcn_fwd_launch<T, 2>(a, grid, lds, s); break;
-    case 3: dcn_fwd_launch<T, 3>(a, grid, lds, s); break;
-    case 4: dcn_fwd_launch<T, 4>(a, grid, lds, s); break;
-    case 5: dcn_fwd_launch<T, 5>(a, grid, lds, s); break;
-    default: dcn_fwd_launch<T, 6>(a, grid, lds, s); break;
+    case 1: dcn_fwd_launch<T, 1>(a, grid, lds, lds_direct, direct, s); break;
+    case 2: dcn_fwd_launch<T, 2>(a, grid, lds, lds_direct, direct, s); break;
+    case 3: dcn_fwd_launch<T, 3>(a, grid, lds, lds_direct, direct, s); break;
+    case 4: dcn_fwd_launch<T, 4>(a, grid, lds, lds_direct, direct, s); break;
+    case 5: dcn_fwd_launch<T, 5>(a, grid, lds, lds_direct, direct, s); break;
+    default: dcn_fwd_launch<T, 6>(a, grid, lds, lds_direct, direct, s); break;
   }
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
@@ -698,6 +876,14 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
   const long total = (long)KS16 * NTt * 256;
   hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS16, NTt);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
+  return FAMI_OK;
+}
+
+// benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
+// 16 + pf = k groups in flight per wave of the direct kernel
+int fami_dcn_tune(int gather) {
+  if (gather >= 16) g_dcn_pf = gather - 16;
+  else g_dcn_gather = gather;
   return FAMI_OK;
 }
 

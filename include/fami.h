@@ -141,6 +141,9 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
                      fami_stream_t stream);
+int fami_dcn_tune(int mode);            /* benchmarks / tests: forward kernel 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel
+                                           (samples fed to the MFMA from registers), -1 = default (direct below 4 GiB);
+                                           16 + n = k groups in flight per wave of the direct kernel (1..3) */
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G);
 int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
                                  fami_stream_t stream);

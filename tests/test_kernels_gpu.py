@@ -257,9 +257,19 @@ def test_shift_bilinear(dev, shape):
     assert relerr(tt.grad, t.grad) < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [(2, 48, 12, 12, 9), (1, 32, 8, 10, 7), (1, 96, 12, 6, 5), (3, 48, 12, 13, 11)])
-def test_dcn_fwd_bwd(dev, cfg):
-    """DeformConv2d(C,C,3,padding=3,dilation=3) with G offset groups vs oracle.deform_conv2d."""
+@pytest.fixture(params=[1, 0], ids=['direct', 'lds_column'])
+def dcn_gather(request):
+    from fami_pose_amd._lib import lib
+    lib().cdll.fami_dcn_tune(request.param)
+    yield request.param
+    lib().cdll.fami_dcn_tune(-1)
+
+
+@pytest.mark.parametrize("cfg", [(2, 48, 12, 12, 9), (1, 32, 8, 10, 7), (1, 96, 12, 6, 5), (3, 48, 12, 13, 11),
+                                 (1, 64, 16, 9, 20)])
+def test_dcn_fwd_bwd(dev, cfg, dcn_gather):
+    """DeformConv2d(C,C,3,padding=3,dilation=3) with G offset groups vs oracle.deform_conv2d; both forward gather
+    kernels (register-fed default, LDS column tile fallback).  Offsets of std 2 px reach outside the map on every side."""
     from oracle import ops as O
     from fami_pose_amd.engine import T
     B, C, G, H, W = cfg
