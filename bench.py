@@ -141,7 +141,7 @@ def dcn_roofline(dev, B, dtype, reps=30):
     ms = e0.elapsed_time(e1) / reps
     nbytes = (C + 3 * G * 9 + C) * H * W * (2.0 if bf else 4.0) * B
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "dcn_fwd_kernel (48ch, 12 groups, 96x72, B=%d, %s)" % (B, dtype),
+    return {"bound": "hbm", "kernel": "dcn_fwd_direct_kernel (48ch, 12 groups, 96x72, B=%d, %s)" % (B, dtype),
             "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
             "traffic": pmc_traffic('dcn_fwd_' + dtype) if B == 4 else None, "avg_launch_us": round(ms * 1e3, 2)}
 

@@ -371,8 +371,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
 //    run in HBM and are copied to LDS with 16-byte accesses before the waves read them in (row, tap) order.
 //  * the (group, tap) decode is a per-workgroup LDS table; out-of-map corners zero the 1-D bilinear weight and clamp
 //    the address (unconditional 16-byte loads, SGPR base + 32-bit byte offset); PF k groups per wave are in flight.
-template <typename T, int NT, int PF>
-__global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
+template <typename T, int NT, int PF, int MINW>
+__global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
   T* smsk = soff + DCN_PIX * GK * 2;                                     // [DCN_PIX][GK]
   const int staged = (DCN_PIX * GK * 3 * (int)sizeof(T) + 15) & ~15;     // bytes
   int4* tapt = reinterpret_cast<int4*>(reinterpret_cast<char*>(smem) + staged);  // [nitem]
-  float* red = reinterpret_cast<float*>(tapt + nitem);                   // [4][NT*256]
+  float* red = smem;  // [4][NT*256], reuses the staged rows once every wave is done with them
   int bxl, byl;
   xcd_tile(1, bxl, byl);
   const int m0 = bxl * DCN_PIX;
@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
       }
     }
   }
+  __syncthreads();  // red aliases the staged offsets
   dcn_reduce_store<T, NT>(p, acc, red, m0);
 }
 
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
 //   B. one work item per (pixel, group*tap): coalesced offset/mask stream, four 16-byte corner loads, then
 //        gmask = <gcol, sample>, goffset = <gcol*mask, d sample / d(y,x)>  (stored, 1 contiguous run / pixel)
 //        col   = sample*mask  (overwrites gcol in LDS; flushed for the weight gradient)
-//        gx   += gcol*mask*bilinear weights, scattered with LDS atomics into a privatised input-gradient
+//        gx   += gcol*mask*bilinear weights, scattered with LDS compare-and-swap adds (lds_add_f32) into a privatised input-gradient
 //                region (tile + dilation halo + DCN_RO pixels of offset reach); samples that leave the region
 //                fall back to global atomics, so any offset magnitude stays correct;
 //   C. the col tile is flushed in contiguous runs.
@@ -506,6 +507,19 @@ __global__ __launch_bounds__(256, 4) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
 // the items, 16 consecutive channels per request instead of one address per lane, and no same-address pile-up.
 #define DCN_TILE 8
 #define DCN_RO 3
+
+// f32 add into LDS as a compare-and-swap loop.  On gfx950 the native ds_add_f32 retires 0.33 lane-operations per clock
+// per CU at this kernel's access pattern (tools/probes/lds_atomic.hip: ds_add_u32 4.7, ds_add_u64 2.5, racy read +
+// write 7.3) -- the 47.8 M adds of a B=4 launch alone were 220 of its 292 us.  A ds_read + ds_cmpst_rtn loop (almost
+// always one trip) measures 1.4 per clock, 4.2x the native instruction, with identical f32 arithmetic.
+__device__ __forceinline__ void lds_add_f32(float* a, float v) {
+  unsigned* ua = reinterpret_cast<unsigned*>(a);
+  unsigned old = *reinterpret_cast<volatile unsigned*>(ua), assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(ua, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
 template <typename T>
 struct DcnBwdArgs {
   const T* x;        // [B,H,W,C]
@@ -644,12 +658,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
         if (gxb) {
           if (inreg) {
             float* r00 = region + ((long)ry * p.RW + rx) * Cc + cl;
+            // Neighbouring pixels of a wave often land on the same input position at the same tap; with every lane on
+            // channel c in step c those lanes collide in the compare-and-swap and retry.  Pixel `pix` walks the
+            // channels starting at pix & 3, so neighbours are on different words in any one step.
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (v00) atomicAdd(r00 + c, gv[c] * w00);
-              if (v01) atomicAdd(r00 + Cc + c, gv[c] * w01);
-              if (v10) atomicAdd(r00 + p.RW * Cc + c, gv[c] * w10);
-              if (v11) atomicAdd(r00 + p.RW * Cc + Cc + c, gv[c] * w11);
+            for (int c0 = 0; c0 < 4; ++c0) {
+              const int c = (c0 + pix) & 3;
+              const float gvc = c == 0 ? gv[0] : c == 1 ? gv[1] : c == 2 ? gv[2] : gv[3];
+              if (v00) lds_add_f32(r00 + c, gvc * w00);
+              if (v01) lds_add_f32(r00 + Cc + c, gvc * w01);
+              if (v10) lds_add_f32(r00 + p.RW * Cc + c, gvc * w10);
+              if (v11) lds_add_f32(r00 + p.RW * Cc + Cc + c, gvc * w11);
             }
           } else {
             float* g00 = gxb + chunk * Cc + cl;
@@ -737,26 +756,39 @@ static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, 
 }
 
 static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, -1 default (= 1)
-static int g_dcn_pf = 0;       // fami_dcn_tune(16 + pf): k groups in flight per wave of the direct kernel (benchmarks)
+static int g_dcn_pf = 0;       // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
+
+template <typename T, int NT, int PF, int MINW>
+static void dcn_fwd_direct_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, PF, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, PF, MINW>), grid, dim3(256), lds, s, a);
+}
 
 template <typename T, int NT>
 static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, size_t lds_direct, bool direct, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)dcn_fwd_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  if (!direct)
+  if (!direct) {
     hipLaunchKernelGGL((dcn_fwd_kernel<T, NT>), grid, dim3(256), lds, s, a);
-  else if (NT > 3 || g_dcn_pf == 1)  // wide outputs: the weight fragments of one k group already take 4*NT registers
-    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 1>), grid, dim3(256), lds_direct, s, a);
-  else if (g_dcn_pf == 3)
-    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 3>), grid, dim3(256), lds_direct, s, a);
+    return;
+  }
+  // Measured (tools/bench_dcn.py, B=4 96x72 48 ch): 1 or 2 k groups in flight x 4..7 waves per SIMD all land within
+  // +-1.5 us in f32 (31-34 us: the corner loads run at the L1's one-line-per-cycle rate), bf16 25.0 (1 x 7) vs 27.6 us
+  // (2 x 4).  Default: one k group per wave in flight, 7 workgroups per CU (62 VGPRs, 22.5 KB LDS) -- the 6.75 tiles a
+  // CU owns at B=4 are then all resident at once.  Wide outputs (NT > 3) carry 4*NT accumulator + 4*NT weight registers.
+  if (NT > 3)
+    dcn_fwd_direct_launch<T, NT, 1, 4>(a, grid, lds_direct, s);
+  else if (g_dcn_pf == 2)
+    dcn_fwd_direct_launch<T, NT, 2, 4>(a, grid, lds_direct, s);
   else
-    hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, 2>), grid, dim3(256), lds_direct, s, a);
+    dcn_fwd_direct_launch<T, NT, 1, 7>(a, grid, lds_direct, s);
 }
 
 template <typename T>
@@ -783,8 +815,8 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   const dim3 grid(fami_cdiv(P, DCN_PIX));
   // the direct kernel addresses x with 32-bit byte offsets (24-bit row / column products)
   const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
-  const size_t lds_direct = (((size_t)DCN_PIX * G * kh * kw * 3 * sizeof(T) + 15) & ~(size_t)15) + (size_t)a.KS * 4 * sizeof(int4) +
-                            4 * (size_t)a.NTt * 256 * sizeof(float);
+  size_t lds_direct = (((size_t)DCN_PIX * G * kh * kw * 3 * sizeof(T) + 15) & ~(size_t)15) + (size_t)a.KS * 4 * sizeof(int4);
+  if (lds_direct < 4 * (size_t)a.NTt * 256 * sizeof(float)) lds_direct = 4 * (size_t)a.NTt * 256 * sizeof(float);
   const bool direct = g_dcn_gather != 0 && (long)B * H * W * C * sizeof(T) < (1L << 32) &&
                       (long)H * W * C * sizeof(T) < (1L << 24) && lds_direct <= 150 * 1024;
   if (!direct && lds > 150 * 1024) {
@@ -880,7 +912,7 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 }
 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
-// 16 + pf = k groups in flight per wave of the direct kernel
+// 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
   if (gather >= 16) g_dcn_pf = gather - 16;
   else g_dcn_gather = gather;

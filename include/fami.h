@@ -143,7 +143,7 @@ int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const f
                      fami_stream_t stream);
 int fami_dcn_tune(int mode);            /* benchmarks / tests: forward kernel 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel
                                            (samples fed to the MFMA from registers), -1 = default (direct below 4 GiB);
-                                           16 + n = k groups in flight per wave of the direct kernel (1..3) */
+                                           16 + 2 / 16 + 0 = direct kernel built for 2 k groups in flight x 4 waves per SIMD / default build */
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G);
 int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
                                  fami_stream_t stream);
