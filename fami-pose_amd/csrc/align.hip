@@ -8,11 +8,12 @@
 //   torchvision.ops.DeformConv2d(48,48,3,padding=3,dilation=3) (Alignment_V15.py:83,89,95,101;
 //   calls :146,150,154,158), offset groups = offset.shape[1]/18, raw (un-sigmoided) masks.
 //
-// DCN forward (dcn_fwd_kernel): a workgroup owns 16 output pixels; offsets and masks (77 % of the
-// algorithmic bytes) are streamed with fully coalesced loads, every bilinear corner is one 16-byte
-// load, the modulated samples are staged in an LDS column tile and contracted with the weights on
-// v_mfma_f32_16x16x4_f32 -- the sampled "column" never exists in HBM, so the traffic is
-// input + offsets + masks + output (the algorithmic bytes of SURVEY.md 8d).
+// DCN forward: a workgroup owns 16 output pixels; offsets and masks (77 % of the algorithmic bytes) are streamed
+// with fully coalesced loads, every bilinear corner is one 16-byte load, and the modulated samples are contracted
+// with the weights on v_mfma_f32_16x16x4_f32 -- the sampled "column" never exists in HBM, so the traffic is
+// input + offsets + masks + output (the algorithmic bytes of SURVEY.md 8d).  dcn_fwd_direct_kernel (default)
+// feeds the samples to the MFMA from the registers of the lane that gathered them; dcn_fwd_kernel (fallback,
+// A/B partner) stages them in an LDS column tile first.
 #include "common.h"
 
 // ------------------------------------------------------------------ bilinear shift
@@ -251,11 +252,11 @@ __device__ __forceinline__ void dcn_contract(const DcnArgs<T>& p, const float* c
   dcn_reduce_store<T, NT>(p, acc, red, m0);
 }
 
-// Forward, two phases per workgroup of DCN_PIX consecutive output pixels:
-//  1. gather: one work item per (pixel, group*tap, 4-channel block).  Consecutive lanes walk consecutive
-//     (group, tap) of one pixel, so the offset (float2) and mask loads of a wave are one contiguous stream --
-//     offsets + masks are 77 % of the algorithmic bytes -- and each bilinear corner is one 16-byte load of
-//     the cg-contiguous NHWC channels.  The modulated samples land in an LDS column tile col[pixel][kidx].
+// Forward, LDS-column-tile form (the default until the register-fed kernel below; now the fallback and A/B
+// partner).  Two phases per workgroup of DCN_PIX consecutive output pixels:
+//  1. gather: one work item per (pixel, tap*group, 4-channel block) in the tap-major column order of the weight
+//     image; each bilinear corner is one 16-byte load of the cg-contiguous NHWC channels.  The modulated samples
+//     land in an LDS column tile col[pixel][kidx].
 //  2. contraction: y[16, Co] = col[16, C*K] x W^T on v_mfma_f32_16x16x4_f32 (exact f32); the 4 waves split
 //     K, partial tiles meet in LDS, bias is added and the [16, Co] block is stored as one contiguous run.
 // The column tile never exists in HBM: traffic = x + offsets + masks + y (SURVEY.md 8d algorithmic bytes).
