@@ -13,6 +13,9 @@
 #include "common.h"
 
 #define BN_MAXG 512
+#ifndef BN_U
+#define BN_U 4  // rows per thread in flight in the statistics passes
+#endif
 
 struct ColMap {
   int cv, prow, rows, CV;
@@ -49,7 +52,22 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   if (m.active) {
     const f32x4 piv = ld4(x + m.cv * 4);
-    for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    // BN_U rows per thread in flight: with one load per thread and <= 512 workgroups the pass is bound by memory
+    // latency (8 KB in flight per CU), not bandwidth.  The sums are taken in the same row order as a rolled loop.
+    const long step = (long)gridDim.x * m.rows;
+    long p = (long)blockIdx.x * m.rows + m.prow;
+    for (; p + (BN_U - 1) * step < P; p += BN_U * step) {
+      f32x4 v[BN_U];
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) v[u] = ld4(x + (p + u * step) * C + m.cv * 4);
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) {
+        const f32x4 d = v[u] - piv;
+        s += d;
+        q += d * d;
+      }
+    }
+    for (; p < P; p += step) {
       const f32x4 v = ld4(x + p * C + m.cv * 4) - piv;
       s += v;
       q += v * v;
@@ -166,7 +184,30 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict
       mu[t] = mean[m.cv * 4 + t];
       is[t] = invstd[m.cv * 4 + t];
     }
-    for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    const long step = (long)gridDim.x * m.rows;
+    long p = (long)blockIdx.x * m.rows + m.prow;
+    for (; p + (BN_U - 1) * step < P; p += BN_U * step) {  // all loads of BN_U rows first (see bn_partial_kernel)
+      f32x4 g[BN_U], yy[BN_U], xx[BN_U];
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) g[u] = ld4(dy + (p + u * step) * C + m.cv * 4);
+      if (relu) {
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) yy[u] = ld4(y + (p + u * step) * C + m.cv * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) xx[u] = ld4(x + (p + u * step) * C + m.cv * 4);
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) {
+        if (relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) g[u][t] = yy[u][t] > 0.f ? g[u][t] : 0.f;
+        }
+        const f32x4 xh = (xx[u] - mu) * is;
+        s += g[u];
+        q += g[u] * xh;
+      }
+    }
+    for (; p < P; p += step) {
       const long o = p * C + m.cv * 4;
       f32x4 g = ld4(dy + o);
       if (relu) {
