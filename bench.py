@@ -29,7 +29,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32-input MFMA dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (not the 2:1-sparsity figure)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 / fp16 MFMA dense peak (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -51,6 +51,8 @@ def build(args, dev):
     model = fp.build_model(cfg, 'train')
     realistic_init_(model, seed=19970808)
     model.set_compute_dtype(args.dtype)
+    if args.deterministic:
+        model.set_deterministic(True)
     return model.to(dev)
 
 
@@ -64,32 +66,10 @@ def pmc_traffic(key):
         return None
 
 
-def conv_roofline(dev, N, dtype, reps=30):
-    """Live HIP-event timing of the dominant kernel: the 48->48 3x3 branch conv at 96x72 (26 % of the
-    step's conv FLOPs, 64 forward launches per step) on the stream it is launched on."""
-    from fami_pose_amd._lib import lib
-    L = lib()
-    H, W, C = 96, 72, 48
-    bf = dtype == 'bf16'
-    tdt = torch.bfloat16 if bf else torch.float32
-    x = torch.randn(N, H, W, C, device=dev).to(tdt)
-    w = torch.randn(C, C, 3, 3, device=dev) * 0.05
-    y = torch.empty(N, H, W, C, device=dev, dtype=tdt)
-    s = torch.cuda.current_stream(dev)
-    if bf:
-        wp = torch.empty(L.cdll.fami_packed_weight_elems_bf16(C, C, 3, 3, 0), device=dev, dtype=tdt)
-        L.call('fami_pack_conv_weight_bf16', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
 
-        def launch():
-            L.call('fami_conv2d_fwd_bf16', x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), N, H, W, C, C, 3, 3, 1, 1, 1,
-                   0, 0, 0, s.cuda_stream)
-    else:
-        wp = torch.empty(L.cdll.fami_packed_weight_elems(C, C, 3, 3, 0), device=dev)
-        L.call('fami_pack_conv_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
 
-        def launch():
-            L.call('fami_conv2d_fwd_f32', x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 3, 3, 1,
-                   1, 1, 0, 0, s.cuda_stream)
+def _time_launches(launch, s, reps):
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,25 +78,54 @@ def conv_roofline(dev, N, dtype, reps=30):
         launch()
     e1.record(s)
     e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps
+
+
+def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
+    """Live HIP-event timing of the dominant kernel: the C->C 3x3 branch conv of the highest-resolution branch (26 % of
+    the step's conv FLOPs at W48, 64 forward launches per step) on the stream it is launched on."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    half = dtype != 'f32'
+    tdt = TORCH_DT[dtype]
+    x = torch.randn(N, H, W, C, device=dev).to(tdt)
+    w = torch.randn(C, C, 3, 3, device=dev) * 0.05
+    y = torch.empty(N, H, W, C, device=dev, dtype=tdt)
+    s = torch.cuda.current_stream(dev)
+    if half:
+        wp = torch.empty(L.cdll.fami_packed_weight_elems_bf16(C, C, 3, 3, 0), device=dev, dtype=tdt)
+        L.call('fami_pack_conv_weight_' + dtype, w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+
+        def launch():
+            L.call('fami_conv2d_fwd_' + dtype, x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), N, H, W, C, C, 3, 3, 1, 1,
+                   1, 0, 0, 0, s.cuda_stream)
+    else:
+        wp = torch.empty(L.cdll.fami_packed_weight_elems(C, C, 3, 3, 0), device=dev)
+        L.call('fami_pack_conv_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, 0, s.cuda_stream)
+
+        def launch():
+            L.call('fami_conv2d_fwd_f32', x.data_ptr(), wp.data_ptr(), None, None, y.data_ptr(), N, H, W, C, C, 3, 3, 1,
+                   1, 1, 0, 0, s.cuda_stream)
+    ms = _time_launches(launch, s, reps)
     flops = 2.0 * N * H * W * C * 9 * C
     ach = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_F32_MFMA_TFLOPS
-    # the library's default route for this shape: direct implicit GEMM in f32, LDS-staged 3x3 kernel in bf16
-    kname = 'conv3x3_lds_bf16' if bf else 'conv_igemm_f32'
-    return {"bound": "mfma", "kernel": "%s (48->48 3x3 @96x72, N=%d frames)" % (kname, N),
+    peak = PEAK_BF16_MFMA_TFLOPS if half else PEAK_F32_MFMA_TFLOPS
+    # the library's default route for this shape: direct implicit GEMM (both dtypes at < 96 channels)
+    kname = ('conv_igemm_h<%s>' % dtype) if half else 'conv_igemm_f32'
+    key = {'f32': 'conv_igemm_f32', 'bf16': 'conv3x3_lds_bf16'}.get(dtype)
+    return {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic(kname) if N == 20 else None,
+            "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
             "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
 
 
-def dcn_roofline(dev, B, dtype, reps=30):
-    """Secondary roofline: the fused DCNv2 gather+contraction (HBM-bound; SURVEY.md 8d algorithmic bytes)."""
+def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
+    """Secondary rooflines: the fused DCNv2 gather+contraction forward and its fused backward (HBM-bound; SURVEY.md 8d
+    algorithmic bytes: fwd (Ci + 3GK + Co) * HW * s, bwd (2Ci + 6GK + Co) * HW * s per sample per layer)."""
     from fami_pose_amd._lib import lib
     L = lib()
-    H, W, C, G = 96, 72, 48, 12
-    bf = dtype == 'bf16'
-    tdt = torch.bfloat16 if bf else torch.float32
+    tdt = TORCH_DT[dtype]
+    sz = 4.0 if dtype == 'f32' else 2.0
     x = torch.randn(B, H, W, C, device=dev).to(tdt)
     off = torch.randn(B, H, W, 18 * G, device=dev).to(tdt)
     msk = torch.randn(B, H, W, 9 * G, device=dev).to(tdt)
@@ -130,27 +139,50 @@ def dcn_roofline(dev, B, dtype, reps=30):
     def launch():
         L.call('fami_dcn_fwd_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),
                y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream)
-    for _ in range(5):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(reps):
-        launch()
-    e1.record(s)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    nbytes = (C + 3 * G * 9 + C) * H * W * (2.0 if bf else 4.0) * B
+    ms = _time_launches(launch, s, reps)
+    nbytes = (C + 3 * G * 9 + C) * H * W * sz * B
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "dcn_fwd_direct_kernel (48ch, 12 groups, 96x72, B=%d, %s)" % (B, dtype),
-            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-            "traffic": pmc_traffic('dcn_fwd_' + dtype) if B == 4 else None, "avg_launch_us": round(ms * 1e3, 2)}
+    fwd = {"bound": "hbm", "kernel": "dcn_fwd_direct_kernel (%dch, %d groups, %dx%d, B=%d, %s)" % (C, G, H, W, B, dtype),
+           "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+           "traffic": pmc_traffic('dcn_fwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
+           "algorithmic_bytes": int(nbytes), "avg_launch_us": round(ms * 1e3, 2)}
+    # backward (the launch the training step issues: column gradient, offset / mask gradients, input-gradient scatter,
+    # modulated samples for the weight gradient)
+    wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
+    L.call('fami_dcn_pack_weight_bwd_f32', w.data_ptr(), wpb.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
+    dy = torch.randn(B, H, W, C, device=dev).to(tdt)
+    col = torch.empty(B * H * W, C * 9, device=dev, dtype=tdt)
+    gx = torch.zeros(B, H, W, C, device=dev)
+    goff, gmsk = torch.empty_like(off), torch.empty_like(msk)
+
+    def launch_b():
+        L.call('fami_dcn_bwd_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
+               col.data_ptr(), gx.data_ptr(), goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0,
+               s.cuda_stream)
+    msb = _time_launches(launch_b, s, reps)
+    nb = (2 * C + 6 * G * 9 + C) * H * W * sz * B
+    achb = nb / (msb * 1e-3) / 1e9
+    bwd = {"bound": "hbm", "kernel": "dcn_bwd_kernel (%dch, %d groups, %dx%d, B=%d, %s; float-atomic scatter)" % (C, G, H, W, B, dtype),
+           "achieved": round(achb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achb / PEAK_HBM_GBS, 4),
+           "traffic": None, "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
+    # the deterministic (64-bit fixed-point) form of the same backward: zero + |dy| max + kernel + conversion pass
+    gxd = torch.empty(B, H, W, C, device=dev, dtype=tdt)
+    ws = torch.empty(L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C) // 4 + 4, device=dev)
+
+    def launch_d():
+        L.call('fami_dcn_bwd_det_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
+               col.data_ptr(), gxd.data_ptr(), goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, 0,
+               ws.data_ptr(), s.cuda_stream)
+    msd = _time_launches(launch_d, s, reps)
+    bwd["deterministic_avg_us"] = round(msd * 1e3, 2)
+    return fwd, bwd
 
 
 def cpu_baseline_worker(args):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores: ONE clip,
     forward + loss + backward + Adam, fp32.  Baseline only.  Runs in its own process (see cpu_baseline)."""
     from oracle import model as om, ops as oops
-    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    cores = min(os.cpu_count() or 1, args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = om.AlignmentOracle(om.make_cfg(args.width), True, args.sup, (args.img_h, args.img_w))
@@ -204,8 +236,8 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)      # >= 20 warm-up + >= 50 timed steps
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=4, help='clips per GPU')
     ap.add_argument('--sup', type=int, default=4, help='supporting frames (4 => 5-frame clips)')
     ap.add_argument('--width', type=int, default=48)
@@ -216,12 +248,15 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bucket-mb', type=int, default=32)
-    ap.add_argument('--also', choices=['f32', 'bf16', 'none'], default='bf16',
+    ap.add_argument('--also', choices=['f32', 'bf16', 'f16', 'none'], default='bf16',
                     help='additionally time this dtype (fewer steps) and report it as an extra "also_<dtype>" object')
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+    ap.add_argument('--dtype', choices=['f32', 'bf16', 'f16'], default='f32',
                     help='activation storage / conv MFMA type (accumulation, master weights, losses are fp32 either way)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-threads', type=int, default=32, help='host threads for the CPU baseline (capped at the core count)')
+    ap.add_argument('--cpu-threads', type=int, default=64,
+                    help='host threads for the CPU baseline (0 = every core).  Default 64: on the 256-thread GPU host the '
+                         'oracle step does not get faster beyond that (profiles/r02_cpu_threads.txt)')
+    ap.add_argument('--deterministic', action='store_true', help='fixed-point DCN backward (bitwise reproducible steps)')
     ap.add_argument('--cpu-timeout', type=int, default=240)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -278,16 +313,23 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         loss = trainer.loss_value()
+        info = {"pck_final": round(trainer.accuracy()[0][1], 4), "pck_kf_backbone": round(trainer.accuracy()[1][1], 4)}
+        if world > 1:
+            info.update({"dist_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
+                         "ddp_plan": (trainer.ddp_plan if use_graph else 'eager-hooks'), "bucket_mb": args.bucket_mb,
+                         "buckets": len(trainer.reducer.ranges()),
+                         "gradient_bytes": int(trainer.grad.numel() * 4), **trainer.plan_summary(),
+                         "allreduce_ms_standalone": round(trainer.measure_allreduce_ms(), 3)})
         del trainer, model
         torch.cuda.empty_cache()
-        return dt, loss
+        return dt, loss, info
 
     primary = args.dtype
-    dt, loss = timed_run(primary, args.steps, args.warmup)
+    dt, loss, info = timed_run(primary, args.steps, args.warmup)
     other = None
     if args.also and args.also != primary and world == 1:      # the extra dtype line is a single-GPU report
-        o_steps = max(3, min(args.steps, 10))
-        o_dt, o_loss = timed_run(args.also, o_steps, max(2, min(args.warmup, 3)))
+        o_steps = max(3, min(args.steps, 20))
+        o_dt, o_loss, _ = timed_run(args.also, o_steps, max(2, min(args.warmup, 5)))
         other = (args.also, o_dt, o_loss, o_steps)
     args.dtype = primary
     frozen = None
@@ -295,15 +337,15 @@ def main():
         # the reference default freezes the backbone (Base_PoseTrack17.yaml:28); reported beside the
         # unfrozen headline (backbone forward only + the head's forward/backward/Adam)
         args.freeze_backbone = True
-        f_steps = max(3, min(args.steps, 10))
-        f_dt, f_loss = timed_run(primary, f_steps, max(2, min(args.warmup, 3)))
+        f_steps = max(3, min(args.steps, 20))
+        f_dt, f_loss, _ = timed_run(primary, f_steps, max(2, min(args.warmup, 5)))
         args.freeze_backbone = False
         frozen = (f_dt, f_loss, f_steps)
 
     if rank == 0:
         clips = args.batch * world * args.steps
         out = {
-            "metric": "train clips/sec (5-frame 384x288 HRNet-W48)", "value": round(clips / dt, 3), "unit": "clips/s",
+            "metric": "train clips/sec (%d-frame %dx%d HRNet-W%d)" % (args.sup + 1, args.img_h, args.img_w, args.width), "value": round(clips / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "HRNet-W%d %dx%d, %d-frame clips + MI loss, batch %d/GPU, backbone %s, Adam, "
@@ -311,20 +353,22 @@ def main():
                                                                    args.batch, "frozen" if args.freeze_backbone else "unfrozen"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hipgraph": use_graph, **({} if backend == 'nccl' or world == 1 else {"dist_backend": backend})},
-            "loss": round(loss, 6),
+            "loss": round(loss, 6), **info,
         }
-        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype)
-        out["roofline_dcn"] = dcn_roofline(dev, args.batch, args.dtype)
+        C, Hf, Wf = args.width, args.img_h // 4, args.img_w // 4
+        G = 12 if C % 48 == 0 else C // 4
+        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype, C=C, H=Hf, W=Wf)
+        out["roofline_dcn"], out["roofline_dcn_bwd"] = dcn_roofline(dev, args.batch, args.dtype, C=C, G=G, H=Hf, W=Wf)
         if other is not None:
             o_dtype, o_dt, o_loss, o_steps = other
             out["also_" + o_dtype] = {
                 "note": "same workload with %s activation storage / conv MFMA (fp32 accumulation, master weights, "
-                        "losses); not the parity-gated configuration" % o_dtype if o_dtype == 'bf16' else
+                        "losses); not the parity-gated configuration" % o_dtype if o_dtype != 'f32' else
                         "same workload in the fp32 parity configuration",
                 "value": round(args.batch * world * o_steps / o_dt, 3), "unit": "clips/s", "steps": o_steps,
                 "ms_per_step": round(o_dt / o_steps * 1e3, 3), "loss": round(o_loss, 6),
-                "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype),
-                "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype)}
+                "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype, C=C, H=Hf, W=Wf),
+                "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype, C=C, G=G, H=Hf, W=Wf)[0]}
         if frozen is not None:
             f_dt, f_loss, f_steps = frozen
             out["also_frozen_backbone"] = {

@@ -50,6 +50,7 @@ class _Lib:
                 "libfami_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C fami-pose_amd/csrc`. There is no CPU fallback." % LIB_PATH)
         self.cdll = ctypes.CDLL(LIB_PATH)
+        self.ncalls = 0                     # entry-point calls so far (a graph capture uses it to detect empty segments)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():
             fn = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
@@ -57,6 +58,7 @@ class _Lib:
             fn.argtypes = argtypes
 
     def call(self, name, *args):
+        self.ncalls += 1
         rc = getattr(self.cdll, name)(*args)
         if self.protos[name][0] is ctypes.c_int and rc != 0:
             raise FamiError('%s failed (%d): %s' % (name, rc, self.cdll.fami_last_error().decode()))

@@ -7,6 +7,10 @@ File format of engine/defaults/checkpoints.py:45-67: ``epoch_{n}_state.pth`` hol
 ``state_dict``; the optimizer part converts between the flat-arena Adam of train.py and a ``torch.optim.Adam``
 state_dict (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, parameters numbered in ``model.parameters()`` order
 restricted to ``requires_grad``, as posetimation/optimizer/optimizer.py:18-22,66-68 builds it).
+
+Limitation: the flat Adam is ONE parameter group.  The reference's optional second group (TRAIN.LR_SECOND_GROUP:
+a list of two Adams, optimizer.py:24-64) is not representable; `load_adam_state_dict` raises on a parameter-count
+mismatch instead of loading a partial state.
 """
 import os
 import os.path as osp
@@ -68,8 +72,11 @@ def load_adam_state_dict(trainer, sd):
         if len(steps) > 1:
             raise ValueError('per-parameter step counts differ; the flat Adam keeps one')
         g = sd['param_groups'][0]
-        opt.betas, opt.eps, opt.wd = tuple(g['betas']), g['eps'], g['weight_decay']
+        # betas / eps / weight decay are kernel arguments baked into a captured hipGraph: set_hyper bumps the
+        # optimizer's hyper_version and a graph-mode Trainer re-captures on its next step()
+        opt.set_hyper(betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'])
         t = steps.pop() if steps else 0.0
+        opt.lr = float(g['lr'])
         opt.state.copy_(torch.tensor([t, g['lr'], 1.0 - opt.betas[0] ** t, 1.0 - opt.betas[1] ** t]))
 
 

@@ -534,7 +534,54 @@ struct DcnBwdArgs {
   T* gmsk;           // [B,Ho,Wo,GK] or null
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil, cg;
   int GC, NTc, KSo, tilesX, tilesY, RH, RW, acc_off;
+  // deterministic mode (DET): the input gradient is accumulated in 64-bit fixed point -- integer adds are associative,
+  // so the result does not depend on the order in which lanes / workgroups arrive -- into gfix [B,H,W,C]; the scale is
+  // derived in-kernel from *amax_bits = bit pattern of max |dy| (fami_dcn_bwd_det_*)
+  long long* gfix;
+  const unsigned* amax_bits;
 };
+
+// Fixed-point scale of the deterministic input-gradient accumulation: 2^(DCN_FIX_BITS - ceil(log2(max|dy|))).  A
+// contribution is gcol*mask*bilinear weight with gcol = sum_co dy*W; the 63-bit accumulator leaves 2^(62-DCN_FIX_BITS)
+// = 2^20 of headroom over max|dy| for |W|, |mask| and the number of samples landing on one input element, and resolves
+// 2^-42 of max|dy| -- 18 bits below fp32's own resolution of that value.
+#define DCN_FIX_BITS 42
+__device__ __forceinline__ float dcn_fix_scale(const unsigned* amax_bits) {
+  const float amax = __uint_as_float(*amax_bits);
+  int e = 0;
+  if (amax > 0.f) (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.f, DCN_FIX_BITS - e);
+}
+__device__ __forceinline__ void fix_add(long long* a, float v, float scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)(long long)__float2ll_rn(v * scale));
+}
+
+// max |x| over a tensor as a float bit pattern (max is order independent: atomicMax on the bits of non-negative floats)
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = fabsf(ld1(x + i));
+    m = v > m ? v : m;          // NaN never wins
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
+}
+__global__ void zero_u64_kernel(unsigned long long* p, long n, unsigned* amax) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *amax = 0u;
+}
+// gx (=|+=) fixed-point accumulator / scale
+template <typename T>
+__global__ __launch_bounds__(256) void fix_to_act_kernel(const long long* __restrict__ fix, T* __restrict__ gx, long n,
+                                                         const unsigned* __restrict__ amax_bits, int accumulate) {
+  const double inv = 1.0 / (double)dcn_fix_scale(amax_bits);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = (float)((double)fix[i] * inv);
+    if (accumulate) v += ld1(gx + i);
+    st1(gx + i, v);
+  }
+}
 
 // wpb[((chunk*NTc + nt)*KSo + ks)*256 + lane*4 + t] = W[co = (ks*4 + (lane>>4))*4 + t][kidx = (chunk*NTc + nt)*16 + (lane&15)],
 // kidx = c*K + tap (the OIHW order of weight.view(Co, C*K))
@@ -552,7 +599,7 @@ __global__ void dcn_pack_wb_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <typename T, int KSO>
+template <typename T, int KSO, bool DET>
 __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -560,7 +607,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2;
   const int CKc = p.NTc * 16, gstride = CKc + 4, Cc = p.GC * p.cg, CK = p.C * K;
   float* gcol = smem;                   // [16][gstride]
-  float* region = smem + 16 * gstride;  // [RH][RW][Cc]
+  float* region = smem + 16 * gstride;  // [RH][RW][Cc] (fp32), or the same shape in 64-bit fixed point (DET)
+  long long* regfix = reinterpret_cast<long long*>(smem + 16 * gstride);   // gstride is a multiple of 4: 8-byte aligned
+  const float fscale = DET ? dcn_fix_scale(p.amax_bits) : 0.f;
   int t, chunk;
   xcd_tile(1, t, chunk);  // neighbouring tiles (overlapping halo / gather regions, all group chunks of a tile) on one XCD
   const int tx = t % p.tilesX;
@@ -569,9 +618,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   const int oy0 = ty * DCN_TILE, ox0 = tx * DCN_TILE;
   const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
   const int rsize = p.RH * p.RW * Cc;
-  for (int i = tid; i < rsize; i += 256) region[i] = 0.f;
+  if (DET) { for (int i = tid; i < rsize; i += 256) regfix[i] = 0ll; }
+  else { for (int i = tid; i < rsize; i += 256) region[i] = 0.f; }
   const T* xb = p.x + (long)b * p.H * p.W * p.C;
-  float* gxb = p.gx ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
+  float* gxb = (!DET && p.gx) ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
+  long long* gfb = (DET && p.gfix) ? p.gfix + (long)b * p.H * p.W * p.C : nullptr;
   const int gtl_n = p.GC * K;  // (group, tap) pairs of this chunk
   __syncthreads();
 
@@ -656,7 +707,31 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
           gpy += gv[c] * dpy[c];
           gpx += gv[c] * dpx[c];
         }
-        if (gxb) {
+        if (DET) {
+          if (gfb) {
+            if (inreg) {
+              long long* r00 = regfix + ((long)ry * p.RW + rx) * Cc + cl;
+#pragma unroll
+              for (int c0 = 0; c0 < 4; ++c0) {
+                const int c = (c0 + pix) & 3;
+                const float gvc = c == 0 ? gv[0] : c == 1 ? gv[1] : c == 2 ? gv[2] : gv[3];
+                if (v00) fix_add(r00 + c, gvc * w00, fscale);
+                if (v01) fix_add(r00 + Cc + c, gvc * w01, fscale);
+                if (v10) fix_add(r00 + p.RW * Cc + c, gvc * w10, fscale);
+                if (v11) fix_add(r00 + p.RW * Cc + Cc + c, gvc * w11, fscale);
+              }
+            } else {
+              long long* g00 = gfb + chunk * Cc + cl;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (v00) fix_add(g00 + o00 + c, gv[c] * w00, fscale);
+                if (v01) fix_add(g00 + o01 + c, gv[c] * w01, fscale);
+                if (v10) fix_add(g00 + o10 + c, gv[c] * w10, fscale);
+                if (v11) fix_add(g00 + o11 + c, gv[c] * w11, fscale);
+              }
+            }
+          }
+        } else if (gxb) {
           if (inreg) {
             float* r00 = region + ((long)ry * p.RW + rx) * Cc + cl;
             // Neighbouring pixels of a wave often land on the same input position at the same tap; with every lane on
@@ -710,7 +785,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
     __syncthreads();
   }
   // ---- region -> gx
-  if (gxb) {
+  if (DET) {
+    if (gfb) {
+      for (int e = tid; e < p.RH * p.RW * Cc; e += 256) {
+        const int c = e % Cc, pos = e / Cc;
+        const int ry = pos / p.RW, rx = pos - ry * p.RW;
+        const int gy = ry0 + ry, gxx = rx0 + rx;
+        if ((unsigned)gy >= (unsigned)p.H || (unsigned)gxx >= (unsigned)p.W) continue;
+        const long long v = regfix[e];
+        if (v != 0ll)
+          atomicAdd(reinterpret_cast<unsigned long long*>(gfb + ((long)gy * p.W + gxx) * p.C + chunk * Cc + c), (unsigned long long)v);
+      }
+    }
+  } else if (gxb) {
     const int c4n = Cc >> 2;
     for (int e = tid; e < p.RH * p.RW * c4n; e += 256) {
       const int c4 = e % c4n, pos = e / c4n;
@@ -843,22 +930,29 @@ static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   return 0;
 }
 
-template <typename T, int KSO>
-static void dcn_bwd_launch(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+template <typename T, int KSO, bool DET>
+static void dcn_bwd_launch1(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<T, KSO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<T, KSO, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_bwd_kernel<T, KSO>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dcn_bwd_kernel<T, KSO, DET>), grid, dim3(256), lds, s, a);
+}
+template <typename T, int KSO>
+static void dcn_bwd_launch(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (a.gfix) dcn_bwd_launch1<T, KSO, true>(a, grid, lds, s);
+  else dcn_bwd_launch1<T, KSO, false>(a, grid, lds, s);
 }
 
 template <typename T>
 static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, float* gx,
                         T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
-                        int pad, int dil, int acc_off, hipStream_t s, const char* nm) {
+                        int pad, int dil, int acc_off, hipStream_t s, const char* nm, long long* gfix = nullptr,
+                        const unsigned* amax_bits = nullptr) {
   FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
   DcnBwdArgs<T> a;
+  a.gfix = gfix; a.amax_bits = amax_bits;
   a.x = x; a.off = off; a.msk = msk; a.dy = dy; a.wpb = wpb; a.col = col; a.gx = gx; a.goff = goff; a.gmsk = gmsk;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
   a.stride = stride; a.pad = pad; a.dil = dil; a.acc_off = acc_off;
@@ -876,7 +970,7 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   a.tilesX = fami_cdiv(a.Wo, DCN_TILE); a.tilesY = fami_cdiv(a.Ho, DCN_TILE);
   a.RH = (DCN_TILE - 1) * stride + (kh - 1) * dil + 2 + 2 * DCN_RO;
   a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
-  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
+  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * (gfix ? 2 : 1)) * sizeof(float);
   if (lds > 150 * 1024) {
     fami_set_error(nm, "tile does not fit LDS");
     return FAMI_ESHAPE;
@@ -894,7 +988,33 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   return FAMI_OK;
 }
 
+// Deterministic variant: |dy| maximum -> fixed-point scale, 64-bit integer accumulation of the input gradient, one
+// conversion pass into gx (activation type, =|+=).  ws: 8*B*H*W*C + 16 bytes.
+template <typename T>
+static int dcn_bwd_det_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, T* gx,
+                            T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
+                            int pad, int dil, int acc_off, int acc_x, void* ws, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(ws && dy, nm, "bad argument");
+  const long n = (long)B * H * W * C;
+  long long* gfix = gx ? reinterpret_cast<long long*>(ws) : nullptr;
+  unsigned* amax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + n * 8);
+  if (!gx) return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm);
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  hipLaunchKernelGGL(zero_u64_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(gfix), n, amax);
+  FAMI_CHECK_LAUNCH(nm);
+  const long ndy = (long)B * Ho * Wo * Co;
+  hipLaunchKernelGGL(absmax_kernel<T>, dim3(fami_ew_grid(ndy)), dim3(256), 0, s, dy, ndy, amax);
+  FAMI_CHECK_LAUNCH(nm);
+  const int rc = dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, gfix, amax);
+  if (rc != FAMI_OK) return rc;
+  hipLaunchKernelGGL(fix_to_act_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, gfix, gx, n, amax, acc_x);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
 extern "C" {
+
+long fami_dcn_bwd_det_workspace(int B, int H, int W, int C) { return (long)B * H * W * C * 8 + 16; }
 
 long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
 
@@ -959,9 +1079,18 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
                          int pad, int dil, int acc_off, hipStream_t s) {                                               \
     return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, gx, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil,     \
                            acc_off, s, "fami_dcn_bwd_" #sfx);                                                          \
+  }                                                                                                                    \
+  /* Run-to-run deterministic form of fami_dcn_bwd: the input gradient is accumulated in 64-bit fixed point (integer  */ \
+  /* atomics: order independent) and written to gx (activation type, =|+= per acc_x) by a conversion pass.            */ \
+  int fami_dcn_bwd_det_##sfx(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, T* gx,     \
+                             T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,  \
+                             int pad, int dil, int acc_off, int acc_x, void* ws, hipStream_t s) {                      \
+    return dcn_bwd_det_impl<T>(x, off, msk, dy, wpb, col, gx, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, \
+                               acc_off, acc_x, ws, s, "fami_dcn_bwd_det_" #sfx);                                       \
   }
 FAMI_ALIGN_ABI(f32, float)
 FAMI_ALIGN_ABI(bf16, bf16_t)
+FAMI_ALIGN_ABI(f16, f16_t)
 #undef FAMI_ALIGN_ABI
 
 }  // extern "C"

@@ -29,8 +29,12 @@ extern "C" void fami_set_error(const char* where, const char* what);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- storage types: activations are fp32 or bf16 (fp32 arithmetic either way) ----------------------------
+// ---- storage types: activations are fp32, bf16 or fp16 (fp32 arithmetic either way) ----------------------
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -43,6 +47,12 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
 }
+__device__ __forceinline__ f32x4 ld4(const f16_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const f16x4*>(p), f32x4);
+}
+__device__ __forceinline__ void st4(f16_t* p, f32x4 v) {
+  *reinterpret_cast<f16x4*>(p) = __builtin_convertvector(v, f16x4);
+}
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
@@ -53,14 +63,41 @@ __device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2
 __device__ __forceinline__ void st2(bf16_t* p, f32x2 v) {
   *reinterpret_cast<bf16x2*>(p) = __builtin_convertvector(v, bf16x2);
 }
+__device__ __forceinline__ f32x2 ld2(const f16_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const f16x2*>(p), f32x2);
+}
+__device__ __forceinline__ void st2(f16_t* p, f32x2 v) {
+  *reinterpret_cast<f16x2*>(p) = __builtin_convertvector(v, f16x2);
+}
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ float ld1(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void st1(f16_t* p, float v) { *p = (f16_t)v; }
+
+// the two 16-bit storage types on the 16x16x32 matrix-core instruction (8 K-elements per lane, fp32 accumulation)
+template <typename H> struct H16;
+template <> struct H16<bf16_t> {
+  typedef bf16x8 x8;
+  __device__ static __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // one 16-bit pattern -> f32
+  __device__ static __forceinline__ float from_bits(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+};
+template <> struct H16<f16_t> {
+  typedef f16x8 x8;
+  __device__ static __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ float from_bits(unsigned short u) { return (float)__builtin_bit_cast(f16_t, u); }
+};
 
 // stamps the two C-ABI instances of an entry point whose body is a template over the activation type
 #define FAMI_DTYPE_NAME_f32 float
 #define FAMI_DTYPE_NAME_bf16 bf16_t
+#define FAMI_DTYPE_NAME_f16 f16_t
 
 static inline int fami_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

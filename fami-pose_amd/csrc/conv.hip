@@ -420,16 +420,16 @@ __global__ __launch_bounds__(256) void conv_igemm32_f32(ConvArgs p) {
   }
 }
 
-// ------------------------------------------------------------------ bf16 implicit GEMM (fwd / dgrad)
-// bf16 activations and weights, fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Same mapping as the f32 kernel with
+// ------------------------------------------------------------------ 16-bit implicit GEMM (fwd / dgrad)
+// bf16 or fp16 activations and weights (template H), fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}.  Same mapping as the f32 kernel with
 // the operand roles swapped: the MFMA A operand is the weight fragment (rows = 16 output channels) and the B operand
 // the activation fragment (cols = 16 pixels), so a lane ends up with 4 CONSECUTIVE output channels of one pixel and
 // the epilogue is one 8-byte (bf16) or 16-byte (f32) store per tile instead of four scattered scalars.
 // K is walked tap-major in chunks of 32 channels; a lane's fragment is 8 consecutive channels = one 16-byte load.
 struct ConvArgsH {
-  const bf16_t* x;   // GEMM input activation  [N,Hi,Wi,Ci]
-  const bf16_t* wp;  // packed weights [taps][KC][NTt][64][8]
-  void* y;           // GEMM output activation [N,Ho,Wo,Co], bf16 or f32 (out_f32)
+  const void* x;     // GEMM input activation  [N,Hi,Wi,Ci] (16-bit storage type H)
+  const void* wp;    // packed weights [taps][KC][NTt][64][8] (H)
+  void* y;           // GEMM output activation [N,Ho,Wo,Co], H or f32 (out_f32)
   const float* bias; // [Co] or null
   int N, Hi, Wi, Ci, Ho, Wo, Co;
   int kh, kw, sh, pad, dil;
@@ -439,8 +439,9 @@ struct ConvArgsH {
 };
 
 // packed[tap][kc][nt][lane][j] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
-__global__ void pack_w_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Co, int Ci, int taps,
-                                   int KC, int NTt, int mode) {
+template <typename H>
+__global__ void pack_w_h_kernel(const float* __restrict__ w, H* __restrict__ wp, int Co, int Ci, int taps,
+                                int KC, int NTt, int mode) {
   const long total = (long)taps * KC * NTt * 512;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -452,7 +453,7 @@ __global__ void pack_w_bf16_kernel(const float* __restrict__ w, bf16_t* __restri
     const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
     float v = 0.f;
     if (co < Co && ci < Ci) v = w[((long)co * Ci + ci) * taps + tap];
-    wp[i] = (bf16_t)v;
+    wp[i] = (H)v;
   }
 }
 
@@ -491,8 +492,9 @@ __global__ void pack_w_batch_kernel(const float* __restrict__ params, T* __restr
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int NT, int MODE, int VEC, int KS, int ST>
-__global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
+template <typename H, int MT, int NT, int MODE, int VEC, int KS, int ST>
+__global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
+  typedef typename H16<H>::x8 hx8;
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
@@ -558,13 +560,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
     }
   };
 
-  auto load = [&](bf16x8(&a)[MT], bf16x8(&b)[NT]) {
+  auto load = [&](hx8(&a)[MT], hx8(&b)[NT]) {
     const int cbase = kc * 32 + kq * 8;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (VEC) {
         const unsigned o = cbase < p.Ci ? aoff[mt] + kc * 64 : FAMI_OOB;
-        a[mt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+        a[mt] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
       } else {
         s16x8 t;
 #pragma unroll
@@ -572,13 +574,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
           const unsigned o = cbase + q < p.Ci ? aoff[mt] + kc * 64 + q * 2 : FAMI_OOB;
           t[q] = (short)__builtin_amdgcn_raw_buffer_load_b16(rx, o, 0, 0);
         }
-        a[mt] = __builtin_bit_cast(bf16x8, t);
+        a[mt] = __builtin_bit_cast(hx8, t);
       }
     }
     const unsigned wb = (unsigned)((tap * p.KC + kc) * p.NTt) * 1024u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      b[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wb + boff[nt], 0, 0));
+      b[nt] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rw, wb + boff[nt], 0, 0));
     kc += KS;
     if (kc >= p.KC) {
       do {
@@ -589,15 +591,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
     }
   };
 
-  auto mma = [&](const bf16x8(&a)[MT], const bf16x8(&b)[NT]) {
+  auto mma = [&](const hx8(&a)[MT], const hx8(&b)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = H16<H>::mfma(b[nt], a[mt], acc[mt][nt]);
   };
 
-  bf16x8 af[ST][MT], bf[ST][NT];
+  hx8 af[ST][MT], bf[ST][NT];
   const int Tall = taps * p.KC;
   const int T = active ? (Tall - kpart + KS - 1) / KS : 0;
   if (T > 0) {
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
           if (p.accumulate) v += ld4(yp);
           st4(yp, v);
         } else {
-          bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx;
+          H* yp = reinterpret_cast<H*>(p.y) + idx;
           if (p.accumulate) v += ld4(yp);
           st4(yp, v);
         }
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16(ConvArgsH p) {
             float* yp = reinterpret_cast<float*>(p.y) + idx + r;
             *yp = p.accumulate ? *yp + u : u;
           } else {
-            bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx + r;
+            H* yp = reinterpret_cast<H*>(p.y) + idx + r;
             st1(yp, p.accumulate ? ld1(yp) + u : u);
           }
         }
@@ -722,14 +724,14 @@ template <> struct LdsTraits<float> {
   }
   __device__ static __forceinline__ frag zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 };
-template <> struct LdsTraits<bf16_t> {
-  typedef bf16x8 frag;
+template <typename H> struct LdsTraits16 {
+  typedef typename H16<H>::x8 frag;
   static constexpr int KSTEP = 32;
-  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc, 0, 0, 0);
-  }
-  __device__ static __forceinline__ frag zero() { return __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u}); }
+  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) { return H16<H>::mfma(w, a, acc); }
+  __device__ static __forceinline__ frag zero() { return __builtin_bit_cast(frag, u32x4{0u, 0u, 0u, 0u}); }
 };
+template <> struct LdsTraits<bf16_t> : LdsTraits16<bf16_t> {};
+template <> struct LdsTraits<f16_t> : LdsTraits16<f16_t> {};
 
 template <typename T, int NT, int KSC>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
       if (p.accumulate) v += ld4(yp);
       st4(yp, v);
     } else {
-      bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + idx;
+      T* yp = reinterpret_cast<T*>(p.y) + idx;
       if (p.accumulate) v += ld4(yp);
       st4(yp, v);
     }
@@ -934,7 +936,11 @@ __device__ __forceinline__ float ldbuf<float>(const __amdgpu_buffer_rsrc_t r, un
 }
 template <>
 __device__ __forceinline__ float ldbuf<bf16_t>(const __amdgpu_buffer_rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float, (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+  return H16<bf16_t>::from_bits((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ float ldbuf<f16_t>(const __amdgpu_buffer_rsrc_t r, unsigned off) {
+  return H16<f16_t>::from_bits((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
 }
 
 template <typename T>
@@ -1277,8 +1283,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct WgradLdsArgs {
-  const bf16_t* x;   // [N,H,W,Ci]
-  const bf16_t* dy;  // [N,H,W,Co]
+  const void* x;     // [N,H,W,Ci] (16-bit storage type)
+  const void* dy;    // [N,H,W,Co]
   float* part;       // [G][9][Ci][Co]
   int N, H, W, Ci, Co, P;
   int chunk;         // pixels per staged sub-chunk (multiple of 32)
@@ -1290,8 +1296,9 @@ struct WgradLdsArgs {
   int xcd;
 };
 
-template <int CIT, int COT>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
+template <typename H, int CIT, int COT>
+__global__ __launch_bounds__(256) void conv_wgrad_h_kernel(WgradLdsArgs p) {
+  typedef typename H16<H>::x8 hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPW = (CIT * 9 + 3) / 4;  // (ci tile, tap) pairs per wave
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1377,7 +1384,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
       pxx[h] = r - py[h] * p.W;
     }
     // B operand (dY): 8 pixels x 16 output channels per tile
-    bf16x8 bfr[COT];
+    hx8 bfr[COT];
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
       s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -1385,7 +1392,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
       s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (lds_s16x4*)(pin[1] ? yt + pl[1] * p.yrow + c * 32 + piece * 8 : zrow + piece * 8));
       s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      bfr[c] = __builtin_bit_cast(bf16x8, t);
+      bfr[c] = __builtin_bit_cast(hx8, t);
     }
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
@@ -1401,9 +1408,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradLdsArgs p) {
       s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
       s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
       s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const bf16x8 afr = __builtin_bit_cast(bf16x8, t);
+      const hx8 afr = __builtin_bit_cast(hx8, t);
 #pragma unroll
-      for (int c = 0; c < COT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[c], acc[i][c], 0, 0, 0);
+      for (int c = 0; c < COT; ++c) acc[i][c] = H16<H>::mfma(afr, bfr[c], acc[i][c]);
     }
   }
 
@@ -2104,14 +2111,14 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
 }
 
 // ---- bf16 implicit GEMM launch
-template <int MODE, int VEC>
+template <typename H, int MODE, int VEC>
 static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hipStream_t s) {
   const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
 #define FAMI_CASE(mt, nt, ks)                                                                        \
   if (MT == mt && NT == nt && KS == ks) {                                                            \
-    if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
-    else if (ST == 4 && mt <= 2) hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 4>), grid, dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((conv_igemm_bf16<mt, nt, MODE, VEC, ks, 2>), grid, dim3(256), 0, s, a);   \
+    if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_h<H, mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
+    else if (ST == 4 && mt <= 2) hipLaunchKernelGGL((conv_igemm_h<H, mt, nt, MODE, VEC, ks, 4>), grid, dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((conv_igemm_h<H, mt, nt, MODE, VEC, ks, 2>), grid, dim3(256), 0, s, a);   \
     return 0;                                                                                        \
   }
   if constexpr (VEC) {
@@ -2125,6 +2132,7 @@ static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hi
   return -1;
 }
 
+template <typename H>
 static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
   const int vec = (a.Ci % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
@@ -2149,9 +2157,9 @@ static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
   const int ST = g_stages ? g_stages : 2;
   int rc;
   if (mode == 0)
-    rc = vec ? launch_igemm_h<0, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<0, 0>(a, MT, NT, KS, 2, s);
+    rc = vec ? launch_igemm_h<H, 0, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<H, 0, 0>(a, MT, NT, KS, 2, s);
   else
-    rc = vec ? launch_igemm_h<1, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<1, 0>(a, MT, NT, KS, 2, s);
+    rc = vec ? launch_igemm_h<H, 1, 1>(a, MT, NT, KS, ST, s) : launch_igemm_h<H, 1, 0>(a, MT, NT, KS, 2, s);
   if (rc != 0) {
     fami_set_error(name, "no kernel instance for tile shape");
     return FAMI_ESHAPE;
@@ -2203,14 +2211,17 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
   return wgrad_impl<float>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
                            "fami_conv2d_wgrad_f32");
 }
-// bf16 activations / gradients, fp32 weight gradient (the f32 MFMA consumes the converted operands)
-int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
-                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                           hipStream_t s) {
+}  // extern "C"
+
+// 16-bit activations / gradients, fp32 weight gradient
+template <typename HT>
+static int wgrad_h_impl(const char* nm, const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,
+                        int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                        hipStream_t s) {
   const WgradLdsPlan l = g_wgrad_lds ? wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
     const long need = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
-    FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_bf16", "workspace too small");
+    FAMI_REQUIRE(ws_bytes >= need, nm, "workspace too small");
     WgradLdsArgs a;
     a.x = x; a.dy = dy; a.part = workspace;
     a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.P = N * H * W;
@@ -2222,64 +2233,45 @@ int fami_conv2d_wgrad_bf16(const bf16_t* x, const bf16_t* dy, float* dw, float* 
   if (l.CIT == cit && l.COT == cot) {                                                                              \
     static bool attr = false;                                                                                      \
     if (!attr) {                                                                                                   \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_h_kernel<HT, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
       attr = true;                                                                                                 \
     }                                                                                                              \
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<cit, cot>), grid, dim3(256), l.lds, s, a);                          \
+    hipLaunchKernelGGL((conv_wgrad_h_kernel<HT, cit, cot>), grid, dim3(256), l.lds, s, a);                         \
     ok = true;                                                                                                     \
   }
     FAMI_WL_CASE(1, 1) FAMI_WL_CASE(1, 2) FAMI_WL_CASE(1, 3) FAMI_WL_CASE(2, 1) FAMI_WL_CASE(2, 2) FAMI_WL_CASE(2, 3)
     FAMI_WL_CASE(3, 1) FAMI_WL_CASE(3, 2) FAMI_WL_CASE(3, 3)
 #undef FAMI_WL_CASE
     if (ok) {
-      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/lds");
+      FAMI_CHECK_LAUNCH(nm);
       launch_reduce_taps(workspace, dw, Co, Ci, 9, l.G, accumulate, s);
-      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_bf16/reduce");
+      FAMI_CHECK_LAUNCH(nm);
       return FAMI_OK;
     }
   }
-  return wgrad_impl<bf16_t>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
-                            "fami_conv2d_wgrad_bf16");
+  return wgrad_impl<HT>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s, nm);
 }
 
-// every weight image of a step in one launch.  desc: device array of n records {long src_elem_off, long dst_elem_off,
-// int Co, int Ci, int taps, int mode} (32 bytes each); params = fp32 parameter arena, packed = destination arena.
-int fami_pack_conv_weights_batch_f32(const float* params, float* packed, const void* desc, int n, hipStream_t s) {
-  FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_f32", "bad argument");
-  hipLaunchKernelGGL(pack_w_batch_kernel<float>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
-  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_f32");
-  return FAMI_OK;
-}
-int fami_pack_conv_weights_batch_bf16(const float* params, bf16_t* packed, const void* desc, int n, hipStream_t s) {
-  FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_bf16", "bad argument");
-  hipLaunchKernelGGL(pack_w_batch_kernel<bf16_t>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
-  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_bf16");
-  return FAMI_OK;
-}
-
-long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode) {
-  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
-  return (long)kh * kw * fami_cdiv(kd, 32) * fami_cdiv(nd, 16) * 512;
-}
-
-int fami_pack_conv_weight_bf16(const float* w_oihw, bf16_t* wp, int Co, int Ci, int kh, int kw, int mode,
-                               hipStream_t s) {
-  FAMI_REQUIRE(w_oihw && wp && Co > 0 && Ci > 0 && (mode == 0 || mode == 1), "fami_pack_conv_weight_bf16", "bad argument");
+template <typename HT>
+static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, int Co, int Ci, int kh, int kw, int mode,
+                                   hipStream_t s) {
+  FAMI_REQUIRE(w_oihw && wp && Co > 0 && Ci > 0 && (mode == 0 || mode == 1), nm, "bad argument");
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
   const int KC = fami_cdiv(kd, 32), NTt = fami_cdiv(nd, 16);
   const long total = (long)kh * kw * KC * NTt * 512;
-  hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, KC, NTt, mode);
-  FAMI_CHECK_LAUNCH("fami_pack_conv_weight_bf16");
+  hipLaunchKernelGGL(pack_w_h_kernel<HT>, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, KC, NTt, mode);
+  FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
 
-// y[N,Ho,Wo,Co] (bf16, or f32 when out_f32) (=|+=) relu?( conv(x[N,H,W,Ci] bf16) + bias ) ; wp packed with mode 0
-int fami_conv2d_fwd_bf16(const bf16_t* x, const bf16_t* wp, const float* bias, void* y, int N, int H, int W, int Ci,
-                         int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate, int out_f32,
-                         hipStream_t s) {
-  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_fwd_bf16", "bad argument");
+// y[N,Ho,Wo,Co] (16-bit, or f32 when out_f32) (=|+=) relu?( conv(x[N,H,W,Ci]) + bias ) ; wp packed with mode 0
+template <typename HT>
+static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const float* bias, void* y, int N, int H, int W,
+                           int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,
+                           int out_f32, hipStream_t s) {
+  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
-    fami_set_error("fami_conv2d_fwd_bf16", "unsupported geometry");
+    fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
   ConvArgsH a;
@@ -2290,21 +2282,22 @@ int fami_conv2d_fwd_bf16(const bf16_t* x, const bf16_t* wp, const float* bias, v
   a.KC = fami_cdiv(Ci, 32); a.NTt = fami_cdiv(Co, 16); a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   const long P = (long)N * a.Ho * a.Wo;
   const long xb = (long)N * H * W * Ci * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_bf16", "tensor >= 2 GiB");
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const int rc = try_conv3x3_lds<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, "fami_conv2d_fwd_bf16");
+    const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
-  return run_igemm_h(a, 0, s, "fami_conv2d_fwd_bf16");
+  return run_igemm_h<HT>(a, 0, s, nm);
 }
 
-// dx[N,H,W,Ci] bf16 (=|+=) conv_transpose(dy[N,Ho,Wo,Co] bf16) ; wp packed with mode 1
-int fami_conv2d_dgrad_bf16(const bf16_t* dy, const bf16_t* wp, bf16_t* dx, int N, int H, int W, int Ci, int Co, int kh,
-                           int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {
-  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_dgrad_bf16", "bad argument");
+// dx[N,H,W,Ci] (=|+=) conv_transpose(dy[N,Ho,Wo,Co]) ; wp packed with mode 1
+template <typename HT>
+static int conv_dgrad_h_impl(const char* nm, const HT* dy, const HT* wp, HT* dx, int N, int H, int W, int Ci, int Co,
+                             int kh, int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
-    fami_set_error("fami_conv2d_dgrad_bf16", "unsupported geometry");
+    fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
   ConvArgsH a;
@@ -2315,13 +2308,66 @@ int fami_conv2d_dgrad_bf16(const bf16_t* dy, const bf16_t* wp, bf16_t* dx, int N
   a.KC = fami_cdiv(Co, 32); a.NTt = fami_cdiv(Ci, 16); a.relu = 0; a.accumulate = accumulate; a.out_f32 = 0;
   const long P = (long)N * H * W;
   const long xb = (long)N * a.Hi * a.Wi * Co * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_bf16", "tensor >= 2 GiB");
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const int rc = try_conv3x3_lds<bf16_t>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, "fami_conv2d_dgrad_bf16");
+    const int rc = try_conv3x3_lds<HT>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, nm);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
-  return run_igemm_h(a, 1, s, "fami_conv2d_dgrad_bf16");
+  return run_igemm_h<HT>(a, 1, s, nm);
 }
+
+extern "C" {
+
+// every weight image of a step in one launch.  desc: device array of n records {long src_elem_off, long dst_elem_off,
+// int Co, int Ci, int taps, int mode} (32 bytes each); params = fp32 parameter arena, packed = destination arena.
+int fami_pack_conv_weights_batch_f32(const float* params, float* packed, const void* desc, int n, hipStream_t s) {
+  FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_f32", "bad argument");
+  hipLaunchKernelGGL(pack_w_batch_kernel<float>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_f32");
+  return FAMI_OK;
+}
+
+// the packed 16-bit image has the same geometry for bf16 and fp16
+long fami_packed_weight_elems_bf16(int Co, int Ci, int kh, int kw, int mode) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  return (long)kh * kw * fami_cdiv(kd, 32) * fami_cdiv(nd, 16) * 512;
+}
+long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
+  return fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode);
+}
+
+#define FAMI_CONV_H_ABI(sfx, HT)                                                                                       \
+  int fami_conv2d_wgrad_##sfx(const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N, int H,     \
+                              int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,     \
+                              hipStream_t s) {                                                                         \
+    return wgrad_h_impl<HT>("fami_conv2d_wgrad_" #sfx, x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw,        \
+                            stride, pad, dil, accumulate, s);                                                          \
+  }                                                                                                                    \
+  int fami_pack_conv_weights_batch_##sfx(const float* params, HT* packed, const void* desc, int n, hipStream_t s) {    \
+    FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_" #sfx, "bad argument");\
+    hipLaunchKernelGGL(pack_w_batch_kernel<HT>, dim3(48, n), dim3(256), 0, s, params, packed,                          \
+                       reinterpret_cast<const PackDesc*>(desc));                                                       \
+    FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_" #sfx);                                                           \
+    return FAMI_OK;                                                                                                    \
+  }                                                                                                                    \
+  int fami_pack_conv_weight_##sfx(const float* w_oihw, HT* wp, int Co, int Ci, int kh, int kw, int mode,               \
+                                  hipStream_t s) {                                                                     \
+    return pack_conv_weight_h_impl<HT>("fami_pack_conv_weight_" #sfx, w_oihw, wp, Co, Ci, kh, kw, mode, s);            \
+  }                                                                                                                    \
+  int fami_conv2d_fwd_##sfx(const HT* x, const HT* wp, const float* bias, void* y, int N, int H, int W, int Ci,        \
+                            int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,            \
+                            int out_f32, hipStream_t s) {                                                              \
+    return conv_fwd_h_impl<HT>("fami_conv2d_fwd_" #sfx, x, wp, bias, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil,     \
+                               relu, accumulate, out_f32, s);                                                          \
+  }                                                                                                                    \
+  int fami_conv2d_dgrad_##sfx(const HT* dy, const HT* wp, HT* dx, int N, int H, int W, int Ci, int Co, int kh,         \
+                              int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {                   \
+    return conv_dgrad_h_impl<HT>("fami_conv2d_dgrad_" #sfx, dy, wp, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil,     \
+                                 accumulate, s);                                                                       \
+  }
+FAMI_CONV_H_ABI(bf16, bf16_t)
+FAMI_CONV_H_ABI(f16, f16_t)
+#undef FAMI_CONV_H_ABI
 
 }  // extern "C"

@@ -373,6 +373,7 @@ extern "C" {
   }
 FAMI_EW_ABI(f32, float)
 FAMI_EW_ABI(bf16, bf16_t)
+FAMI_EW_ABI(f16, f16_t)
 #undef FAMI_EW_ABI
 
 int fami_incr_i64(long long* v, long n, hipStream_t s) {

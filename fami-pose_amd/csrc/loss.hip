@@ -224,6 +224,53 @@ __global__ void final_preds_kernel(const float* __restrict__ hm, const long long
   preds[r * 2 + 1] = center[b * 2 + 1] + (y - 0.5f * (float)H) * s;
 }
 
+// PCK on heatmap argmax (engine/core/utils/evaluate.py:13-75 `calc_dists` / `dist_acc` / `accuracy`): one workgroup.
+// pidx/tidx, pmax/tmax: argmax rows of the prediction / target stacks [B*J].  get_max_preds zeroes coordinates whose
+// maximum is <= 0; a target joint counts only if both of its coordinates are > 1; x is normalised by H/10 and y by
+// W/10 (the reference multiplies (x, y) by [h, w]/10 in that order); distances in fp64 as numpy computes them.
+// out[0] = mean of the per-joint accuracies that exist (0 if none), out[1..J] = per-joint accuracy or -1,
+// out[J+1] = avg_acc (== out[0] when cnt > 0), out[J+2] = cnt.
+__global__ __launch_bounds__(256) void pck_kernel(const long long* __restrict__ pidx, const float* __restrict__ pmax,
+                                                  const long long* __restrict__ tidx, const float* __restrict__ tmax,
+                                                  float* __restrict__ out, int B, int J, int H, int W, double thr) {
+  __shared__ int hit[64], val[64];
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    const double nx = (double)H / 10.0, ny = (double)W / 10.0;
+    int h = 0, v = 0;
+    for (int b = 0; b < B; ++b) {
+      const int r = b * J + j;
+      const long long pi = pidx[r], ti = tidx[r];
+      const float pm = pmax[r] > 0.f ? 1.f : 0.f, tm = tmax[r] > 0.f ? 1.f : 0.f;
+      const float px = (float)(pi % W) * pm, py = (float)(pi / W) * pm;
+      const float tx = (float)(ti % W) * tm, ty = (float)(ti / W) * tm;
+      if (tx > 1.f && ty > 1.f) {
+        const double dx = (double)px / nx - (double)tx / nx, dy = (double)py / ny - (double)ty / ny;
+        ++v;
+        if (sqrt(dx * dx + dy * dy) < thr) ++h;
+      }
+    }
+    hit[j] = h;
+    val[j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double avg = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < J; ++j) {
+      const double a = val[j] > 0 ? (double)hit[j] * 1.0 / (double)val[j] : -1.0;
+      out[1 + j] = (float)a;
+      if (a >= 0.0) {
+        avg += a;
+        ++cnt;
+      }
+    }
+    avg = cnt != 0 ? avg / cnt : 0.0;
+    out[0] = cnt != 0 ? (float)avg : 0.f;
+    out[J + 1] = (float)avg;
+    out[J + 2] = (float)cnt;
+  }
+}
+
 extern "C" {
 
 // joints [B,J,2] px, vis [B,J] -> target [B,J,Hh,Wh] (NCHW), weight [B,J]
@@ -295,6 +342,22 @@ int fami_final_preds_f32(const float* hm, const float* center, const float* scal
   hipLaunchKernelGGL(final_preds_kernel, dim3(fami_cdiv(B * J, 64)), dim3(64), 0, s, hm, idx_ws, maxvals, center, scale,
                      preds, B, J, H, W);
   FAMI_CHECK_LAUNCH("fami_final_preds_f32");
+  return FAMI_OK;
+}
+
+// PCK accuracy of a heatmap stack against the target stack, entirely on the device (no host sync):
+// out[J+3] as documented at pck_kernel; idx_ws: 2*B*J int64, max_ws: 2*B*J floats (scratch)
+int fami_pck_accuracy_f32(const float* pred_hm, const float* target_hm, float* out, long long* idx_ws, float* max_ws,
+                          int B, int J, int H, int W, float thr, hipStream_t s) {
+  FAMI_REQUIRE(pred_hm && target_hm && out && idx_ws && max_ws && B > 0 && J > 0 && J <= 64 && H > 0 && W > 0,
+               "fami_pck_accuracy_f32", "bad argument (J <= 64)");
+  const int R = B * J;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(R), dim3(256), 0, s, pred_hm, idx_ws, max_ws, H * W);
+  FAMI_CHECK_LAUNCH("fami_pck_accuracy_f32/argmax");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(R), dim3(256), 0, s, target_hm, idx_ws + R, max_ws + R, H * W);
+  FAMI_CHECK_LAUNCH("fami_pck_accuracy_f32/argmax");
+  hipLaunchKernelGGL(pck_kernel, dim3(1), dim3(256), 0, s, idx_ws, max_ws, idx_ws + R, max_ws + R, out, B, J, H, W, (double)thr);
+  FAMI_CHECK_LAUNCH("fami_pck_accuracy_f32");
   return FAMI_OK;
 }
 

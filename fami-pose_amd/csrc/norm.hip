@@ -640,6 +640,7 @@ int fami_bn_running_update_f32(float* running_mean, float* running_var, const fl
   }
 FAMI_BN_ABI(f32, float)
 FAMI_BN_ABI(bf16, bf16_t)
+FAMI_BN_ABI(f16, f16_t)
 #undef FAMI_BN_ABI
 
 }  // extern "C"

@@ -7,8 +7,9 @@ torch compute op on this path: torch provides device memory (tensors), the
 stream and (optionally) hipGraph capture of the whole launch sequence.
 
 Activations are NHWC (`T.data` of shape [N,H,W,C]) in the engine's activation dtype -- fp32 (parity
-configuration) or bf16 (BASELINE config 3: bf16 storage + bf16 MFMA convolutions, fp32 accumulation) -- and
-every activation-touching C-ABI entry point exists as a `_f32` / `_bf16` pair.  Heatmap-producing convolutions
+configuration), bf16 (BASELINE config 3: bf16 storage + bf16 MFMA convolutions, fp32 accumulation) or fp16
+(BASELINE config 5: the same with IEEE half storage + fp16 MFMA) -- and every activation-touching C-ABI entry point
+exists as a `_f32` / `_bf16` / `_f16` triple.  Heatmap-producing convolutions
 write fp32 in either mode; parameters, BatchNorm statistics, weight gradients, the translation regressor's
 dense layers ([M,K] tensors) and everything at the NCHW boundary are always fp32.
 """
@@ -26,8 +27,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_SFX = {torch.float32: '_f32', torch.bfloat16: '_bf16', torch.float16: '_f16'}
+
+
 def _sfx(t):
-    return '_bf16' if t.dtype == torch.bfloat16 else '_f32'
+    return _SFX[t.dtype]
 
 
 class T:
@@ -48,10 +52,15 @@ class T:
 
 
 class Engine:
-    def __init__(self, device, grad_views=None, record=True, dtype=torch.float32):
-        assert dtype in (torch.float32, torch.bfloat16)
+    def __init__(self, device, grad_views=None, record=True, dtype=torch.float32, deterministic=None):
+        assert dtype in _SFX
         self.dt = dtype                # activation storage dtype
-        self.sfx = '_bf16' if dtype == torch.bfloat16 else '_f32'
+        self.sfx = _SFX[dtype]
+        self.half = dtype != torch.float32     # 16-bit storage (bf16 | fp16): 16x16x32 MFMA convolutions
+        # deterministic: every kernel of the step is run-to-run reproducible.  The one order-dependent reduction of the
+        # path is the DCN input-gradient scatter (float atomics); this flag routes it through the 64-bit fixed-point
+        # form (fami_dcn_bwd_det_*).  Default from FAMI_DETERMINISTIC (0).
+        self.deterministic = (os.environ.get('FAMI_DETERMINISTIC', '0') != '0') if deterministic is None else bool(deterministic)
         self.L = lib()
         self.record = record           # False: forward only (no tape, no gradient flags)
         self.dev = device
@@ -278,6 +287,8 @@ class Engine:
     # dtype / version counter, so it can never outlive or be confused with another model's weights); trainable
     # parameters and ad-hoc tensors are packed every forward
     def packed(self, w, mode):
+        if w.requires_grad and getattr(w, '_fami_packed', None):
+            w._fami_packed = {}            # being trained again: an image cached while it was frozen must not survive
         if self.prepacked is not None:
             hit = self.prepacked.get((id(w), mode))
             if hit is not None:
@@ -289,10 +300,10 @@ class Engine:
             hit = getattr(w, '_fami_packed', {}).get(key)
             if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
                 return hit[1]
-        if self.dt == torch.bfloat16:
+        if self.half:
             n = self.L.cdll.fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode)
             wp = self.act(n)
-            self.call('fami_pack_conv_weight_bf16', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
+            self.acall('fami_pack_conv_weight', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
         else:
             n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
             wp = self.empty(n)
@@ -348,9 +359,9 @@ class Engine:
         Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         wp = self.packed(weight, 0)
-        if self.dt == torch.bfloat16:
+        if self.half:
             y = self.empty(N, Ho, Wo, Co) if out_f32 else self.act(N, Ho, Wo, Co)
-            self.call('fami_conv2d_fwd_bf16', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
+            self.acall('fami_conv2d_fwd', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
                       N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0, int(out_f32))
         else:
             y = self.empty(N, Ho, Wo, Co)
@@ -381,8 +392,8 @@ class Engine:
                 if x.requires_grad:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
-                    if self.dt == torch.bfloat16:
-                        self.call('fami_conv2d_dgrad_bf16', _p(dy), _p(wpd), _p(gx), *geo, acc)
+                    if self.half:
+                        self.acall('fami_conv2d_dgrad', _p(dy), _p(wpd), _p(gx), *geo, acc)
                     else:
                         self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
             self.record_bwd(bwd, [weight, bias])
@@ -659,22 +670,29 @@ class Engine:
                 col = self.act(P, CK) if self.rq(weight) else None
                 gx = gx32 = goff = gmsk = None
                 acco = accx = 0
-                if x.requires_grad:
-                    gx, accx = self.gbuf(x)
-                    if self.dt == torch.bfloat16:      # the scatter accumulates in an fp32 buffer (float atomics)
-                        gx32 = self.fill(self.empty(*gx.shape))
-                    else:
-                        gx32 = gx
-                        if not accx:
-                            self.fill(gx)
                 if off.requires_grad:
                     goff, acco = self.gbuf(off)
                     gmsk, accm = self.gbuf(msk)
                     assert acco == accm
-                self.acall('fami_dcn_bwd', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
-                           _p(gx32), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
-                if gx is not None and gx32 is not gx:
-                    self.call('fami_cast_add_bf16', _p(gx32), _p(gx), gx.numel(), accx)
+                if self.deterministic:
+                    if x.requires_grad:
+                        gx, accx = self.gbuf(x)
+                    ws = self.ws(self.L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C))
+                    self.acall('fami_dcn_bwd_det', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                               _p(gx), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco, accx, _p(ws))
+                else:
+                    if x.requires_grad:
+                        gx, accx = self.gbuf(x)
+                        if self.half:      # the scatter accumulates in an fp32 buffer (float atomics)
+                            gx32 = self.fill(self.empty(*gx.shape))
+                        else:
+                            gx32 = gx
+                            if not accx:
+                                self.fill(gx)
+                    self.acall('fami_dcn_bwd', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                               _p(gx32), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
+                    if gx is not None and gx32 is not gx:
+                        self.acall('fami_cast_add', _p(gx32), _p(gx), gx.numel(), accx)
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)

@@ -15,7 +15,7 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, owner, body, n_in, *tensors):
         inputs, params = tensors[:n_in], tensors[n_in:]
         eng = Engine(inputs[0].device, grad_views=getattr(owner, '_grad_views', None), record=True,
-                     dtype=owner.act_dtype)
+                     dtype=owner.act_dtype, deterministic=owner.deterministic)
         outs, seeds = body(eng, *inputs)
         owner._advance_bn_counters(eng)
         ctx.eng, ctx.seeds, ctx.params, ctx.n_in = eng, seeds, params, n_in
@@ -40,15 +40,24 @@ class EngineModule(nn.Module):
     _nbt_flat = None
     _nbt_index = None
     _nbt_inc = None
-    act_dtype = torch.float32      # activation storage / conv MFMA dtype of the HIP engine (fp32 | bf16)
+    act_dtype = torch.float32      # activation storage / conv MFMA dtype of the HIP engine (fp32 | bf16 | fp16)
 
     def set_compute_dtype(self, dtype):
-        """'f32' (parity configuration: exact-f32 MFMA) or 'bf16' (bf16 activations + bf16 MFMA, fp32 accumulation,
-        fp32 master weights -- BASELINE config 3).  Parameters stay fp32 either way."""
-        dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16}.get(dtype, dtype)
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError('compute dtype must be f32 or bf16')
+        """'f32' (parity configuration: exact-f32 MFMA), 'bf16' (bf16 activations + bf16 MFMA, fp32 accumulation,
+        fp32 master weights -- BASELINE config 3) or 'f16' (the same with IEEE half storage + fp16 MFMA -- BASELINE
+        config 5).  Parameters, BatchNorm statistics, heatmaps and losses stay fp32 in every mode."""
+        dtype = {'f32': torch.float32, 'fp32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16,
+                 'fp16': torch.float16}.get(dtype, dtype)
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError('compute dtype must be f32, bf16 or f16')
         self.act_dtype = dtype
+        return self
+
+    deterministic = None           # None: FAMI_DETERMINISTIC decides; True / False: this model's engines
+
+    def set_deterministic(self, on=True):
+        """Run-to-run reproducible kernels for this model (the DCN input-gradient scatter takes its fixed-point form)."""
+        self.deterministic = on
         return self
 
     def _trainable(self):
@@ -61,17 +70,16 @@ class EngineModule(nn.Module):
         inputs = tuple(t.float().contiguous() for t in inputs)
         params = self._trainable() if torch.is_grad_enabled() else []
         if not params:
-            eng = Engine(inputs[0].device, record=False, dtype=self.act_dtype)
+            eng = Engine(inputs[0].device, record=False, dtype=self.act_dtype, deterministic=self.deterministic)
             outs, _ = body(eng, *inputs)
             self._advance_bn_counters(eng)
             return tuple(outs)
         return _EngineFn.apply(self, body, len(inputs), *inputs, *params)
 
     # nn.BatchNorm2d.num_batches_tracked: all counters live in one int64 arena and advance in ONE launch
-    def _advance_bn_counters(self, eng):
-        if not eng.bn_trained:
-            return
-        dev = eng.dev
+    def _ensure_nbt(self, dev):
+        """Move every BatchNorm's num_batches_tracked into one int64 arena on `dev` (idempotent).  A Trainer calls this
+        before it snapshots the module buffers, so the capture warm-up's rollback restores the live counters."""
         if self._nbt_flat is None or self._nbt_flat.device != dev:
             bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
             flat = torch.stack([m.num_batches_tracked.to(dev) for m in bns]) if bns else None
@@ -81,6 +89,12 @@ class EngineModule(nn.Module):
                 self._nbt_index[id(m)] = i
             self._nbt_flat = flat
             self._nbt_inc = {}
+
+    def _advance_bn_counters(self, eng):
+        if not eng.bn_trained:
+            return
+        dev = eng.dev
+        self._ensure_nbt(dev)
         counts = {}
         for m in eng.bn_trained:
             i = self._nbt_index[id(m)]

@@ -33,24 +33,71 @@ def _stream(dev):
 
 
 class FlatAdam:
-    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) on one flat fp32 arena."""
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) on one flat fp32 arena
+    (posetimation/optimizer/optimizer.py:66-68 builds the reference's).  The step count, the learning rate and the two
+    bias corrections live in a device vector, so an LR schedule needs no re-capture of a hipGraph; betas / eps /
+    weight decay are kernel arguments: changing them (set_hyper, or loading a checkpoint) bumps `hyper_version`,
+    which makes a graph-mode Trainer re-capture."""
 
     def __init__(self, flat_param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.p = flat_param
         self.grad = torch.zeros_like(flat_param)
         self.m = torch.zeros_like(flat_param)
         self.v = torch.zeros_like(flat_param)
-        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.betas, self.eps, self.wd = tuple(betas), eps, weight_decay
+        self.lr = float(lr)
+        self.hyper_version = 0
         self.state = torch.tensor([0.0, lr, 1.0, 1.0], device=flat_param.device)   # step, lr, bc1, bc2
 
     def set_lr(self, lr):
-        self.state[1] = lr
+        self.lr = float(lr)
+        self.state[1] = self.lr
+
+    def set_hyper(self, betas=None, eps=None, weight_decay=None):
+        new = (tuple(betas) if betas is not None else self.betas, self.eps if eps is None else eps,
+               self.wd if weight_decay is None else weight_decay)
+        if new != (self.betas, self.eps, self.wd):
+            self.betas, self.eps, self.wd = new
+            self.hyper_version += 1
 
     def step(self):
         s = _stream(self.p.device)
         lib().call('fami_adam_prep_f32', _p(self.state), self.betas[0], self.betas[1], s)
         lib().call('fami_adam_f32', _p(self.p), _p(self.grad), _p(self.m), _p(self.v), self.p.numel(), _p(self.state),
                    self.betas[0], self.betas[1], self.eps, self.wd, s)
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma, last_epoch) for the flat Adam: what
+    posetimation/optimizer/scheduler.py:14-35 builds from TRAIN.LR_STEP / TRAIN.LR_FACTOR ([8, 12, 16] x 0.1 in
+    configs/Alignment/Base_PoseTrack17.yaml) and engine/defaults/trainer.py steps once per epoch.  `opt` is a FlatAdam
+    or a Trainer; the new rate is written into the optimizer's device-resident state, so captured graphs keep replaying."""
+
+    def __init__(self, opt, milestones, gamma=0.1, last_epoch=-1, base_lr=None):
+        import bisect
+        self._bisect = bisect.bisect_right
+        self.opt = opt.opt if hasattr(opt, 'opt') else opt
+        self.milestones = sorted(int(m) for m in milestones)
+        self.gamma = float(gamma)
+        self.base_lr = float(self.opt.lr if base_lr is None else base_lr)
+        self.last_epoch = int(last_epoch)
+        self.step()          # like torch: construction performs the step to epoch last_epoch + 1
+
+    def get_last_lr(self):
+        return [self.base_lr * self.gamma ** self._bisect(self.milestones, self.last_epoch)]
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.set_lr(self.get_last_lr()[0])
+
+    def state_dict(self):
+        return {'milestones': list(self.milestones), 'gamma': self.gamma, 'base_lr': self.base_lr,
+                'last_epoch': self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.milestones, self.gamma = sorted(sd['milestones']), float(sd['gamma'])
+        self.base_lr, self.last_epoch = float(sd['base_lr']), int(sd['last_epoch'])
+        self.opt.set_lr(self.get_last_lr()[0])
 
 
 def flatten_parameters(model):
@@ -63,6 +110,8 @@ def flatten_parameters(model):
         n = p.numel()
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view(p.shape)
+        if hasattr(p, '_fami_packed'):          # a packed image cached while the parameter was frozen is stale now
+            del p._fami_packed
         table.append((p, off, n))
         off += n
     return flat, table
@@ -75,7 +124,8 @@ class WeightPacker:
     def __init__(self, model, flat, table, dtype):
         import numpy as np
         L = lib().cdll
-        bf = dtype == torch.bfloat16
+        from .engine import _SFX
+        bf = dtype != torch.float32      # 16-bit images (bf16 | fp16) share one geometry
         elems = L.fami_packed_weight_elems_bf16 if bf else L.fami_packed_weight_elems
         convs = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Conv2d)}
         recs, self.views, off = [], {}, 0
@@ -97,7 +147,7 @@ class WeightPacker:
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(flat.device)
         for pid, mode, o, n in spans:
             self.views[(pid, mode)] = self.arena[o:o + n]
-        self.fn = 'fami_pack_conv_weights_batch_bf16' if bf else 'fami_pack_conv_weights_batch_f32'
+        self.fn = 'fami_pack_conv_weights_batch' + _SFX[dtype]
 
     def run(self, stream):
         if self.n:
@@ -172,34 +222,54 @@ def _ends(pending):
 
 
 class Trainer:
-    """One optimisation step per call: forward, loss, backward, (all-reduce), Adam -- all HIP kernels."""
+    """One optimisation step per call: forward, loss, backward, (all-reduce), Adam, PCK of both heatmap outputs -- all
+    HIP kernels, no host synchronisation (core fn :104-174).
+
+    loss_scale: gradients of the 16-bit activation modes are seeded with `loss_scale * dLoss` and the flat fp32
+    gradient arena is divided by it before Adam (static scaling; fp16's smallest normal is 6e-5 while the MSE seed is
+    ~2e-6 * error).  Default: 8192 for fp16, 1 otherwise (bf16 has fp32's exponent range).
+    """
 
     def __init__(self, model, lr=1e-3, mse_weight=1.0, alpha=0.5, beta=0.1, use_mi=True, bucket_mb=32,
-                 process_group=None, use_graph=True, targets_from_joints=False, sigma=3, force_ddp=False):
+                 process_group=None, use_graph=True, targets_from_joints=False, sigma=3, force_ddp=False,
+                 loss_scale=None, pck=True, data_parallel=None):
         self.model = model
         self.targets_from_joints, self.sigma = targets_from_joints, sigma
         self.dev = next(model.parameters()).device
         if self.dev.type != 'cuda':
             raise RuntimeError('Trainer needs the model on the GPU (HIP path only)')
         self.mse_weight, self.alpha, self.beta, self.use_mi = mse_weight, alpha, beta, use_mi
+        self.act_dtype = getattr(model, 'act_dtype', torch.float32)
+        self.loss_scale = float(loss_scale if loss_scale is not None else
+                                (8192.0 if self.act_dtype == torch.float16 else 1.0))
         self.flat, self.table = flatten_parameters(model)
         self.opt = FlatAdam(self.flat, lr=lr)
         self.grad = self.opt.grad
         self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        if data_parallel is False:          # a single-process trainer inside an initialised process group (tests, tools)
+            self.world = 1
         if self.world > 1 and process_group is None:
             self.pg = dist.group.WORLD
         # force_ddp: run the bucketed all-reduce path even with one rank (exercises the hooks / RCCL stream ordering
         # on a single GPU; an all-reduce over one rank is the identity)
         self.ddp = self.world > 1 or (force_ddp and dist.is_initialized())
         self.reducer = BucketReducer(self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg)
-        self.packer = WeightPacker(model, self.flat, self.table, getattr(model, 'act_dtype', torch.float32))
-        # FAMI_DDP_GRAPH=0 forces the eager, hook-overlapped launch sequence on the data-parallel path
+        self.reducer.world = self.world
+        self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype)
+        # data-parallel launch plan: 'overlap' (default) = hipGraph segments cut at the bucket boundaries with each
+        # bucket's all-reduce issued between two segment replays (graph replay AND overlap with the rest of backward);
+        # 'serial' = one graph for forward + backward, then every all-reduce; FAMI_DDP_GRAPH=0 = no graphs at all
+        # (eager launches, all-reduces fired from the Engine.backward hooks)
+        self.ddp_plan = os.environ.get('FAMI_DDP_PLAN', 'overlap')
         self.use_graph = use_graph and (not self.ddp or os.environ.get('FAMI_DDP_GRAPH', '1') != '0')
         self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
-        self._graphs = None
-        self._static = None
+        self.pck = pck
+        self.acc = None           # [2, J+3] device floats of the last step: PCK of final_hm / kf_bb_hm (see accuracy())
+        self._cache = {}          # batch shapes -> (plan, static inputs, static outputs, optimizer hyper version)
+        if hasattr(model, '_ensure_nbt'):
+            model._ensure_nbt(self.dev)      # BatchNorm counters move into their arena BEFORE any snapshot is taken
         if self.ddp:
             self.broadcast_parameters()
 
@@ -210,10 +280,32 @@ class Trainer:
             if b.dtype.is_floating_point:
                 dist.broadcast(b, src=0, group=self.pg)
 
+    def measure_allreduce_ms(self, reps=3):
+        """Wall time of one bucketed all-reduce of the whole gradient arena with nothing else running (reporting only;
+        the arena content is scaled back afterwards)."""
+        if not self.ddp:
+            return 0.0
+        import time
+        torch.cuda.synchronize(self.dev)
+        best = None
+        for _ in range(reps):
+            dist.barrier(group=self.pg)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for lo, hi in self.reducer.ranges():
+                self.reducer.allreduce(lo, hi)
+            self.reducer.wait()
+            torch.cuda.synchronize(self.dev)
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+            self.grad.mul_(1.0 / self.world)
+        return best
+
     # ------------------------------------------------------------------ the step (eager launch sequence)
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
         model = self.model
-        eng = Engine(self.dev, grad_views=self.views, dtype=getattr(model, 'act_dtype', torch.float32))
+        eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
+                     deterministic=getattr(model, 'deterministic', None))
         self.packer.run(eng.stream)             # every conv weight image of this step, one launch
         eng.prepacked = self.packer.views
         if self.targets_from_joints:
@@ -229,22 +321,33 @@ class Trainer:
         model._advance_bn_counters(eng)
         aux = eng.aux
         final_nchw = outs[0]
-        B, J = final_nchw.shape[:2]
-        L = final_nchw[0, 0].numel()
+        B, J, Hh, Wh = final_nchw.shape
+        L = Hh * Wh
         scale = self.mse_weight / (B * L * J)
         w = weight.reshape(B * J)
         ws = eng.ws(B * J * 4)
         eng.call('fami_wmse_fwd_f32', _p(final_nchw), _p(target), _p(w), _p(self.loss_parts[0:1]), B * J, L,
                  float(scale), _p(ws))
+        if self.pck:
+            # accuracy(pred_heatmaps, target) and accuracy(kf_bb_heatmaps, target), core fn :159-163, without the four
+            # device-to-host heatmap copies
+            if self.acc is None or self.acc.shape[1] != J + 3:
+                self.acc = torch.zeros(2, J + 3, device=self.dev)
+            iws = eng.empty(2 * B * J, dtype=torch.int64)
+            mws = eng.empty(2 * B * J)
+            for k, hm in enumerate((final_nchw, outs[1])):
+                eng.call('fami_pck_accuracy_f32', _p(hm), _p(target), _p(self.acc[k]), _p(iws), _p(mws), B, J, Hh, Wh,
+                         0.5)
+        ls = self.loss_scale
         dpred = torch.empty_like(final_nchw)
-        eng.call('fami_wmse_bwd_f32', _p(final_nchw), _p(target), _p(w), _p(dpred), B * J, L, float(scale), None, 0)
+        eng.call('fami_wmse_bwd_f32', _p(final_nchw), _p(target), _p(w), _p(dpred), B * J, L, float(scale * ls), None, 0)
         eng.seed_nchw(aux['final'], dpred)
         if self.use_mi and aux['mis']:
             a, b = self.alpha, self.beta
             coef = [-b * a, b * a, a, -a, a, -a]        # core fn :119-148
             for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
                 eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
-                seed(c)
+                seed(c * ls)
         hook = None
         if on_bucket is not None:
             def bucket_ready(lo, hi):
@@ -253,17 +356,28 @@ class Trainer:
             hook = self.reducer.begin(bucket_ready)
         eng.backward(on_params_done=hook)
         if on_bucket is not None:
-            self.reducer.flush()
+            self._flushing = True
+            try:
+                self.reducer.flush()
+            finally:
+                self._flushing = False
         return outs
+
+    _flushing = False
+
+    def _unscale(self):
+        """gradient arena *= 1 / (world * loss_scale): the data-parallel mean and the static loss scale in one pass."""
+        f = 1.0 / ((self.world if self.ddp else 1) * self.loss_scale)
+        if f != 1.0:
+            lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), f, 0.0, _stream(self.dev))
 
     def _eager_step(self, kf_x, sup_x, target, weight):
         if self.ddp:
             outs = self._forward_backward(kf_x, sup_x, target, weight, on_bucket=self.reducer.allreduce)
             self.reducer.wait()
-            lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world, 0.0,
-                       _stream(self.dev))
         else:
             outs = self._forward_backward(kf_x, sup_x, target, weight)
+        self._unscale()
         self.opt.step()
         return outs
 
@@ -271,8 +385,8 @@ class Trainer:
     def _capture(self, kf_x, sup_x, target, weight):
         st = {'kf': kf_x.clone(), 'sup': sup_x.clone(), 'target': target.clone(), 'weight': weight.clone()}
         # warm-up on a side stream (allocator + pack caches).  The warm-up steps must not count as training steps: the
-        # parameters, Adam state and module buffers (BN running statistics) are restored afterwards, so the first
-        # step() of a graph-mode Trainer is exactly one optimisation step, like the eager one.
+        # parameters, Adam state and module buffers (BN running statistics, batch counters) are restored afterwards, so
+        # the first step() of a graph-mode Trainer is exactly one optimisation step, like the eager one.
         snap = [t.clone() for t in (self.flat, self.opt.m, self.opt.v, self.opt.state)]
         bufs = [(b, b.clone()) for b in self.model.buffers()]
         side = torch.cuda.Stream(self.dev)
@@ -291,13 +405,12 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
+                self._unscale()
                 self.opt.step()
-            self._graphs = [('graph', g)]
-        else:
-            # data parallel: graph 1 = forward + backward, then the bucketed all-reduce of the flat gradient arena
-            # (RCCL, outside any graph), then graph 2 = 1/world scale + Adam.  The exchange is ~260 MB of fp32 per
-            # step, ~2 ms on 8 xGMI-linked GPUs against a ~75 ms step, so it is not overlapped with backward here; the
-            # eager path (use_graph=False) overlaps it bucket by bucket through the Engine.backward hooks.
+            plan = [('graph', g)]
+        elif self.ddp_plan == 'serial':
+            # graph 1 = forward + backward, then the bucketed all-reduce of the flat gradient arena (RCCL, outside any
+            # graph), then graph 2 = 1/world scale + Adam
             pool = torch.cuda.graph_pool_handle()
             g1 = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread may query events while this thread captures
@@ -308,36 +421,101 @@ class Trainer:
             plan.append(('wait', None))
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=pool, capture_error_mode='thread_local'):
-                lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), 1.0 / self.world,
-                           0.0, _stream(self.dev))
+                self._unscale()
                 self.opt.step()
             plan.append(('graph', g2))
-            self._graphs = plan
-        self._static = st
-        self._static_outs = outs
-        return outs
+        else:
+            outs, plan = self._capture_overlap(st)
+        entry = (plan, st, outs, self.opt.hyper_version)
+        return entry
+
+    def _capture_overlap(self, st):
+        """Data-parallel plan with graph replay AND overlap: the launch sequence of forward + backward is captured into
+        one hipGraph per gradient bucket -- a segment ends where the backward tape has enqueued the last contribution
+        to a bucket (BucketReducer's frontier; only outside forked stream-lane regions, so no cross-segment event) --
+        and at replay the bucket's RCCL all-reduce is issued between two segment launches: it runs on RCCL's stream
+        beside the next segment's kernels.  The tail segment is followed by wait + (1/world scale, Adam)."""
+        pool = torch.cuda.graph_pool_handle()
+        plan = []
+        cap = torch.cuda.Stream(self.dev)
+        cap.wait_stream(torch.cuda.current_stream(self.dev))
+        torch.cuda.synchronize(self.dev)
+        late = []
+        with torch.cuda.stream(cap):
+            cur = [torch.cuda.CUDAGraph()]
+            cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
+            mark = [lib().ncalls]
+
+            def cut(lo, hi):
+                if self._flushing:              # buckets without a gradient: nothing was enqueued since the last cut
+                    late.append((lo, hi))
+                    return
+                if lib().ncalls == mark[0]:     # two buckets completed by the same tape entry: no empty segment
+                    plan.append(('allreduce', (lo, hi)))
+                    return
+                cur[0].capture_end()
+                plan.append(('graph', cur[0]))
+                plan.append(('allreduce', (lo, hi)))
+                cur[0] = torch.cuda.CUDAGraph()
+                cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
+                mark[0] = lib().ncalls
+
+            try:
+                outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], on_bucket=cut)
+                # a (possibly tiny) tail always exists: the stem's gradients complete after the last bucket boundary
+                lib().call('fami_axpby_f32', _p(self.loss_parts), None, _p(self.loss_parts), 7, 1.0, 0.0, _stream(self.dev))
+            finally:
+                cur[0].capture_end()
+            plan.append(('graph', cur[0]))
+            plan += [('allreduce', r) for r in late]
+            plan.append(('wait', None))
+            g2 = torch.cuda.CUDAGraph()
+            g2.capture_begin(pool=pool, capture_error_mode='thread_local')
+            try:
+                self._unscale()
+                self.opt.step()
+            finally:
+                g2.capture_end()
+            plan.append(('graph', g2))
+        torch.cuda.current_stream(self.dev).wait_stream(cap)
+        torch.cuda.synchronize(self.dev)
+        return outs, plan
 
     def step(self, kf_x, sup_x, target, weight):
-        """-> (final_hm, kf_bb_hm, ...) of this step; self.loss_parts holds [mse*W, mi_1..mi_6] on device."""
+        """-> (final_hm, kf_bb_hm, ...) of this step; self.loss_parts holds [mse*W, mi_1..mi_6] on device, self.acc
+        the PCK rows.  Graph mode keeps one captured plan per batch shape: the DataLoader of the reference has no
+        drop_last, so the last batch of an epoch is usually smaller (datasets/zoo/build.py:32-50)."""
         weight = weight.reshape(weight.shape[0], -1).float().contiguous()
         target = target.float().contiguous()
+        if not (kf_x.shape[0] == sup_x.shape[0] == target.shape[0] == weight.shape[0]):
+            raise ValueError('batch sizes differ: kf %s sup %s target %s weight %s' %
+                             (tuple(kf_x.shape), tuple(sup_x.shape), tuple(target.shape), tuple(weight.shape)))
         if not self.use_graph:
             return self._eager_step(kf_x, sup_x, target, weight)
-        if self._graphs is None:
-            self._capture(kf_x, sup_x, target, weight)
-        st = self._static
+        key = (tuple(kf_x.shape), tuple(sup_x.shape), tuple(target.shape), tuple(weight.shape))
+        entry = self._cache.get(key)
+        if entry is None or entry[3] != self.opt.hyper_version:
+            entry = self._cache[key] = self._capture(kf_x, sup_x, target, weight)
+        plan, st, outs, _ = entry
         st['kf'].copy_(kf_x, non_blocking=True)
         st['sup'].copy_(sup_x, non_blocking=True)
         st['target'].copy_(target, non_blocking=True)
         st['weight'].copy_(weight, non_blocking=True)
-        for kind, obj in self._graphs:
+        for kind, obj in plan:
             if kind == 'graph':
                 obj.replay()
             elif kind == 'allreduce':
                 self.reducer.allreduce(*obj)
             else:
                 self.reducer.wait()
-        return self._static_outs
+        return outs
+
+    def plan_summary(self):
+        """{'graphs': n, 'allreduces': n} of the most recently captured plan (reporting)."""
+        if not self._cache:
+            return {'graphs': 0, 'allreduces': len(self.reducer.ranges()) if self.ddp else 0}
+        plan = list(self._cache.values())[-1][0]
+        return {'graphs': sum(1 for k, _ in plan if k == 'graph'), 'allreduces': sum(1 for k, _ in plan if k == 'allreduce')}
 
     def loss_value(self):
         """Total loss of the last step (host float; forces a sync -- logging only)."""
@@ -345,3 +523,12 @@ class Trainer:
         a, b = self.alpha, self.beta
         mi = a * (-b * p[1] + b * p[2] + p[3] - p[4] + p[5] - p[6]) if self.use_mi else 0.0
         return p[0] + mi
+
+    def accuracy(self):
+        """PCK of the last step as the reference's `accuracy` returns it, for (final_hm, kf_bb_hm):
+        -> [(acc[J+1] ndarray, avg_acc, cnt), (...)]  (host values; forces a sync -- logging only)."""
+        if self.acc is None:
+            return None
+        rows = self.acc.cpu().numpy().astype('float64')
+        J = rows.shape[1] - 3
+        return [(r[:J + 1].copy(), float(r[J + 1]), int(r[J + 2])) for r in rows]

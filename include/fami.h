@@ -155,6 +155,16 @@ int fami_dcn_bwd_f32(const float* x, const float* off, const float* msk, const f
                      float* col, float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int Co, int G,
                      int kh, int kw, int stride, int pad, int dil, int acc_off, fami_stream_t stream);
 
+/* Run-to-run deterministic form of fami_dcn_bwd_f32 ("an fp32 deterministic path for the parity config"):
+ * the scatter of the input gradient adds 64-bit fixed-point integers (associative, so independent of arrival order)
+ * scaled by 2^(42 - ceil(log2 max|dy|)); gx [B,H,W,C] is then written (=|+= per acc_x) by a conversion pass.
+ * Overflow needs one input element to collect more than 2^20 x max|dy|.  ws: fami_dcn_bwd_det_workspace bytes. */
+long fami_dcn_bwd_det_workspace(int B, int H, int W, int C);
+int fami_dcn_bwd_det_f32(const float* x, const float* off, const float* msk, const float* dy, const float* wpb,
+                         float* col, float* gx, float* goff, float* gmsk, int B, int H, int W, int C, int Co, int G,
+                         int kh, int kw, int stride, int pad, int dil, int acc_off, int acc_x, void* ws,
+                         fami_stream_t stream);
+
 /* ---- dense layers of the translation regressor: nn.Linear x3 (Alignment_V15.py:69-71) ------- */
 int fami_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
                         fami_stream_t stream);
@@ -183,6 +193,13 @@ int fami_argmax2d_f32(const float* hm, long long* idx, float* maxval, int R, int
  * preds [B,J,2]; maxvals [B,J]; idx_ws: B*J int64 scratch */
 int fami_final_preds_f32(const float* hm, const float* center, const float* scale, float* preds, float* maxvals,
                          long long* idx_ws, int B, int J, int H, int W, fami_stream_t stream);
+
+/* PCK accuracy on heatmap argmax, engine/core/utils/evaluate.py:39-75 (`accuracy`, called twice per training step at
+ * engine/core/functions/alignment_mi_function_term6_1.py:159-163 after D2H copies of four heatmap stacks): here
+ * three launches and no host sync.  pred_hm / target_hm [B,J,H,W]; out[J+3] = {acc[0] = mean of the defined
+ * per-joint accuracies, acc[1..J] (-1 where no valid target), avg_acc, cnt}; idx_ws 2*B*J int64, max_ws 2*B*J floats */
+int fami_pck_accuracy_f32(const float* pred_hm, const float* target_hm, float* out, long long* idx_ws, float* max_ws,
+                          int B, int J, int H, int W, float thr, fami_stream_t stream);
 
 /* ---- input pipeline on the device -------------------------------------------------------------
  * cv2.warpAffine(frame, trans, (Wd, Hd), flags=INTER_LINEAR) on the F 8-bit HWC frames of one clip (one transform
@@ -268,6 +285,84 @@ int fami_dcn_bwd_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_b
                       const float* wpb, fami_bf16_t* col, float* gx, fami_bf16_t* goff, fami_bf16_t* gmsk, int B,
                       int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_off,
                       fami_stream_t stream);
+int fami_dcn_bwd_det_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_bf16_t* msk, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col,
+                         fami_bf16_t* gx, fami_bf16_t* goff, fami_bf16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
+                         int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
+
+
+/* ======================================================================================================
+ * fp16 activation storage (BASELINE config 5: "fp16 MFMA convs + fp32 loss accumulation").  Identical in every
+ * respect to the bf16 family above -- same argument order, same fp32 accumulation / BatchNorm statistics / master
+ * weights / losses -- with IEEE binary16 storage and v_mfma_f32_16x16x32_f16.  The packed weight image has the
+ * bf16 geometry.  (posetimation/backbones/hrnet.py:569-629 driven by STAGE*.NUM_CHANNELS = 64/128/256/512.)
+ * ====================================================================================================== */
+typedef unsigned short fami_f16_t; /* IEEE binary16 bit pattern */
+
+long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode);
+int fami_pack_conv_weight_f16(const float* w_oihw, fami_f16_t* wp, int Co, int Ci, int kh, int kw, int mode,
+                               fami_stream_t stream);
+int fami_pack_conv_weights_batch_f16(const float* params, fami_f16_t* packed, const void* desc, int n,
+                                      fami_stream_t stream);
+/* y is fp16, or fp32 when out_f32 (heatmap-producing layers) */
+int fami_conv2d_fwd_f16(const fami_f16_t* x, const fami_f16_t* wp, const float* bias, void* y, int N, int H, int W,
+                         int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,
+                         int out_f32, fami_stream_t stream);
+int fami_conv2d_dgrad_f16(const fami_f16_t* dy, const fami_f16_t* wp, fami_f16_t* dx, int N, int H, int W, int Ci,
+                           int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                           fami_stream_t stream);
+int fami_conv2d_wgrad_f16(const fami_f16_t* x, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
+                           int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                           int accumulate, fami_stream_t stream);
+
+int fami_bn_stats_f16(const fami_f16_t* x, long P, int C, float* mean, float* invstd, float* running_mean,
+                       float* running_var, float momentum, float eps, float* ws, fami_stream_t stream);
+int fami_bn_train_fwd_f16(const fami_f16_t* x, const fami_f16_t* residual, fami_f16_t* y, const float* gamma,
+                           const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
+                           long P, int C, int relu, float momentum, float eps, float* ws, fami_stream_t stream);
+int fami_bn_apply_f16(const fami_f16_t* x, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, const fami_f16_t* residual, fami_f16_t* y, long P, int C, int relu,
+                       fami_stream_t stream);
+int fami_bn_bwd_f16(const fami_f16_t* dy, const fami_f16_t* x, const fami_f16_t* y, const float* mean,
+                     const float* invstd, const float* gamma, fami_f16_t* dx, float* dgamma, float* dbeta,
+                     fami_f16_t* dres, long P, int C, int relu, int acc_dx, int acc_param, int acc_dres, float* ws,
+                     fami_stream_t stream);
+int fami_channel_sum_f16(const fami_f16_t* x, long P, int C, float* out, int accumulate, float* ws,
+                          fami_stream_t stream);
+
+int fami_nchw_to_nhwc_f16(const float* src, fami_f16_t* dst, int N, int C, int H, int W, fami_stream_t stream);
+int fami_nhwc_to_nchw_f16(const fami_f16_t* src, float* dst, int N, int C, int H, int W, int accumulate,
+                           fami_stream_t stream);
+int fami_pack_frames_f16(const float* kf_nchw, const float* sup_nchw, fami_f16_t* frames_nhwc, int B, int S, int H,
+                          int W, fami_stream_t stream);
+int fami_copy_channels_f16(const fami_f16_t* src, fami_f16_t* dst, long P, int Cs, int src_off, int Cd,
+                            int dst_off, int Cc, int accumulate, fami_stream_t stream);
+int fami_axpby_f16(const fami_f16_t* a, const fami_f16_t* b, fami_f16_t* out, long n, float alpha, float beta,
+                    fami_stream_t stream);
+int fami_cast_add_f16(const float* src, fami_f16_t* dst, long n, int accumulate, fami_stream_t stream);
+int fami_fill_f16(fami_f16_t* out, long n, float v, fami_stream_t stream);
+int fami_fuse_sum_f16(int nterms, const fami_f16_t* const* x, const float* const* mean, const float* const* invstd,
+                       const float* const* gamma, const float* const* beta, const int* shift, fami_f16_t* y, int N,
+                       int H, int W, int C, int relu, fami_stream_t stream);
+int fami_relu_bwd_f16(const fami_f16_t* dy, const fami_f16_t* y, fami_f16_t* dx, long n, int accumulate,
+                       fami_stream_t stream);
+int fami_pool_relu_bwd_f16(const fami_f16_t* dy, const fami_f16_t* y, fami_f16_t* out, int N, int Hl, int Wl,
+                            int C, int shift, int relu, fami_stream_t stream);
+
+int fami_shift_bilinear_fwd_f16(const fami_f16_t* src, const float* t, fami_f16_t* out, int B, int H, int W, int C,
+                                 fami_stream_t stream);
+int fami_shift_bilinear_bwd_f16(const fami_f16_t* gout, const fami_f16_t* src, const float* t, fami_f16_t* gsrc,
+                                 float* gt, int B, int H, int W, int C, int acc_src, int acc_t, float* ws,
+                                 fami_stream_t stream);
+int fami_dcn_fwd_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_t* msk, const float* wp,
+                      const float* bias, fami_f16_t* y, int B, int H, int W, int C, int Co, int G, int kh, int kw,
+                      int stride, int pad, int dil, fami_stream_t stream);
+int fami_dcn_bwd_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_t* msk, const fami_f16_t* dy,
+                      const float* wpb, fami_f16_t* col, float* gx, fami_f16_t* goff, fami_f16_t* gmsk, int B,
+                      int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_off,
+                      fami_stream_t stream);
+int fami_dcn_bwd_det_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_t* msk, const fami_f16_t* dy, const float* wpb, fami_f16_t* col,
+                         fami_f16_t* gx, fami_f16_t* goff, fami_f16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
+                         int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
 
 #ifdef __cplusplus
 }

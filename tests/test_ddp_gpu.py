@@ -1,0 +1,119 @@
+"""Data-parallel equivalence on hardware without an 8-GPU box (SURVEY.md 4 item v; the reference's mechanism is
+torch.nn.DataParallel at engine/defaults/trainer.py:57-58): two ranks share the one MI355X (gloo process group -- RCCL
+refuses two ranks on one device), each takes its own shard of the minibatch, and
+  * rank r's gradients BEFORE the exchange equal a single-process run on shard r (bitwise, deterministic mode),
+  * the exchanged gradients equal the mean over ranks (bitwise: a two-term sum is order independent),
+  * parameters after Adam are identical on both ranks,
+  * the graph plans ('overlap': hipGraph segments cut at the bucket boundaries with the all-reduces issued between
+    segment launches; 'serial') reproduce the eager, hook-driven plan bit for bit.
+BatchNorm statistics stay per replica, as under DataParallel."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+S, H, W, B = 2, 128, 96, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import fami_pose_amd as fp
+        from fami_pose_amd.train import Trainer
+        from oracle import model as om
+        dev = torch.device('cuda:0')
+
+        def model():
+            orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(48), True, S, (H, W)), 5)
+            m = fp.build_model(fp.default_cfg(48, image_size=(W, H), num_sup=S), 'train')
+            m.load_state_dict(orc.state_dict())
+            return m.to(dev).set_deterministic(True)
+
+        gen = torch.Generator().manual_seed(100 + rank)            # this rank's shard of the global batch
+        kf, sup = torch.randn(B, 3, H, W, generator=gen).to(dev), torch.randn(B, 3 * S, H, W, generator=gen).to(dev)
+        joints = (torch.rand(B, 17, 2, generator=gen) * torch.tensor([W, H], dtype=torch.float32)).to(dev)
+        vis = (torch.rand(B, 17, generator=gen) < 0.8).float().to(dev)
+
+        # (1) single-process run on shard r
+        tr_a = Trainer(model(), use_graph=False, targets_from_joints=True, data_parallel=False)
+        assert not tr_a.ddp
+        tr_a.step(kf, sup, joints, vis)
+        g_a = tr_a.grad.clone()
+
+        # (2) two ranks, eager plan: all-reduces fired from the backward hooks
+        tr_b = Trainer(model(), use_graph=False, targets_from_joints=True, bucket_mb=8)
+        assert tr_b.ddp and tr_b.world == world
+        pre = torch.zeros_like(tr_b.grad)
+        inner = tr_b.reducer.allreduce
+
+        def spy(lo, hi):
+            pre[lo:hi].copy_(tr_b.grad[lo:hi])
+            return inner(lo, hi)
+        tr_b.reducer.allreduce = spy
+        tr_b.step(kf, sup, joints, vis)
+        assert torch.equal(pre, g_a), 'rank %d: pre-exchange gradients differ from the single-process run on its shard' % rank
+        both = [torch.empty_like(g_a.cpu()) for _ in range(world)]
+        dist.all_gather(both, g_a.cpu())
+        mean = (both[0] + both[1]) * 0.5
+        assert torch.equal(tr_b.grad.cpu(), mean), 'exchanged gradients are not the mean over ranks'
+        ps = [torch.empty_like(mean) for _ in range(world)]
+        dist.all_gather(ps, tr_b.flat.cpu())
+        assert torch.equal(ps[0], ps[1]), 'parameters diverged across ranks after Adam'
+        assert not torch.equal(tr_b.flat, tr_a.flat)
+        # BatchNorm statistics are per replica
+        rm = [torch.empty(64) for _ in range(world)]
+        dist.all_gather(rm, tr_b.model.hrnet.bn1.running_mean.cpu())
+        assert not torch.equal(rm[0], rm[1])
+
+        # (3) graph plans == eager plan
+        for plan in ('overlap', 'serial'):
+            os.environ['FAMI_DDP_PLAN'] = plan
+            tr_c = Trainer(model(), use_graph=True, targets_from_joints=True, bucket_mb=8)
+            tr_c.step(kf, sup, joints, vis)
+            assert torch.equal(tr_c.flat, tr_b.flat), plan
+            summ = tr_c.plan_summary()
+            if plan == 'overlap':
+                assert summ['graphs'] >= 4 and summ['allreduces'] == len(tr_c.reducer.ranges()), summ
+            else:
+                assert summ['graphs'] == 2, summ
+            tr_c.step(kf, sup, joints, vis)                         # replay keeps working
+            assert torch.isfinite(tr_c.loss_parts).all()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok'))
+    except Exception as e:       # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put((rank, 'FAILED: %s\n%s' % (e, traceback.format_exc())))
+
+
+def test_two_ranks_on_one_gpu_equal_their_shards(dev):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, msg = q.get(timeout=900)
+        res[r] = msg
+    for p in procs:
+        p.join(60)
+    assert res == {0: 'ok', 1: 'ok'}, res

@@ -61,6 +61,7 @@ CONV_CASES = [
     (1, 9, 7, 36, 72, 1, 1, 0, 1, True),        # 1x1 on the 32x32-tile kernel with K and N tails
     (3, 7, 5, 32, 64, 3, 1, 1, 1, True),        # LDS weight gradient: odd map, 2 / 4 channel tiles
     (2, 5, 3, 16, 16, 3, 1, 1, 1, False),       # map narrower than one K step
+    (20, 96, 72, 48, 48, 3, 1, 1, 1, False),    # the benchmark's dominant launch at full size (N = 20 frames, grid 552960)
 ]
 
 

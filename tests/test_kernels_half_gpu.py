@@ -1,8 +1,8 @@
-"""bf16 activation mode (BASELINE config 3) of the HIP kernels, through the C ABI, against torch fp32 evaluated on
-the SAME bf16-rounded operands.  What separates the two is then only (a) the bf16 rounding of each kernel's
-output (relative 2^-9 = 2e-3 per element) and (b) fp32 summation order, so the tolerance is 1e-2 of the tensor's
-max magnitude for activations / activation gradients and 2e-3 for fp32 results (weight / BN-parameter gradients,
-statistics)."""
+"""16-bit activation modes of the HIP kernels -- bf16 (BASELINE config 3) and fp16 (BASELINE config 5) -- through the
+C ABI, against torch fp32 evaluated on the SAME 16-bit-rounded operands.  What separates the two is then only (a) the
+rounding of each kernel's output to the storage type (relative 2^-9 = 2e-3 per element for bf16, 2^-12 = 2.4e-4 for
+fp16) and (b) fp32 summation order.  Tolerances (of the tensor's max magnitude): activations / activation gradients
+1e-2 (bf16) and 1.5e-3 (fp16); fp32 results (weight / BN-parameter gradients, statistics, heatmap outputs) 2e-3 / 1e-3."""
 import pytest
 import torch
 import torch.nn as nn
@@ -18,8 +18,20 @@ def lds_mode(request):
     lib().cdll.fami_conv_tune_lds(request.param)
     yield request.param
     lib().cdll.fami_conv_tune_lds(-1)
-BF = torch.bfloat16
+BF = torch.bfloat16          # module globals re-pointed by the `half` fixture below (bf16 | fp16)
 ACT_TOL, F32_TOL = 1e-2, 2e-3
+
+
+@pytest.fixture(params=['bf16', 'f16'], autouse=True)
+def half(request):
+    """Every test of this module runs once per 16-bit storage type."""
+    global BF, ACT_TOL, F32_TOL
+    if request.param == 'bf16':
+        BF, ACT_TOL, F32_TOL = torch.bfloat16, 1e-2, 2e-3
+    else:
+        BF, ACT_TOL, F32_TOL = torch.float16, 1.5e-3, 1e-3
+    yield request.param
+    BF, ACT_TOL, F32_TOL = torch.bfloat16, 1e-2, 2e-3
 
 
 def _eng(dev):
@@ -28,7 +40,7 @@ def _eng(dev):
 
 
 def rb(x):
-    """round to bf16, keep fp32 storage (the reference operand)"""
+    """round to the 16-bit storage type, keep fp32 storage (the reference operand)"""
     return x.to(BF).float()
 
 
@@ -65,7 +77,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_bf16(dev, case, lds_mode):
+def test_conv_half(dev, case, lds_mode):
     N, H, W, Ci, Co, k, s, p, d, has_bias = case
     torch.manual_seed(hash(case) % 1000)
     conv = nn.Conv2d(Ci, Co, k, s, p, d, bias=has_bias)
@@ -94,7 +106,7 @@ def test_conv_bf16(dev, case, lds_mode):
 
 
 @pytest.mark.parametrize("C,relu,res", [(48, True, True), (96, False, False), (384, True, True)])
-def test_bn_bf16(dev, C, relu, res):
+def test_bn_half(dev, C, relu, res):
     torch.manual_seed(C)
     N, H, W = 3, 10, 7
     bn = nn.BatchNorm2d(C, momentum=0.1)
@@ -127,7 +139,7 @@ def test_bn_bf16(dev, C, relu, res):
     assert relerr(eng.param_grads[id(bd.bias)], bn.bias.grad) < 5 * F32_TOL
 
 
-def test_fuse_concat_shift_dcn_bf16(dev):
+def test_shift_dcn_half(dev):
     from oracle import ops as O
     from fami_pose_amd.engine import T
     torch.manual_seed(3)

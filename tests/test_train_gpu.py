@@ -1,0 +1,192 @@
+"""The train step around the model on the MI355X (engine/core/functions/alignment_mi_function_term6_1.py:104-174,
+engine/defaults/trainer.py:54-89, engine/defaults/checkpoints.py:45-107, posetimation/optimizer/scheduler.py:14-35):
+per-step PCK on the device, checkpoint save / resume into a fresh trainer, the epoch's last (smaller) batch under
+graph replay, the LR schedule under graph replay, frozen -> trained -> frozen weight images.
+
+Bitwise comparisons run with `set_deterministic(True)`: the DCN input-gradient scatter then adds 64-bit fixed-point
+integers instead of floats, and every other kernel of the step already has a fixed summation order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fami_pose_amd as fp
+from oracle import model as om, ops as oops
+
+pytestmark = pytest.mark.gpu
+
+S, H, W, B = 2, 128, 96, 2
+
+
+def _model(seed=5, freeze=False, phase='train'):
+    orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(48), phase == 'train', S, (H, W)), seed)
+    model = fp.build_model(fp.default_cfg(48, image_size=(W, H), num_sup=S, freeze_backbone=freeze), phase)
+    model.load_state_dict(orc.state_dict())
+    return model, orc
+
+
+def _batch(dev, seed=9, b=B):
+    gen = torch.Generator().manual_seed(seed)
+    kf, sup = torch.randn(b, 3, H, W, generator=gen), torch.randn(b, 3 * S, H, W, generator=gen)
+    joints = torch.rand(b, 17, 2, generator=gen) * torch.tensor([W, H], dtype=torch.float32)
+    vis = (torch.rand(b, 17, generator=gen) < 0.8).float()
+    return tuple(t.to(dev) for t in (kf, sup, joints, vis))
+
+
+def test_pck_inside_the_step_matches_reference_accuracy(dev):
+    """core fn :159-163 calls accuracy(pred, target) and accuracy(kf_bb, target) every iteration on host copies of four
+    heatmap stacks; Trainer.step produces the same numbers with three launches each and no copy."""
+    from fami_pose_amd.train import Trainer
+    model, _ = _model()
+    tr = Trainer(model.to(dev), use_graph=False, targets_from_joints=True)
+    kf, sup, joints, vis = _batch(dev)
+    final, kf_hm = tr.step(kf, sup, joints, vis)[:2]
+    tg = np.zeros((B, 17, H // 4, W // 4), np.float32)
+    for b in range(B):
+        j3 = np.concatenate([joints[b].cpu().numpy(), np.zeros((17, 1), np.float32)], 1)
+        v3 = np.repeat(vis[b].cpu().numpy()[:, None], 3, 1)
+        tg[b], _ = oops.generate_heatmaps(j3, v3, 3, np.array([W, H]), np.array([W // 4, H // 4]), 17)
+    got = tr.accuracy()
+    for (acc, avg, cnt), hm in zip(got, (final, kf_hm)):
+        a0, avg0, cnt0, _ = oops.accuracy(hm.cpu().numpy(), tg)
+        assert cnt == cnt0 and avg == pytest.approx(avg0, abs=1e-6)
+        assert np.allclose(acc, a0, atol=1e-6)
+    # a crafted case with known answers: perfect prediction, a miss, an invisible joint, an ignored target at x <= 1
+    from fami_pose_amd._lib import lib
+    hm_t = torch.zeros(1, 4, 24, 18)
+    hm_p = torch.zeros(1, 4, 24, 18)
+    hm_t[0, 0, 10, 9] = 1.0; hm_p[0, 0, 10, 9] = 0.7           # hit
+    hm_t[0, 1, 10, 9] = 1.0; hm_p[0, 1, 20, 2] = 0.9           # miss
+    hm_t[0, 2, 5, 1] = 1.0; hm_p[0, 2, 5, 1] = 1.0             # target at x = 1: ignored
+    hm_p[0, 3] = -1.0                                          # no target at all (all-zero map -> (0, 0)): ignored
+    out = torch.zeros(7, device=dev)
+    iws = torch.empty(8, dtype=torch.int64, device=dev)
+    mws = torch.empty(8, device=dev)
+    lib().call('fami_pck_accuracy_f32', hm_p.to(dev).data_ptr(), hm_t.to(dev).data_ptr(), out.data_ptr(), iws.data_ptr(),
+               mws.data_ptr(), 1, 4, 24, 18, 0.5, torch.cuda.current_stream(dev).cuda_stream)
+    a0, avg0, cnt0, _ = oops.accuracy(hm_p.numpy(), hm_t.numpy())
+    assert out.cpu().tolist() == pytest.approx(list(a0) + [avg0, cnt0])
+    assert out.cpu().tolist() == pytest.approx([0.5, 1.0, 0.0, -1.0, -1.0, 0.5, 2.0])
+
+
+def _run(dev, steps, use_graph, resume_from=None, save_at=None, tmp=None, batches=None):
+    from fami_pose_amd import checkpoint as ck
+    from fami_pose_amd.train import Trainer
+    model, _ = _model()
+    model = model.to(dev).set_deterministic(True)
+    tr = Trainer(model, lr=1e-3, use_graph=use_graph, targets_from_joints=True)
+    start = 0
+    if resume_from is not None:
+        _, _, start = ck.resume(model, tr, resume_from)
+    losses = []
+    for k in range(start, steps):
+        tr.step(*batches[k])
+        losses.append(tr.loss_parts.clone())
+        if save_at is not None and k + 1 == save_at:
+            ck.save_checkpoint(k, tmp, model, tr)       # begin_epoch = k -> resume continues at k + 1
+    return tr, losses
+
+
+def test_deterministic_steps_and_checkpoint_resume(dev, tmp_path):
+    """(a) two identical runs are bitwise identical (deterministic DCN backward); (b) hipGraph replay is bitwise the
+    eager launch sequence; (c) train 2 steps, save, resume into a FRESH model + Trainer, take step 3: parameters, Adam
+    moments, BatchNorm buffers and loss equal the uninterrupted 3-step run bit for bit (checkpoints.py:45-107)."""
+    from fami_pose_amd import checkpoint as ck
+    batches = [_batch(dev, 9 + k) for k in range(3)]
+    tr_a, la = _run(dev, 3, False, batches=batches)
+    tr_b, lb = _run(dev, 3, False, batches=batches)
+    assert torch.equal(tr_a.flat, tr_b.flat) and all(torch.equal(x, y) for x, y in zip(la, lb))
+    tr_g, lg = _run(dev, 3, True, batches=batches)
+    assert torch.equal(tr_a.flat, tr_g.flat) and all(torch.equal(x, y) for x, y in zip(la, lg))
+    # the capture warm-up is rolled back completely: three steps -> counters at 3 (one BN call per step for the stem)
+    assert int(tr_g.model.hrnet.bn1.num_batches_tracked) == 3 == int(tr_a.model.hrnet.bn1.num_batches_tracked)
+    assert int(tr_g.model.feat_global_offset_layers[1].bn.num_batches_tracked) == 3 * S
+
+    folder = str(tmp_path / 'ckpt')
+    _run(dev, 2, False, save_at=2, tmp=folder, batches=batches)
+    path = ck.get_latest_checkpoint(folder)
+    assert os.path.basename(path) == 'epoch_1_state.pth'
+    for use_graph in (False, True):
+        tr_r, lr_ = _run(dev, 3, use_graph, resume_from=path, batches=batches)
+        assert len(lr_) == 1 and torch.equal(lr_[0], la[2])
+        assert torch.equal(tr_r.flat, tr_a.flat)
+        assert torch.equal(tr_r.opt.m, tr_a.opt.m) and torch.equal(tr_r.opt.v, tr_a.opt.v)
+        assert torch.equal(tr_r.opt.state, tr_a.opt.state)
+        for (n1, b1), (n2, b2) in zip(tr_r.model.named_buffers(), tr_a.model.named_buffers()):
+            assert n1 == n2 and torch.equal(b1, b2), n1
+
+
+def test_smaller_last_batch_under_graph_replay(dev):
+    """The reference DataLoader has no drop_last: the last batch of an epoch is smaller.  A graph-mode Trainer keeps
+    one captured plan per batch shape; the sequence B=2, B=1, B=2 must equal the eager sequence bit for bit."""
+    from fami_pose_amd.train import Trainer
+    seq = [_batch(dev, 20, 2), _batch(dev, 21, 1), _batch(dev, 22, 2)]
+    res = []
+    for use_graph in (False, True):
+        model, _ = _model()
+        tr = Trainer(model.to(dev).set_deterministic(True), use_graph=use_graph, targets_from_joints=True)
+        ls = []
+        for bt in seq:
+            out = tr.step(*bt)
+            assert out[0].shape[0] == bt[0].shape[0]
+            ls.append(tr.loss_parts.clone())
+        res.append((tr.flat.clone(), ls))
+        if use_graph:
+            assert len(tr._cache) == 2
+    assert torch.equal(res[0][0], res[1][0]) and all(torch.equal(x, y) for x, y in zip(res[0][1], res[1][1]))
+    with pytest.raises(ValueError):
+        tr.step(seq[0][0], seq[1][1], seq[0][2], seq[0][3])
+
+
+def test_lr_schedule_drives_captured_adam(dev):
+    """MultiStepLR (scheduler.py:14-35; TRAIN.LR_STEP / LR_FACTOR) writes the device-resident learning rate: the captured
+    hipGraph keeps replaying and the very next update is gamma times smaller.  Changing betas re-captures."""
+    from fami_pose_amd.train import MultiStepLR, Trainer
+    model, _ = _model()
+    tr = Trainer(model.to(dev).set_deterministic(True), lr=1e-3, use_graph=True, targets_from_joints=True)
+    sched = MultiStepLR(tr, [1, 2], 0.1)
+    bt = _batch(dev)
+    w = model.agg_final_layer.weight
+    deltas = []
+    for epoch in range(3):
+        before = w.detach().clone()
+        tr.step(*bt)
+        deltas.append((w.detach() - before).abs().max().item())
+        sched.step()
+    # Adam's update is ~lr in magnitude for its first steps
+    assert deltas[0] == pytest.approx(1e-3, rel=0.05)
+    assert deltas[1] == pytest.approx(1e-4, rel=0.35) and deltas[2] == pytest.approx(1e-5, rel=0.5)
+    assert tr.opt.state[1].item() == pytest.approx(1e-5, rel=1e-5) and len(tr._cache) == 1
+    plan0 = list(tr._cache.values())[0][0]
+    tr.opt.set_hyper(betas=(0.8, 0.99))
+    tr.step(*bt)
+    assert list(tr._cache.values())[0][0] is not plan0          # re-captured with the new kernel arguments
+
+
+def test_frozen_weight_image_is_not_reused_after_training(dev):
+    """freeze -> forward (packed images cached on the frozen parameters) -> unfreeze -> train -> freeze -> forward must
+    use the trained weights (the cache key did not see in-place arena updates)."""
+    from fami_pose_amd.train import Trainer
+    model, _ = _model()
+    model = model.to(dev).set_deterministic(True)
+    kf, sup, joints, vis = _batch(dev)
+    tr = Trainer(model, lr=1e-2, use_graph=False, targets_from_joints=True)     # parameters move into the arena
+    model.hrnet.freeze_weight()
+    with torch.no_grad():
+        y0 = model(kf, sup)[0].clone()
+    for p in model.hrnet.parameters():
+        p.requires_grad = True
+    for _ in range(2):
+        tr.step(kf, sup, joints, vis)
+    model.hrnet.freeze_weight()
+    with torch.no_grad():
+        y1 = model(kf, sup)[0].clone()
+    fresh, _ = _model()
+    fresh.load_state_dict(model.state_dict())
+    fresh = fresh.to(dev)
+    fresh.hrnet.freeze_weight()
+    with torch.no_grad():
+        y2 = fresh(kf, sup)[0]
+    assert (y1 - y0).abs().max().item() > 1e-4           # training moved the output
+    assert torch.equal(y1, y2)                           # and the re-frozen model runs on the trained weights
