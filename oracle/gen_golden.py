@@ -385,6 +385,56 @@ def g9_alignment(ns):
     _save('g9_alignment_v15.npz', **out)
 
 
+def g14_posetrack_json(ns_unused):
+    """The reference's PoseTrack JSON writer (PoseTrack_Alignment.evaluate, :883-1017) run on synthetic predictions:
+    inputs and the written files are stored as one JSON fixture (data only)."""
+    import json
+    import tempfile
+    import types
+    ns = rh.load_posetrack_evaluate()
+    rng = np.random.RandomState(14)
+    out = {'cases': []}
+    for is18 in (False, True):
+        with tempfile.TemporaryDirectory() as tmp:
+            annot = os.path.join(tmp, 'annot')
+            os.makedirs(annot)
+            zf = 6 if is18 else 8
+            vids = [('images/bonn/000001_bonn', 5, 'images'), ('images/mpii_5sec/024159_mpii', 4, 'annolist')]
+            annots = {}
+            for vid, nfr, style in vids:
+                fname = vid.split('/')[-1] + '.json'
+                first = vid + '/' + str(0 if is18 else 1).zfill(zf) + '.jpg'
+                if style == 'images':
+                    data = {'images': [{'file_name': first, 'nframes': nfr}]}
+                else:
+                    data = {'annolist': [{'image': [{'name': first}]}] + [{'image': [{'name': 'x'}]} for _ in range(nfr - 1)]}
+                annots[fname] = data
+                with open(os.path.join(annot, fname), 'w') as f:
+                    json.dump(data, f)
+            # detections: video 1 frames {first+1: 2 people, first+3: 1 person}; video 2 frame {first: 1 person}
+            f0 = 0 if is18 else 1
+            names = ['/data/posetrack/' + vids[0][0] + '/' + str(f0 + 1).zfill(zf) + '.jpg',
+                     '/data/posetrack/' + vids[0][0] + '/' + str(f0 + 3).zfill(zf) + '.jpg',
+                     '/data/posetrack/' + vids[1][0] + '/' + str(f0).zfill(zf) + '.jpg']
+            fmap = {names[0]: [0, 2], names[1]: [1], names[2]: [3]}
+            preds = np.concatenate([rng.uniform(0, 500, (4, 17, 2)), rng.uniform(0, 1, (4, 17, 1))], 2)
+            boxes = np.concatenate([rng.uniform(50, 400, (4, 2)), rng.uniform(0.5, 2, (4, 2)),
+                                    rng.uniform(1e3, 1e5, (4, 1)), rng.uniform(0.3, 1, (4, 1))], 1)
+            fake = types.SimpleNamespace(phase='validate', annotation_dir=annot, is_posetrack18=is18)
+            outdir = os.path.join(tmp, 'out')
+            ns.PoseTrack_Alignment.evaluate(fake, None, preds, outdir, boxes, fmap)
+            files = {}
+            resdir = os.path.join(outdir, 'val_set_json_results')
+            for fn in sorted(os.listdir(resdir)):
+                with open(os.path.join(resdir, fn)) as f:
+                    files[fn] = json.load(f)
+            out['cases'].append({'is_posetrack18': is18, 'annotations': annots, 'filenames_map': fmap,
+                                 'preds': preds.tolist(), 'boxes': boxes.tolist(), 'written': files})
+    with open(os.path.join(OUT, 'g14_posetrack_json.json'), 'w') as f:
+        json.dump(out, f)
+    print('g14_posetrack_json.json', os.path.getsize(os.path.join(OUT, 'g14_posetrack_json.json')), 'bytes')
+
+
 def main():
     assert rh.available(), 'needs /root/reference (build container only)'
     os.makedirs(OUT, exist_ok=True)
@@ -404,6 +454,7 @@ def main():
     g6_targets(ns)
     g7_decode(ns)
     g9_alignment(ns)
+    g14_posetrack_json(ns)
 
 
 if __name__ == '__main__':

@@ -133,6 +133,69 @@ def load():
     return ns
 
 
+def load_posetrack_evaluate():
+    """-> the reference's PoseTrack_Alignment class (datasets/zoo/posetrack/PoseTrack_Alignment.py), imported only so
+    that its `evaluate` method (:883-1037, the PoseTrack JSON writer) can be run on synthetic predictions.  Everything
+    the module imports but the image lacks is a stand-in that `evaluate` never touches, with three exceptions that it
+    does reach: the two joint-name lists (`datasets.zoo.coco.COCO_joint`, `datasets.zoo.posetrack.pose_topology.
+    POSETRACK_joint` -- modules MISSING from the released reference, keypoints_ord.py:10-11; the standard COCO-17 /
+    PoseTrack-15 orders are supplied) and `evaluate_simple.evaluate` (vendored poseval: needs shapely + ground truth;
+    replaced by a function returning zeros AFTER the JSON files have been written)."""
+    ns = load()
+    import numpy as np
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    coco = ['nose', 'left_eye', 'right_eye', 'left_ear', 'right_ear', 'left_shoulder', 'right_shoulder', 'left_elbow',
+            'right_elbow', 'left_wrist', 'right_wrist', 'left_hip', 'right_hip', 'left_knee', 'right_knee',
+            'left_ankle', 'right_ankle']
+    ptk = ['right_ankle', 'right_knee', 'right_hip', 'left_hip', 'left_knee', 'left_ankle', 'right_wrist',
+           'right_elbow', 'right_shoulder', 'left_shoulder', 'left_elbow', 'left_wrist', 'neck', 'nose', 'head_top']
+    _pkg('datasets.zoo', os.path.join(REF, 'datasets', 'zoo'))
+    mod('datasets.zoo.coco', COCO_joint=coco, COCO_joint_paris=[])
+    _pkg('datasets.zoo.posetrack', os.path.join(REF, 'datasets', 'zoo', 'posetrack'))
+    mod('datasets.zoo.posetrack.pose_topology', POSETRACK_joint=ptk)
+    _pkg('datasets.zoo.jhmdb')
+    mod('datasets.zoo.jhmdb.pose_topology', JHMDB_Keypoint_Ordering=[])
+    mod('pycocotools')
+    mod('pycocotools.coco', COCO=object)
+    mod('termcolor', colored=lambda s, *a, **k: s)
+    # `from datasets.process import ...`: the package __init__ is broken as shipped (SURVEY 2.3 #5); expose the names
+    # PoseTrack_Alignment imports from the sub-modules that do import
+    proc = sys.modules['datasets.process']
+    aff = importlib.import_module('datasets.process.affine_transform')
+    pp = importlib.import_module('datasets.process.pose_process')
+    hp = importlib.import_module('datasets.process.heatmaps_process')
+    st = importlib.import_module('datasets.process.structure.data_format')
+    for m, names in ((aff, ('get_affine_transform', 'exec_affine_transform', 'dark_get_affine_transform')),
+                     (pp, ('fliplr_joints', 'half_body_transform')), (hp, ('generate_heatmaps',)),
+                     (st, ('convert_data_to_annorect_struct',))):
+        for n in names:
+            setattr(proc, n, getattr(m, n))
+    mod('datasets.transforms', build_transforms=lambda *a, **k: None)
+    mod('datasets.zoo.base', VideoDataset=object)
+    sys.modules['engine.defaults.constant'].DATASET_REGISTRY = sys.modules['engine.defaults.constant'].DATASET_REGISTRY
+    cv2 = sys.modules['cv2']
+    for n in ('IMREAD_COLOR', 'IMREAD_IGNORE_ORIENTATION', 'COLOR_BGR2RGB', 'INTER_LINEAR'):
+        setattr(cv2, n, 0)
+    pu = _load_by_path('ref_posetrack_utils', 'datasets/zoo/posetrack/posetrack_utils/posetrack_utils.py')
+    calls = []
+    es = types.SimpleNamespace(evaluate=lambda annot_dir, out_dir, eval_track=False: (calls.append(out_dir), [np.zeros(8)])[1])
+    mod('datasets.zoo.posetrack.posetrack_utils', video2filenames=pu.video2filenames, evaluate_simple=es)
+    _pkg('thirdparty')
+    mod('thirdparty.clustering', k_means=None)
+    m = _load_by_path('datasets.zoo.posetrack.PoseTrack_Alignment', 'datasets/zoo/posetrack/PoseTrack_Alignment.py')
+    ns.PoseTrack_Alignment = m.PoseTrack_Alignment
+    ns.convert_data_to_annorect_struct = st.convert_data_to_annorect_struct
+    ns.video2filenames = pu.video2filenames
+    return ns
+
+
 def ref_cfg(width=48, freeze=False):
     from .model import make_cfg
     c = make_cfg(width=width, freeze=freeze)

@@ -190,3 +190,45 @@ def test_frozen_weight_image_is_not_reused_after_training(dev):
         y2 = fresh(kf, sup)[0]
     assert (y1 - y0).abs().max().item() > 1e-4           # training moved the output
     assert torch.equal(y1, y2)                           # and the re-frozen model runs on the trained weights
+
+
+def test_evaluate_loop_accumulates_like_the_reference(dev, tmp_path):
+    """The validation loop (core fn :222-328) on the HIP path: decode + PCK on device, accumulation arrays as the
+    reference fills them, then the PoseTrack JSON files -- against oracle forward + oracle decode + oracle accuracy."""
+    import json
+    from fami_pose_amd import evaluate as ev
+    model, orc = _model(seed=7, phase=fp.VAL_PHASE)
+    model = model.to(dev)
+    orc.eval()
+    gen = torch.Generator().manual_seed(3)
+    batches, want_preds, want_acc = [], [], [0.0, 0]
+    names_all = ['/d/images/bonn/000001_bonn/0000000%d.jpg' % i for i in (1, 2, 4)]
+    k = 0
+    for b in (2, 1):
+        kf, sup = torch.randn(b, 3, H, W, generator=gen), torch.randn(b, 3 * S, H, W, generator=gen)
+        tgt = torch.rand(b, 17, H // 4, W // 4, generator=gen)
+        meta = {'image': names_all[k:k + b], 'center': np.random.RandomState(k).uniform(100, 300, (b, 2)).astype(np.float32),
+                'scale': np.random.RandomState(k + 9).uniform(0.8, 2.0, (b, 2)).astype(np.float32),
+                'score': np.random.RandomState(k + 5).uniform(0.3, 1.0, b)}
+        k += b
+        batches.append((kf, sup, tgt, meta))
+        with torch.no_grad():
+            f0, _ = orc(kf, sup)
+        p0, m0 = oops.get_final_preds(f0.numpy().copy(), meta['center'], meta['scale'])
+        want_preds.append(np.concatenate([p0, m0], 2))
+        _, avg, cnt, _ = oops.accuracy(f0.numpy(), tgt.numpy())
+        want_acc[0] += avg * cnt
+        want_acc[1] += cnt
+    acc = ev.evaluate_loop(model, batches, 3)
+    want = np.concatenate(want_preds)
+    assert np.abs(acc.all_preds[:, :, :2] - want[:, :, :2]).max() < 1e-2 and np.abs(acc.all_preds[:, :, 2] - want[:, :, 2]).max() < 1e-3
+    assert acc.acc_cnt[0] == want_acc[1] and acc.accuracy(0) == pytest.approx(want_acc[0] / want_acc[1], abs=1e-6)
+    assert list(acc.filenames_map) == names_all and acc.idx == 3
+    annot = tmp_path / 'annot'
+    annot.mkdir()
+    for nm in ('000001_bonn.json', 'other.json'):
+        (annot / nm).write_text(json.dumps({'images': [{'file_name': 'images/bonn/%s/00000001.jpg' % nm[:-5], 'nframes': 4}]}))
+    written = ev.write_posetrack_results(acc.all_preds, acc.all_boxes, acc.filenames_map, str(annot), str(tmp_path / 'res'))
+    (path,) = written
+    data = json.load(open(path))['annolist']
+    assert [el['imgnum'][0] for el in data] == [1, 2, 3, 4] and data[2]['annorect'][0]['score'] == [0]      # frame 3: dummy
