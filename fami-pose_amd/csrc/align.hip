@@ -492,6 +492,225 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
   dcn_reduce_store<T, NT>(p, acc, red, m0);
 }
 
+
+// ------------------------------------------------------------------ DCN forward, LDS-window form (default where eligible)
+// The register-fed kernel above is bound by the L1's one-cache-line-per-clock rate: every one of its 11.9 M bilinear
+// corner loads (B = 4) is a scattered 16-byte global access, 64 distinct lines per wave instruction (~19 us).  Here a
+// workgroup of 8 waves owns a TH x TW tile of output pixels and
+//   * copies the input WINDOW the tile can reach -- tile + dilation halo + R pixels of offset reach on every side --
+//     once into LDS, coalesced, zero-filled outside the image (so the four corners of an in-window sample need no
+//     validity logic: zero padding IS the "corner contributes only inside the map" rule).  Pixels are padded to C + 4
+//     elements so that neighbouring pixels start in different bank groups;
+//   * gathers every bilinear corner with one ds_read (16 bytes f32 / 8 bytes 16-bit) from that window; a sample whose
+//     offset leaves the window (|offset| >= R: never for realistic offsets, 6e-5 of N(0,1) draws at R = 4) takes the
+//     per-corner global path of the older kernels, so any offset magnitude stays exact;
+//   * each wave owns whole 16-pixel sub-tiles and walks ALL of K for them: no split-K, no cross-wave reduction, no
+//     barrier after the fill.  The MFMA operand comes from the registers of the lane that gathered it, as in the
+//     register-fed kernel;
+//   * offsets and masks (77 % of the bytes) are read straight from HBM, two "quad groups" ahead of their use.  Columns
+//     are GROUP-major here (item = g*K + tap, the order of the offset tensor itself) and lane (pixel, kq) of a quad
+//     group takes the 4 consecutive items 16Q + 4kq .. +3: its 4 offset pairs are one 32-byte run and its 4 masks
+//     one 16-byte run, and the 4 kq lanes of a pixel cover 128 contiguous bytes -- whole lines per pixel.
+// Weight image: wq[((Q*4 + j)*NTt + nt)*256 + lane*4 + t] = W[nt*16 + (lane&15)][g*cg + t][tap], item 16Q + 4(lane>>4) + j.
+template <typename T>
+struct DcnWinArgs {
+  const T* x;
+  const T* off;
+  const T* msk;       // may be null => 1
+  const float* wq;
+  const float* bias;
+  T* y;
+  int B, H, W, C, Ho, Wo, Co, G, K, kw, pad, dil;
+  int TH, TW, tilesX, tilesY, R, WR, WC, PS;  // window rows / cols, LDS elements per window pixel (C + 4)
+  int NQ, NTt, nsub;
+};
+
+__global__ void dcn_pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int Co, int C, int K, int G,
+                                   int NQ, int NTt) {
+  const long total = (long)NQ * 4 * NTt * 256;
+  const int cg = C / G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int j = (int)(r & 3), Q = (int)(r >> 2);
+    const int item = 16 * Q + 4 * (lane >> 4) + j, co = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (item < G * K && co < Co) {
+      const int g = item / K, tap = item - g * K;
+      v = w[((long)co * C + g * cg + t) * K + tap];
+    }
+    wq[i] = v;
+  }
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(512) void dcn_fwd_win_kernel(DcnWinArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  T* win = reinterpret_cast<T*>(wsm);      // [WR][WC][PS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = lane & 15, kq = lane >> 4;
+  int t, unused;
+  xcd_tile(1, t, unused);                  // neighbouring tiles (overlapping windows) on one XCD's L2
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY, b = t / p.tilesY;
+  const int oy0 = ty * p.TH, ox0 = tx * p.TW;
+  const int wy0 = oy0 - p.pad - p.R, wx0 = ox0 - p.pad - p.R;   // window origin in input coordinates (stride 1)
+  const int GK = p.G * p.K, GK2 = GK * 2;
+  const T* xb = p.x + (long)b * p.H * p.W * p.C;
+  const long mb = (long)b * p.Ho * p.Wo;
+
+  // ---- this lane's items: offsets / masks of quad group Q for pixel `m` (clamped addresses for padding lanes)
+  const int nitem = GK;
+  auto load_om = [&](long m, int Q, f32x4 (&o)[2], f32x4& mk) {
+    int it0 = 16 * Q + 4 * kq;
+    if (it0 + 4 > nitem) it0 = nitem - 4;          // padding items: any valid address (their weights are zero)
+    const T* po = p.off + m * GK2 + it0 * 2;
+    o[0] = ld4(po);
+    o[1] = ld4(po + 4);
+    mk = p.msk ? ld4(p.msk + m * GK + it0) : f32x4{1.f, 1.f, 1.f, 1.f};
+  };
+
+  // first sub-tile of this wave: start its offset stream before the window fill
+  const int npx = p.TH * p.TW;
+  auto pixel_of = [&](int sub, int& oy, int& ox, bool& valid) {
+    const int i = sub * 16 + row;
+    const int py = i / p.TW, px = i - py * p.TW;
+    oy = oy0 + py;
+    ox = ox0 + px;
+    valid = i < npx && oy < p.Ho && ox < p.Wo;
+  };
+  f32x4 o_nx[2][2], m_nx[2];
+  {
+    int oy, ox;
+    bool v;
+    pixel_of(wave, oy, ox, v);
+    const long m = v ? mb + (long)oy * p.Wo + ox : mb;
+    if (wave < p.nsub) {
+      load_om(m, 0, o_nx[0], m_nx[0]);
+      load_om(m, p.NQ > 1 ? 1 : 0, o_nx[1], m_nx[1]);
+    }
+  }
+
+  // ---- window fill: 16-byte pieces, zero outside the image
+  {
+    constexpr int EPP = 16 / (int)sizeof(T);        // elements per piece
+    const int ppp = p.C / EPP;                      // pieces per pixel
+    const int total = p.WR * p.WC * ppp;
+    for (int i0 = tid; i0 < total; i0 += 512 * 4) {
+      uint4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 512;
+        v[u] = uint4{0u, 0u, 0u, 0u};
+        dst[u] = -1;
+        if (i < total) {
+          const int px = i / ppp, pc = i - px * ppp;
+          const int wy = px / p.WC, wx = px - wy * p.WC;
+          const int yy = wy0 + wy, xx = wx0 + wx;
+          dst[u] = px * p.PS + pc * EPP;
+          if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+            v[u] = *reinterpret_cast<const uint4*>(xb + ((long)yy * p.W + xx) * p.C + pc * EPP);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(win + dst[u]) = v[u];
+    }
+  }
+  __syncthreads();
+
+  const int rowb = p.WC * p.PS;                    // window elements per row
+  const float Rlo = (float)(wy0), Clo = (float)(wx0);
+  for (int sub = wave; sub < p.nsub; sub += 8) {
+    int oy, ox;
+    bool valid;
+    pixel_of(sub, oy, ox, valid);
+    const long m = valid ? mb + (long)oy * p.Wo + ox : mb;
+    const int by = oy - p.pad, bx = ox - p.pad;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sub != wave) {                              // later sub-tiles of this wave: restart the offset stream
+      load_om(m, 0, o_nx[0], m_nx[0]);
+      load_om(m, p.NQ > 1 ? 1 : 0, o_nx[1], m_nx[1]);
+    }
+    for (int Q = 0; Q < p.NQ; ++Q) {
+      f32x4 o[2] = {o_nx[0][0], o_nx[0][1]};
+      f32x4 mk = m_nx[0];
+      o_nx[0][0] = o_nx[1][0]; o_nx[0][1] = o_nx[1][1]; m_nx[0] = m_nx[1];
+      if (Q + 2 < p.NQ) load_om(m, Q + 2, o_nx[1], m_nx[1]);
+      int it0 = 16 * Q + 4 * kq;
+      const bool padq = it0 + 4 > nitem;            // this lane's 4 items are padding (only in the last quad group)
+      if (padq) it0 = nitem - 4;
+      f32x4 val[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int item = it0 + j;
+        const int g = item / p.K, tap = item - g * p.K;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const float oyv = j < 2 ? o[0][2 * j] : o[1][2 * j - 4], oxv = j < 2 ? o[0][2 * j + 1] : o[1][2 * j - 3];
+        const float mv = (valid && !padq) ? mk[j] : 0.f;
+        const float py = (float)(by + ky * p.dil) + oyv, px = (float)(bx + kx * p.dil) + oxv;
+        const float fy = floorf(py), fx = floorf(px);
+        const float ly = py - fy, lx = px - fx;
+        // window coordinates of the (y0, x0) corner; clamp in float first so the conversion cannot overflow
+        const float ryf = fy - Rlo, rxf = fx - Clo;
+        const bool inwin = ryf >= 0.f && ryf <= (float)(p.WR - 2) && rxf >= 0.f && rxf <= (float)(p.WC - 2);
+        const int ry = inwin ? (int)ryf : 0, rx = inwin ? (int)rxf : 0;
+        const T* c00 = win + ry * rowb + rx * p.PS + g * 4;
+        f32x4 a0 = ld4(c00), a1 = ld4(c00 + p.PS), a2 = ld4(c00 + rowb), a3 = ld4(c00 + rowb + p.PS);
+        float wy0m = (1.f - ly) * mv, wy1m = ly * mv, wx0 = 1.f - lx, wx1 = lx;
+        if (__builtin_expect(!inwin && mv != 0.f, 0)) {
+          // the sample leaves the window: per-corner global loads with the image-bounds rule of the other kernels
+          const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
+          const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+          const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+          const T* cb = xb + g * 4;
+          const long o00 = ((long)y0 * p.W + x0) * p.C;
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          a0 = (yv0 && xv0) ? ld4(cb + o00) : z;
+          a1 = (yv0 && xv1) ? ld4(cb + o00 + p.C) : z;
+          a2 = (yv1 && xv0) ? ld4(cb + o00 + (long)p.W * p.C) : z;
+          a3 = (yv1 && xv1) ? ld4(cb + o00 + (long)p.W * p.C + p.C) : z;
+        }
+        // corner order and association of the oracle's sum (mask folded into the row weights, as dcn_fwd_direct_kernel)
+        val[j] = ((a0 * (wy0m * wx0) + a1 * (wy0m * wx1)) + a2 * (wy1m * wx0)) + a3 * (wy1m * wx1);
+      }
+      const float* wb = p.wq + ((long)Q * 4 * p.NTt) * 256 + lane * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 bw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + ((long)j * p.NTt + nt) * 256);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[j][tt], bw[nt][tt], acc[nt], 0, 0, 0);
+      }
+    }
+    // D row = kq*4 + r (pixel of the sub-tile), col = lane & 15 (channel of tile nt): 64-byte runs per pixel
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = sub * 16 + kq * 4 + r;
+      const int py = i / p.TW, px = i - py * p.TW;
+      const int yy = oy0 + py, xx = ox0 + px;
+      if (i >= npx || yy >= p.Ho || xx >= p.Wo) continue;
+      T* yp = p.y + (mb + (long)yy * p.Wo + xx) * p.Co;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + row;
+        if (co < p.Co) st1(yp + co, acc[nt][r] + (p.bias ? p.bias[co] : 0.f));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ DCN backward (fused)
 // One workgroup owns a TILE x TILE block of output pixels of one sample and one CHUNK of offset groups
 // (GC groups = Cc channels = CKc = Cc*K columns, a multiple of 16).  Per 16-pixel sub-tile:
@@ -843,7 +1062,51 @@ static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, 
   return FAMI_OK;
 }
 
-static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, -1 default (= 1)
+static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, 2 = dcn_fwd_win_kernel, -1 default (window where eligible, else direct)
+static int g_dcn_win_r = 0;    // fami_dcn_tune(32 + r): force the window's offset reach (benchmarks); 0 = largest that fits, up to 4
+
+// LDS-window forward: tile / window plan.  Eligible: stride 1, 4 channels per offset group (every HRNet width),
+// C a multiple of 16 bytes' worth of elements, window within 150 KB.
+struct DcnWinPlan { int ok, TH, TW, R, WR, WC, PS, tilesX, tilesY, NQ, nsub; size_t lds; };
+static DcnWinPlan dcn_win_plan(int B, int Ho, int Wo, int C, int G, int kh, int kw, int stride, int dil, int esz) {
+  DcnWinPlan q;
+  q.ok = 0;
+  if (stride != 1 || C != 4 * G || (C * esz) % 16 != 0 || G * kh * kw < 4) return q;
+  static const int cand[][2] = {{8, 16}, {6, 18}, {8, 8}, {4, 16}, {6, 12}, {4, 8}, {12, 16}, {8, 24}, {16, 16}};
+  double best = 1e30;
+  const int PS = C + 4 * (4 / esz > 0 ? 4 / esz : 1) ;   // + 16 bytes: neighbouring pixels start in different bank groups
+  for (int Rr = (g_dcn_win_r ? g_dcn_win_r : 4); Rr >= (g_dcn_win_r ? g_dcn_win_r : 2); --Rr) {
+    for (auto& c : cand) {
+      const int TH = c[0] < Ho ? c[0] : Ho, TW = c[1] < Wo ? c[1] : Wo;
+      const int WR = TH + (kh - 1) * dil + 2 * Rr, WC = TW + (kw - 1) * dil + 2 * Rr;
+      const size_t lds = (size_t)WR * WC * PS * esz;
+      if (lds > 150 * 1024) continue;
+      const int tX = fami_cdiv(Wo, TW), tY = fami_cdiv(Ho, TH);
+      const long wgs = (long)tX * tY * B;
+      const int nsub = fami_cdiv(TH * TW, 16);
+      // cost model: rounds over 256 CUs x (sub-tile rounds over 8 waves x K work + window fill)
+      const double cost = (double)fami_cdiv(wgs, 256) * (fami_cdiv(nsub, 8) * 9.0 + lds / 65536.0);
+      if (cost < best) {
+        best = cost;
+        q.ok = 1; q.TH = TH; q.TW = TW; q.R = Rr; q.WR = WR; q.WC = WC; q.PS = PS; q.tilesX = tX; q.tilesY = tY;
+        q.nsub = nsub; q.lds = lds;
+      }
+    }
+    if (q.ok) break;      // the largest reach that fits
+  }
+  q.NQ = fami_cdiv(G * kh * kw, 16);
+  return q;
+}
+
+template <typename T, int NT>
+static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_win_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dcn_fwd_win_kernel<T, NT>), grid, dim3(512), lds, s, a);
+}
 static int g_dcn_pf = 0;       // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
 
 template <typename T, int NT, int PF, int MINW>
@@ -900,6 +1163,27 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   const long P = (long)B * a.Ho * a.Wo;
   FAMI_REQUIRE(P < (1L << 31), nm, "size out of range");
   a.P = (int)P;
+  if (g_dcn_gather < 0 || g_dcn_gather == 2) {
+    const DcnWinPlan q = dcn_win_plan(B, a.Ho, a.Wo, C, G, kh, kw, stride, dil, (int)sizeof(T));
+    if (q.ok && a.NTt <= 4 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(off) | reinterpret_cast<uintptr_t>(msk)) & 15) == 0) {
+      DcnWinArgs<T> w;
+      w.x = x; w.off = off; w.msk = msk; w.bias = bias; w.y = y;
+      w.wq = wp + (long)a.KS * a.NTt * 256;      // the quad-order image follows the tap-major one
+      w.B = B; w.H = H; w.W = W; w.C = C; w.Ho = a.Ho; w.Wo = a.Wo; w.Co = Co; w.G = G; w.K = kh * kw; w.kw = kw;
+      w.pad = pad; w.dil = dil;
+      w.TH = q.TH; w.TW = q.TW; w.tilesX = q.tilesX; w.tilesY = q.tilesY; w.R = q.R; w.WR = q.WR; w.WC = q.WC; w.PS = q.PS;
+      w.NQ = q.NQ; w.NTt = a.NTt; w.nsub = q.nsub;
+      const dim3 grid(q.tilesX * q.tilesY * B);
+      switch (a.NTt) {
+        case 1: dcn_fwd_win_launch<T, 1>(w, grid, q.lds, s); break;
+        case 2: dcn_fwd_win_launch<T, 2>(w, grid, q.lds, s); break;
+        case 3: dcn_fwd_win_launch<T, 3>(w, grid, q.lds, s); break;
+        default: dcn_fwd_win_launch<T, 4>(w, grid, q.lds, s); break;
+      }
+      FAMI_CHECK_LAUNCH(nm);
+      return FAMI_OK;
+    }
+  }
   const dim3 grid(fami_cdiv(P, DCN_PIX));
   // the direct kernel addresses x with 32-bit byte offsets (24-bit row / column products)
   const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
@@ -1018,8 +1302,10 @@ long fami_dcn_bwd_det_workspace(int B, int H, int W, int C) { return (long)B * H
 
 long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
 
+// two images: tap-major (dcn_fwd_kernel / dcn_fwd_direct_kernel) followed by quad-group order (dcn_fwd_win_kernel)
 long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
-  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
+  const long nt = fami_cdiv(Co, 16);
+  return (long)fami_cdiv((long)C * kh * kw, 16) * nt * 256 + (long)fami_cdiv((long)G * kh * kw, 16) * 4 * nt * 256;
 }
 
 // forward weight image (fp32 for both activation types: the contraction runs on the exact f32 MFMA)
@@ -1029,13 +1315,17 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
   const long total = (long)KS16 * NTt * 256;
   hipLaunchKernelGGL(dcn_pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, C, K, cg, KS16, NTt);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32");
+  const int NQ = fami_cdiv((long)G * K, 16);
+  hipLaunchKernelGGL(dcn_pack_wq_kernel, dim3(fami_ew_grid((long)NQ * 4 * NTt * 256)), dim3(256), 0, s, w_oihw, wp + total, Co, C, K, G, NQ, NTt);
+  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32/quad");
   return FAMI_OK;
 }
 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
-  if (gather >= 16) g_dcn_pf = gather - 16;
+  if (gather >= 32) g_dcn_win_r = gather - 32;       // benchmarks: offset reach of the window kernel (0 = automatic)
+  else if (gather >= 16) g_dcn_pf = gather - 16;
   else g_dcn_gather = gather;
   return FAMI_OK;
 }

@@ -42,7 +42,7 @@ def _shifted(x, dy, dx):
     return out
 
 
-@pytest.mark.parametrize('direct', [0, 1], ids=['lds-columns', 'register-fed'])
+@pytest.mark.parametrize('direct', [0, 1, 2], ids=['lds-columns', 'register-fed', 'lds-window'])
 @pytest.mark.parametrize('C,G,H,W', [(48, 12, 24, 18), (64, 16, 13, 11)])
 def test_dcn_zero_offsets_is_dilated_conv(dev, direct, C, G, H, W):
     from fami_pose_amd._lib import lib
@@ -72,7 +72,7 @@ def test_dcn_zero_offsets_is_dilated_conv(dev, direct, C, G, H, W):
         lib().cdll.fami_dcn_tune(-1)
 
 
-@pytest.mark.parametrize('direct', [0, 1], ids=['lds-columns', 'register-fed'])
+@pytest.mark.parametrize('direct', [0, 1, 2], ids=['lds-columns', 'register-fed', 'lds-window'])
 def test_dcn_integer_offsets_are_shifted_taps(dev, direct):
     from fami_pose_amd._lib import lib
     from fami_pose_amd.engine import Engine, T

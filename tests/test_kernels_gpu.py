@@ -258,7 +258,7 @@ def test_shift_bilinear(dev, shape):
     assert relerr(tt.grad, t.grad) < 1e-4
 
 
-@pytest.fixture(params=[1, 0], ids=['direct', 'lds_column'])
+@pytest.fixture(params=[2, 1, 0], ids=['lds_window', 'direct', 'lds_column'])
 def dcn_gather(request):
     from fami_pose_amd._lib import lib
     lib().cdll.fami_dcn_tune(request.param)

@@ -63,7 +63,8 @@ def test_pck_inside_the_step_matches_reference_accuracy(dev):
     out = torch.zeros(7, device=dev)
     iws = torch.empty(8, dtype=torch.int64, device=dev)
     mws = torch.empty(8, device=dev)
-    lib().call('fami_pck_accuracy_f32', hm_p.to(dev).data_ptr(), hm_t.to(dev).data_ptr(), out.data_ptr(), iws.data_ptr(),
+    hm_pd, hm_td = hm_p.to(dev), hm_t.to(dev)                  # named: a temporary would be freed (and its block reused) before the launch
+    lib().call('fami_pck_accuracy_f32', hm_pd.data_ptr(), hm_td.data_ptr(), out.data_ptr(), iws.data_ptr(),
                mws.data_ptr(), 1, 4, 24, 18, 0.5, torch.cuda.current_stream(dev).cuda_stream)
     a0, avg0, cnt0, _ = oops.accuracy(hm_p.numpy(), hm_t.numpy())
     assert out.cpu().tolist() == pytest.approx(list(a0) + [avg0, cnt0])

@@ -31,15 +31,15 @@ L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s
 P = B * H * W
 fwd_bytes = (C + 27 * G + C) * P * 4.0
 ys = []
-for gather, pf, nm in ((0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (1, 2, 'direct 2x4'), (0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (1, 2, 'direct 2x4')):
+for gather, pf, nm in ((0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (2, 0, 'lds-window'), (0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (2, 0, 'lds-window')):
     L.cdll.fami_dcn_tune(gather); L.cdll.fami_dcn_tune(16 + pf)
     us = time_it(lambda: L.call('fami_dcn_fwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),
                                 y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream), reps=50)
     ys.append(y.clone())
     print('dcn fwd %-15s %8.1f us  %7.1f GB/s algorithmic (%.1f MB)' % (nm, us, fwd_bytes / us / 1e3, fwd_bytes / 1e6))
-print('max |direct - lds-column| = %.3g (|y| max %.3g)' % ((ys[1] - ys[0]).abs().max().item(), ys[0].abs().max().item()))
+print('max |direct - lds-column| = %.3g, |window - lds-column| = %.3g (|y| max %.3g)' % ((ys[1] - ys[0]).abs().max().item(), (ys[2] - ys[0]).abs().max().item(), ys[0].abs().max().item()))
 xb, ob, mb, yb = x.bfloat16(), off.bfloat16(), msk.bfloat16(), y.bfloat16()
-for gather, pf, nm in ((0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (1, 2, 'direct 2x4')):
+for gather, pf, nm in ((0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (2, 0, 'lds-window')):
     L.cdll.fami_dcn_tune(gather); L.cdll.fami_dcn_tune(16 + pf)
     us = time_it(lambda: L.call('fami_dcn_fwd_bf16', xb.data_ptr(), ob.data_ptr(), mb.data_ptr(), wp.data_ptr(), bias.data_ptr(),
                                 yb.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, s.cuda_stream), reps=50)
