@@ -493,24 +493,33 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
 }
 
 
-// ------------------------------------------------------------------ DCN forward, LDS-window form (default where eligible)
+// ------------------------------------------------------------------ DCN forward, LDS-window form (opt-in: fami_dcn_tune(2))
+// Measured 29.8 us against the register-fed kernel's 32.0 us (f32, B = 4, 96x72x48; tools/bench_dcn_win.py, profiles/
+// r02_dcn_window.txt) -- not the 2x its LDS gather was built for, because the gather was never the whole story:
+// v_mfma_f32_16x16x4_f32 executes on the vector ALUs (tools/probes/mfma_valu_overlap.hip: MFMA + v_fma times ADD, unlike
+// the bf16 matrix instructions), so the 1.15 GFLOP contraction (~10 us at the ~1.9 GHz the part sustains here) and the
+// ~4.4 M wave-instructions of address / bilinear arithmetic (~5.5 us) share one pipe and the ~5 us prologue / epilogue
+// of a 133 KB-window workgroup comes on top.  It stays opt-in: 7 % is not worth a second default path whose speed
+// depends on the offsets staying within R pixels.
 // The register-fed kernel above is bound by the L1's one-cache-line-per-clock rate: every one of its 11.9 M bilinear
 // corner loads (B = 4) is a scattered 16-byte global access, 64 distinct lines per wave instruction (~19 us).  Here a
-// workgroup of 8 waves owns a TH x TW tile of output pixels and
+// workgroup of 16 waves owns a TH x TW tile of output pixels (<= 128) and
 //   * copies the input WINDOW the tile can reach -- tile + dilation halo + R pixels of offset reach on every side --
-//     once into LDS, coalesced, zero-filled outside the image (so the four corners of an in-window sample need no
-//     validity logic: zero padding IS the "corner contributes only inside the map" rule).  Pixels are padded to C + 4
-//     elements so that neighbouring pixels start in different bank groups;
+//     once into LDS, coalesced (all of a thread's 16-byte pieces are requested before the first is stored), zero-filled
+//     outside the image: the four corners of an in-window sample need no validity logic, zero padding IS the "corner
+//     contributes only inside the map" rule.  Pixels are padded to C + 16 bytes so that neighbours start in different
+//     bank groups;
 //   * gathers every bilinear corner with one ds_read (16 bytes f32 / 8 bytes 16-bit) from that window; a sample whose
 //     offset leaves the window (|offset| >= R: never for realistic offsets, 6e-5 of N(0,1) draws at R = 4) takes the
 //     per-corner global path of the older kernels, so any offset magnitude stays exact;
-//   * each wave owns whole 16-pixel sub-tiles and walks ALL of K for them: no split-K, no cross-wave reduction, no
-//     barrier after the fill.  The MFMA operand comes from the registers of the lane that gathered it, as in the
-//     register-fed kernel;
-//   * offsets and masks (77 % of the bytes) are read straight from HBM, two "quad groups" ahead of their use.  Columns
-//     are GROUP-major here (item = g*K + tap, the order of the offset tensor itself) and lane (pixel, kq) of a quad
-//     group takes the 4 consecutive items 16Q + 4kq .. +3: its 4 offset pairs are one 32-byte run and its 4 masks
-//     one 16-byte run, and the 4 kq lanes of a pixel cover 128 contiguous bytes -- whole lines per pixel.
+//   * a PAIR of waves owns a 16-pixel sub-tile, each wave one half of K (4 + 3 quad groups at G*K = 108): four waves per
+//     SIMD, so one wave's address / bilinear arithmetic (VALU) runs under another's MFMAs; the halves meet in LDS once
+//     at the end.  The MFMA operand comes from the registers of the lane that gathered it, as in the register-fed kernel;
+//   * offsets and masks (77 % of the bytes) are read straight from HBM one quad group ahead of their use.  Columns are
+//     GROUP-major here (item = g*K + tap, the order of the offset tensor itself) and lane (pixel, kq) of a quad group
+//     takes the 4 consecutive items 16Q + 4kq .. +3: its 4 offset pairs are one 32-byte run and its 4 masks one 16-byte
+//     run, and the 4 kq lanes of a pixel cover 128 contiguous bytes -- whole lines per pixel;
+//   * the (group, tap) decode of an item is one packed word of a per-workgroup LDS table (no integer division in the loop).
 // Weight image: wq[((Q*4 + j)*NTt + nt)*256 + lane*4 + t] = W[nt*16 + (lane&15)][g*cg + t][tap], item 16Q + 4(lane>>4) + j.
 template <typename T>
 struct DcnWinArgs {
@@ -521,8 +530,10 @@ struct DcnWinArgs {
   const float* bias;
   T* y;
   int B, H, W, C, Ho, Wo, Co, G, K, kw, pad, dil;
-  int TH, TW, tilesX, tilesY, R, WR, WC, PS;  // window rows / cols, LDS elements per window pixel (C + 4)
+  int TH, TW, tilesX, tilesY, R, WR, WC, PS;  // window rows / cols, LDS elements per window pixel (C + 16 bytes)
   int NQ, NTt, nsub;
+  unsigned mul_row, mul_px;                   // exact-division multipliers (>> 24) by the pieces per window row / per pixel
+  int abl;                                    // ablation bits (benchmarks): 1 no MFMA, 2 no LDS gather, 4 no offset stream, 8 no window fill
 };
 
 __global__ void dcn_pack_wq_kernel(const float* __restrict__ w, float* __restrict__ wq, int Co, int C, int K, int G,
@@ -545,10 +556,15 @@ __global__ void dcn_pack_wq_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <typename T, int NT>
-__global__ __launch_bounds__(512) void dcn_fwd_win_kernel(DcnWinArgs<T> p) {
+// KSPLIT = waves per 16-pixel sub-tile: 1 = 8 waves, each walks all of K; 2 = 16 waves (4 per SIMD), K halves met in LDS
+template <typename T, int NT, bool ABL, int KSPLIT>
+__global__ __launch_bounds__(512 * KSPLIT) void dcn_fwd_win_kernel(DcnWinArgs<T> p) {
+  constexpr int DCN_WIN_THREADS = 512 * KSPLIT;
+  const int abl = ABL ? p.abl : 0;   // benchmark instrumentation: compiled out of the production instance
   extern __shared__ __attribute__((aligned(16))) char wsm[];
-  T* win = reinterpret_cast<T*>(wsm);      // [WR][WC][PS]
+  T* win = reinterpret_cast<T*>(wsm);                                        // [WR][WC][PS]
+  const int winb = p.WR * p.WC * p.PS * (int)sizeof(T);                       // a multiple of 16
+  unsigned* tab = reinterpret_cast<unsigned*>(wsm + winb);                   // [NQ*16] packed (ky*dil, kx*dil, g*4)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = lane & 15, kq = lane >> 4;
@@ -563,150 +579,218 @@ __global__ __launch_bounds__(512) void dcn_fwd_win_kernel(DcnWinArgs<T> p) {
   const T* xb = p.x + (long)b * p.H * p.W * p.C;
   const long mb = (long)b * p.Ho * p.Wo;
 
-  // ---- this lane's items: offsets / masks of quad group Q for pixel `m` (clamped addresses for padding lanes)
-  const int nitem = GK;
-  auto load_om = [&](long m, int Q, f32x4 (&o)[2], f32x4& mk) {
-    int it0 = 16 * Q + 4 * kq;
-    if (it0 + 4 > nitem) it0 = nitem - 4;          // padding items: any valid address (their weights are zero)
-    const T* po = p.off + m * GK2 + it0 * 2;
-    o[0] = ld4(po);
-    o[1] = ld4(po + 4);
-    mk = p.msk ? ld4(p.msk + m * GK + it0) : f32x4{1.f, 1.f, 1.f, 1.f};
-  };
-
-  // first sub-tile of this wave: start its offset stream before the window fill
-  const int npx = p.TH * p.TW;
-  auto pixel_of = [&](int sub, int& oy, int& ox, bool& valid) {
+  // ---- this wave: sub-tile `sub` (16 output pixels), quad groups [Q0, NQ)
+  const int sub = KSPLIT == 2 ? wave >> 1 : wave, half = KSPLIT == 2 ? wave & 1 : 0;
+  const bool active = sub < p.nsub;          // wave-uniform
+  const int Qh = (p.NQ + 1) >> 1;
+  const int Q0 = half ? Qh : 0, NQ = (KSPLIT == 2 && !half) ? Qh : p.NQ;
+  int oy, ox;
+  bool valid;
+  {
     const int i = sub * 16 + row;
     const int py = i / p.TW, px = i - py * p.TW;
     oy = oy0 + py;
     ox = ox0 + px;
-    valid = i < npx && oy < p.Ho && ox < p.Wo;
+    valid = active && i < p.TH * p.TW && oy < p.Ho && ox < p.Wo;
+  }
+  const long m = valid ? mb + (long)oy * p.Wo + ox : mb;
+  struct OM { f32x4 o0, o1, mk; };           // one quad group's 4 offset pairs and 4 masks of this lane
+  auto load_om = [&](int Q, OM& r) {
+    if (abl & 4) { r.o0 = r.o1 = r.mk = f32x4{0.25f, 0.5f, 0.75f, 0.125f}; return; }
+    int it0 = 16 * Q + 4 * kq;
+    if (it0 + 4 > GK) it0 = GK - 4;                // padding items: any valid address (their weights are zero)
+    const T* po = p.off + m * GK2 + it0 * 2;
+    r.o0 = ld4(po);
+    r.o1 = ld4(po + 4);
+    r.mk = p.msk ? ld4(p.msk + m * GK + it0) : f32x4{1.f, 1.f, 1.f, 1.f};
   };
-  f32x4 o_nx[2][2], m_nx[2];
-  {
-    int oy, ox;
-    bool v;
-    pixel_of(wave, oy, ox, v);
-    const long m = v ? mb + (long)oy * p.Wo + ox : mb;
-    if (wave < p.nsub) {
-      load_om(m, 0, o_nx[0], m_nx[0]);
-      load_om(m, p.NQ > 1 ? 1 : 0, o_nx[1], m_nx[1]);
-    }
+  OM om0, om1;
+  om0.o0 = om0.o1 = om0.mk = om1.o0 = om1.o1 = om1.mk = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) {                                    // the offset stream starts before the window fill
+    load_om(Q0 < NQ ? Q0 : NQ - 1, om0);
+    load_om(Q0 + 1 < NQ ? Q0 + 1 : NQ - 1, om1);
   }
 
-  // ---- window fill: 16-byte pieces, zero outside the image
+  // ---- item decode table
+  for (int it = tid; it < p.NQ * 16; it += DCN_WIN_THREADS) {
+    unsigned e = 0u;
+    if (it < GK) {
+      const int g = it / p.K, tap = it - g * p.K;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      e = (unsigned)(ky * p.dil) | ((unsigned)(kx * p.dil) << 8) | ((unsigned)(g * 4) << 16);
+    }
+    tab[it] = e;
+  }
+  // ---- window fill: 16-byte pieces, zero outside the image; every request of a thread is in flight before its first store
   {
     constexpr int EPP = 16 / (int)sizeof(T);        // elements per piece
     const int ppp = p.C / EPP;                      // pieces per pixel
-    const int total = p.WR * p.WC * ppp;
-    for (int i0 = tid; i0 < total; i0 += 512 * 4) {
-      uint4 v[4];
-      int dst[4];
+    const int rowp = p.WC * ppp;                    // pieces per window row
+    const int total = p.WR * rowp;
+    constexpr int FU = 8;
+    for (int i0 = tid; i0 < total && !(abl & 8); i0 += DCN_WIN_THREADS * FU) {
+      uint4 v[FU];
+      int dst[FU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 512;
+      for (int u = 0; u < FU; ++u) {
+        const int i = i0 + u * DCN_WIN_THREADS;
         v[u] = uint4{0u, 0u, 0u, 0u};
         dst[u] = -1;
         if (i < total) {
-          const int px = i / ppp, pc = i - px * ppp;
-          const int wy = px / p.WC, wx = px - wy * p.WC;
+          const int wy = (int)(((unsigned)i * p.mul_row) >> 24);
+          const int ir = i - wy * rowp;
+          const int wx = (int)(((unsigned)ir * p.mul_px) >> 24), pc = ir - wx * ppp;
           const int yy = wy0 + wy, xx = wx0 + wx;
-          dst[u] = px * p.PS + pc * EPP;
+          dst[u] = (wy * p.WC + wx) * p.PS + pc * EPP;
           if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
             v[u] = *reinterpret_cast<const uint4*>(xb + ((long)yy * p.W + xx) * p.C + pc * EPP);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < FU; ++u)
         if (dst[u] >= 0) *reinterpret_cast<uint4*>(win + dst[u]) = v[u];
     }
   }
   __syncthreads();
+  if (KSPLIT == 1 && !active) return;
 
-  const int rowb = p.WC * p.PS;                    // window elements per row
-  const float Rlo = (float)(wy0), Clo = (float)(wx0);
-  for (int sub = wave; sub < p.nsub; sub += 8) {
-    int oy, ox;
-    bool valid;
-    pixel_of(sub, oy, ox, valid);
-    const long m = valid ? mb + (long)oy * p.Wo + ox : mb;
-    const int by = oy - p.pad, bx = ox - p.pad;
-    f32x4 acc[NT];
+  const int rowbB = p.WC * p.PS * (int)sizeof(T), PSB = p.PS * (int)sizeof(T);   // window bytes per row / per pixel
+  const char* winc = reinterpret_cast<const char*>(win);
+  const int by = oy - p.pad, bx = ox - p.pad;
+  const float Rlo = (float)wy0, Clo = (float)wx0;
+  const float rmax = (float)(p.WR - 2), cmax = (float)(p.WC - 2);
+
+  // modulated samples of quad group Q for this lane's 4 items, from the LDS window.  Branch-free: the window reads are
+  // unconditional at clamped coordinates; bit j of the result flags item j as outside the window (fixed up by the caller).
+  auto gather = [&](int Q, const OM& om, f32x4 (&val)[4]) -> unsigned {
+    const int it0 = 16 * Q + 4 * kq;
+    const bool live = valid && it0 < GK;             // G*K is a multiple of 4: a lane's 4 items are real or padding together
+    const u32x4 te = *reinterpret_cast<const u32x4*>(tab + it0);
+    unsigned oob = 0u;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (sub != wave) {                              // later sub-tiles of this wave: restart the offset stream
-      load_om(m, 0, o_nx[0], m_nx[0]);
-      load_om(m, p.NQ > 1 ? 1 : 0, o_nx[1], m_nx[1]);
-    }
-    for (int Q = 0; Q < p.NQ; ++Q) {
-      f32x4 o[2] = {o_nx[0][0], o_nx[0][1]};
-      f32x4 mk = m_nx[0];
-      o_nx[0][0] = o_nx[1][0]; o_nx[0][1] = o_nx[1][1]; m_nx[0] = m_nx[1];
-      if (Q + 2 < p.NQ) load_om(m, Q + 2, o_nx[1], m_nx[1]);
-      int it0 = 16 * Q + 4 * kq;
-      const bool padq = it0 + 4 > nitem;            // this lane's 4 items are padding (only in the last quad group)
-      if (padq) it0 = nitem - 4;
-      f32x4 val[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int item = it0 + j;
-        const int g = item / p.K, tap = item - g * p.K;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        const float oyv = j < 2 ? o[0][2 * j] : o[1][2 * j - 4], oxv = j < 2 ? o[0][2 * j + 1] : o[1][2 * j - 3];
-        const float mv = (valid && !padq) ? mk[j] : 0.f;
-        const float py = (float)(by + ky * p.dil) + oyv, px = (float)(bx + kx * p.dil) + oxv;
-        const float fy = floorf(py), fx = floorf(px);
-        const float ly = py - fy, lx = px - fx;
-        // window coordinates of the (y0, x0) corner; clamp in float first so the conversion cannot overflow
-        const float ryf = fy - Rlo, rxf = fx - Clo;
-        const bool inwin = ryf >= 0.f && ryf <= (float)(p.WR - 2) && rxf >= 0.f && rxf <= (float)(p.WC - 2);
-        const int ry = inwin ? (int)ryf : 0, rx = inwin ? (int)rxf : 0;
-        const T* c00 = win + ry * rowb + rx * p.PS + g * 4;
-        f32x4 a0 = ld4(c00), a1 = ld4(c00 + p.PS), a2 = ld4(c00 + rowb), a3 = ld4(c00 + rowb + p.PS);
-        float wy0m = (1.f - ly) * mv, wy1m = ly * mv, wx0 = 1.f - lx, wx1 = lx;
-        if (__builtin_expect(!inwin && mv != 0.f, 0)) {
-          // the sample leaves the window: per-corner global loads with the image-bounds rule of the other kernels
-          const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
-          const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
-          const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
-          const T* cb = xb + g * 4;
-          const long o00 = ((long)y0 * p.W + x0) * p.C;
-          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          a0 = (yv0 && xv0) ? ld4(cb + o00) : z;
-          a1 = (yv0 && xv1) ? ld4(cb + o00 + p.C) : z;
-          a2 = (yv1 && xv0) ? ld4(cb + o00 + (long)p.W * p.C) : z;
-          a3 = (yv1 && xv1) ? ld4(cb + o00 + (long)p.W * p.C + p.C) : z;
-        }
-        // corner order and association of the oracle's sum (mask folded into the row weights, as dcn_fwd_direct_kernel)
-        val[j] = ((a0 * (wy0m * wx0) + a1 * (wy0m * wx1)) + a2 * (wy1m * wx0)) + a3 * (wy1m * wx1);
+    for (int j = 0; j < 4; ++j) {
+      const unsigned e = te[j];
+      const float oyv = j < 2 ? om.o0[2 * j] : om.o1[2 * j - 4], oxv = j < 2 ? om.o0[2 * j + 1] : om.o1[2 * j - 3];
+      const float mv = live ? om.mk[j] : 0.f;
+      const float py = (float)(by + (int)(e & 255u)) + oyv, px = (float)(bx + (int)((e >> 8) & 255u)) + oxv;
+      const float fy = floorf(py), fx = floorf(px);
+      const float ly = py - fy, lx = px - fx;
+      // window coordinates of the (y0, x0) corner (integer-valued floats: exact), clamped into the window
+      const float ryf = fy - Rlo, rxf = fx - Clo;
+      const float ryc = __builtin_amdgcn_fmed3f(ryf, 0.f, rmax), rxc = __builtin_amdgcn_fmed3f(rxf, 0.f, cmax);
+      const bool inwin = ryf == ryc && rxf == rxc;
+      const char* c00 = winc + (__mul24((int)ryc, rowbB) + __mul24((int)rxc, PSB) + (int)(e >> 16) * (int)sizeof(T));
+      f32x4 a0, a1, a2, a3;
+      if (abl & 2) { a0 = a1 = a2 = a3 = f32x4{ly, lx, mv, oyv}; }
+      else {
+        a0 = ld4(reinterpret_cast<const T*>(c00));
+        a1 = ld4(reinterpret_cast<const T*>(c00 + PSB));
+        a2 = ld4(reinterpret_cast<const T*>(c00 + rowbB));
+        a3 = ld4(reinterpret_cast<const T*>(c00 + rowbB + PSB));
       }
-      const float* wb = p.wq + ((long)Q * 4 * p.NTt) * 256 + lane * 4;
+      const float wy0m = (1.f - ly) * mv, wy1m = ly * mv, wx0 = 1.f - lx, wx1 = lx;
+      // corner order and association of the oracle's sum (mask folded into the row weights, as dcn_fwd_direct_kernel)
+      val[j] = ((a0 * (wy0m * wx0) + a1 * (wy0m * wx1)) + a2 * (wy1m * wx0)) + a3 * (wy1m * wx1);
+      oob |= (!inwin && mv != 0.f) ? (1u << j) : 0u;
+    }
+    return oob;
+  };
+  // the rare sample that leaves the window: per-corner global loads with the image-bounds rule of the other kernels
+  auto fixup = [&](int Q, const OM& om, f32x4 (&val)[4], unsigned oob) {
+    const int it0 = 16 * Q + 4 * kq;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 bw[NT];
+    for (int j = 0; j < 4; ++j) {
+      if (!((oob >> j) & 1u)) continue;
+      const unsigned e = tab[it0 + j];
+      const float oyv = j < 2 ? om.o0[2 * j] : om.o1[2 * j - 4], oxv = j < 2 ? om.o0[2 * j + 1] : om.o1[2 * j - 3];
+      const float mv = om.mk[j];
+      const float py = (float)(by + (int)(e & 255u)) + oyv, px = (float)(bx + (int)((e >> 8) & 255u)) + oxv;
+      const float fy = floorf(py), fx = floorf(px);
+      const float ly = py - fy, lx = px - fx;
+      const int y0 = (int)fminf(fmaxf(fy, -4.f), (float)p.H + 2.f), x0 = (int)fminf(fmaxf(fx, -4.f), (float)p.W + 2.f);
+      const bool yv0 = (unsigned)y0 < (unsigned)p.H, yv1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+      const bool xv0 = (unsigned)x0 < (unsigned)p.W, xv1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+      const T* cb = xb + (e >> 16);
+      const long o00 = ((long)y0 * p.W + x0) * p.C;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 a0 = (yv0 && xv0) ? ld4(cb + o00) : z;
+      const f32x4 a1 = (yv0 && xv1) ? ld4(cb + o00 + p.C) : z;
+      const f32x4 a2 = (yv1 && xv0) ? ld4(cb + o00 + (long)p.W * p.C) : z;
+      const f32x4 a3 = (yv1 && xv1) ? ld4(cb + o00 + (long)p.W * p.C + p.C) : z;
+      const float wy0m = (1.f - ly) * mv, wy1m = ly * mv, wx0 = 1.f - lx, wx1 = lx;
+      val[j] = ((a0 * (wy0m * wx0) + a1 * (wy0m * wx1)) + a2 * (wy1m * wx0)) + a3 * (wy1m * wx1);
+    }
+  };
+
+  f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bw[nt] = *reinterpret_cast<const f32x4*>(wb + ((long)j * p.NTt + nt) * 256);
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // v_mfma_f32_16x16x4_f32 runs on the vector ALUs (tools/probes/mfma_valu_overlap.hip: N MFMAs + M v_fma take the SUM of
+  // their times, unlike the bf16 matrix instructions), so gather arithmetic cannot hide under the contraction: the loop
+  // only has to keep the memory requests ahead.  Request order matters (vmcnt counts requests in issue order): this quad
+  // group's weight fragments FIRST, then the offsets / masks of quad group Q+2 -- the MFMAs then wait for all but the 3
+  // youngest requests and the offset stream keeps flying under them.  Issued the other way round, every wait for a
+  // weight fragment also waited for the HBM round trip of the prefetch.
+  auto step = [&](int Q, OM& cur, OM& nxt) {   // consumes cur (quad group Q), refills it with quad group Q+2
+    f32x4 val[4];
+    const unsigned oob = gather(Q, cur, val);
+    if (__builtin_amdgcn_ballot_w64(oob != 0u) != 0ull) fixup(Q, cur, val, oob);
+    f32x4 bw[4][NT];
+    const float* wb = p.wq + ((long)Q * 4 * p.NTt) * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bw[j][nt] = (abl & 16) ? f32x4{0.5f, 0.25f, 0.125f, 1.f} : *reinterpret_cast<const f32x4*>(wb + (j * p.NTt + nt) * 256);
+    __builtin_amdgcn_sched_barrier(0);
+    load_om(Q + 2 < NQ ? Q + 2 : NQ - 1, cur);     // unconditional (the tail re-reads the last group): no branch to merge wait counts over
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (abl & 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] += val[j] * bw[j][nt];
+      } else {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[j][tt], bw[nt][tt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[j][tt], bw[j][nt][tt], acc[nt], 0, 0, 0);
       }
     }
-    // D row = kq*4 + r (pixel of the sub-tile), col = lane & 15 (channel of tile nt): 64-byte runs per pixel
+  };
+  for (int Q = Q0; active && Q < NQ && !(abl & 32); Q += 2) {   // two quad groups per trip: the offset registers alternate, no copies
+    step(Q, om0, om1);
+    if (Q + 1 < NQ) step(Q + 1, om1, om0);
+  }
+  float* red = reinterpret_cast<float*>(wsm);        // [nsub][NT*4][64]: aliases the window once every wave is done with it
+  if (KSPLIT == 2) {
+    __syncthreads();
+    if (active && half) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = sub * 16 + kq * 4 + r;
-      const int py = i / p.TW, px = i - py * p.TW;
-      const int yy = oy0 + py, xx = ox0 + px;
-      if (i >= npx || yy >= p.Ho || xx >= p.Wo) continue;
-      T* yp = p.y + (mb + (long)yy * p.Wo + xx) * p.Co;
+      for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 16 + row;
-        if (co < p.Co) st1(yp + co, acc[nt][r] + (p.bias ? p.bias[co] : 0.f));
-      }
+        for (int r = 0; r < 4; ++r) red[(sub * NT * 4 + nt * 4 + r) * 64 + lane] = acc[nt][r];
+    }
+    __syncthreads();
+    if (!active || half) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[nt][r] += red[(sub * NT * 4 + nt * 4 + r) * 64 + lane];
+  }
+  // D row = kq*4 + r (pixel of the sub-tile), col = lane & 15 (channel of tile nt): 64-byte runs per pixel
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = sub * 16 + kq * 4 + r;
+    const int py = i / p.TW, px = i - py * p.TW;
+    const int yy = oy0 + py, xx = ox0 + px;
+    if (i >= p.TH * p.TW || yy >= p.Ho || xx >= p.Wo) continue;
+    T* yp = p.y + (mb + (long)yy * p.Wo + xx) * p.Co;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = nt * 16 + row;
+      if (co < p.Co) st1(yp + co, acc[nt][r] + (p.bias ? p.bias[co] : 0.f));
     }
   }
 }
@@ -1062,50 +1146,72 @@ static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, 
   return FAMI_OK;
 }
 
-static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, 2 = dcn_fwd_win_kernel, -1 default (window where eligible, else direct)
+static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, 2 = dcn_fwd_win_kernel where eligible, -1 default (= 1)
+static int g_dcn_abl = 0;
 static int g_dcn_win_r = 0;    // fami_dcn_tune(32 + r): force the window's offset reach (benchmarks); 0 = largest that fits, up to 4
 
 // LDS-window forward: tile / window plan.  Eligible: stride 1, 4 channels per offset group (every HRNet width),
-// C a multiple of 16 bytes' worth of elements, window within 150 KB.
-struct DcnWinPlan { int ok, TH, TW, R, WR, WC, PS, tilesX, tilesY, NQ, nsub; size_t lds; };
+// G*K a multiple of 4, C a multiple of 16 bytes' worth of elements, window (+ decode table) within 156 KB.
+struct DcnWinPlan { int ok, TH, TW, R, WR, WC, PS, tilesX, tilesY, NQ, nsub; unsigned mul_row, mul_px; size_t lds; };
+// m with (i * m) >> 24 == i / d for every 0 <= i < n (0 if there is none below 2^32 / n)
+static unsigned dcn_div_mul(int d, int n) {
+  const unsigned long m = ((1ul << 24) + d - 1) / d;
+  if (m * (unsigned long)n >= (1ul << 32)) return 0;
+  if ((m * d - (1ul << 24)) * (unsigned long)n >= (1ul << 24)) return 0;   // error term stays below one quotient step
+  return (unsigned)m;
+}
 static DcnWinPlan dcn_win_plan(int B, int Ho, int Wo, int C, int G, int kh, int kw, int stride, int dil, int esz) {
   DcnWinPlan q;
   q.ok = 0;
-  if (stride != 1 || C != 4 * G || (C * esz) % 16 != 0 || G * kh * kw < 4) return q;
-  static const int cand[][2] = {{8, 16}, {6, 18}, {8, 8}, {4, 16}, {6, 12}, {4, 8}, {12, 16}, {8, 24}, {16, 16}};
+  const int GK = G * kh * kw;
+  if (stride != 1 || C != 4 * G || (C * esz) % 16 != 0 || GK < 4 || (GK & 3) || (kh - 1) * dil > 255 || (kw - 1) * dil > 255) return q;
+  static const int cand[][2] = {{8, 16}, {6, 18}, {8, 8}, {4, 16}, {6, 12}, {4, 8}};   // <= 128 pixels = 8 sub-tiles = 16 waves
   double best = 1e30;
-  const int PS = C + 4 * (4 / esz > 0 ? 4 / esz : 1) ;   // + 16 bytes: neighbouring pixels start in different bank groups
+  const int PS = C + 16 / esz;   // + 16 bytes: neighbouring pixels start in different bank groups
+  q.NQ = fami_cdiv(GK, 16);
+  const int ppp = C * esz / 16;
   for (int Rr = (g_dcn_win_r ? g_dcn_win_r : 4); Rr >= (g_dcn_win_r ? g_dcn_win_r : 2); --Rr) {
     for (auto& c : cand) {
       const int TH = c[0] < Ho ? c[0] : Ho, TW = c[1] < Wo ? c[1] : Wo;
       const int WR = TH + (kh - 1) * dil + 2 * Rr, WC = TW + (kw - 1) * dil + 2 * Rr;
-      const size_t lds = (size_t)WR * WC * PS * esz;
-      if (lds > 150 * 1024) continue;
+      const size_t lds = (size_t)WR * WC * PS * esz + (size_t)q.NQ * 16 * 4;
+      if (lds > 156 * 1024) continue;
+      const int nsub = fami_cdiv(TH * TW, 16);
+      if ((size_t)nsub * fami_cdiv(96, 16) * 4 * 64 * 4 > (size_t)WR * WC * PS * esz) continue;   // the K-half reduction reuses the window
+      const unsigned mr = dcn_div_mul(WC * ppp, WR * WC * ppp), mp = dcn_div_mul(ppp, WC * ppp);
+      if (!mr || !mp) continue;
       const int tX = fami_cdiv(Wo, TW), tY = fami_cdiv(Ho, TH);
       const long wgs = (long)tX * tY * B;
-      const int nsub = fami_cdiv(TH * TW, 16);
-      // cost model: rounds over 256 CUs x (sub-tile rounds over 8 waves x K work + window fill)
-      const double cost = (double)fami_cdiv(wgs, 256) * (fami_cdiv(nsub, 8) * 9.0 + lds / 65536.0);
+      // cost model: rounds over 256 CUs x (K work of the sub-tiles actually populated + window fill)
+      const double cost = (double)fami_cdiv(wgs, 256) * (9.0 * nsub / 8.0 + lds / 65536.0) * ((double)nsub * 16 / (TH * TW));
       if (cost < best) {
         best = cost;
         q.ok = 1; q.TH = TH; q.TW = TW; q.R = Rr; q.WR = WR; q.WC = WC; q.PS = PS; q.tilesX = tX; q.tilesY = tY;
-        q.nsub = nsub; q.lds = lds;
+        q.nsub = nsub; q.lds = lds; q.mul_row = mr; q.mul_px = mp;
       }
     }
     if (q.ok) break;      // the largest reach that fits
   }
-  q.NQ = fami_cdiv(G * kh * kw, 16);
   return q;
 }
 
-template <typename T, int NT>
-static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+template <typename T, int NT, bool ABL, int KSPLIT>
+static void dcn_fwd_win_launch1(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_win_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_win_kernel<T, NT, ABL, KSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_fwd_win_kernel<T, NT>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((dcn_fwd_win_kernel<T, NT, ABL, KSPLIT>), grid, dim3(512 * KSPLIT), lds, s, a);
+}
+static int g_dcn_ksplit = 1;   // fami_dcn_tune(256 + k): 2 = the 16-wave K-split build (measured slower: 35.5 vs 29.8 us)
+template <typename T, int NT>
+static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  if (NT == 3 && sizeof(T) == 4 && a.abl) {   // tools/bench_dcn_win.py
+    if (g_dcn_ksplit == 2) dcn_fwd_win_launch1<T, NT == 3 ? NT : 3, sizeof(T) == 4, 2>(a, grid, lds, s);
+    else dcn_fwd_win_launch1<T, NT == 3 ? NT : 3, sizeof(T) == 4, 1>(a, grid, lds, s);
+  } else if (g_dcn_ksplit == 2) dcn_fwd_win_launch1<T, NT, false, 2>(a, grid, lds, s);
+  else dcn_fwd_win_launch1<T, NT, false, 1>(a, grid, lds, s);
 }
 static int g_dcn_pf = 0;       // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
 
@@ -1163,7 +1269,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   const long P = (long)B * a.Ho * a.Wo;
   FAMI_REQUIRE(P < (1L << 31), nm, "size out of range");
   a.P = (int)P;
-  if (g_dcn_gather < 0 || g_dcn_gather == 2) {
+  if (g_dcn_gather == 2) {
     const DcnWinPlan q = dcn_win_plan(B, a.Ho, a.Wo, C, G, kh, kw, stride, dil, (int)sizeof(T));
     if (q.ok && a.NTt <= 4 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(off) | reinterpret_cast<uintptr_t>(msk)) & 15) == 0) {
       DcnWinArgs<T> w;
@@ -1172,7 +1278,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
       w.B = B; w.H = H; w.W = W; w.C = C; w.Ho = a.Ho; w.Wo = a.Wo; w.Co = Co; w.G = G; w.K = kh * kw; w.kw = kw;
       w.pad = pad; w.dil = dil;
       w.TH = q.TH; w.TW = q.TW; w.tilesX = q.tilesX; w.tilesY = q.tilesY; w.R = q.R; w.WR = q.WR; w.WC = q.WC; w.PS = q.PS;
-      w.NQ = q.NQ; w.NTt = a.NTt; w.nsub = q.nsub;
+      w.NQ = q.NQ; w.NTt = a.NTt; w.nsub = q.nsub; w.mul_row = q.mul_row; w.mul_px = q.mul_px; w.abl = g_dcn_abl;
       const dim3 grid(q.tilesX * q.tilesY * B);
       switch (a.NTt) {
         case 1: dcn_fwd_win_launch<T, 1>(w, grid, q.lds, s); break;
@@ -1324,7 +1430,9 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
-  if (gather >= 32) g_dcn_win_r = gather - 32;       // benchmarks: offset reach of the window kernel (0 = automatic)
+  if (gather >= 256) g_dcn_ksplit = gather - 256;
+  else if (gather >= 64) g_dcn_abl = gather - 64;
+  else if (gather >= 32) g_dcn_win_r = gather - 32;       // benchmarks: offset reach of the window kernel (0 = automatic)
   else if (gather >= 16) g_dcn_pf = gather - 16;
   else g_dcn_gather = gather;
   return FAMI_OK;

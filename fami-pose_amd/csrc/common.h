@@ -28,6 +28,7 @@ extern "C" void fami_set_error(const char* where, const char* what);
   } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- storage types: activations are fp32, bf16 or fp16 (fp32 arithmetic either way) ----------------------
 typedef __bf16 bf16_t;

@@ -82,7 +82,6 @@ __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ w
     wp[i] = pack_f32_elem(w, i, Co, Ci, taps, mode);
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FAMI_OOB 0x80000000u  // byte offset beyond any tensor: the buffer unit returns 0 for it
 
 // KS = number of K partitions among the 4 waves of a workgroup (split-K for the low-resolution

@@ -13,6 +13,8 @@ N, H, W, C = int(os.environ.get('N', 20)), int(os.environ.get('H', 96)), int(os.
 kind, dt = what.rsplit('_', 1)
 tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
 st = s.cuda_stream
+for code in [c for c in os.environ.get('DCN_TUNE', '').split(',') if c]:      # e.g. DCN_TUNE=2 (window kernel), 2,95 (+ ablation bits)
+    L.cdll.fami_dcn_tune(int(code))
 if os.environ.get('XCD'):
     L.cdll.fami_conv_tune_xcd(int(os.environ['XCD']))
 if kind in ('conv', 'dgrad', 'wgrad'):
