@@ -460,18 +460,48 @@ __global__ void pack_w_h_kernel(const float* __restrict__ w, H* __restrict__ wp,
 // offset (packed arena), Co, Ci, taps, mode}; blockIdx.y walks the descriptors.  Replaces ~600 pack launches per step.
 struct PackDesc { long src, dst; int Co, Ci, taps, mode; };
 template <typename T>
-__global__ void pack_w_batch_kernel(const float* __restrict__ params, T* __restrict__ packed,
-                                    const PackDesc* __restrict__ desc) {
+__global__ __launch_bounds__(256) void pack_w_batch_kernel(const float* __restrict__ params, T* __restrict__ packed,
+                                                           const PackDesc* __restrict__ desc) {
   const PackDesc d = desc[blockIdx.y];
   const float* w = params + d.src;
   T* wp = packed + d.dst;
   const int kd = d.mode == 0 ? d.Ci : d.Co, nd = d.mode == 0 ? d.Co : d.Ci;
+  constexpr int KG = sizeof(T) == 4 ? 16 : 32, FR = sizeof(T) == 4 ? 4 : 8;  // channels per K group / elements per lane fragment
+  if (d.taps > 1 && d.taps <= 9) {
+    // 3x3 images (every byte but ~2 % of a step's packing): OIHW keeps the taps of one (co, ci) pair adjacent, the
+    // fragment image wants a tap's [K group][channel tile] blocks adjacent -- a stride-`taps` gather if done element by
+    // element (1.5 TB/s).  Per (K group, channel tile) block the source is 16 (or KG) runs of KG*taps (16*taps)
+    // contiguous floats: copy them coalesced into LDS, write each tap's 1 KiB fragment block as one contiguous run.
+    __shared__ float tile[32 * (16 * 9 + 1) + 16];
+    const int taps = d.taps;
+    const int KC = (kd + KG - 1) / KG, NTt = (nd + 15) / 16;
+    const int rows = d.mode == 0 ? 16 : KG, cols = d.mode == 0 ? KG : 16;   // co-local x ci-local extent of a block
+    const int run = cols * taps, pitch = run + 1;
+    for (int b = blockIdx.x; b < KC * NTt; b += gridDim.x) {
+      const int kc = b / NTt, nt = b - kc * NTt;
+      const int co0 = d.mode == 0 ? nt * 16 : kc * KG, ci0 = d.mode == 0 ? kc * KG : nt * 16;
+      __syncthreads();
+      for (int i = threadIdx.x; i < rows * run; i += 256) {
+        const int r = i / run, c = i - r * run;
+        const int co = co0 + r, ci = ci0 + c / taps;
+        tile[r * pitch + c] = (co < d.Co && ci < d.Ci) ? w[((long)co * d.Ci + ci0) * taps + c] : 0.f;
+      }
+      __syncthreads();
+      for (int o = threadIdx.x; o < taps * 64 * FR; o += 256) {
+        const int tap = o / (64 * FR), within = o - tap * (64 * FR);
+        const int lane = within / FR, j = within - lane * FR;
+        const int kl = (lane >> 4) * FR + j, nl = lane & 15;
+        const int col = d.mode == 0 ? nl : kl, cil = d.mode == 0 ? kl : nl;
+        st1(wp + ((long)(tap * KC + kc) * NTt + nt) * (64 * FR) + within, tile[col * pitch + cil * taps + tap]);
+      }
+    }
+    return;
+  }
   if constexpr (sizeof(T) == 4) {
     const long total = pack16_elems(kd, nd, d.taps) + pack32_elems(kd, nd, d.taps);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
       st1(wp + i, pack_f32_elem(w, i, d.Co, d.Ci, d.taps, d.mode));
   } else {
-    constexpr int KG = 32, FR = 8;  // channels per K group / elements per lane fragment (bf16 16x16x32)
     const int KC = (kd + KG - 1) / KG, NTt = (nd + 15) / 16;
     const long total = (long)d.taps * KC * NTt * 64 * FR;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -710,6 +740,7 @@ struct ConvLdsArgs {
   int sgn;            // +1 forward, -1 dgrad
   int relu, accumulate, out_f32;
   int patch_bytes;
+  int simz;           // 0 (cost simulation of the 3-plane split kernel: an offset the compiler cannot fold)
 };
 
 template <typename T> struct LdsTraits;
@@ -732,7 +763,7 @@ template <typename H> struct LdsTraits16 {
 template <> struct LdsTraits<bf16_t> : LdsTraits16<bf16_t> {};
 template <> struct LdsTraits<f16_t> : LdsTraits16<f16_t> {};
 
-template <typename T, int NT, int KSC>
+template <typename T, int NT, int KSC, int SIM = 0>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef LdsTraits<T> TR;
@@ -851,6 +882,35 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
         const int t = g * TPS + tt;
         const char* wb = wbuf + (g & 1) * WSLAB + tt * (KSC * NT * 1024) + lane * 16;
         const int toff = p.sgn * ((t / 3 - 1) * p.W + (t % 3 - 1)) * p.PSTRIDE;
+        if constexpr (SIM == 1 && SZ == 2) {
+          // cost model of the split-operand kernel: 3 planes of each operand (same bytes re-read through offsets the
+          // compiler cannot fold), 6 products per tile pair
+#pragma unroll
+          for (int ks = 0; ks < KSC; ++ks) {
+            frag a3[3][3], w3[NT][3], wx3[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+              for (int sl = 0; sl < 3; ++sl) {
+                a3[sl][pl] = TR::zero();
+                if ((vmask[sl] >> t) & 1) a3[sl][pl] = *reinterpret_cast<const frag*>(patch + base[sl] + toff + ks * 64 + pl * p.simz);
+              }
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) w3[nt][pl] = *reinterpret_cast<const frag*>(wb + (ks * NT + nt) * 1024 + pl * p.simz);
+              wx3[pl] = *reinterpret_cast<const frag*>(wb + (ks * NT + nt2) * 1024 + pl * p.simz);
+            }
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PW[6] = {0, 1, 2, 0, 1, 0};   // small terms first
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+#pragma unroll
+              for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[sl][nt] = TR::mma(w3[nt][PW[q]], a3[sl][PA[q]], acc[sl][nt]);
+              acc2 = TR::mma(wx3[PW[q]], a3[2][PA[q]], acc2);
+            }
+          }
+          continue;
+        }
         frag a[KSC][3], w[KSC][NT], wx[KSC];
 #pragma unroll
         for (int ks = 0; ks < KSC; ++ks) {  // every fragment of the tap is requested before the first MFMA
@@ -1741,6 +1801,7 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // with it (42.3 -> 40.6 ms) and the f32 step 4 % slower (77.3 -> 80.7 ms; interleaved A/B, tools/ab_step.py).
 // Default (-1): bf16 staged, f32 direct.  fami_conv_tune_lds(0/1) forces one path for both (tests exercise both).
 static int g_use_lds = -1;
+static int g_lds_sim = 0;  // fami_conv_tune_lds(2): LDS kernel in its split-operand cost-simulation form (benchmarks)
 static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
 static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
@@ -1783,7 +1844,7 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
   if (lds > 156 * 1024) return 0;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt; a.sgn = sgn;
-  a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32; a.simz = 0;
   const dim3 grid(N * a.bands, Co / (16 * NT));
   const int KSC = a.CHP / KSTEP;
   bool launched = false;
@@ -1794,6 +1855,14 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
       (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<T, nt, ksc>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
       attr = true;                                                                                                 \
     }                                                                                                              \
+    if (g_lds_sim && SZ == 2) {                                                                                    \
+      static bool attr2 = false;                                                                                   \
+      if (!attr2) {                                                                                                \
+        (void)hipFuncSetAttribute((const void*)conv3x3_lds_kernel<T, nt, ksc, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); \
+        attr2 = true;                                                                                              \
+      }                                                                                                            \
+      hipLaunchKernelGGL((conv3x3_lds_kernel<T, nt, ksc, 1>), grid, dim3(256), lds, s, a);                         \
+    } else                                                                                                         \
     hipLaunchKernelGGL((conv3x3_lds_kernel<T, nt, ksc>), grid, dim3(256), lds, s, a);                              \
     launched = true;                                                                                               \
   }
@@ -1829,6 +1898,7 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
   g_use_lds = on < 0 ? -1 : (on ? 1 : 0);
+  g_lds_sim = on == 2;
   return FAMI_OK;
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)

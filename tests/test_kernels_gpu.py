@@ -507,3 +507,38 @@ def test_prepare_clip_writes_batch_slices(dev):
         if fv[j, 0] > 0:
             assert np.allclose(j2[j, :2], O.exec_affine_transform(fj[j, :2], trans), atol=1e-4)
     assert (v2[5] == 0).all() or (fv[5] != 0).any()
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+def test_batch_weight_pack_equals_single_pack(dev, dt):
+    """fami_pack_conv_weights_batch_* (one launch for every weight image of a step; 3x3 images go through an LDS block
+    transpose) must produce bit for bit the images of fami_pack_conv_weight_* (element-wise gather), both orientations,
+    including channel counts that are not a multiple of the K group (3, 17, 48 at K = 32) and 1x1 / 7x7 kernels."""
+    import numpy as np
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    tdt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[dt]
+    elems = L.cdll.fami_packed_weight_elems if dt == 'f32' else L.cdll.fami_packed_weight_elems_bf16
+    shapes = [(48, 48, 3), (64, 3, 3), (216, 48, 3), (256, 64, 1), (48, 256, 3), (17, 40, 3), (96, 96, 3), (32, 32, 7)]
+    torch.manual_seed(3)
+    ws = [torch.randn(co, ci, k, k) for co, ci, k in shapes]
+    flat = torch.cat([w.reshape(-1) for w in ws]).to(dev)
+    recs, singles, off, src = [], [], 0, 0
+    for w, (co, ci, k) in zip(ws, shapes):
+        for mode in (0, 1):
+            n = elems(co, ci, k, k, mode)
+            recs.append((src, off, co, ci, k * k, mode))
+            one = torch.full((n,), 7.0, device=dev).to(tdt)
+            L.call('fami_pack_conv_weight_' + dt, w.to(dev).contiguous().data_ptr(), one.data_ptr(), co, ci, k, k, mode, st)
+            singles.append((off, n, one))
+            off += n
+        src += w.numel()
+    arena = torch.full((off,), 5.0, device=dev).to(tdt)
+    desc = np.array(recs, dtype=[('src', '<i8'), ('dst', '<i8'), ('Co', '<i4'), ('Ci', '<i4'), ('taps', '<i4'), ('mode', '<i4')])
+    dd = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+    L.call('fami_pack_conv_weights_batch_' + dt, flat.data_ptr(), arena.data_ptr(), dd.data_ptr(), len(recs), st)
+    torch.cuda.synchronize()
+    for (o, n, one), rec in zip(singles, recs):
+        assert torch.equal(arena[o:o + n].view(torch.int16 if dt != 'f32' else torch.int32),
+                           one.view(torch.int16 if dt != 'f32' else torch.int32)), rec
