@@ -253,9 +253,11 @@ def main():
     ap.add_argument('--dtype', choices=['f32', 'bf16', 'f16'], default='f32',
                     help='activation storage / conv MFMA type (accumulation, master weights, losses are fp32 either way)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-threads', type=int, default=64,
-                    help='host threads for the CPU baseline (0 = every core).  Default 64: on the 256-thread GPU host the '
-                         'oracle step does not get faster beyond that (profiles/r02_cpu_threads.txt)')
+    ap.add_argument('--cpu-threads', type=int, default=16,
+                    help='host threads for the CPU baseline (0 = every core).  Default 16: the thread sweep on the 256-thread '
+                         'GPU host (profiles/r02_cpu_threads.txt: 8 / 16 / 32 / 64 / 128 threads = 0.68 / 0.81 / 0.48 / 0.19 / '
+                         '0.05 clips/s) peaks there -- beyond it torch\'s CPU backward of this many small convolutions '
+                         'loses more to thread hand-offs across the sockets than it gains')
     ap.add_argument('--deterministic', action='store_true', help='fixed-point DCN backward (bitwise reproducible steps)')
     ap.add_argument('--cpu-timeout', type=int, default=240)
     args = ap.parse_args()

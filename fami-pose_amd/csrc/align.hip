@@ -842,6 +842,8 @@ struct DcnBwdArgs {
   // derived in-kernel from *amax_bits = bit pattern of max |dy| (fami_dcn_bwd_det_*)
   long long* gfix;
   const unsigned* amax_bits;
+  const float* wnorm;   // 1 float: max over columns k of sum_co |W[co][k]| (tail of the backward weight image)
+  int fixl;             // 1: the LDS region accumulates in 64-bit fixed point (per-workgroup scale), flushed to gx as f32
 };
 
 // Fixed-point scale of the deterministic input-gradient accumulation: 2^(DCN_FIX_BITS - ceil(log2(max|dy|))).  A
@@ -857,6 +859,12 @@ __device__ __forceinline__ float dcn_fix_scale(const unsigned* amax_bits) {
 }
 __device__ __forceinline__ void fix_add(long long* a, float v, float scale) {
   atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)(long long)__float2ll_rn(v * scale));
+}
+
+// one contribution (already scaled, |v| < 2^30) into a 64-bit LDS accumulator: 32-bit conversion, sign extension, ds_add_u64
+__device__ __forceinline__ void lds_fix_add(long long* a, float v) {
+  const int i = __float2int_rn(v);
+  atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)(long long)i);
 }
 
 // max |x| over a tensor as a float bit pattern (max is order independent: atomicMax on the bits of non-negative floats)
@@ -902,8 +910,32 @@ __global__ void dcn_pack_wb_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-template <typename T, int KSO, bool DET>
+// MODE 0: f32 LDS region through compare-and-swap adds (lds_add_f32), f32 global atomics.
+// MODE 1 (deterministic): 64-bit fixed-point LDS region AND 64-bit fixed-point global accumulator (fami_dcn_bwd_det_*).
+// MODE 2 (default): 64-bit fixed-point LDS region -- native ds_add_u64 retires 2.5 lane-operations per clock per CU against
+//   the compare-and-swap loop's 1.4 at this access pattern (tools/probes/lds_atomic.hip) and needs a conversion and a shift
+//   per contribution instead of the loop -- flushed to gx with f32 global atomics like MODE 0.  The scale is per
+//   workgroup: 2^(30 - e) with 2^e > max|dy| (tile) x max_k sum_co |W[co][k]| x max|mask| (tile, chunk) >= any |gcol x mask|,
+//   so one contribution fits 31 bits, a cell (at most 64 pixels x 9 taps contributions) 41, and the bound's slack
+//   (~sqrt(Co) for random signs) still leaves ~2^-24 of the largest contribution as resolution -- fp32's own.
+// out[0] = max over columns k of sum_co |w[co][k]|  (w = weight.view(Co, CK)); out[1..3] = 0
+__global__ __launch_bounds__(256) void dcn_wnorm_kernel(const float* __restrict__ w, float* __restrict__ out, int Co, int CK) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int k = threadIdx.x; k < CK; k += 256) {
+    float sum = 0.f;
+    for (int co = 0; co < Co; ++co) sum += fabsf(w[(long)co * CK + k]);
+    m = fmaxf(m, sum);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x == 0 ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 0.f;
+}
+
+template <typename T, int KSO, int MODE>
 __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
+  constexpr bool DET = MODE == 1, FIXL = MODE == 2;
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = lane & 15, kq = lane >> 4;
@@ -912,7 +944,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   float* gcol = smem;                   // [16][gstride]
   float* region = smem + 16 * gstride;  // [RH][RW][Cc] (fp32), or the same shape in 64-bit fixed point (DET)
   long long* regfix = reinterpret_cast<long long*>(smem + 16 * gstride);   // gstride is a multiple of 4: 8-byte aligned
-  const float fscale = DET ? dcn_fix_scale(p.amax_bits) : 0.f;
+  float fscale = DET ? dcn_fix_scale(p.amax_bits) : 0.f;
+  float finv = 0.f;
   int t, chunk;
   xcd_tile(1, t, chunk);  // neighbouring tiles (overlapping halo / gather regions, all group chunks of a tile) on one XCD
   const int tx = t % p.tilesX;
@@ -921,12 +954,50 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   const int oy0 = ty * DCN_TILE, ox0 = tx * DCN_TILE;
   const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
   const int rsize = p.RH * p.RW * Cc;
-  if (DET) { for (int i = tid; i < rsize; i += 256) regfix[i] = 0ll; }
+  if (DET || FIXL) { for (int i = tid; i < rsize; i += 256) regfix[i] = 0ll; }
   else { for (int i = tid; i < rsize; i += 256) region[i] = 0.f; }
   const T* xb = p.x + (long)b * p.H * p.W * p.C;
   float* gxb = (!DET && p.gx) ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
   long long* gfb = (DET && p.gfix) ? p.gfix + (long)b * p.H * p.W * p.C : nullptr;
   const int gtl_n = p.GC * K;  // (group, tap) pairs of this chunk
+  if (FIXL && gxb) {           // per-workgroup fixed-point scale from the tile's |dy| and |mask| maxima
+    __shared__ float smax[2][4];
+    float mdy = 0.f, mmk = p.msk ? 0.f : 1.f;
+    const int co4 = p.Co >> 2;
+    for (int i = tid; i < DCN_TILE * DCN_TILE * co4; i += 256) {
+      const int pix = i / co4, c4 = i - pix * co4;
+      const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
+      if (py < p.Ho && px < p.Wo) {
+        const f32x4 v = ld4(p.dy + (((long)b * p.Ho + py) * p.Wo + px) * p.Co + c4 * 4);
+        mdy = fmaxf(fmaxf(mdy, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
+    }
+    if (p.Co & 3) {
+      for (int i = tid; i < DCN_TILE * DCN_TILE * (p.Co & 3); i += 256) {
+        const int pix = i / (p.Co & 3), c = co4 * 4 + i % (p.Co & 3);
+        const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
+        if (py < p.Ho && px < p.Wo) mdy = fmaxf(mdy, fabsf(ld1(p.dy + (((long)b * p.Ho + py) * p.Wo + px) * p.Co + c)));
+      }
+    }
+    if (p.msk) {
+      for (int i = tid; i < DCN_TILE * DCN_TILE * gtl_n; i += 256) {
+        const int pix = i / gtl_n, gtl = i - pix * gtl_n;
+        const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
+        if (py < p.Ho && px < p.Wo) mmk = fmaxf(mmk, fabsf(ld1(p.msk + (((long)b * p.Ho + py) * p.Wo + px) * GK + chunk * gtl_n + gtl)));
+      }
+    }
+    mdy = wave_max(mdy);
+    mmk = wave_max(mmk);
+    if (lane == 0) { smax[0][wave] = mdy; smax[1][wave] = mmk; }
+    __syncthreads();
+    const float bound = fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])) *
+                        fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])) * p.wnorm[0];
+    int e = -60;
+    if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);   // bound = m * 2^e, m in [0.5, 1): every |gcol * mask| < 2^e
+    e = e < -60 ? -60 : (e > 90 ? 90 : e);
+    fscale = ldexpf(1.f, 30 - e);
+    finv = ldexpf(1.f, e - 30);
+  }
   __syncthreads();
 
   for (int sub = 0; sub < (DCN_TILE * DCN_TILE) / 16; ++sub) {
@@ -1034,6 +1105,29 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
               }
             }
           }
+        } else if (FIXL && gxb) {
+          if (inreg) {
+            long long* r00 = regfix + ((long)ry * p.RW + rx) * Cc + cl;
+            const f32x4 gs = gv * fscale;
+#pragma unroll
+            for (int c0 = 0; c0 < 4; ++c0) {
+              const int c = (c0 + pix) & 3;                       // neighbours start on different words (see below)
+              const float gvc = c == 0 ? gs[0] : c == 1 ? gs[1] : c == 2 ? gs[2] : gs[3];
+              if (v00) lds_fix_add(r00 + c, gvc * w00);
+              if (v01) lds_fix_add(r00 + Cc + c, gvc * w01);
+              if (v10) lds_fix_add(r00 + p.RW * Cc + c, gvc * w10);
+              if (v11) lds_fix_add(r00 + p.RW * Cc + Cc + c, gvc * w11);
+            }
+          } else {
+            float* g00 = gxb + chunk * Cc + cl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (v00) unsafeAtomicAdd(g00 + o00 + c, gv[c] * w00);
+              if (v01) unsafeAtomicAdd(g00 + o01 + c, gv[c] * w01);
+              if (v10) unsafeAtomicAdd(g00 + o10 + c, gv[c] * w10);
+              if (v11) unsafeAtomicAdd(g00 + o11 + c, gv[c] * w11);
+            }
+          }
         } else if (gxb) {
           if (inreg) {
             float* r00 = region + ((long)ry * p.RW + rx) * Cc + cl;
@@ -1099,6 +1193,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
         if (v != 0ll)
           atomicAdd(reinterpret_cast<unsigned long long*>(gfb + ((long)gy * p.W + gxx) * p.C + chunk * Cc + c), (unsigned long long)v);
       }
+    }
+  } else if (FIXL && gxb) {
+    for (int e = tid; e < p.RH * p.RW * Cc; e += 256) {
+      const long long v = regfix[e];
+      if (v == 0ll) continue;
+      const int c = e % Cc, pos = e / Cc;
+      const int ry = pos / p.RW, rx = pos - ry * p.RW;
+      const int gy = ry0 + ry, gxx = rx0 + rx;
+      if ((unsigned)gy >= (unsigned)p.H || (unsigned)gxx >= (unsigned)p.W) continue;
+      unsafeAtomicAdd(gxb + ((long)gy * p.W + gxx) * p.C + chunk * Cc + c, (float)v * finv);
     }
   } else if (gxb) {
     const int c4n = Cc >> 2;
@@ -1313,6 +1417,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   return FAMI_OK;
 }
 
+static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = 64-bit fixed-point LDS adds
 static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   // smallest group count whose column span cg*K*GC is a multiple of 16 and divides G
   for (int gc = 1; gc <= G; ++gc)
@@ -1320,19 +1425,20 @@ static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   return 0;
 }
 
-template <typename T, int KSO, bool DET>
+template <typename T, int KSO, int MODE>
 static void dcn_bwd_launch1(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<T, KSO, DET>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_kernel<T, KSO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_bwd_kernel<T, KSO, DET>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dcn_bwd_kernel<T, KSO, MODE>), grid, dim3(256), lds, s, a);
 }
 template <typename T, int KSO>
 static void dcn_bwd_launch(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
-  if (a.gfix) dcn_bwd_launch1<T, KSO, true>(a, grid, lds, s);
-  else dcn_bwd_launch1<T, KSO, false>(a, grid, lds, s);
+  if (a.gfix) dcn_bwd_launch1<T, KSO, 1>(a, grid, lds, s);
+  else if (a.fixl) dcn_bwd_launch1<T, KSO, 2>(a, grid, lds, s);
+  else dcn_bwd_launch1<T, KSO, 0>(a, grid, lds, s);
 }
 
 template <typename T>
@@ -1360,7 +1466,13 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   a.tilesX = fami_cdiv(a.Wo, DCN_TILE); a.tilesY = fami_cdiv(a.Ho, DCN_TILE);
   a.RH = (DCN_TILE - 1) * stride + (kh - 1) * dil + 2 + 2 * DCN_RO;
   a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
-  const size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * (gfix ? 2 : 1)) * sizeof(float);
+  a.wnorm = wpb + (long)fami_cdiv((long)C * K, 16) * a.KSo * 256;       // written by fami_dcn_pack_weight_bwd_f32 behind the image
+  a.fixl = (!gfix && gx && g_dcn_bwd_scatter != 0) ? 1 : 0;
+  size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * ((gfix || a.fixl) ? 2 : 1)) * sizeof(float);
+  if (a.fixl && lds > 150 * 1024) {                                       // the f32 region is half the size
+    a.fixl = 0;
+    lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
+  }
   if (lds > 150 * 1024) {
     fami_set_error(nm, "tile does not fit LDS");
     return FAMI_ESHAPE;
@@ -1430,7 +1542,8 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
-  if (gather >= 256) g_dcn_ksplit = gather - 256;
+  if (gather >= 512) g_dcn_bwd_scatter = gather - 512;
+  else if (gather >= 256) g_dcn_ksplit = gather - 256;
   else if (gather >= 64) g_dcn_abl = gather - 64;
   else if (gather >= 32) g_dcn_win_r = gather - 32;       // benchmarks: offset reach of the window kernel (0 = automatic)
   else if (gather >= 16) g_dcn_pf = gather - 16;
@@ -1438,8 +1551,9 @@ int fami_dcn_tune(int gather) {
   return FAMI_OK;
 }
 
+// the image of dcn_pack_wb_kernel + 4 floats: [0] = max_k sum_co |W[co][k]| (fixed-point scale bound of dcn_bwd_kernel)
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G) {
-  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256;
+  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256 + 4;
 }
 
 // weight image of the backward column-gradient GEMM (see dcn_pack_wb_kernel)
@@ -1450,6 +1564,8 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
   const long total = (long)NT * KSo * 256;
   hipLaunchKernelGGL(dcn_pack_wb_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wpb, Co, C, K, cg, NT, KSo);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32");
+  hipLaunchKernelGGL(dcn_wnorm_kernel, dim3(1), dim3(256), 0, s, w_oihw, wpb + total, Co, C * K);
+  FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32/norm");
   return FAMI_OK;
 }
 

@@ -542,3 +542,40 @@ def test_batch_weight_pack_equals_single_pack(dev, dt):
     for (o, n, one), rec in zip(singles, recs):
         assert torch.equal(arena[o:o + n].view(torch.int16 if dt != 'f32' else torch.int32),
                            one.view(torch.int16 if dt != 'f32' else torch.int32)), rec
+
+
+@pytest.mark.parametrize('dyscale', [1.0, 1e-6, 3e4])
+def test_dcn_bwd_scatter_modes(dev, dyscale):
+    """Input gradient of the DCN through both LDS scatter forms -- f32 compare-and-swap region (fami_dcn_tune(512)) and the
+    default 64-bit fixed-point region with its per-workgroup scale (513) -- against the oracle, at gradient magnitudes six
+    orders apart (the scale is derived from the tile's |dy| and |mask| maxima, so the relative error must not move)."""
+    from oracle import ops as O
+    from fami_pose_amd._lib import lib
+    from fami_pose_amd.engine import T
+    B, C, G, H, W = 2, 48, 12, 20, 13
+    torch.manual_seed(11)
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    off = (torch.randn(B, 18 * G, H, W) * 2.0).requires_grad_(True)
+    msk = (torch.randn(B, 9 * G, H, W) * 3.0).requires_grad_(True)
+    w = (torch.randn(C, C, 3, 3) * 0.1).requires_grad_(True)
+    y = O.deform_conv2d(x, off, msk, w, None, 1, 3, 3)
+    g = torch.randn_like(y) * dyscale
+    g[0, :, 3, 4] *= 50.0                                    # one hot pixel: the workgroup's bound is far above the typical value
+    y.backward(g)
+    for mode in (0, 1):
+        lib().cdll.fami_dcn_tune(512 + mode)
+        try:
+            eng = _eng(dev)
+            wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(torch.zeros(C, device=dev))
+            xt = T(nhwc(x.detach()).to(dev), True)
+            ot = T(nhwc(off.detach()).to(dev), True)
+            mt = T(nhwc(msk.detach()).to(dev), True)
+            yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+            yt.grad = nhwc(g).to(dev)
+            eng.backward()
+            assert relerr(nchw(xt.grad), x.grad) < 5e-6, mode
+            # away from the hot pixel the gradient is 50x smaller than the bound assumes: still resolved
+            far = (nchw(xt.grad).cpu()[1] - x.grad[1]).abs().max() / x.grad[1].abs().max()
+            assert far.item() < 5e-6, mode
+        finally:
+            lib().cdll.fami_dcn_tune(513)

@@ -54,12 +54,21 @@ gmsk = torch.empty_like(msk)
 wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
 L.call('fami_dcn_pack_weight_bwd_f32', w.data_ptr(), wpb.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
 bwd_bytes = (2 * C + 54 * G + C) * P * 4.0
-for name, a_col, a_gx in (('bwd fused full', col, gx), ('bwd fused no-gx', col, None), ('bwd fused no-gx no-col', None, None),
+for sc in (0, 1):
+  L.cdll.fami_dcn_tune(512 + sc)
+  print('scatter mode %d (0 = f32 compare-and-swap region, 1 = 64-bit fixed-point region)' % sc)
+  for name, a_col, a_gx in (('bwd fused full', col, gx), ('bwd fused no-gx', col, None), ('bwd fused no-gx no-col', None, None),
                           ('bwd fused gx no-col', None, gx)):
     us = time_it(lambda: L.call('fami_dcn_bwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
                                 None if a_col is None else a_col.data_ptr(), None if a_gx is None else a_gx.data_ptr(),
                                 goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream))
     print('%-24s %8.1f us  %7.1f GB/s algorithmic' % (name, us, bwd_bytes / us / 1e3))
+  gx.zero_()
+  L.call('fami_dcn_bwd_f32', x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(), col.data_ptr(), gx.data_ptr(),
+         goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream)
+  ys.append(gx.clone())
+print('gx: max |fixed-point - f32 region| = %.3g (|gx| max %.3g)' % ((ys[-1] - ys[-2]).abs().max().item(), ys[-1].abs().max().item()))
+L.cdll.fami_dcn_tune(513)
 
 t = torch.randn(B, 2, device=dev)
 o = torch.empty_like(x)
