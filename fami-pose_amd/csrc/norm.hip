@@ -292,6 +292,256 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- two-launch forms (fami_bn_train_fwd2 / fami_bn_bwd2): the statistics pass adds its per-workgroup partial sums into
+// NS slot rows of fp64 (global_atomic_add_f64; slot = workgroup % NS, so an address sees grid/NS adds), and the apply
+// pass folds the NS rows itself in its prologue -- the one-workgroup-per-channel finalize launch in between (4-6.6 us of
+// pure dependent latency per BatchNorm, ~600 launches per training step) is gone.  The slots must be zero on entry
+// (the caller hands out slices of an arena it clears once per step).  fp64 adds in arrival order: the sums are
+// reproducible to ~1e-16 relative, i.e. the fp32 mean / invstd almost always bit for bit, but not guaranteed -- the
+// three-launch forms above stay for the deterministic mode.
+#define BN_NS_MAX 8
+static inline int bn_slots(int C) { return C <= 96 ? 8 : (C <= 192 ? 4 : 2); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial2_kernel(const T* __restrict__ x, double* __restrict__ slots, int NS,
+                                                          long P, int C) {
+  extern __shared__ float sm[];  // [rows][2][C]
+  const ColMap m = col_map(C);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    const f32x4 piv = ld4(x + m.cv * 4);
+    const long step = (long)gridDim.x * m.rows;
+    long p = (long)blockIdx.x * m.rows + m.prow;
+    for (; p + (BN_U - 1) * step < P; p += BN_U * step) {
+      f32x4 v[BN_U];
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) v[u] = ld4(x + (p + u * step) * C + m.cv * 4);
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) {
+        const f32x4 d = v[u] - piv;
+        s += d;
+        q += d * d;
+      }
+    }
+    for (; p < P; p += step) {
+      const f32x4 v = ld4(x + p * C + m.cv * 4) - piv;
+      s += v;
+      q += v * v;
+    }
+    float* d = sm + (long)m.prow * 2 * C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d[m.cv * 4 + t] = s[t];
+      d[C + m.cv * 4 + t] = q[t];
+    }
+  }
+  __syncthreads();
+  double* row = slots + (long)(blockIdx.x % NS) * 2 * C;
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    float tot = 0.f;
+    for (int r = 0; r < m.rows; ++r) tot += sm[(long)r * 2 * C + e];
+    unsafeAtomicAdd(row + e, (double)tot);
+  }
+}
+
+// scale / shift of the normalisation exactly as the forward applies them; the backward recomputes the ReLU mask from them
+__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sf) {
+  sc = invstd * gamma;
+  sf = __builtin_fmaf(-mean, sc, beta);
+}
+
+// y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ), mean / invstd folded from the slot rows by every workgroup
+// (workgroup 0 also stores them and advances the running statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x, const double* __restrict__ slots, int NS,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const T* __restrict__ residual, T* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ invstd,
+                                                        float* running_mean, float* running_var, long P, int C,
+                                                        int relu, float momentum, float eps) {
+  extern __shared__ float sm[];  // [2][C]: scale, shift
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < NS; ++k) {
+      s += slots[(long)k * 2 * C + c];
+      q += slots[(long)k * 2 * C + C + c];
+    }
+    const double invP = 1.0 / (double)P;
+    const double dm = s * invP;                       // mean of (x - pivot)
+    double var = q * invP - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double mu = (double)ld1(x + c) + dm;
+    const float muf = (float)mu;
+    const float isf = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0) {
+      mean[c] = muf;
+      invstd[c] = isf;
+      if (running_mean) {
+        const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      }
+    }
+    float sc, sf;
+    bn_scale_shift(muf, isf, gamma[c], beta[c], sc, sf);
+    sm[c] = sc;
+    sm[C + c] = sf;
+  }
+  __syncthreads();
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(sm + m.cv * 4), sf = *reinterpret_cast<const f32x4*>(sm + C + m.cv * 4);
+  for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    const long o = p * C + m.cv * 4;
+    const f32x4 xv = ld4(x + o);
+    f32x4 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = __builtin_fmaf(xv[t], sc[t], sf[t]);
+    if (residual) v += ld4(residual + o);
+    if (relu) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+    }
+    st4(y + o, v);
+  }
+}
+
+// ReLU mask of a BatchNorm output: relu 1 = from the stored output y, relu 2 = recomputed from x (only valid without a
+// residual, and only against a forward that applied bn_scale_shift with explicit fused multiply-adds: bn_apply2_kernel)
+__device__ __forceinline__ f32x4 bn_relu_mask(f32x4 g, int relu, f32x4 yy, f32x4 xv, f32x4 sc, f32x4 sf) {
+  if (relu == 1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = yy[t] > 0.f ? g[t] : 0.f;
+  } else if (relu == 2) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = __builtin_fmaf(xv[t], sc[t], sf[t]) > 0.f ? g[t] : 0.f;
+  }
+  return g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const T* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              double* __restrict__ slots, int NS, long P, int C, int relu) {
+  extern __shared__ float sm[];
+  const ColMap m = col_map(C);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (m.active) {
+    f32x4 mu, is, sc, sf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = m.cv * 4 + t;
+      mu[t] = mean[c];
+      is[t] = invstd[c];
+      float a, b;
+      bn_scale_shift(mu[t], is[t], gamma[c], beta[c], a, b);
+      sc[t] = a;
+      sf[t] = b;
+    }
+    const long step = (long)gridDim.x * m.rows;
+    for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += BN_U * step) {
+      f32x4 g[BN_U], yy[BN_U], xx[BN_U];
+      long o[BN_U];
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) {
+        const long pu = p + u * step;
+        o[u] = (pu < P ? pu : p) * C + m.cv * 4;
+        g[u] = ld4(dy + o[u]);
+      }
+      if (relu == 1) {
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) yy[u] = ld4(y + o[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) xx[u] = ld4(x + o[u]);
+#pragma unroll
+      for (int u = 0; u < BN_U; ++u) {
+        g[u] = bn_relu_mask(g[u], relu, yy[u], xx[u], sc, sf);
+        if (p + u * step >= P) g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 xh = (xx[u] - mu) * is;
+        s += g[u];
+        q += g[u] * xh;
+      }
+    }
+    float* d = sm + (long)m.prow * 2 * C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      d[m.cv * 4 + t] = s[t];
+      d[C + m.cv * 4 + t] = q[t];
+    }
+  }
+  __syncthreads();
+  double* row = slots + (long)(blockIdx.x % NS) * 2 * C;
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    float tot = 0.f;
+    for (int r = 0; r < m.rows; ++r) tot += sm[(long)r * 2 * C + e];
+    unsafeAtomicAdd(row + e, (double)tot);
+  }
+}
+
+// dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) ; dres (=|+=) dz ; the two means folded from the slot rows by
+// every workgroup (workgroup 0 also stores dgamma / dbeta)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const double* __restrict__ slots, int NS, T* __restrict__ dx,
+                                                            float* dgamma, float* dbeta, T* __restrict__ dres, long P,
+                                                            int C, int relu, int acc_dx, int acc_param, int acc_dres) {
+  extern __shared__ float sm[];  // [2][C]: mean(dz), mean(dz*xhat)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < NS; ++k) {
+      s += slots[(long)k * 2 * C + c];
+      q += slots[(long)k * 2 * C + C + c];
+    }
+    sm[c] = (float)(s / (double)P);
+    sm[C + c] = (float)(q / (double)P);
+    if (blockIdx.x == 0) {
+      if (dgamma) dgamma[c] = acc_param ? dgamma[c] + (float)q : (float)q;
+      if (dbeta) dbeta[c] = acc_param ? dbeta[c] + (float)s : (float)s;
+    }
+  }
+  __syncthreads();
+  const ColMap m = col_map(C);
+  if (!m.active) return;
+  f32x4 mu, is, gi, sc, sf;
+  const f32x4 c1 = *reinterpret_cast<const f32x4*>(sm + m.cv * 4), c2 = *reinterpret_cast<const f32x4*>(sm + C + m.cv * 4);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = m.cv * 4 + t;
+    mu[t] = mean[c];
+    is[t] = invstd[c];
+    gi[t] = gamma[c] * invstd[c];
+    float a, b;
+    bn_scale_shift(mu[t], is[t], gamma[c], beta[c], a, b);
+    sc[t] = a;
+    sf[t] = b;
+  }
+  for (long p = (long)blockIdx.x * m.rows + m.prow; p < P; p += (long)gridDim.x * m.rows) {
+    const long o = p * C + m.cv * 4;
+    f32x4 g = ld4(dy + o);
+    const f32x4 xv = ld4(x + o);
+    f32x4 yy = {0.f, 0.f, 0.f, 0.f};
+    if (relu == 1) yy = ld4(y + o);
+    g = bn_relu_mask(g, relu, yy, xv, sc, sf);
+    const f32x4 xh = (xv - mu) * is;
+    f32x4 d = gi * (g - c1 - xh * c2);
+    if (acc_dx) d += ld4(dx + o);
+    st4(dx + o, d);
+    if (dres) {
+      f32x4 r = g;
+      if (acc_dres) r += ld4(dres + o);
+      st4(dres + o, r);
+    }
+  }
+}
+
 // ---- small-tensor BatchNorm: statistics + apply (forward) / both reductions + apply (backward) in ONE launch.
 // One workgroup per 4-channel column: the tensor of a low-resolution HRNet branch (P <= BN_SMALL_P pixels) is
 // L2-resident, so the second pass re-reads it from cache and the three launches of the general path collapse
@@ -572,6 +822,71 @@ static int bn_train_fwd_impl(const T* x, const T* residual, T* y, const float* g
   return bn_apply_impl<T>(x, mean, invstd, gamma, beta, residual, y, P, C, relu, s, nm);
 }
 
+// two-launch forms: `slots` = fami_bn_slots_bytes(C) bytes, ZERO on entry
+static inline int bn_apply_grid(long P, int C) {
+  const int rows = 256 / (C >> 2);
+  long g = (P + rows - 1) / rows;
+  if (g > 1024) g = 1024;   // every workgroup folds the slot rows in its prologue: fewer, longer workgroups than bn_apply_impl
+  return (int)g;
+}
+
+template <typename T>
+static int bn_train_fwd2_impl(const T* x, const T* residual, T* y, const float* gamma, const float* beta, float* mean,
+                              float* invstd, float* running_mean, float* running_var, long P, int C, int relu,
+                              float momentum, float eps, void* slots, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(x && y && gamma && beta && mean && invstd && slots, nm, "null pointer");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  if (bn_small_ok(P, C)) {
+    hipLaunchKernelGGL(bn_small_fwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, x, residual, y, gamma, beta, mean, invstd,
+                       running_mean, running_var, P, C, relu, momentum, eps);
+    FAMI_CHECK_LAUNCH(nm);
+    return FAMI_OK;
+  }
+  const int G = bn_grid(P, C), NS = bn_slots(C);
+  const int rows = 256 / (C >> 2);
+  hipLaunchKernelGGL(bn_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x,
+                     reinterpret_cast<double*>(slots), NS, P, C);
+  FAMI_CHECK_LAUNCH(nm);
+  hipLaunchKernelGGL(bn_apply2_kernel<T>, dim3(bn_apply_grid(P, C)), dim3(256), (size_t)2 * C * sizeof(float), s, x,
+                     reinterpret_cast<const double*>(slots), NS, gamma, beta, residual, y, mean, invstd, running_mean,
+                     running_var, P, C, relu, momentum, eps);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
+template <typename T>
+static int bn_bwd2_impl(const T* dy, const T* x, const T* y, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, T* dx, float* dgamma, float* dbeta, T* dres, long P, int C, int relu,
+                        int acc_dx, int acc_param, int acc_dres, void* slots, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && slots, nm, "null pointer");
+  FAMI_REQUIRE(relu != 1 || y, nm, "relu = 1 needs y");
+  FAMI_REQUIRE(relu >= 0 && relu <= 2, nm, "relu must be 0, 1 (mask from y) or 2 (mask recomputed from x)");
+  if (!bn_shape_ok(P, C)) {
+    fami_set_error(nm, "C must be a multiple of 4, <= 1024");
+    return FAMI_ESHAPE;
+  }
+  if (bn_small_ok(P, C)) {  // the one-launch kernel takes its mask from y
+    FAMI_REQUIRE(relu != 2 || y, nm, "small tensors take the ReLU mask from y");
+    hipLaunchKernelGGL(bn_small_bwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, dx, dgamma,
+                       dbeta, dres, P, C, relu ? 1 : 0, acc_dx, acc_param, acc_dres);
+    FAMI_CHECK_LAUNCH(nm);
+    return FAMI_OK;
+  }
+  const int G = bn_grid(P, C), NS = bn_slots(C);
+  const int rows = 256 / (C >> 2);
+  hipLaunchKernelGGL(bn_bwd_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y, mean,
+                     invstd, gamma, beta, reinterpret_cast<double*>(slots), NS, P, C, relu);
+  FAMI_CHECK_LAUNCH(nm);
+  hipLaunchKernelGGL(bn_bwd_apply2_kernel<T>, dim3(bn_apply_grid(P, C)), dim3(256), (size_t)2 * C * sizeof(float), s, dy, x,
+                     y, mean, invstd, gamma, beta, reinterpret_cast<const double*>(slots), NS, dx, dgamma, dbeta, dres, P,
+                     C, relu, acc_dx, acc_param, acc_dres);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
 template <typename T>
 static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s,
                             const char* nm) {
@@ -590,6 +905,7 @@ static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulat
 extern "C" {
 
 long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
+long fami_bn_slots_bytes(int C) { return (long)BN_NS_MAX * 2 * C * (long)sizeof(double); }
 long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
 
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
@@ -633,6 +949,21 @@ int fami_bn_running_update_f32(float* running_mean, float* running_var, const fl
                               int relu, float momentum, float eps, float* ws, hipStream_t s) {                         \
     return bn_train_fwd_impl<T>(x, residual, y, gamma, beta, mean, invstd, running_mean, running_var, P, C, relu,      \
                                 momentum, eps, ws, s, "fami_bn_train_fwd_" #sfx);                                      \
+  }                                                                                                                    \
+  /* two-launch forms (statistics with fp64 slot atomics + apply that folds the slots itself): `slots` =           */ \
+  /* fami_bn_slots_bytes(C) bytes, ZERO on entry.  relu (backward): 0 none, 1 mask from y, 2 mask recomputed from x   */ \
+  /* (no residual; y may be null) -- valid against fami_bn_train_fwd2 only.                                           */ \
+  int fami_bn_train_fwd2_##sfx(const T* x, const T* residual, T* y, const float* gamma, const float* beta,             \
+                               float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,     \
+                               int relu, float momentum, float eps, void* slots, hipStream_t s) {                      \
+    return bn_train_fwd2_impl<T>(x, residual, y, gamma, beta, mean, invstd, running_mean, running_var, P, C, relu,     \
+                                 momentum, eps, slots, s, "fami_bn_train_fwd2_" #sfx);                                 \
+  }                                                                                                                    \
+  int fami_bn_bwd2_##sfx(const T* dy, const T* x, const T* y, const float* mean, const float* invstd,                  \
+                         const float* gamma, const float* beta, T* dx, float* dgamma, float* dbeta, T* dres, long P,   \
+                         int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, hipStream_t s) {       \
+    return bn_bwd2_impl<T>(dy, x, y, mean, invstd, gamma, beta, dx, dgamma, dbeta, dres, P, C, relu, acc_dx,           \
+                           acc_param, acc_dres, slots, s, "fami_bn_bwd2_" #sfx);                                       \
   }                                                                                                                    \
   /* out[c] (=|+=) sum_p x[p][c] */                                                                      \
   int fami_channel_sum_##sfx(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {        \

@@ -94,7 +94,11 @@ class Engine:
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
                                        # the caching allocator must not recycle a block across lanes within a step
+        # two-launch BatchNorm (fami_bn_train_fwd2 / fami_bn_bwd2: fp64 slot atomics, finalize folded into the apply pass).
+        # Sums arrive in atomic order, so the deterministic mode keeps the three-launch forms.
+        self.bn2 = (not self.deterministic) and os.environ.get('FAMI_BN2', '1') != '0'
         self.sync_stream()
+        self._zero_begin()
 
     # ------------------------------------------------------------------ plumbing
     def rq(self, p):
@@ -224,6 +228,34 @@ class Engine:
     def fill(self, t, v=0.0):
         self.call('fami_fill' + _sfx(t), _p(t), t.numel(), float(v))
         return t
+
+    # zero-initialised scratch for the step (the slot rows of the two-launch BatchNorm): slices of ONE arena per
+    # (device, stream) that is cleared by one launch when the step's Engine is created, sized from the steps before.
+    _zero_arenas = {}
+
+    def _zero_begin(self):
+        st = Engine._zero_arenas.setdefault((self.dev.index, self.stream), {'buf': None, 'high': 0})
+        self._zst, self._zoff, self._zfilled = st, 0, 0
+        cap = 0 if st['buf'] is None else st['buf'].numel() * 4
+        if st['high'] > cap and not torch.cuda.is_current_stream_capturing():
+            st['buf'] = torch.empty((st['high'] * 5 // 4 + 1023) // 4, dtype=torch.float32, device=self.dev)
+            cap = st['buf'].numel() * 4
+        if st['buf'] is not None and st['high'] > 0:
+            self._zfilled = min(cap, (st['high'] + 255) & ~255)
+            self.fill(st['buf'][:self._zfilled // 4])
+
+    def zeros_bytes(self, nbytes):
+        """-> zero-filled fp32 buffer of >= nbytes (256-byte aligned slice of the step's arena; before the arena has been
+        sized -- the first step -- or past its end, a fresh buffer cleared on the current lane)."""
+        nbytes = (int(nbytes) + 255) & ~255
+        st, off = self._zst, self._zoff
+        self._zoff += nbytes
+        st['high'] = max(st['high'], self._zoff)
+        if off + nbytes <= self._zfilled:
+            return st['buf'][off // 4:(off + nbytes) // 4]
+        t = torch.empty(nbytes // 4, dtype=torch.float32, device=self.dev)
+        self._keep.append(t)
+        return self.fill(t)
 
     def gbuf(self, t):
         """-> (gradient buffer of t, accumulate flag)."""
@@ -410,9 +442,11 @@ class Engine:
             deferred = self.defer_bn is not None and bn.running_mean is not None
             if not deferred:
                 self._lane_guard(('running statistics', id(bn)))
-            ws = self.ws(self.L.cdll.fami_bn_workspace(C))
             mom = 0.1 if bn.momentum is None else bn.momentum
-            self.acall('fami_bn_train_fwd', _p(x.data), _p(None if residual is None else residual.data), _p(y),
+            bn2 = self.bn2
+            ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if bn2 else self.ws(self.L.cdll.fami_bn_workspace(C))
+            self.acall('fami_bn_train_fwd2' if bn2 else 'fami_bn_train_fwd', _p(x.data),
+                       _p(None if residual is None else residual.data), _p(y),
                        _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
                        _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
                        int(relu), float(mom), float(bn.eps), _p(ws))
@@ -444,10 +478,17 @@ class Engine:
                 gr, accr = (None, 0)
                 if residual is not None and residual.requires_grad:
                     gr, accr = self.gbuf(residual)
-                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
-                self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
-                           _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
-                           _p(ws))
+                if self.bn2:
+                    # ReLU mask: from y when a residual was added, else recomputed from x (one tensor read less per pass)
+                    rmode = (1 if residual is not None else 2) if relu else 0
+                    self.acall('fami_bn_bwd2', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
+                               _p(bn.weight.data), _p(bn.bias.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, rmode, accx,
+                               accp, accr, _p(self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C))))
+                else:
+                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                    self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
+                               _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
+                               _p(ws))
             self.record_bwd(bwd, [bn.weight, bn.bias])
         return out
 

@@ -91,6 +91,19 @@ int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, co
 int fami_bn_bwd_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                     const float* gamma, float* dx, float* dgamma, float* dbeta, float* dres, long P, int C, int relu,
                     int acc_dx, int acc_param, int acc_dres, float* ws, fami_stream_t stream);
+/* Two-launch forms of the two calls above (fami_bn_{stats,finalize,apply,bwd}; the finalize launch is folded
+ * into the apply pass): the statistics pass adds its partial sums into fp64 slot rows, every workgroup of the apply pass
+ * folds them in its prologue.  `slots`: fami_bn_slots_bytes(C) bytes, ZERO on entry (the caller clears one arena per
+ * step).  Backward relu: 0 none, 1 mask from y, 2 mask recomputed from x (no residual; y may be NULL) -- the latter only
+ * against a forward run by fami_bn_train_fwd2 (same fused multiply-add of scale / shift).  Sums arrive in atomic order:
+ * reproducible to fp64 rounding, not bit for bit -- the three-launch forms stay for the deterministic mode. */
+long fami_bn_slots_bytes(int C);
+int fami_bn_train_fwd2_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
+                           float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
+                           int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd2_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, float* dres, long P,
+                     int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, fami_stream_t stream);
 long fami_channel_sum_workspace(int C);
 /* out[c] (=|+=) sum_p x[p][c] : bias gradients of the biased convs */
 int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumulate, float* ws, fami_stream_t stream);
@@ -247,6 +260,12 @@ int fami_bn_train_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* residual, fa
 int fami_bn_apply_bf16(const fami_bf16_t* x, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, const fami_bf16_t* residual, fami_bf16_t* y, long P, int C, int relu,
                        fami_stream_t stream);
+int fami_bn_train_fwd2_bf16(const fami_bf16_t* x, const fami_bf16_t* residual, fami_bf16_t* y, const float* gamma, const float* beta,
+                           float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
+                           int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd2_bf16(const fami_bf16_t* dy, const fami_bf16_t* x, const fami_bf16_t* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, fami_bf16_t* dx, float* dgamma, float* dbeta, fami_bf16_t* dres, long P,
+                     int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, fami_stream_t stream);
 int fami_bn_bwd_bf16(const fami_bf16_t* dy, const fami_bf16_t* x, const fami_bf16_t* y, const float* mean,
                      const float* invstd, const float* gamma, fami_bf16_t* dx, float* dgamma, float* dbeta,
                      fami_bf16_t* dres, long P, int C, int relu, int acc_dx, int acc_param, int acc_dres, float* ws,
@@ -322,6 +341,12 @@ int fami_bn_train_fwd_f16(const fami_f16_t* x, const fami_f16_t* residual, fami_
 int fami_bn_apply_f16(const fami_f16_t* x, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, const fami_f16_t* residual, fami_f16_t* y, long P, int C, int relu,
                        fami_stream_t stream);
+int fami_bn_train_fwd2_f16(const fami_f16_t* x, const fami_f16_t* residual, fami_f16_t* y, const float* gamma, const float* beta,
+                           float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
+                           int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd2_f16(const fami_f16_t* dy, const fami_f16_t* x, const fami_f16_t* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, fami_f16_t* dx, float* dgamma, float* dbeta, fami_f16_t* dres, long P,
+                     int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, fami_stream_t stream);
 int fami_bn_bwd_f16(const fami_f16_t* dy, const fami_f16_t* x, const fami_f16_t* y, const float* mean,
                      const float* invstd, const float* gamma, fami_f16_t* dx, float* dgamma, float* dbeta,
                      fami_f16_t* dres, long P, int C, int relu, int acc_dx, int acc_param, int acc_dres, float* ws,

@@ -92,9 +92,13 @@ def test_conv_fwd_bwd(dev, case, lds_mode):
 
 @pytest.mark.parametrize("C,relu,res", [(48, True, True), (48, True, False), (96, False, False), (16, True, False),
                                         (384, True, True), (256, False, True)])
-@pytest.mark.parametrize("size", [(3, 10, 7), (4, 30, 23)], ids=['small', 'large'])
-def test_bn_train_fwd_bwd(dev, C, relu, res, size):
-    """(3,10,7): single-launch small-tensor kernels for C <= 96; (4,30,23): the statistics / finalize / apply path."""
+@pytest.mark.parametrize("size", [(3, 10, 7), (4, 30, 23), (9, 48, 36)], ids=['small', 'large', 'multi-slot'])
+@pytest.mark.parametrize("two_launch", [True, False], ids=['fwd2_bwd2', 'three_launch'])
+def test_bn_train_fwd_bwd(dev, C, relu, res, size, two_launch):
+    """(3,10,7): single-launch small-tensor kernels for C <= 96; (4,30,23): the statistics / (finalize /) apply path;
+    (9,48,36): enough rows that every fp64 slot row of the two-launch form collects several workgroups.  two_launch:
+    fami_bn_train_fwd2 / fami_bn_bwd2 (default; ReLU mask recomputed from x when there is no residual) against the
+    three-launch forms kept for the deterministic mode."""
     torch.manual_seed(C)
     N, H, W = size
     bn = nn.BatchNorm2d(C, momentum=0.1)
@@ -117,6 +121,7 @@ def test_bn_train_fwd_bwd(dev, C, relu, res, size):
 
     from fami_pose_amd.engine import T
     eng = _eng(dev)
+    eng.bn2 = two_launch
     xt = T(nhwc(x.detach()).to(dev), True)
     rt = T(nhwc(r.detach()).to(dev), True) if res else None
     yt = eng.bn(xt, bd, relu=relu, residual=rt)
