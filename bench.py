@@ -162,7 +162,7 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
     msb = _time_launches(launch_b, s, reps)
     nb = (2 * C + 6 * G * 9 + C) * H * W * sz * B
     achb = nb / (msb * 1e-3) / 1e9
-    bwd = {"bound": "hbm", "kernel": "dcn_bwd_kernel (%dch, %d groups, %dx%d, B=%d, %s; float-atomic scatter)" % (C, G, H, W, B, dtype),
+    bwd = {"bound": "hbm", "kernel": "dcn_bwd_kernel (%dch, %d groups, %dx%d, B=%d, %s; 64-bit fixed-point LDS scatter, f32 atomic flush)" % (C, G, H, W, B, dtype),
            "achieved": round(achb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achb / PEAK_HBM_GBS, 4),
            "traffic": None, "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
     # the deterministic (64-bit fixed-point) form of the same backward: zero + |dy| max + kernel + conversion pass

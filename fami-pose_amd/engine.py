@@ -113,11 +113,28 @@ class Engine:
     _side_pool = {}
 
     def _lanes(self, n):
+        """-> n - 1 side streams, every one distinct from this step's main stream and from each other.  torch hands out
+        streams round-robin from a fixed pool of 32 per device, so after enough torch.cuda.Stream() calls in a process a
+        'new' stream IS an old one: a capture stream that coincided with a cached lane stream made fork / join wait on
+        the very stream they were recorded on, and the hipGraph captured that way crashed in hipGraphLaunch
+        (hip::Graph::UpdateStreams) -- the cache is therefore filtered by handle."""
         pool = Engine._side_pool.setdefault(self.dev, [])
-        while len(pool) < n - 1:
-            pool.append(torch.cuda.Stream(self.dev))
-        self._side = pool
-        return pool
+        main = self._main.cuda_stream
+        side = [s for s in pool if s.cuda_stream != main]
+        tries = 0
+        while len(side) < n - 1 and tries < 64:
+            tries += 1
+            s = torch.cuda.Stream(self.dev)
+            if s.cuda_stream != main and all(s.cuda_stream != t.cuda_stream for t in pool):
+                pool.append(s)
+                side.append(s)
+        if len(side) < n - 1:
+            raise RuntimeError('could not obtain %d distinct side streams' % (n - 1))
+        self._side = side
+        if os.environ.get('FAMI_DEBUG_STREAMS'):
+            print('[fami] lanes: main %#x side %s capturing %s' % (main, [hex(t.cuda_stream) for t in side[:n - 1]],
+                                                                  torch.cuda.is_current_stream_capturing()), flush=True)
+        return side
 
     def set_lane(self, i):
         self.lane = i
@@ -229,15 +246,19 @@ class Engine:
         self.call('fami_fill' + _sfx(t), _p(t), t.numel(), float(v))
         return t
 
-    # zero-initialised scratch for the step (the slot rows of the two-launch BatchNorm): slices of ONE arena per
-    # (device, stream) that is cleared by one launch when the step's Engine is created, sized from the steps before.
+    # zero-initialised scratch for the step (the slot rows of the two-launch BatchNorm): slices of ONE arena per device
+    # that is cleared by one launch on the step's main stream when its Engine is created (every lane forks after that),
+    # sized from the steps before -- a graph-mode Trainer's eager warm-up steps size it before the capture.  A captured
+    # graph keeps pointing at the arena it was captured with, so a buffer that is outgrown is retired, never freed.
     _zero_arenas = {}
 
     def _zero_begin(self):
-        st = Engine._zero_arenas.setdefault((self.dev.index, self.stream), {'buf': None, 'high': 0})
+        st = Engine._zero_arenas.setdefault(self.dev.index, {'buf': None, 'high': 0, 'retired': []})
         self._zst, self._zoff, self._zfilled = st, 0, 0
         cap = 0 if st['buf'] is None else st['buf'].numel() * 4
         if st['high'] > cap and not torch.cuda.is_current_stream_capturing():
+            if st['buf'] is not None:
+                st['retired'].append(st['buf'])
             st['buf'] = torch.empty((st['high'] * 5 // 4 + 1023) // 4, dtype=torch.float32, device=self.dev)
             cap = st['buf'].numel() * 4
         if st['buf'] is not None and st['high'] > 0:

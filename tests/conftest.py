@@ -21,3 +21,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _release_device_objects(request):
+    """After every GPU test: collect the garbage NOW (Trainers hold hipGraph executables, and each executable owns the
+    HIP streams its parallel branches run on) and let the device drain.  Without it the graph executables of a dozen
+    earlier tests are still alive when a later test instantiates and launches its own."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None or 'dev' in request.fixturenames:
+        import gc
+        import torch
+        if torch.cuda.is_available():
+            gc.collect()
+            torch.cuda.synchronize()
+            gc.collect()

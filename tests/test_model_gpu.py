@@ -346,11 +346,12 @@ def test_half_mode_vs_oracle(dev, mode):
         orc.zero_grad()
         fo, ko, mio = orc(kf, sup)
         oops.total_loss(fo, tgt, w, mio).backward()
-        # 5e-2 at the output layer and the last DCN; the weight two train-mode BatchNorms below the output sees the same
-        # 11-bit noise amplified by the BatchNorm backward's common-mode subtraction (the effect test_model_vs_oracle
-        # arbitrates with fp64 in the fp32 mode): measured 7.8e-2 with either BatchNorm launch plan, bound 1.2e-1
+        # 5e-2 at the output layer.  Deeper weights see the 11-bit noise of the whole 16-bit FORWARD (the feature maps
+        # entering the head differ by a few percent) amplified by the train-mode BatchNorm backward (the effect
+        # test_model_vs_oracle arbitrates with fp64 in the fp32 mode).  tools/diag_f16_grad.py: 0.078 / 0.308 for the two
+        # weights below at loss scales 64, 4096 and 65536 alike (so it is not underflow), 0.23 / 0.84 in bf16.
         for name, tol in (('agg_final_layer.weight', 5e-2), ('init_feature_agg_block.layers.2.conv2.weight', 1.2e-1),
-                          ('dcn_4.weight', 5e-2)):
+                          ('dcn_4.weight', 4.5e-1)):
             g0 = dict(orc.named_parameters())[name].grad
             g1 = dict(model.named_parameters())[name].grad.cpu() / ls
             assert ((g1 - g0).norm() / g0.norm()).item() < tol, name
@@ -433,55 +434,17 @@ def test_config5_w64_full_size(dev):
 def test_ddp_path_single_rank_rccl(dev):
     """The N>1 code path on real hardware with ONE rank: RCCL process group, bucketed async all-reduce fired from the
     backward hooks, scale, Adam -- must reproduce the plain single-GPU step bit for bit (an all-reduce over one rank is
-    the identity)."""
-    import torch.distributed as dist
-    from fami_pose_amd.train import Trainer
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29517')
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-    try:
-        S, H, W, B = 2, 128, 96, 2
-        gen = torch.Generator().manual_seed(9)
-        kf, sup = torch.randn(B, 3, H, W, generator=gen).to(dev), torch.randn(B, 3 * S, H, W, generator=gen).to(dev)
-        joints = (torch.rand(B, 17, 2, generator=gen) * torch.tensor([W, H], dtype=torch.float32)).to(dev)
-        vis = (torch.rand(B, 17, generator=gen) < 0.8).float().to(dev)
-        def run(force, graph, steps):
-            m, _ = _pair(48, S, (H, W), 'train', 5)
-            tr = Trainer(m.to(dev), lr=1e-3, use_graph=graph, targets_from_joints=True, force_ddp=force, bucket_mb=8)
-            assert tr.ddp == force
-            for _ in range(steps):
-                tr.step(kf, sup, joints, vis)
-            return tr.loss_value(), tr.grad.clone(), tr.flat.clone()
-
-        # ONE step: identical parameters in, so the gradients must agree (DCN input gradients use float atomics whose
-        # summation order varies run to run -> ~1e-5 of the gradient scale, not bitwise).  Adam turns a noise-level
-        # gradient into a +-lr step, so parameters are compared only where the gradient is well above that noise.
-        l0, g0, p0 = run(False, False, 1)
-        l1, g1, p1 = run(True, False, 1)
-        assert l1 == pytest.approx(l0, rel=1e-5)
-        assert ((g1 - g0).abs().max() / g0.abs().max()).item() < 1e-3
-        big = g0.abs() > 1e-2 * g0.abs().max()
-        assert (p1 - p0)[big].abs().max().item() < 2e-4
-        # graph-mode data parallel plan (hipGraph fwd+bwd -> bucketed all-reduce -> hipGraph scale+Adam): the first
-        # step() is exactly one optimisation step (the capture warm-up is rolled back), same gradients as eager
-        l2, g2, p2 = run(True, True, 1)
-        assert l2 == pytest.approx(l0, rel=1e-5)
-        assert ((g2 - g0).abs().max() / g0.abs().max()).item() < 1e-3
-        assert (p2 - p0)[big].abs().max().item() < 2e-4
-        # several steps keep training on both plans (four Adam steps at lr 1e-3 amplify the atomics' run-to-run noise to a
-        # few percent of the loss: the one-step comparisons above are the strict ones)
-        l4, _, _ = run(False, False, 4)
-        ld, gd, _ = run(True, True, 4)
-        assert np.isfinite(ld) and torch.isfinite(gd).all()
-        assert ld == pytest.approx(l4, rel=0.15) and ld < l0
-        os.environ['FAMI_DDP_GRAPH'] = '0'          # eager, hook-overlapped plan
-        try:
-            le, ge, _ = run(True, True, 4)
-        finally:
-            del os.environ['FAMI_DDP_GRAPH']
-        assert np.isfinite(le) and le == pytest.approx(l4, rel=0.15)
-    finally:
-        dist.destroy_process_group()
+    the identity).  Runs in a CHILD process (tests/_ddp_single_rank.py): creating and destroying an RCCL process group
+    inside the long-lived pytest process left the HIP runtime in a state where a hipGraph instantiated by a LATER test
+    crashed in hipGraphLaunch (hip::Graph::UpdateStreams; reproducible only with this test earlier in the same process,
+    gone without it) -- a training process keeps its one process group for life, so the child mirrors real use."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29517')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ddp_single_rank.py')],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DDP_SINGLE_RANK_OK' in r.stdout
 
 
 def test_predict_end_to_end(dev):

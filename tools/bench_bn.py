@@ -25,5 +25,13 @@ for dt in ('f32', 'bf16'):
         t1 = timeit(lambda: L.call('fami_bn_stats_' + dt, x.data_ptr(), P, C, mean.data_ptr(), inv.data_ptr(), None, None, 0.1, 1e-5, ws.data_ptr(), st))
         t2 = timeit(lambda: L.call('fami_bn_apply_' + dt, x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(), b.data_ptr(), None, y.data_ptr(), P, C, 1, st))
         t3 = timeit(lambda: L.call('fami_bn_bwd_' + dt, dy.data_ptr(), x.data_ptr(), y.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, P, C, 1, 0, 0, 0, ws.data_ptr(), st))
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        slots = torch.zeros(L.cdll.fami_bn_slots_bytes(C) // 4, device=dev)     # never re-zeroed here: timing only
+        t4 = timeit(lambda: L.call('fami_bn_train_fwd_' + dt, x.data_ptr(), None, y.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(), inv.data_ptr(), rm.data_ptr(), rv.data_ptr(), P, C, 1, 0.1, 1e-5, ws.data_ptr(), st))
+        t5 = timeit(lambda: L.call('fami_bn_train_fwd2_' + dt, x.data_ptr(), None, y.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(), inv.data_ptr(), rm.data_ptr(), rv.data_ptr(), P, C, 1, 0.1, 1e-5, slots.data_ptr(), st))
+        mean.zero_(); inv.fill_(1.0)
+        t6 = timeit(lambda: L.call('fami_bn_bwd2_' + dt, dy.data_ptr(), x.data_ptr(), y.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, P, C, 1, 0, 0, 0, slots.data_ptr(), st))
+        t7 = timeit(lambda: L.call('fami_bn_bwd2_' + dt, dy.data_ptr(), x.data_ptr(), y.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(), b.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), None, P, C, 2, 0, 0, 0, slots.data_ptr(), st))
+        print('   train_fwd 3-launch %5.1f us, 2-launch %5.1f us | bwd 3-launch %5.1f us, 2-launch (mask from y) %5.1f us, (mask from x) %5.1f us' % (t4, t5, t3, t6, t7))
         print('%s %3dx%-3d C=%-3d %6.1f MB | stats %5.1f us (%4.0f GB/s) | apply %5.1f us (%4.0f GB/s, r+w) | bwd %5.1f us (%4.0f GB/s: 2x(dy,x,y) + dx)' %
               (dt, H, W, C, nb / 1e6, t1, nb / t1 / 1e3, t2, 2 * nb / t2 / 1e3, t3, 7 * nb / t3 / 1e3))
