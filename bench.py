@@ -146,6 +146,12 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
            "traffic": pmc_traffic('dcn_fwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
            "algorithmic_bytes": int(nbytes), "avg_launch_us": round(ms * 1e3, 2)}
+    # the opt-in LDS-window forward kernel on the same launch (measured, not the default)
+    L.cdll.fami_dcn_tune(2)
+    try:
+        fwd["lds_window_kernel_us"] = round(_time_launches(launch, s, reps) * 1e3, 2)
+    finally:
+        L.cdll.fami_dcn_tune(-1)
     # backward (the launch the training step issues: column gradient, offset / mask gradients, input-gradient scatter,
     # modulated samples for the weight gradient)
     wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)

@@ -875,8 +875,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ x, lo
     const float v = fabsf(ld1(x + i));
     m = v > m ? v : m;          // NaN never wins
   }
+  // one atomic per workgroup (the host launches <= 256 of them): one per wave of a 2048-workgroup grid serialised 8192
+  // same-address atomics, 95 us for a 1.3 M-element tensor
+  __shared__ float red[4];
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax(out, __float_as_uint(fminf(m, 3.0e38f)));
+  }
 }
 __global__ void zero_u64_kernel(unsigned long long* p, long n, unsigned* amax) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0ull;
@@ -1505,7 +1513,7 @@ static int dcn_bwd_det_impl(const T* x, const T* off, const T* msk, const T* dy,
   hipLaunchKernelGGL(zero_u64_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(gfix), n, amax);
   FAMI_CHECK_LAUNCH(nm);
   const long ndy = (long)B * Ho * Wo * Co;
-  hipLaunchKernelGGL(absmax_kernel<T>, dim3(fami_ew_grid(ndy)), dim3(256), 0, s, dy, ndy, amax);
+  hipLaunchKernelGGL(absmax_kernel<T>, dim3(fami_ew_grid(ndy) < 256 ? fami_ew_grid(ndy) : 256), dim3(256), 0, s, dy, ndy, amax);
   FAMI_CHECK_LAUNCH(nm);
   const int rc = dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, gfix, amax);
   if (rc != FAMI_OK) return rc;

@@ -1285,6 +1285,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps4_kernel(const float* __
   if (i < n4) {
     const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + i;
     int k = g;
+    // eight slabs per thread in flight: the 48-channel layers give this kernel only ~1.3 workgroups per CU (324 blocks),
+    // so the bytes in flight per CU -- not the bandwidth -- set its time (42 MB in 16.7 us with four loads in flight)
+    for (; k + 7 * SG < psplit; k += 8 * SG) {
+      const f32x4 v0 = p4[(long)k * n4], v1 = p4[(long)(k + SG) * n4], v2 = p4[(long)(k + 2 * SG) * n4],
+                  v3 = p4[(long)(k + 3 * SG) * n4], v4 = p4[(long)(k + 4 * SG) * n4], v5 = p4[(long)(k + 5 * SG) * n4],
+                  v6 = p4[(long)(k + 6 * SG) * n4], v7 = p4[(long)(k + 7 * SG) * n4];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+    }
     for (; k + 3 * SG < psplit; k += 4 * SG) {
       s0 += p4[(long)k * n4];
       s1 += p4[(long)(k + SG) * n4];
