@@ -20,6 +20,7 @@
 // rate (32 cycles / instruction / SIMD) operand traffic is ~25 B/clk/CU.
 // dgrad is the same kernel with the transposed position map (MODE 1).
 #include "common.h"
+#include <type_traits>
 
 struct ConvArgs {
   const float* x;       // GEMM input activation  [N,Hi,Wi,Ci]
@@ -1238,6 +1239,114 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
     }
 }
 
+// The same kernel for stride-1 "same"-size convolutions (Ho = H, Wo = W; Ci, Co multiples of 16; W >= 4) with the
+// per-iteration bookkeeping taken off the vector pipe.  f32-input MFMA and VALU share one pipe on gfx950
+// (tools/probes/mfma_valu_overlap.hip), and the general kernel above spends ~35 VALU instructions per 9 MFMAs on pixel
+// -> (n, y, x) wrap logic, bounds tests and two quarter-rate 64-bit multiply-adds: ~170 of every ~460 pipe cycles.  Here
+//  * the input address of output pixel `pix` at tap (dy, dx) is LINEAR in NHWC: (pix + dy*W + dx)*Ci -- image and row
+//    wraps only matter for VALIDITY, so the per-lane offsets advance by one v_add each per iteration;
+//  * the position of the wave's 4-pixel group (ox0, oy0) is tracked in SGPRs; a group that lies inside one row, away from
+//    the border this tap looks across and inside the chunk takes the fast path (no per-lane test at all: 94 % of the
+//    groups at W = 72); the others take a wave-uniform branch to the per-lane test.
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(576) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
+  const int lane = threadIdx.x & 63;
+  const int tap = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c16 = lane & 15, kq = lane >> 4;
+  int ps, byl;
+  xcd_tile(p.xcd, ps, byl);
+  const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int taps = p.kh * p.kw;
+  const int dky = ky * p.dil - p.pad, dkx = kx * p.dil - p.pad;
+  const int w_lo = ps * p.chunk;                 // multiple of 16
+  const int w_hi = min(p.P, w_lo + p.chunk);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+  // per-lane byte offsets of this lane's pixel (pix0 + kq) at tile 0; tiles are +64 B immediates
+  unsigned vx = (unsigned)(((w_lo + kq + dky * p.W + dkx) * p.Ci + cib * MT * 16 + c16) * (int)sizeof(T));
+  unsigned vy = (unsigned)(((w_lo + kq) * p.Co + cob * NT * 16 + c16) * (int)sizeof(T));
+  const unsigned sx = 4u * (unsigned)p.Ci * (unsigned)sizeof(T), sy = 4u * (unsigned)p.Co * (unsigned)sizeof(T);
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // wave-uniform position of the group's first pixel
+  int pix0 = w_lo;
+  int oy0, ox0;
+  {
+    const int r = w_lo % (p.H * p.W);
+    oy0 = r / p.W;
+    ox0 = r - oy0 * p.W;
+  }
+  auto load = [&](float(&a)[MT], float(&b)[NT]) {
+    const bool fast = (ox0 + 3 < p.W) && (ox0 + dkx >= 0) && (ox0 + 3 + dkx < p.W) && ((unsigned)(oy0 + dky) < (unsigned)p.H) &&
+                      (pix0 + 3 < w_hi);
+    unsigned xo = vx, yo = vy;
+    if (!fast) {
+      asm volatile("" ::: "memory");   // keep this a branch: if-converted it would run for every group
+      int ox = ox0 + kq, oy = oy0;
+      if (ox >= p.W) {
+        ox -= p.W;
+        oy = oy + 1 >= p.H ? 0 : oy + 1;
+      }
+      const bool pv = pix0 + kq < w_hi;
+      const bool xin = pv && (unsigned)(ox + dkx) < (unsigned)p.W && (unsigned)(oy + dky) < (unsigned)p.H;
+      xo = xin ? vx : FAMI_OOB;
+      yo = pv ? vy : FAMI_OOB;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = ldbuf<T>(rx, xo + (unsigned)(mt * 16 * (int)sizeof(T)));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = ldbuf<T>(ry, yo + (unsigned)(nt * 16 * (int)sizeof(T)));
+    vx += sx;
+    vy += sy;
+    pix0 += 4;
+    ox0 += 4;
+    if (ox0 >= p.W) {
+      ox0 -= p.W;
+      oy0 = oy0 + 1 >= p.H ? 0 : oy0 + 1;
+    }
+  };
+  auto mma = [&](const float(&a)[MT], const float(&b)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  };
+  const int Tn = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
+  float a0[MT], b0[NT], a1[MT], b1[NT];
+  if (Tn > 0) {
+    load(a0, b0);
+    for (int it = 0; it < Tn; it += 2) {
+      // the scheduler would sink each load group below the MFMAs that precede its use (one buffer instead of two)
+      load(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      load(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+    }
+  }
+  float* slab = p.part + ((long)ps * taps + tap) * p.Ci * p.Co;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cci = (cib * MT + mt) * 16 + kq * 4 + r;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int cco = (cob * NT + nt) * 16 + c16;
+        slab[(long)cci * p.Co + cco] = acc[mt][nt][r];
+      }
+    }
+}
+
 // slabs [psplit][tap][ci][co] -> dw OIHW (=|+=).  64 outputs x 16 slab groups per block: the reduction is
 // latency-bound (each output owns a strided column), so parallelism comes from splitting the slab axis.
 __global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __restrict__ part,
@@ -1816,6 +1925,7 @@ static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split 
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
 static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
 static int g_wgrad_lds_f32 = 2;  // f32 LDS weight gradient: 0 never, 1 whenever eligible, 2 only where it measured faster
+static int g_wgrad_lin = 1;      // fami_conv_tune_wgrad_lds(50 / 51): linear-address per-tap f32 kernel off / on
 
 // LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
 template <typename T>
@@ -1916,6 +2026,10 @@ int fami_conv_tune_wgrad_lds(int on) {
     g_wgrad_ps = on - 1000;
     return FAMI_OK;
   }
+  if (on == 50 || on == 51) {  // benchmarks / tests: general (50) or linear-address (51) per-tap f32 kernel
+    g_wgrad_lin = on - 50;
+    return FAMI_OK;
+  }
   if (on >= 100) {  // benchmarks: 100 + mt caps the input-channel tiles per workgroup of the f32 kernels
     g_wgrad_mt = on - 100;
     return FAMI_OK;
@@ -1924,6 +2038,7 @@ int fami_conv_tune_wgrad_lds(int on) {
     g_wgrad_lds = 1;
     g_wgrad_lds_f32 = 2;
     g_wgrad_nsub = 1;
+    g_wgrad_lin = 1;
     return FAMI_OK;
   }
   g_wgrad_lds = on ? 1 : 0;
@@ -2147,9 +2262,17 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
   if (q.pertap) {
     const dim3 grid(q.psplit, q.ciBlocks * q.coBlocks), block(kh * kw * 64);
     bool ok = false;
+    // stride-1 same-size convolutions of whole 16-channel tiles: linear-address kernel (f32 storage only)
+    const bool lin = std::is_same<T, float>::value && g_wgrad_lin && stride == 1 && a.Ho == H && a.Wo == W && W >= 4 &&
+                     Ci % 16 == 0 && Co % 16 == 0;
 #define FAMI_TCASE(mt, nt)                                                                  \
   if (q.MT == mt && q.NT == nt) {                                                           \
-    hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);             \
+    if constexpr (std::is_same<T, float>::value) {                                          \
+      if (lin) hipLaunchKernelGGL((conv_wgrad_taps_lin_f32<T, mt, nt>), grid, block, 0, s, a); \
+      else hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);      \
+    } else {                                                                                \
+      hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);           \
+    }                                                                                       \
     ok = true;                                                                              \
   }
     FAMI_TCASE(1, 1) FAMI_TCASE(1, 2) FAMI_TCASE(1, 3) FAMI_TCASE(1, 4)

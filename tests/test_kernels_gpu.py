@@ -514,6 +514,43 @@ def test_prepare_clip_writes_batch_slices(dev):
     assert (v2[5] == 0).all() or (fv[5] != 0).any()
 
 
+@pytest.mark.parametrize("shape", [(20, 96, 72, 48, 48, 1), (5, 48, 36, 96, 96, 1), (3, 24, 18, 192, 192, 1),
+                                   (2, 12, 9, 96, 48, 1), (2, 24, 18, 48, 48, 3), (1, 7, 5, 32, 64, 1), (3, 6, 4, 16, 16, 1),
+                                   (1, 1, 300, 16, 32, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_wgrad_linear_address_kernel_is_bitwise_the_general_one(dev, shape):
+    """conv_wgrad_taps_lin_f32 (stride-1 same-size convolutions: linear input addresses, wave-uniform border test) walks
+    the pixels in the order of conv_wgrad_taps_f32, so the two weight gradients are equal bit for bit -- on maps whose
+    width is / is not a multiple of the 4-pixel K group, a dilated 3x3, ragged last chunks, one-row maps -- and both
+    match ATen's weight gradient on the CPU."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    N, H, W, Ci, Co, dil = shape
+    torch.manual_seed(N * H + Ci)
+    x = torch.randn(N, H, W, Ci, device=dev)
+    dy = torch.randn(N, H, W, Co, device=dev)
+    nb = L.cdll.fami_conv2d_wgrad_workspace(N, H, W, Ci, Co, 3, 3, 1, dil, dil)
+    ws = torch.empty(nb // 4 + 16, device=dev)
+    out = []
+    try:
+        L.cdll.fami_conv_tune_wgrad_lds(0)                     # per-tap kernels also where the LDS form is the default
+        for knob in (50, 51):
+            L.cdll.fami_conv_tune_wgrad_lds(knob)
+            dw = torch.full((Co, Ci, 3, 3), 7.0, device=dev)
+            L.call('fami_conv2d_wgrad_f32', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                   N, H, W, Ci, Co, 3, 3, 1, dil, dil, 0, st)
+            torch.cuda.synchronize()
+            out.append(dw)
+    finally:
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
+    assert torch.equal(out[0], out[1])
+    if N * H * W <= 20000:
+        xc = x.cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(False)
+        w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+        F.conv2d(xc, w, None, 1, dil, dil).backward(dy.cpu().permute(0, 3, 1, 2).contiguous())
+        assert relerr(out[1], w.grad) < 5e-5
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
 def test_batch_weight_pack_equals_single_pack(dev, dt):
     """fami_pack_conv_weights_batch_* (one launch for every weight image of a step; 3x3 images go through an LDS block
