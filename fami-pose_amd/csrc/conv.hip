@@ -1012,6 +1012,7 @@ struct WgradArgs {
   int P, chunk, ciBlocks, coBlocks;
   unsigned x_bytes, dy_bytes;
   int xcd;
+  int psplit, w8;   // linear-address kernel: number of pixel chunks; 8-wave workgroups (3x3 only)
 };
 
 // dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
@@ -1249,18 +1250,43 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
 //    the border this tap looks across and inside the chunk takes the fast path (no per-lane test at all: 94 % of the
 //    groups at W = 72); the others take a wave-uniform branch to the per-lane test.
 template <typename T, int MT, int NT>
-__global__ __launch_bounds__(576) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
+__global__ __launch_bounds__(1024) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
   const int lane = threadIdx.x & 63;
-  const int tap = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, kq = lane >> 4;
-  int ps, byl;
-  xcd_tile(p.xcd, ps, byl);
+  int bx, byl;
+  xcd_tile(p.xcd, bx, byl);
+  // 9 waves on 4 SIMDs leave one SIMD of the CU with a third wave's worth of extra MFMA work.  3x3 kernels therefore run
+  // workgroups of 8 (w8 = 1) or 16 (w8 = 2) waves: workgroup c < psplit takes taps 0..7 of slab c, the workgroups behind
+  // them take tap 8 of eight slabs each (their operands are L2 hits: the first kind reads the same rows at the same
+  // time).  With 16 waves a slab is the sum of TWO pixel chunks: the upper eight waves hand their accumulators to the
+  // lower eight through LDS, which halves the slab traffic and the reduce pass behind it.
+  int tap = wave, slab = bx, ps = bx, half = 0;
+  bool active = true;
+  if (p.w8 == 1) {
+    if (bx >= p.psplit) {
+      slab = ps = (bx - p.psplit) * 8 + wave;
+      tap = 8;
+      active = slab < p.psplit;
+    }
+  } else if (p.w8 == 2) {
+    half = wave >> 3;
+    const int w = wave & 7;
+    if (bx < p.psplit) {
+      tap = w;
+    } else {
+      slab = (bx - p.psplit) * 8 + w;
+      tap = 8;
+      active = slab < p.psplit;
+    }
+    ps = 2 * slab + half;
+  }
   const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
   const int taps = p.kh * p.kw;
   const int dky = ky * p.dil - p.pad, dkx = kx * p.dil - p.pad;
-  const int w_lo = ps * p.chunk;                 // multiple of 16
-  const int w_hi = min(p.P, w_lo + p.chunk);
+  const int w_lo = active ? min(ps * p.chunk, p.P) : 0;   // multiple of 16 (or the end)
+  const int w_hi = active ? min(p.P, w_lo + p.chunk) : 0;
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
@@ -1333,7 +1359,28 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
       mma(a1, b1);
     }
   }
-  float* slab = p.part + ((long)ps * taps + tap) * p.Ci * p.Co;
+  if (p.w8 == 2) {
+    extern __shared__ float wg_sm[];   // [8 waves][MT*NT tiles][4][64 lanes]
+    float* mine = wg_sm + (wave & 7) * (MT * NT * 256) + lane;
+    if (half) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mine[((mt * NT + nt) * 4 + r) * 64] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (half) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][nt][r] += mine[((mt * NT + nt) * 4 + r) * 64];
+  }
+  if (!active) return;
+  float* slabp = p.part + ((long)slab * taps + tap) * p.Ci * p.Co;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1342,7 +1389,7 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int cco = (cob * NT + nt) * 16 + c16;
-        slab[(long)cci * p.Co + cco] = acc[mt][nt][r];
+        slabp[(long)cci * p.Co + cco] = acc[mt][nt][r];
       }
     }
 }
@@ -1997,6 +2044,10 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
   return 1;
 }
 
+static bool wgrad_lin_ok(int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  return stride == 1 && 2 * pad == dil * (kh - 1) && 2 * pad == dil * (kw - 1) && kh * kw > 1 && kh * kw <= 9 && W >= 4 &&
+         Ci % 16 == 0 && Co % 16 == 0;
+}
 static bool geom_ok(int kh, int kw, int stride, int pad, int dil) {
   return kh >= 1 && kw >= 1 && kh <= 7 && kw <= 7 && (stride == 1 || stride == 2) && pad >= 0 && dil >= 1;
 }
@@ -2026,7 +2077,7 @@ int fami_conv_tune_wgrad_lds(int on) {
     g_wgrad_ps = on - 1000;
     return FAMI_OK;
   }
-  if (on == 50 || on == 51) {  // benchmarks / tests: general (50) or linear-address (51) per-tap f32 kernel
+  if (on >= 50 && on <= 54) {  // benchmarks / tests: general (50) / linear-address per-tap f32 kernel (51: default mix; 52: 9-wave workgroups; 53: 8-wave; 54: 16-wave, two chunks per slab)
     g_wgrad_lin = on - 50;
     return FAMI_OK;
   }
@@ -2125,8 +2176,9 @@ int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend,
   return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
 }
 
-struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk, pertap; long P; };
-static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk, pertap, w8; long P; };
+static bool wgrad_lin_ok(int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int w8 = 0) {
   WgradPlan q;
   const int Ho = out_dim(H, kh, stride, pad, dil), Wo = out_dim(W, kw, stride, pad, dil);
   q.P = (long)N * Ho * Wo;
@@ -2138,12 +2190,28 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   q.pertap = (kh * kw > 1 && kh * kw <= 9) ? 1 : 0;   // one wave per tap (3x3): workgroups of kh*kw waves
   const long by = q.pertap ? (long)q.ciBlocks * q.coBlocks : (long)kh * kw * q.ciBlocks * q.coBlocks;
   long ps = ((q.pertap ? (g_wgrad_ps ? g_wgrad_ps : 512) : 1024) + by - 1) / by;
+  q.w8 = 0;
+  // w8 = 3: 16-wave workgroups for the <= 3x3-tile instances (48 / 96 channels: 66.9 vs 69.2 us and half the slabs),
+  // 8-wave ones for the 4x4-tile instances (384 channels with 16 waves and 128 KB of LDS: 120 vs 78 us)
+  if (w8 == 3) w8 = q.MT * q.NT <= 9 ? 2 : 1;
+  if (w8 && q.pertap && kh * kw == 9 && ps >= 9) {
+    // 8-/16-wave workgroups: c slabs need c + ceil(c/8) workgroups.  Never more workgroups than the target (one
+    // workgroup beyond the resident set costs a whole extra round: 192 channels, 9 columns x 57 = 513 workgroups ran
+    // 90 us against 80 us for 9 x 43)
+    q.w8 = w8;
+    const long T = (g_wgrad_ps ? g_wgrad_ps : (w8 == 2 ? 256 : 512)) / by;
+    ps = T * 8 / 9;
+    while (ps > 1 && ps + (ps + 7) / 8 > T) --ps;
+    if (ps < 1) ps = 1;
+    if (w8 == 2) ps *= 2;   // pixel chunks: two per slab
+  }
   const long maxps = q.pertap ? (q.P + 63) / 64 : (q.P + 255) / 256;
   if (ps > maxps) ps = maxps;
   if (ps < 1) ps = 1;
   long chunk = (q.P + ps - 1) / ps;
   chunk = ((chunk + 15) / 16) * 16;
   ps = (q.P + chunk - 1) / chunk;
+  if (q.w8 == 2) ps = (ps + 1) / 2;   // slabs
   q.psplit = (int)ps;
   q.chunk = (int)chunk;
   return q;
@@ -2245,7 +2313,9 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
     fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
-  const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
+  // stride-1 same-size convolutions of whole 16-channel tiles: linear-address kernel (f32 storage only)
+  const bool lin = std::is_same<T, float>::value && g_wgrad_lin && wgrad_lin_ok(H, W, Ci, Co, kh, kw, stride, pad, dil);
+  const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil, !lin ? 0 : (g_wgrad_lin == 1 ? 3 : (g_wgrad_lin == 3 ? 1 : (g_wgrad_lin == 4 ? 2 : 0))));
   const long need = (long)q.psplit * Co * Ci * kh * kw * (long)sizeof(float);
   FAMI_REQUIRE(ws_bytes >= need, nm, "workspace too small");
   FAMI_REQUIRE(q.P < (1L << 31), nm, "size out of range");
@@ -2260,15 +2330,21 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
   const long n = (long)Co * Ci * kh * kw;
   if (q.pertap) {
-    const dim3 grid(q.psplit, q.ciBlocks * q.coBlocks), block(kh * kw * 64);
+    const dim3 grid(q.w8 ? q.psplit + (q.psplit + 7) / 8 : q.psplit, q.ciBlocks * q.coBlocks), block(q.w8 ? 512 * q.w8 : kh * kw * 64);
+    const size_t lin_lds = q.w8 == 2 ? (size_t)8 * q.MT * q.NT * 1024 : 0;
+    a.psplit = q.psplit; a.w8 = q.w8;
     bool ok = false;
-    // stride-1 same-size convolutions of whole 16-channel tiles: linear-address kernel (f32 storage only)
-    const bool lin = std::is_same<T, float>::value && g_wgrad_lin && stride == 1 && a.Ho == H && a.Wo == W && W >= 4 &&
-                     Ci % 16 == 0 && Co % 16 == 0;
 #define FAMI_TCASE(mt, nt)                                                                  \
   if (q.MT == mt && q.NT == nt) {                                                           \
     if constexpr (std::is_same<T, float>::value) {                                          \
-      if (lin) hipLaunchKernelGGL((conv_wgrad_taps_lin_f32<T, mt, nt>), grid, block, 0, s, a); \
+      if (lin) {                                                                            \
+        static bool attr = false;                                                           \
+        if (!attr) {                                                                        \
+          (void)hipFuncSetAttribute((const void*)conv_wgrad_taps_lin_f32<T, mt, nt>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * mt * nt * 1024); \
+          attr = true;                                                                      \
+        }                                                                                   \
+        hipLaunchKernelGGL((conv_wgrad_taps_lin_f32<T, mt, nt>), grid, block, lin_lds, s, a); \
+      }                                                                                     \
       else hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);      \
     } else {                                                                                \
       hipLaunchKernelGGL((conv_wgrad_taps_f32<T, mt, nt>), grid, block, 0, s, a);           \
@@ -2377,7 +2453,10 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
   WgradLdsPlan l = g_wgrad_lds_f32 ? wgrad_lds_plan_f32(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   // measured (tools/bench_wgrad.py f32): the staged kernel wins once the channel blocks alone give >= 64 workgroup
   // columns (384 channels: 136 vs 151 us); below that the per-tap scalar-operand kernel is faster (85 vs 105 us)
-  if (g_wgrad_lds_f32 == 2 && l.ok && l.ciBlocks * l.coBlocks < 64) l.ok = 0;
+  // ... and the linear-address per-tap kernel beats both wherever it applies (384 channels: 78 vs 103 us)
+  if (g_wgrad_lds_f32 == 2 && l.ok &&
+      (l.ciBlocks * l.coBlocks < 64 || (g_wgrad_lin && wgrad_lin_ok(H, W, Ci, Co, kh, kw, stride, pad, dil))))
+    l.ok = 0;
   if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
     const long need = (long)l.G * Co * Ci * 9 * (long)sizeof(float);
     FAMI_REQUIRE(ws_bytes >= need, "fami_conv2d_wgrad_f32", "workspace too small");

@@ -12,7 +12,7 @@ L = lib().cdll
 dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
 dtype = sys.argv[1]
 states = [dict((kv.split('=')[0], kv.split('=')[1]) for kv in a.split(',')) for a in sys.argv[2:4]]
-args = types.SimpleNamespace(width=48, img_w=288, img_h=384, sup=4, freeze_backbone=False, dtype=dtype)
+args = types.SimpleNamespace(width=48, img_w=288, img_h=384, sup=4, freeze_backbone=False, dtype=dtype, deterministic=False)
 kf, sup, joints, vis = bench.synth_batch(4, 4, 384, 288, 17, dev, 19970808)
 trainers = []
 for st in states:
