@@ -87,7 +87,13 @@ __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ w
 
 // KS = number of K partitions among the 4 waves of a workgroup (split-K for the low-resolution
 // branches, whose pixel count alone cannot fill 1024 SIMDs); partial accumulators meet in LDS.
-template <int MT, int NT, int MODE, int VEC, int KS, int ST>
+// LIN = 1 (stride 1, Ci % 16 == 0, <= 25 taps): the K-loop bookkeeping leaves the vector pipe, which the f32-input MFMA
+// shares with the VALU on gfx950.  A lane's pixel never changes and the input address of tap (dy, dx) is the pixel's
+// own address plus the wave-uniform (dy*Wi + dx)*Ci, so a tap switch is one v_add plus a select on a per-lane tap
+// validity mask built once in the prologue (was: two bounds tests and two quarter-rate 64-bit multiply-adds), and the
+// per-iteration K offsets (kc*64 into the pixel, the weight block) travel in the buffer instructions' SGPR offset
+// instead of one v_add per load and a channel-tail test.
+template <int MT, int NT, int MODE, int VEC, int KS, int ST, int LIN = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63;
@@ -129,15 +135,61 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   unsigned aoff[MT];
   const int taps = p.kh * p.kw;
   int tap = 0, kc = kpart;
+  int lky = 0, lkx = 0;   // LIN: (ky, kx) of `tap`, kept in step with it (no division per tap switch)
+  auto next_tap = [&]() {
+    ++tap;
+    if (LIN) {
+      if (++lkx == p.kw) {
+        lkx = 0;
+        ++lky;
+      }
+    }
+  };
   while (kc >= p.KC) {
     kc -= p.KC;
-    ++tap;
+    next_tap();
   }
   unsigned boff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) boff[nt] = (unsigned)(min(ntg0 + nt, p.NTt - 1) * 256 + lane * 4) * 4u;
 
+  // LIN: per-lane pixel address and tap validity (bit t set = tap t reads padding; bits >= taps stay set: drain)
+  unsigned lbase[MT], linv[MT];
+  if (LIN) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      lbase[mt] = (unsigned)((((pn[mt] * p.Hi + py[mt]) * p.Wi + px[mt]) * p.Ci + kq * 4) * 4);
+      linv[mt] = 0xffffffffu;
+    }
+    int ky = 0, kx = 0;
+    for (int t = 0; t < taps; ++t) {
+      const int dy = MODE == 0 ? ky * p.dil - p.pad : p.pad - ky * p.dil;
+      const int dx = MODE == 0 ? kx * p.dil - p.pad : p.pad - kx * p.dil;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool v = pv[mt] && (unsigned)(py[mt] + dy) < (unsigned)p.Hi && (unsigned)(px[mt] + dx) < (unsigned)p.Wi;
+        linv[mt] &= ~((v ? 1u : 0u) << t);
+      }
+      if (++kx == p.kw) {
+        kx = 0;
+        ++ky;
+      }
+    }
+  }
+
   auto tap_setup = [&](int tp) {
+    if (LIN) {
+      const int dy = MODE == 0 ? lky * p.dil - p.pad : p.pad - lky * p.dil;
+      const int dx = MODE == 0 ? lkx * p.dil - p.pad : p.pad - lkx * p.dil;
+      const unsigned delta = (unsigned)((dy * p.Wi + dx) * p.Ci * 4);
+      const int tb = tp < 31 ? tp : 31;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned m = (unsigned)((int)(linv[mt] << (31 - tb)) >> 31);   // all ones: padding / drain
+        aoff[mt] = ((lbase[mt] + delta) & ~m) | (FAMI_OOB & m);
+      }
+      return;
+    }
     const int ky = tp / p.kw, kx = tp - ky * p.kw;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -158,6 +210,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   };
 
   auto load = [&](f32x4(&a)[MT], f32x4(&b)[NT]) {
+    if (LIN) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mt], kc * 64, 0));
+      const int wbs = (tap * p.KC + kc) * p.NTt * 1024;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, boff[nt], wbs, 0));
+      kc += KS;
+      if (kc >= p.KC) {
+        do {
+          kc -= p.KC;
+          next_tap();
+        } while (kc >= p.KC);
+        tap_setup(tap);
+      }
+      return;
+    }
     const int cbase = kc * 16 + kq * 4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1850,9 +1920,21 @@ static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int
   }
 }
 
+static int g_lin_conv = 1;  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
 template <int MODE, int VEC>
 static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipStream_t s) {
   const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
+  if constexpr (VEC) {
+    if (g_lin_conv && MT == 1 && ST == 2 && a.sh == 0 && a.Ci % 16 == 0 && a.kh * a.kw <= 25 && (NT == 3 || NT == 4)) {
+#define FAMI_LIN(nt, ks)                                                                            \
+  if (NT == nt && KS == ks) {                                                                       \
+    hipLaunchKernelGGL((conv_igemm_f32<1, nt, MODE, 1, ks, 2, 1>), grid, dim3(256), 0, s, a);       \
+    return 0;                                                                                       \
+  }
+      FAMI_LIN(3, 1) FAMI_LIN(3, 2) FAMI_LIN(3, 4) FAMI_LIN(4, 1) FAMI_LIN(4, 2) FAMI_LIN(4, 4)
+#undef FAMI_LIN
+    }
+  }
 #define FAMI_CASE(mt, nt, ks)                                                                       \
   if (MT == mt && NT == nt && KS == ks) {                                                           \
     if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_f32<mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
@@ -2104,6 +2186,10 @@ int fami_conv_tune_xcd(int mode) {
   return FAMI_OK;
 }
 int fami_conv_tune_stages(int stages) {
+  if (stages == 100 || stages == 101) {   // benchmarks / tests: linear-address f32 implicit GEMM off / on
+    g_lin_conv = stages - 100;
+    return FAMI_OK;
+  }
   g_stages = (stages >= 2 && stages <= 4) ? stages : 0;
   return FAMI_OK;
 }
