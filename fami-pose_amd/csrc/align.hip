@@ -844,6 +844,7 @@ struct DcnBwdArgs {
   const unsigned* amax_bits;
   const float* wnorm;   // 1 float: max over columns k of sum_co |W[co][k]| (tail of the backward weight image)
   int fixl;             // 1: the LDS region accumulates in 64-bit fixed point (per-workgroup scale), flushed to gx as f32
+  int abl;              // benchmarks (fami_dcn_tune(1024 + bits)): 1 = no region flush, 2 = no LDS adds, 4 = constant scale (no maxima pass)
 };
 
 // Fixed-point scale of the deterministic input-gradient accumulation: 2^(DCN_FIX_BITS - ceil(log2(max|dy|))).  A
@@ -968,7 +969,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   float* gxb = (!DET && p.gx) ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
   long long* gfb = (DET && p.gfix) ? p.gfix + (long)b * p.H * p.W * p.C : nullptr;
   const int gtl_n = p.GC * K;  // (group, tap) pairs of this chunk
-  if (FIXL && gxb) {           // per-workgroup fixed-point scale from the tile's |dy| and |mask| maxima
+  if (FIXL && gxb && (p.abl & 4)) {
+    fscale = 1048576.f;
+    finv = 1.f / 1048576.f;
+  } else if (FIXL && gxb) {           // per-workgroup fixed-point scale from the tile's |dy| and |mask| maxima
     __shared__ float smax[2][4];
     float mdy = 0.f, mmk = p.msk ? 0.f : 1.f;
     const int co4 = p.Co >> 2;
@@ -1114,7 +1118,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
             }
           }
         } else if (FIXL && gxb) {
-          if (inreg) {
+          if (p.abl & 2) {
+          } else if (inreg) {
             long long* r00 = regfix + ((long)ry * p.RW + rx) * Cc + cl;
             const f32x4 gs = gv * fscale;
 #pragma unroll
@@ -1203,6 +1208,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
       }
     }
   } else if (FIXL && gxb) {
+    if (p.abl & 1) return;
     for (int e = tid; e < p.RH * p.RW * Cc; e += 256) {
       const long long v = regfix[e];
       if (v == 0ll) continue;
@@ -1425,6 +1431,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   return FAMI_OK;
 }
 
+static int g_dcn_bwd_abl = 0;       // fami_dcn_tune(1024 + bits): ablations of the backward kernel (benchmarks)
 static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = 64-bit fixed-point LDS adds
 static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   // smallest group count whose column span cg*K*GC is a multiple of 16 and divides G
@@ -1476,6 +1483,7 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
   a.wnorm = wpb + (long)fami_cdiv((long)C * K, 16) * a.KSo * 256;       // written by fami_dcn_pack_weight_bwd_f32 behind the image
   a.fixl = (!gfix && gx && g_dcn_bwd_scatter != 0) ? 1 : 0;
+  a.abl = g_dcn_bwd_abl;
   size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * ((gfix || a.fixl) ? 2 : 1)) * sizeof(float);
   if (a.fixl && lds > 150 * 1024) {                                       // the f32 region is half the size
     a.fixl = 0;
@@ -1550,7 +1558,8 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
-  if (gather >= 512) g_dcn_bwd_scatter = gather - 512;
+  if (gather >= 1024) g_dcn_bwd_abl = gather - 1024;
+  else if (gather >= 512) g_dcn_bwd_scatter = gather - 512;
   else if (gather >= 256) g_dcn_ksplit = gather - 256;
   else if (gather >= 64) g_dcn_abl = gather - 64;
   else if (gather >= 32) g_dcn_win_r = gather - 32;       // benchmarks: offset reach of the window kernel (0 = automatic)

@@ -1416,17 +1416,23 @@ __global__ __launch_bounds__(1024) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) 
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   };
   const int Tn = (w_hi > w_lo) ? (w_hi - w_lo + 3) / 4 : 0;
-  float a0[MT], b0[NT], a1[MT], b1[NT];
+  // three operand sets: two K steps in flight behind the one being multiplied (inside the step the other stream lanes
+  // stretch the memory latency).  The scheduler would sink each load group below the MFMAs that precede its use (one
+  // buffer instead of three), hence the barriers.  Steps past the chunk load zeros.
+  float a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
   if (Tn > 0) {
     load(a0, b0);
-    for (int it = 0; it < Tn; it += 2) {
-      // the scheduler would sink each load group below the MFMAs that precede its use (one buffer instead of two)
-      load(a1, b1);
+    load(a1, b1);
+    for (int it = 0; it < Tn; it += 3) {
+      load(a2, b2);
       __builtin_amdgcn_sched_barrier(0);
       mma(a0, b0);
       load(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
       mma(a1, b1);
+      load(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a2, b2);
     }
   }
   if (p.w8 == 2) {
@@ -2049,7 +2055,8 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // Default (-1): bf16 staged, f32 direct.  fami_conv_tune_lds(0/1) forces one path for both (tests exercise both).
 static int g_use_lds = -1;
 static int g_lds_sim = 0;  // fami_conv_tune_lds(2): LDS kernel in its split-operand cost-simulation form (benchmarks)
-static int g_wgrad_nsub = 1; // sub-chunks per workgroup of the bf16 LDS wgrad (fewer, larger partial slabs)
+static int g_wgrad_nsub = 2; // sub-chunks per workgroup of the 16-bit LDS wgrad (fewer, larger partial slabs): 2 = half the slab
+                             // traffic and reduce pass, bf16 step 34.6 -> 33.3 ms in both A/B orders; 3 and 4 equal to 2
 static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
 static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
 static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
@@ -2170,7 +2177,7 @@ int fami_conv_tune_wgrad_lds(int on) {
   if (on < 0) {  // defaults
     g_wgrad_lds = 1;
     g_wgrad_lds_f32 = 2;
-    g_wgrad_nsub = 1;
+    g_wgrad_nsub = 2;
     g_wgrad_lin = 1;
     return FAMI_OK;
   }
@@ -2277,9 +2284,9 @@ static WgradPlan wgrad_plan(int N, int H, int W, int Ci, int Co, int kh, int kw,
   const long by = q.pertap ? (long)q.ciBlocks * q.coBlocks : (long)kh * kw * q.ciBlocks * q.coBlocks;
   long ps = ((q.pertap ? (g_wgrad_ps ? g_wgrad_ps : 512) : 1024) + by - 1) / by;
   q.w8 = 0;
-  // w8 = 3: 16-wave workgroups for the <= 3x3-tile instances (48 / 96 channels: 66.9 vs 69.2 us and half the slabs),
-  // 8-wave ones for the 4x4-tile instances (384 channels with 16 waves and 128 KB of LDS: 120 vs 78 us)
-  if (w8 == 3) w8 = q.MT * q.NT <= 9 ? 2 : 1;
+  // w8 = 3: 16-wave workgroups while a column of the grid still has >= 16 of them (48 / 96 / 192 channels: 66.9 vs 69.2,
+  // 64.3 vs 67.7, 67.1 vs 70.2 us, and half the slabs), 8-wave ones beyond (384 channels, 7 per column: 120 vs 78 us)
+  if (w8 == 3) w8 = 256 / by >= 16 ? 2 : 1;
   if (w8 && q.pertap && kh * kw == 9 && ps >= 9) {
     // 8-/16-wave workgroups: c slabs need c + ceil(c/8) workgroups.  Never more workgroups than the target (one
     // workgroup beyond the resident set costs a whole extra round: 192 channels, 9 columns x 57 = 513 workgroups ran

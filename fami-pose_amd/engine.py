@@ -591,9 +591,13 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ glue ops
-    def batch_slice(self, x, n0, n1):
-        """torch.chunk on the batch axis (Alignment_V15.py:121-125): a view; gradients land in the parent slice."""
-        if x.requires_grad and all(x is not p for p in self._sliced):
+    def batch_slice(self, x, n0, n1, terminal=False):
+        """torch.chunk on the batch axis (Alignment_V15.py:121-125): a view; gradients land in the parent slice.
+        terminal: a model output that nothing inside the graph consumes -- its gradient can only arrive through a seed
+        (gbuf creates the parent's buffer then), so the parent is not zero-filled up front: without a seed the
+        producer's backward is skipped, as autograd skips a branch whose .grad is None (kf_hm made the
+        final layer's weight gradient and a dgrad of zeros run every step)."""
+        if x.requires_grad and not terminal and all(x is not p for p in self._sliced):
             self._sliced.append(x)
         return T(x.data[n0:n1], x.requires_grad, parent=x, n0=n0, n1=n1)
 

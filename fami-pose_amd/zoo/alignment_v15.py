@@ -141,7 +141,7 @@ class Alignment_V15(EngineModule):
         S = sup_x.shape[1] // 3
         hm, feats, _ = self.hrnet.run(eng, eng.frames(kf_x, sup_x))
         feat = feats[0]
-        kf_hm = eng.batch_slice(hm, 0, B)
+        kf_hm = eng.batch_slice(hm, 0, B, terminal=True)
         kf = eng.batch_slice(feat, 0, B)
         # The S translation regressors SHARE their weights and BatchNorm modules (Alignment_V15.py:125-135 applies the same
         # feat_global_offset_layers to every supporting frame) and are chains of ~40 tiny kernels each: they run on
