@@ -811,6 +811,7 @@ __global__ __launch_bounds__(512 * KSPLIT) void dcn_fwd_win_kernel(DcnWinArgs<T>
 // the items, 16 consecutive channels per request instead of one address per lane, and no same-address pile-up.
 #define DCN_TILE 8
 #define DCN_RO 3
+#define DCN_MASK_BOUND 8.f   // fixed-point LDS scatter: |mask| above this takes the global-atomic path (see dcn_bwd_kernel)
 
 // f32 add into LDS as a compare-and-swap loop.  On gfx950 the native ds_add_f32 retires 0.33 lane-operations per clock
 // per CU at this kernel's access pattern (tools/probes/lds_atomic.hip: ds_add_u32 4.7, ds_add_u64 2.5, racy read +
@@ -843,7 +844,7 @@ struct DcnBwdArgs {
   long long* gfix;
   const unsigned* amax_bits;
   const float* wnorm;   // 1 float: max over columns k of sum_co |W[co][k]| (tail of the backward weight image)
-  int fixl;             // 1: the LDS region accumulates in 64-bit fixed point (per-workgroup scale), flushed to gx as f32
+  int fixl;             // 1 / 2: the LDS region accumulates in 64- / 32-bit fixed point (per-workgroup scale), flushed to gx as f32
   int abl;              // benchmarks (fami_dcn_tune(1024 + bits)): 1 = no region flush, 2 = no LDS adds, 4 = constant scale (no maxima pass)
 };
 
@@ -924,7 +925,7 @@ __global__ void dcn_pack_wb_kernel(const float* __restrict__ w, float* __restric
 // MODE 2 (default): 64-bit fixed-point LDS region -- native ds_add_u64 retires 2.5 lane-operations per clock per CU against
 //   the compare-and-swap loop's 1.4 at this access pattern (tools/probes/lds_atomic.hip) and needs a conversion and a shift
 //   per contribution instead of the loop -- flushed to gx with f32 global atomics like MODE 0.  The scale is per
-//   workgroup: 2^(30 - e) with 2^e > max|dy| (tile) x max_k sum_co |W[co][k]| x max|mask| (tile, chunk) >= any |gcol x mask|,
+//   workgroup: 2^(30 - e) with 2^e > max|dy| (tile) x max_k sum_co |W[co][k]| x DCN_MASK_BOUND >= any |gcol x mask| it accepts,
 //   so one contribution fits 31 bits, a cell (at most 64 pixels x 9 taps contributions) 41, and the bound's slack
 //   (~sqrt(Co) for random signs) still leaves ~2^-24 of the largest contribution as resolution -- fp32's own.
 // out[0] = max over columns k of sum_co |w[co][k]|  (w = weight.view(Co, CK)); out[1..3] = 0
@@ -944,7 +945,8 @@ __global__ __launch_bounds__(256) void dcn_wnorm_kernel(const float* __restrict_
 
 template <typename T, int KSO, int MODE>
 __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
-  constexpr bool DET = MODE == 1, FIXL = MODE == 2;
+  constexpr bool DET = MODE == 1, FIX32 = MODE == 3, FIXL = MODE == 2 || FIX32;
+  constexpr int FIXB = FIX32 ? 20 : 30;   // bits of one contribution at the bound
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = lane & 15, kq = lane >> 4;
@@ -953,6 +955,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   float* gcol = smem;                   // [16][gstride]
   float* region = smem + 16 * gstride;  // [RH][RW][Cc] (fp32), or the same shape in 64-bit fixed point (DET)
   long long* regfix = reinterpret_cast<long long*>(smem + 16 * gstride);   // gstride is a multiple of 4: 8-byte aligned
+  int* reg32 = reinterpret_cast<int*>(smem + 16 * gstride);                 // MODE 3: 32-bit fixed point
   float fscale = DET ? dcn_fix_scale(p.amax_bits) : 0.f;
   float finv = 0.f;
   int t, chunk;
@@ -963,7 +966,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   const int oy0 = ty * DCN_TILE, ox0 = tx * DCN_TILE;
   const int ry0 = oy0 * p.stride - p.pad - DCN_RO, rx0 = ox0 * p.stride - p.pad - DCN_RO;
   const int rsize = p.RH * p.RW * Cc;
-  if (DET || FIXL) { for (int i = tid; i < rsize; i += 256) regfix[i] = 0ll; }
+  if (FIX32) { for (int i = tid; i < rsize; i += 256) reg32[i] = 0; }
+  else if (DET || FIXL) { for (int i = tid; i < rsize; i += 256) regfix[i] = 0ll; }
   else { for (int i = tid; i < rsize; i += 256) region[i] = 0.f; }
   const T* xb = p.x + (long)b * p.H * p.W * p.C;
   float* gxb = (!DET && p.gx) ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
@@ -972,43 +976,36 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   if (FIXL && gxb && (p.abl & 4)) {
     fscale = 1048576.f;
     finv = 1.f / 1048576.f;
-  } else if (FIXL && gxb) {           // per-workgroup fixed-point scale from the tile's |dy| and |mask| maxima
-    __shared__ float smax[2][4];
-    float mdy = 0.f, mmk = p.msk ? 0.f : 1.f;
-    const int co4 = p.Co >> 2;
-    for (int i = tid; i < DCN_TILE * DCN_TILE * co4; i += 256) {
-      const int pix = i / co4, c4 = i - pix * co4;
-      const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
-      if (py < p.Ho && px < p.Wo) {
-        const f32x4 v = ld4(p.dy + (((long)b * p.Ho + py) * p.Wo + px) * p.Co + c4 * 4);
-        mdy = fmaxf(fmaxf(mdy, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      }
-    }
-    if (p.Co & 3) {
-      for (int i = tid; i < DCN_TILE * DCN_TILE * (p.Co & 3); i += 256) {
-        const int pix = i / (p.Co & 3), c = co4 * 4 + i % (p.Co & 3);
-        const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
-        if (py < p.Ho && px < p.Wo) mdy = fmaxf(mdy, fabsf(ld1(p.dy + (((long)b * p.Ho + py) * p.Wo + px) * p.Co + c)));
-      }
-    }
-    if (p.msk) {
-      for (int i = tid; i < DCN_TILE * DCN_TILE * gtl_n; i += 256) {
-        const int pix = i / gtl_n, gtl = i - pix * gtl_n;
-        const int py = oy0 + pix / DCN_TILE, px = ox0 + pix % DCN_TILE;
-        if (py < p.Ho && px < p.Wo) mmk = fmaxf(mmk, fabsf(ld1(p.msk + (((long)b * p.Ho + py) * p.Wo + px) * GK + chunk * gtl_n + gtl)));
+  } else if (FIXL && gxb) {
+    // per-workgroup fixed-point scale from the tile's max |dy|, read with phase A's own access pattern: every wave sees the
+    // whole tile, so a wave reduction is all it takes (no LDS, no barrier, 16-byte loads that phase A then finds in L2).
+    // |mask| is bounded by the constant DCN_MASK_BOUND instead of a second maxima pass over the tile's masks (scalar loads:
+    // the two passes together were 21 of the kernel's 169 us); a sample whose |mask| exceeds it goes to gx through the
+    // global-atomic path that samples leaving the region already take.
+    float mdy = 0.f;
+    for (int sub = 0; sub < (DCN_TILE * DCN_TILE) / 16; ++sub) {
+      const int py = oy0 + sub * 2 + (row >> 3), px = ox0 + (row & 7);
+      if (py >= p.Ho || px >= p.Wo) continue;
+      const long m = ((long)b * p.Ho + py) * p.Wo + px;
+#pragma unroll
+      for (int ks = 0; ks < KSO; ++ks) {
+        const int c0 = (ks * 4 + kq) * 4;
+        if (c0 + 3 < p.Co) {
+          const f32x4 v = ld4(p.dy + m * p.Co + c0);
+          mdy = fmaxf(fmaxf(mdy, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        } else {
+          for (int q = 0; q < 4; ++q)
+            if (c0 + q < p.Co) mdy = fmaxf(mdy, fabsf(ld1(p.dy + m * p.Co + c0 + q)));
+        }
       }
     }
     mdy = wave_max(mdy);
-    mmk = wave_max(mmk);
-    if (lane == 0) { smax[0][wave] = mdy; smax[1][wave] = mmk; }
-    __syncthreads();
-    const float bound = fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])) *
-                        fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])) * p.wnorm[0];
+    const float bound = mdy * (p.msk ? DCN_MASK_BOUND : 1.f) * p.wnorm[0];
     int e = -60;
     if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);   // bound = m * 2^e, m in [0.5, 1): every |gcol * mask| < 2^e
     e = e < -60 ? -60 : (e > 90 ? 90 : e);
-    fscale = ldexpf(1.f, 30 - e);
-    finv = ldexpf(1.f, e - 30);
+    fscale = ldexpf(1.f, FIXB - e);
+    finv = ldexpf(1.f, e - FIXB);
   }
   __syncthreads();
 
@@ -1069,7 +1066,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
       const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
       // region coordinates of the (y0, x0) corner; the four corners are inside iff 0 <= r < R-1
       const int ry = y0 - ry0, rx = x0 - rx0;
-      const bool inreg = ry >= 0 && ry + 1 < p.RH && rx >= 0 && rx + 1 < p.RW;
+      const bool inreg = ry >= 0 && ry + 1 < p.RH && rx >= 0 && rx + 1 < p.RW && (!FIXL || fabsf(mk) <= DCN_MASK_BOUND);
       float gm = 0.f, gpy = 0.f, gpx = 0.f;
       for (int q = 0; q < q4; ++q) {
         const int cl = (gtl / K) * p.cg + q * 4;  // channel within the chunk
@@ -1115,6 +1112,29 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
                 if (v10) fix_add(g00 + o10 + c, gv[c] * w10, fscale);
                 if (v11) fix_add(g00 + o11 + c, gv[c] * w11, fscale);
               }
+            }
+          }
+        } else if (FIX32 && gxb) {
+          if (inreg) {
+            int* r00 = reg32 + (ry * p.RW + rx) * Cc + cl;
+            const f32x4 gs = gv * fscale;
+#pragma unroll
+            for (int c0 = 0; c0 < 4; ++c0) {
+              const int c = (c0 + pix) & 3;
+              const float gvc = c == 0 ? gs[0] : c == 1 ? gs[1] : c == 2 ? gs[2] : gs[3];
+              if (v00) atomicAdd(r00 + c, __float2int_rn(gvc * w00));
+              if (v01) atomicAdd(r00 + Cc + c, __float2int_rn(gvc * w01));
+              if (v10) atomicAdd(r00 + p.RW * Cc + c, __float2int_rn(gvc * w10));
+              if (v11) atomicAdd(r00 + p.RW * Cc + Cc + c, __float2int_rn(gvc * w11));
+            }
+          } else {
+            float* g00 = gxb + chunk * Cc + cl;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (v00) unsafeAtomicAdd(g00 + o00 + c, gv[c] * w00);
+              if (v01) unsafeAtomicAdd(g00 + o01 + c, gv[c] * w01);
+              if (v10) unsafeAtomicAdd(g00 + o10 + c, gv[c] * w10);
+              if (v11) unsafeAtomicAdd(g00 + o11 + c, gv[c] * w11);
             }
           }
         } else if (FIXL && gxb) {
@@ -1210,7 +1230,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   } else if (FIXL && gxb) {
     if (p.abl & 1) return;
     for (int e = tid; e < p.RH * p.RW * Cc; e += 256) {
-      const long long v = regfix[e];
+      const long long v = FIX32 ? (long long)reg32[e] : regfix[e];
       if (v == 0ll) continue;
       const int c = e % Cc, pos = e / Cc;
       const int ry = pos / p.RW, rx = pos - ry * p.RW;
@@ -1432,7 +1452,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
 }
 
 static int g_dcn_bwd_abl = 0;       // fami_dcn_tune(1024 + bits): ablations of the backward kernel (benchmarks)
-static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = 64-bit fixed-point LDS adds
+static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = fixed-point LDS adds (64-bit for f32, 32-bit for 16-bit storage), 2 = 64-bit for every type
 static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   // smallest group count whose column span cg*K*GC is a multiple of 16 and divides G
   for (int gc = 1; gc <= G; ++gc)
@@ -1452,7 +1472,9 @@ static void dcn_bwd_launch1(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipSt
 template <typename T, int KSO>
 static void dcn_bwd_launch(const DcnBwdArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   if (a.gfix) dcn_bwd_launch1<T, KSO, 1>(a, grid, lds, s);
-  else if (a.fixl) dcn_bwd_launch1<T, KSO, 2>(a, grid, lds, s);
+  else if (a.fixl == 2) {
+    if constexpr (sizeof(T) == 2) dcn_bwd_launch1<T, KSO, 3>(a, grid, lds, s);
+  } else if (a.fixl) dcn_bwd_launch1<T, KSO, 2>(a, grid, lds, s);
   else dcn_bwd_launch1<T, KSO, 0>(a, grid, lds, s);
 }
 
@@ -1483,9 +1505,13 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   a.RW = (DCN_TILE - 1) * stride + (kw - 1) * dil + 2 + 2 * DCN_RO;
   a.wnorm = wpb + (long)fami_cdiv((long)C * K, 16) * a.KSo * 256;       // written by fami_dcn_pack_weight_bwd_f32 behind the image
   a.fixl = (!gfix && gx && g_dcn_bwd_scatter != 0) ? 1 : 0;
+  // 16-bit storage: a 32-bit fixed-point region (20 bits per contribution at the bound: ~2^-17 of the largest one, far
+  // below bf16 / fp16 resolution) -- half the LDS (4 workgroups per CU instead of 2) and ds_add_u32 (4.7 against 2.5
+  // lane-operations per clock per CU); fami_dcn_tune(514) keeps the 64-bit region
+  if (a.fixl && sizeof(T) == 2 && g_dcn_bwd_scatter != 2) a.fixl = 2;
   a.abl = g_dcn_bwd_abl;
-  size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * ((gfix || a.fixl) ? 2 : 1)) * sizeof(float);
-  if (a.fixl && lds > 150 * 1024) {                                       // the f32 region is half the size
+  size_t lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg * ((gfix || a.fixl == 1) ? 2 : 1)) * sizeof(float);
+  if (a.fixl == 1 && lds > 150 * 1024) {                                  // the f32 region is half the size
     a.fixl = 0;
     lds = ((size_t)16 * (a.NTc * 16 + 4) + (size_t)a.RH * a.RW * a.GC * a.cg) * sizeof(float);
   }

@@ -167,15 +167,25 @@ def test_shift_dcn_half(dev):
     y = O.deform_conv2d(x, off, msk, w, b, 1, 3, 3)
     g = rb(torch.randn_like(y))
     y.backward(g)
-    eng = _eng(dev)
-    wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(b.detach().to(dev))
-    xt, ot, mt = (T(nhwc(v.detach()).to(dev).to(BF), True) for v in (x, off, msk))
-    yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
-    assert yt.data.dtype == BF and relerr(nchw(yt.data), y) < ACT_TOL
-    yt.grad = nhwc(g).to(dev).to(BF)
-    eng.backward()
-    assert relerr(nchw(xt.grad), x.grad) < ACT_TOL
-    assert relerr(nchw(ot.grad), off.grad) < ACT_TOL and relerr(nchw(mt.grad), msk.grad) < ACT_TOL
-    # col (the weight-gradient operand) is stored in bf16: one extra rounding of the modulated samples
-    assert relerr(eng.param_grads[id(wd)], w.grad) < 3 * F32_TOL
-    assert relerr(eng.param_grads[id(bd)], b.grad) < F32_TOL
+    from fami_pose_amd._lib import lib
+    gxs = []
+    for knob in (513, 514):            # input-gradient scatter: 32-bit fixed-point LDS region (16-bit default), 64-bit region
+        lib().cdll.fami_dcn_tune(knob)
+        try:
+            eng = _eng(dev)
+            wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(b.detach().to(dev))
+            xt, ot, mt = (T(nhwc(v.detach()).to(dev).to(BF), True) for v in (x, off, msk))
+            yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+            assert yt.data.dtype == BF and relerr(nchw(yt.data), y) < ACT_TOL
+            yt.grad = nhwc(g).to(dev).to(BF)
+            eng.backward()
+            assert relerr(nchw(xt.grad), x.grad) < ACT_TOL
+            assert relerr(nchw(ot.grad), off.grad) < ACT_TOL and relerr(nchw(mt.grad), msk.grad) < ACT_TOL
+            # col (the weight-gradient operand) is stored in bf16: one extra rounding of the modulated samples
+            assert relerr(eng.param_grads[id(wd)], w.grad) < 3 * F32_TOL
+            assert relerr(eng.param_grads[id(bd)], b.grad) < F32_TOL
+            gxs.append(xt.grad.float().clone())
+        finally:
+            lib().cdll.fami_dcn_tune(513)
+    # 20 bits per contribution at the bound: the two regions differ far below the storage type's resolution
+    assert relerr(gxs[0], gxs[1]) < 1e-4
