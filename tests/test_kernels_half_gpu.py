@@ -187,5 +187,6 @@ def test_shift_dcn_half(dev):
             gxs.append(xt.grad.float().clone())
         finally:
             lib().cdll.fami_dcn_tune(513)
-    # 20 bits per contribution at the bound: the two regions differ far below the storage type's resolution
-    assert relerr(gxs[0], gxs[1]) < 1e-4
+    # 20 bits per contribution at the bound: the two regions differ far below the storage type's resolution, i.e. the
+    # stored 16-bit gradients differ by roundings that fall the other way (at most an ulp of the largest value or two)
+    assert relerr(gxs[0], gxs[1]) < 8e-3
