@@ -303,11 +303,44 @@ def main():
     use_graph = (not args.no_graph) and (world == 1 or os.environ.get('FAMI_DDP_GRAPH', '1') != '0')
     kf, sup, joints, vis = synth_batch(args.batch, args.sup, args.img_h, args.img_w, 17, dev, 19970808 + rank)
 
+    def make_trainer():
+        """-> (trainer, model, plan name, fallback notes).  N>1: the launch plans in order of preference -- segmented graphs
+        with overlapped all-reduce, serial graphs, eager hooks; a plan whose capture / first step fails on ANY rank is
+        dropped by all of them (agreed through a MIN all-reduce), so a scaling run reports a number and says which plan
+        produced it instead of dying in the capture."""
+        if world == 1:
+            model = build(args, dev)
+            return Trainer(model, lr=1e-3, use_mi=True, use_graph=use_graph, targets_from_joints=True,
+                           bucket_mb=args.bucket_mb), model, None, []
+        first = os.environ.get('FAMI_DDP_PLAN', 'overlap')
+        plans = ([(first, True)] + [(q, True) for q in ('overlap', 'serial') if q != first and first == 'overlap']
+                 if use_graph else []) + [('eager-hooks', False)]
+        notes = []
+        for name, ug in plans:
+            if ug:
+                os.environ['FAMI_DDP_PLAN'] = name
+            ok, trainer, model = 1, None, None
+            try:
+                model = build(args, dev)
+                trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=ug, targets_from_joints=True, bucket_mb=args.bucket_mb)
+                trainer.step(kf, sup, joints, vis)
+                torch.cuda.synchronize(dev)
+            except Exception as e:                       # noqa: BLE001 -- reported in the JSON line
+                ok = 0
+                notes.append('%s failed on rank %d: %s' % (name, rank, repr(e)[:200]))
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                return trainer, model, name, notes
+            if ok:
+                notes.append('%s dropped: failed on another rank' % name)
+            del trainer, model
+            torch.cuda.empty_cache()
+        raise SystemExit('no data-parallel launch plan ran: ' + '; '.join(notes))
+
     def timed_run(dtype, steps, warmup):
         args.dtype = dtype
-        model = build(args, dev)
-        trainer = Trainer(model, lr=1e-3, use_mi=True, use_graph=use_graph, targets_from_joints=True,
-                          bucket_mb=args.bucket_mb)
+        trainer, model, plan_name, plan_notes = make_trainer()
         for _ in range(max(warmup, 1)):
             trainer.step(kf, sup, joints, vis)
         barrier()
@@ -324,7 +357,7 @@ def main():
         info = {"pck_final": round(trainer.accuracy()[0][1], 4), "pck_kf_backbone": round(trainer.accuracy()[1][1], 4)}
         if world > 1:
             info.update({"dist_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
-                         "ddp_plan": (trainer.ddp_plan if use_graph else 'eager-hooks'), "bucket_mb": args.bucket_mb,
+                         "ddp_plan": plan_name, "ddp_plan_fallbacks": plan_notes, "bucket_mb": args.bucket_mb,
                          "buckets": len(trainer.reducer.ranges()),
                          "gradient_bytes": int(trainer.grad.numel() * 4), **trainer.plan_summary(),
                          "allreduce_ms_standalone": round(trainer.measure_allreduce_ms(), 3)})

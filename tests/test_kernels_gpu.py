@@ -62,6 +62,9 @@ CONV_CASES = [
     (3, 7, 5, 32, 64, 3, 1, 1, 1, True),        # LDS weight gradient: odd map, 2 / 4 channel tiles
     (2, 5, 3, 16, 16, 3, 1, 1, 1, False),       # map narrower than one K step
     (20, 96, 72, 48, 48, 3, 1, 1, 1, False),    # the benchmark's dominant launch at full size (N = 20 frames, grid 552960)
+    (2, 10, 9, 48, 48, 3, 1, 0, 1, True),       # linear-address implicit GEMM with Ho != Hi (no padding) ...
+    (2, 10, 9, 48, 64, 3, 1, 2, 1, False),      # ... and with more padding than "same" needs (Ho = Hi + 2)
+    (2, 11, 7, 64, 48, 5, 1, 2, 1, False),      # 25 taps: the widest kernel the tap-validity mask of that form covers
 ]
 
 
