@@ -44,10 +44,15 @@ int fami_conv_tune(int mt, int nt, int ks);
 int fami_conv_tune_lds(int on);          /* 1 / 0 = route eligible 3x3 stride-1 convs through the LDS-staged / direct kernel,
                                           * -1 = default (bf16 staged, f32 direct: measured per dtype inside the step) */
 int fami_conv_tune_wgrad_lds(int on);    /* 0 = weight gradients on the scalar-operand kernels, 1 = LDS-staged kernels wherever eligible,
-                                          * -1 = defaults (bf16: staged; f32: staged only where it measured faster) */
+                                          * 1 + n = the same with n sub-chunks per workgroup of the 16-bit kernel (default 2),
+                                          * -1 = defaults (16-bit storage: LDS-staged; f32: linear-address per-tap kernel on stride-1
+                                          * same-size convs, general per-tap kernel elsewhere, LDS-staged kernel opt-in);
+                                          * 50 / 51 = f32 per-tap kernel in its general / linear-address form (52 / 53 / 54: the latter in
+                                          * 9- / 8- / 16-wave workgroups); 100 + mt, 1000 + n = benchmarks (tile cap, workgroup target) */
 int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous workgroup->tile order in the implicit-GEMM kernels,
                                         * bit 1 = in the weight-gradient kernels; -1 = default (both on) */
-int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default */
+int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default;
+                                        * 100 / 101 = linear-address form of the f32 implicit GEMM off / on (default on) */
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);
@@ -156,7 +161,10 @@ int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const f
                      fami_stream_t stream);
 int fami_dcn_tune(int mode);            /* benchmarks / tests: forward kernel 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel
                                            (samples fed to the MFMA from registers), -1 = default (direct below 4 GiB);
-                                           16 + 2 / 16 + 0 = direct kernel built for 2 k groups in flight x 4 waves per SIMD / default build */
+                                           16 + 2 / 16 + 0 = direct kernel built for 2 k groups in flight x 4 waves per SIMD / default build;
+                                           2 = LDS-window forward kernel where eligible; 512 + m = backward input-gradient scatter: 0 f32
+                                           compare-and-swap LDS region, 1 fixed-point region (64-bit for f32, 32-bit for 16-bit storage; default),
+                                           2 64-bit region for every type; 1024 + bits = backward ablations (benchmarks) */
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G);
 int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
                                  fami_stream_t stream);
