@@ -256,14 +256,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     }
   };
 
+  // LIN: a second accumulator set takes the odd K quarters, so an accumulator is reused every 2*MT*NT MFMAs instead of
+  // every MT*NT: register-only loops issue v_mfma_f32_16x16x4_f32 at 126 TFLOP/s with 4 and 139 with 8 independent
+  // accumulators per wave at 8 waves per SIMD (tools/probes/mfma_peak2.hip)
+  f32x4 accB[LIN ? MT : 1][LIN ? NT : 1];
+  if (LIN) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) accB[LIN ? mt : 0][LIN ? nt : 0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   auto mma = [&](const f32x4(&a)[MT], const f32x4(&b)[NT]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          if (LIN && (t & 1))
+            accB[LIN ? mt : 0][LIN ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], accB[LIN ? mt : 0][LIN ? nt : 0], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][t], b[nt][t], acc[mt][nt], 0, 0, 0);
+        }
   };
 
   f32x4 af[ST][MT], bf[ST][NT];
@@ -285,6 +299,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     }
   }
 
+  if (LIN) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += accB[LIN ? mt : 0][LIN ? nt : 0];
+  }
   if (KS > 1) {
     // partial sums of k-parts 1..KS-1 go through LDS to the k-part-0 wave of the same pixel group
     if (kpart > 0) {
