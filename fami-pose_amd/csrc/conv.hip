@@ -33,6 +33,7 @@ struct ConvArgs {
   int KC, NTt, relu, accumulate, P;
   unsigned x_bytes, wp_bytes;  // buffer-descriptor extents (out-of-range lanes read 0)
   int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
+  int par;                     // stride-2 dgrad (f32): waves own pixels of ONE parity class and walk only its taps
 };
 
 // f32 weight image = [16x16-tile image][32x32-tile image]:
@@ -102,8 +103,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int kpart = wave % KS, mgrp = wave / KS;
   int bx, by;
   xcd_tile(p.xcd, bx, by);
-  const int m0 = (bx * (4 / KS) + mgrp) * (MT * 16);
-  const bool active = m0 < p.P;  // wave-uniform
+  // The input gradient of a stride-2 convolution: an output pixel (y, x) only receives the taps with (y + pad - ky*dil)
+  // and (x + pad - kx*dil) even -- for a 3x3 kernel 1, 2, 2 or 4 of the 9 taps depending on the parities of y and x.  Walking
+  // all taps with zero operands (the general path) spends 3/4 of the MFMAs on zeros.  With p.par the pixel tiles are
+  // dealt per parity class (class-major tile order: 4 runs of tiles), a wave's pixels share one class, and its K loop
+  // walks that class's taps only.
+  const bool par = MODE == 1 && p.par;
+  const int tix = bx * (4 / KS) + mgrp;   // pixel-tile index of this wave
+  int m0 = tix * (MT * 16);
+  bool active = m0 < p.P;  // wave-uniform
+  int ca = 0, cb = 0, cHa = 0, cWb = 0, cP = 0, crem = 0;   // par: row / column parity, class extent, tile within the class
+  if (par) {
+    const int H0 = (p.Ho + 1) >> 1, H1 = p.Ho >> 1, W0 = (p.Wo + 1) >> 1, W1 = p.Wo >> 1;
+    int rem = tix, c = 0;
+    for (; c < 4; ++c) {
+      cHa = (c >> 1) ? H1 : H0;
+      cWb = (c & 1) ? W1 : W0;
+      cP = p.N * cHa * cWb;
+      const int tl = (cP + MT * 16 - 1) / (MT * 16);
+      if (rem < tl) break;
+      rem -= tl;
+    }
+    active = c < 4;
+    ca = c >> 1;
+    cb = c & 1;
+    crem = rem;
+  }
   if (KS == 1 && !active) return;
   const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
@@ -112,6 +137,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   bool pv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (par) {
+      const int ml = (crem * MT + mt) * 16 + row;
+      pv[mt] = active && ml < cP;
+      const int mm = pv[mt] ? ml : 0;
+      const int hw = cHa * cWb;
+      const int n = mm / hw, r = mm - n * hw;
+      const int yy = r / cWb;
+      pn[mt] = n;
+      py[mt] = 2 * yy + ca;
+      px[mt] = 2 * (r - yy * cWb) + cb;
+      continue;
+    }
     const int m = m0 + mt * 16 + row;
     pv[mt] = m < p.P;
     const int mm = pv[mt] ? m : 0;
@@ -136,8 +173,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   const int taps = p.kh * p.kw;
   int tap = 0, kc = kpart;
   int lky = 0, lkx = 0;   // LIN: (ky, kx) of `tap`, kept in step with it (no division per tap switch)
+  // par: is tap tp one of this wave's parity class?  (wave-uniform)
+  auto tap_ok = [&](int tp) {
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+    return (((ca + p.pad - ky * p.dil) | (cb + p.pad - kx * p.dil)) & 1) == 0;
+  };
   auto next_tap = [&]() {
     ++tap;
+    if (par) {
+      while (tap < taps && !tap_ok(tap)) ++tap;
+    }
     if (LIN) {
       if (++lkx == p.kw) {
         lkx = 0;
@@ -145,6 +190,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
       }
     }
   };
+  int ntap_mine = taps;
+  if (par) {
+    ntap_mine = 0;
+    for (int t = 0; t < taps; ++t) ntap_mine += tap_ok(t) ? 1 : 0;
+    while (tap < taps && !tap_ok(tap)) ++tap;   // first tap of the class
+  }
   while (kc >= p.KC) {
     kc -= p.KC;
     next_tap();
@@ -250,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     if (kc >= p.KC) {
       do {
         kc -= p.KC;
-        ++tap;
+        next_tap();
       } while (kc >= p.KC);
       tap_setup(tap);
     }
@@ -281,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   };
 
   f32x4 af[ST][MT], bf[ST][NT];
-  const int Tall = taps * p.KC;
+  const int Tall = ntap_mine * p.KC;
   const int T = active ? (Tall - kpart + KS - 1) / KS : 0;  // iterations owned by this wave
   // ST-stage register pipeline (ST-1 operand sets in flight: the loop is bound by memory latency x concurrency, not
   // by MFMA issue) with an unconditional body: loads issued past the last iteration carry out-of-range offsets
@@ -339,9 +390,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    // par: the flat output pixel of tile row j lives in lane j (any kq): fetch it from there
+    const int pm_mine = pv[mt] ? (pn[mt] * p.Ho + py[mt]) * p.Wo + px[mt] : -1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = m0 + mt * 16 + kq * 4 + r;
+      int m = m0 + mt * 16 + kq * 4 + r;
+      if (par) {
+        m = __shfl(pm_mine, kq * 4 + r);
+        if (m < 0) continue;
+      }
       if (m >= p.P) continue;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -1943,9 +2000,20 @@ static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int
 }
 
 static int g_lin_conv = 1;  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
+static int g_par = 1;       // fami_conv_tune_stages(110 / 111): parity-class stride-2 input gradient off / on
+// pixel tiles of MT*16 pixels: all of them, or (stride-2 dgrad by parity class) the sum over the four classes
+static long igemm_tiles(const ConvArgs& a, int MT) {
+  if (!a.par) return fami_cdiv(a.P, MT * 16);
+  long t = 0;
+  for (int c = 0; c < 4; ++c) {
+    const long Ha = (c >> 1) ? a.Ho / 2 : (a.Ho + 1) / 2, Wb = (c & 1) ? a.Wo / 2 : (a.Wo + 1) / 2;
+    t += fami_cdiv(a.N * Ha * Wb, MT * 16);
+  }
+  return t;
+}
 template <int MODE, int VEC>
 static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipStream_t s) {
-  const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
+  const dim3 grid(fami_cdiv(igemm_tiles(a, MT), 4 / KS), fami_cdiv(a.NTt, NT));
   if constexpr (VEC) {
     if (g_lin_conv && MT == 1 && ST == 2 && a.sh == 0 && a.Ci % 16 == 0 && a.kh * a.kw <= 25 && (NT == 3 || NT == 4)) {
 #define FAMI_LIN(nt, ks)                                                                            \
@@ -2027,6 +2095,7 @@ static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
 
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
+  a.par = (mode == 1 && a.sh == 1 && g_par) ? 1 : 0;
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   if (vec && g_use32 && (g_force_mt == 0 || g_force_mt == 32) && pack32_elems(a.Ci, a.Co, a.kh * a.kw) > 0 &&
       (long)a.kh * a.kw * fami_cdiv(a.Ci, 8) * fami_cdiv(a.Co, 32) * 1024 < (1L << 31))
@@ -2209,6 +2278,10 @@ int fami_conv_tune_xcd(int mode) {
   return FAMI_OK;
 }
 int fami_conv_tune_stages(int stages) {
+  if (stages == 110 || stages == 111) {   // benchmarks / tests: parity-class stride-2 input gradient off / on
+    g_par = stages - 110;
+    return FAMI_OK;
+  }
   if (stages == 100 || stages == 101) {   // benchmarks / tests: linear-address f32 implicit GEMM off / on
     g_lin_conv = stages - 100;
     return FAMI_OK;
