@@ -583,6 +583,7 @@ struct ConvArgsH {
   int KC, NTt, relu, accumulate, P, out_f32;
   unsigned x_bytes, wp_bytes;
   int xcd;
+  int par;           // stride-2 dgrad by parity class (see ConvArgs)
 };
 
 // packed[tap][kc][nt][lane][j] ; mode 0: K = Cin, N = Cout ; mode 1 (dgrad): K = Cout, N = Cin
@@ -679,8 +680,28 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
   const int kpart = wave % KS, mgrp = wave / KS;
   int bx, by;
   xcd_tile(p.xcd, bx, by);
-  const int m0 = (bx * (4 / KS) + mgrp) * (MT * 16);
-  const bool active = m0 < p.P;  // wave-uniform
+  // stride-2 input gradient by parity class (see conv_igemm_f32)
+  const bool par = MODE == 1 && p.par;
+  const int tix = bx * (4 / KS) + mgrp;
+  const int m0 = tix * (MT * 16);
+  bool active = m0 < p.P;  // wave-uniform
+  int ca = 0, cb = 0, cHa = 0, cWb = 0, cP = 0, crem = 0;
+  if (par) {
+    const int H0 = (p.Ho + 1) >> 1, H1 = p.Ho >> 1, W0 = (p.Wo + 1) >> 1, W1 = p.Wo >> 1;
+    int rem = tix, c = 0;
+    for (; c < 4; ++c) {
+      cHa = (c >> 1) ? H1 : H0;
+      cWb = (c & 1) ? W1 : W0;
+      cP = p.N * cHa * cWb;
+      const int tl = (cP + MT * 16 - 1) / (MT * 16);
+      if (rem < tl) break;
+      rem -= tl;
+    }
+    active = c < 4;
+    ca = c >> 1;
+    cb = c & 1;
+    crem = rem;
+  }
   if (KS == 1 && !active) return;
   const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
@@ -689,6 +710,18 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
   bool pv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (par) {
+      const int ml = (crem * MT + mt) * 16 + col;
+      pv[mt] = active && ml < cP;
+      const int mm = pv[mt] ? ml : 0;
+      const int hw = cHa * cWb;
+      const int n = mm / hw, r = mm - n * hw;
+      const int yy = r / cWb;
+      pn[mt] = n;
+      py[mt] = 2 * yy + ca;
+      px[mt] = 2 * (r - yy * cWb) + cb;
+      continue;
+    }
     const int m = m0 + mt * 16 + col;
     pv[mt] = m < p.P;
     const int mm = pv[mt] ? m : 0;
@@ -709,9 +742,25 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
   unsigned aoff[MT];
   const int taps = p.kh * p.kw;
   int tap = 0, kc = kpart;
+  auto tap_ok = [&](int tp) {   // par: is tap tp one of this wave's parity class?  (wave-uniform)
+    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+    return (((ca + p.pad - ky * p.dil) | (cb + p.pad - kx * p.dil)) & 1) == 0;
+  };
+  auto next_tap = [&]() {
+    ++tap;
+    if (par) {
+      while (tap < taps && !tap_ok(tap)) ++tap;
+    }
+  };
+  int ntap_mine = taps;
+  if (par) {
+    ntap_mine = 0;
+    for (int t = 0; t < taps; ++t) ntap_mine += tap_ok(t) ? 1 : 0;
+    while (tap < taps && !tap_ok(tap)) ++tap;
+  }
   while (kc >= p.KC) {
     kc -= p.KC;
-    ++tap;
+    next_tap();
   }
   unsigned boff[NT];
 #pragma unroll
@@ -762,7 +811,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
     if (kc >= p.KC) {
       do {
         kc -= p.KC;
-        ++tap;
+        next_tap();
       } while (kc >= p.KC);
       tap_setup(tap);
     }
@@ -777,7 +826,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
   };
 
   hx8 af[ST][MT], bf[ST][NT];
-  const int Tall = taps * p.KC;
+  const int Tall = ntap_mine * p.KC;
   const int T = active ? (Tall - kpart + KS - 1) / KS : 0;
   if (T > 0) {
     tap_setup(tap);
@@ -820,7 +869,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
   const bool cvec = (p.Co & 3) == 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + mt * 16 + col;
+    const int m = par ? (pv[mt] ? (pn[mt] * p.Ho + py[mt]) * p.Wo + px[mt] : p.P) : m0 + mt * 16 + col;
     if (m >= p.P) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -2572,7 +2621,15 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
 // ---- bf16 implicit GEMM launch
 template <typename H, int MODE, int VEC>
 static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hipStream_t s) {
-  const dim3 grid(fami_cdiv(a.P, (4 / KS) * MT * 16), fami_cdiv(a.NTt, NT));
+  long tiles = fami_cdiv(a.P, MT * 16);
+  if (a.par) {
+    tiles = 0;
+    for (int c = 0; c < 4; ++c) {
+      const long Ha = (c >> 1) ? a.Ho / 2 : (a.Ho + 1) / 2, Wb = (c & 1) ? a.Wo / 2 : (a.Wo + 1) / 2;
+      tiles += fami_cdiv(a.N * Ha * Wb, MT * 16);
+    }
+  }
+  const dim3 grid(fami_cdiv(tiles, 4 / KS), fami_cdiv(a.NTt, NT));
 #define FAMI_CASE(mt, nt, ks)                                                                        \
   if (MT == mt && NT == nt && KS == ks) {                                                            \
     if (ST == 3 && mt <= 2) hipLaunchKernelGGL((conv_igemm_h<H, mt, nt, MODE, VEC, ks, 3>), grid, dim3(256), 0, s, a); \
@@ -2594,6 +2651,7 @@ static int launch_igemm_h(const ConvArgsH& a, int MT, int NT, int KS, int ST, hi
 template <typename H>
 static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
+  a.par = (mode == 1 && a.sh == 1 && g_par) ? 1 : 0;
   const int vec = (a.Ci % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   int NT = pick_nt(a.NTt);
   if (NT == 6) NT = 3;
