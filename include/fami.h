@@ -52,7 +52,8 @@ int fami_conv_tune_wgrad_lds(int on);    /* 0 = weight gradients on the scalar-o
 int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous workgroup->tile order in the implicit-GEMM kernels,
                                         * bit 1 = in the weight-gradient kernels; -1 = default (both on) */
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default;
-                                        * 100 / 101 = linear-address form of the f32 implicit GEMM off / on (default on) */
+                                        * 100 / 101 = linear-address form of the f32 implicit GEMM off / on (default on);
+                                        * 110 / 111 = stride-2 input gradient: all taps / the pixel's parity class only (default) */
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);
