@@ -167,6 +167,21 @@ class Engine:
             self._main.wait_event(ev)
             self._wdirty = False
 
+    def side_launch(self, fn):
+        """fn(raw_stream) on the first side lane, ordered after everything enqueued on lane 0 so far -> event to hand to
+        wait_main().  For work nothing on the forward path reads (the dgrad weight images): it runs beside lane 0."""
+        side = self._lanes(2)[0]
+        ev = torch.cuda.Event()
+        ev.record(self._main)
+        side.wait_event(ev)
+        fn(side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+        return done
+
+    def wait_main(self, ev):
+        self._main.wait_event(ev)
+
     def _do_fork(self, n):
         side = self._lanes(n)
         ev = torch.cuda.Event()

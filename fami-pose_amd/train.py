@@ -139,7 +139,12 @@ class WeightPacker:
                 recs.append((src, off, Co, Ci, kh * kw, mode))
                 spans.append((id(prm), mode, off, n))
                 off += n
+        # forward images first, input-gradient images behind them: the two halves can be packed by separate launches
+        # (run(stream, 0) before the forward pass, run(side_stream, 1) beside it -- nothing reads a mode-1 image before
+        # the backward pass)
+        recs.sort(key=lambda r: r[5])
         self.n = len(recs)
+        self.n_fwd = sum(1 for r in recs if r[5] == 0)
         self.flat = flat
         self.arena = torch.empty(max(off, 1), dtype=dtype, device=flat.device)
         desc = np.array(recs, dtype=[('src', '<i8'), ('dst', '<i8'), ('Co', '<i4'), ('Ci', '<i4'), ('taps', '<i4'),
@@ -149,9 +154,11 @@ class WeightPacker:
             self.views[(pid, mode)] = self.arena[o:o + n]
         self.fn = 'fami_pack_conv_weights_batch' + _SFX[dtype]
 
-    def run(self, stream):
-        if self.n:
-            lib().call(self.fn, _p(self.flat), _p(self.arena), _p(self.desc), self.n, stream)
+    def run(self, stream, part=None):
+        """part None: every image; 0: the forward images; 1: the input-gradient images."""
+        lo, hi = (0, self.n) if part is None else ((0, self.n_fwd) if part == 0 else (self.n_fwd, self.n))
+        if hi > lo:
+            lib().call(self.fn, _p(self.flat), _p(self.arena), self.desc.data_ptr() + 32 * lo, hi - lo, stream)
 
 
 class BucketReducer:
@@ -306,7 +313,14 @@ class Trainer:
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
                      deterministic=getattr(model, 'deterministic', None))
-        self.packer.run(eng.stream)             # every conv weight image of this step, one launch
+        # conv weight images of this step: the forward orientation in one launch now, the input-gradient orientation in a
+        # second launch on a side lane beside the forward pass (first read by the backward pass, which waits for it)
+        if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
+            self.packer.run(eng.stream, 0)
+            packed_bwd = eng.side_launch(lambda st: self.packer.run(st, 1))
+        else:
+            self.packer.run(eng.stream)
+            packed_bwd = None
         eng.prepacked = self.packer.views
         if self.targets_from_joints:
             # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
@@ -354,6 +368,8 @@ class Trainer:
                 eng.sync_wgrad_lane()       # the slice's weight gradients live on the engine's wgrad stream
                 return on_bucket(lo, hi)
             hook = self.reducer.begin(bucket_ready)
+        if packed_bwd is not None:
+            eng.wait_main(packed_bwd)
         eng.backward(on_params_done=hook)
         if on_bucket is not None:
             self._flushing = True
