@@ -49,3 +49,29 @@ def test_flat_adam_hyper_version():
     assert opt.hyper_version == v and opt.state[1].item() == pytest.approx(5e-4)
     opt.set_hyper(eps=1e-6)
     assert opt.hyper_version == v + 1 and opt.eps == 1e-6
+
+
+def test_weight_packer_orders_forward_images_first():
+    """WeightPacker splits its batch launch by orientation (forward images packed before the forward pass, input-gradient
+    images on a side lane beside it): the descriptor array must hold every mode-0 record before the first mode-1 record,
+    the two halves must cover every conv weight once each, and the views must tile the arena without overlap."""
+    import numpy as np
+    from fami_pose_amd.train import WeightPacker
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3), torch.nn.BatchNorm2d(16), torch.nn.Conv2d(16, 48, 3, 2, 1),
+                                torch.nn.Conv2d(48, 17, 1), torch.nn.Linear(4, 2))
+    table, off = [], 0
+    for p in model.parameters():
+        table.append((p, off, p.numel()))
+        off += p.numel()
+    flat = torch.zeros(off)
+    pk = WeightPacker(model, flat, table, torch.float32)
+    desc = np.frombuffer(pk.desc.numpy().tobytes(), dtype=[('src', '<i8'), ('dst', '<i8'), ('Co', '<i4'), ('Ci', '<i4'),
+                                                             ('taps', '<i4'), ('mode', '<i4')])
+    assert pk.n == 6 and pk.n_fwd == 3
+    assert list(desc['mode']) == [0, 0, 0, 1, 1, 1]
+    convs = [m for m in model if isinstance(m, torch.nn.Conv2d)]
+    for half in (desc[:3], desc[3:]):
+        assert sorted(zip(half['Co'], half['Ci'], half['taps'])) == sorted((c.out_channels, c.in_channels, c.kernel_size[0] ** 2) for c in convs)
+    spans = sorted((v.storage_offset(), v.numel()) for v in pk.views.values())
+    assert spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:]))
+    assert spans[-1][0] + spans[-1][1] == pk.arena.numel() and len(pk.views) == 6
