@@ -75,3 +75,36 @@ def test_weight_packer_orders_forward_images_first():
     spans = sorted((v.storage_offset(), v.numel()) for v in pk.views.values())
     assert spans[0][0] == 0 and all(a + n == b for (a, n), (b, _) in zip(spans, spans[1:]))
     assert spans[-1][0] + spans[-1][1] == pk.arena.numel() and len(pk.views) == 6
+
+
+@pytest.mark.parametrize('N,Ho,Wo,k,pad,dil,MT', [(2, 12, 9, 3, 1, 1, 1), (1, 7, 5, 3, 1, 1, 2), (3, 6, 4, 3, 1, 1, 1), (2, 9, 8, 5, 2, 1, 1),
+                                                  (1, 1, 6, 3, 1, 1, 1), (2, 10, 7, 3, 3, 3, 1)])
+def test_parity_class_tiling_of_the_stride2_input_gradient(N, Ho, Wo, k, pad, dil, MT):
+    """Index arithmetic of ConvArgs.par (conv.hip, stride-2 dgrad by parity class), restated in numpy: the class-major
+    tile order must cover every output pixel exactly once, and the taps a class walks must be exactly the taps that can
+    reach a pixel of that class ((y + pad - ky*dil) and (x + pad - kx*dil) even) -- so skipping the others drops nothing."""
+    import numpy as np
+    seen = np.zeros((N, Ho, Wo), dtype=int)
+    H0, H1, W0, W1 = (Ho + 1) // 2, Ho // 2, (Wo + 1) // 2, Wo // 2
+    tiles = []
+    for c in range(4):
+        Ha, Wb = (H1 if c >> 1 else H0), (W1 if c & 1 else W0)
+        tiles.append(-(-N * Ha * Wb // (MT * 16)))
+    for tix in range(sum(tiles)):
+        rem, c = tix, 0
+        while rem >= tiles[c]:
+            rem -= tiles[c]
+            c += 1
+        ca, cb = c >> 1, c & 1
+        Ha, Wb = (H1 if ca else H0), (W1 if cb else W0)
+        mine = [t for t in range(k * k) if ((ca + pad - (t // k) * dil) | (cb + pad - (t % k) * dil)) & 1 == 0]
+        for ml in range(rem * MT * 16, (rem + 1) * MT * 16):
+            if ml >= N * Ha * Wb:
+                continue
+            n, r = divmod(ml, Ha * Wb)
+            yy, xx = divmod(r, Wb)
+            y, x = 2 * yy + ca, 2 * xx + cb
+            seen[n, y, x] += 1
+            reach = [t for t in range(k * k) if (y + pad - (t // k) * dil) % 2 == 0 and (x + pad - (t % k) * dil) % 2 == 0]
+            assert reach == mine, (y, x, reach, mine)
+    assert (seen == 1).all()
