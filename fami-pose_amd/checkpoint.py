@@ -46,7 +46,7 @@ def adam_state_dict(trainer):
     for i, (p, off, n) in enumerate(trainer.table):
         state[i] = {'step': torch.tensor(step), 'exp_avg': opt.m[off:off + n].view(p.shape).detach().cpu().clone(),
                     'exp_avg_sq': opt.v[off:off + n].view(p.shape).detach().cpu().clone()}
-    group = {'lr': float(opt.state[1].item()), 'betas': tuple(opt.betas), 'eps': opt.eps, 'weight_decay': opt.wd,
+    group = {'lr': float(opt.state[1].item()), 'initial_lr': float(getattr(opt, 'initial_lr', opt.lr)), 'betas': tuple(opt.betas), 'eps': opt.eps, 'weight_decay': opt.wd,
              'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
              'fused': None, 'params': list(range(len(trainer.table)))}
     return {'state': state, 'param_groups': [group]}
@@ -77,6 +77,8 @@ def load_adam_state_dict(trainer, sd):
         opt.set_hyper(betas=g['betas'], eps=g['eps'], weight_decay=g['weight_decay'])
         t = steps.pop() if steps else 0.0
         opt.lr = float(g['lr'])
+        # torch writes `initial_lr` once a scheduler has been attached; a checkpoint without it was never scheduled
+        opt.initial_lr = float(g.get('initial_lr', g['lr']))
         opt.state.copy_(torch.tensor([t, g['lr'], 1.0 - opt.betas[0] ** t, 1.0 - opt.betas[1] ** t]))
 
 

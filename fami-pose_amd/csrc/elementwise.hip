@@ -81,6 +81,16 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, T* __restrict__ 
 }
 
 // out = alpha*a + beta*b (b may be null; out may alias a or b)
+// out[i][0..1] (=|+=) in[i][0..1] * (sx, sy): the legacy kornia.warp_affine translation scaling (MODEL.WARP_ALIGN_CORNERS
+// False: kornia <= 0.4 normalises the matrix for [0, W-1] but builds its grid with align_corners=False, so a translation
+// of t pixels samples at x - t*W/(W-1); Alignment_V15.py:135) and its gradient.
+__global__ void scale_pairs_kernel(const float* __restrict__ in, float* __restrict__ out, long n, float sx, float sy, int acc) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  const float v = in[i] * ((i & 1) ? sy : sx);
+  out[i] = acc ? out[i] + v : v;
+}
+
 template <typename T>
 __global__ void axpby_kernel(const T* a, const T* b, T* out, long n, float alpha, float beta, int vec) {
   const long n4 = vec ? n >> 2 : 0;
@@ -375,6 +385,13 @@ FAMI_EW_ABI(f32, float)
 FAMI_EW_ABI(bf16, bf16_t)
 FAMI_EW_ABI(f16, f16_t)
 #undef FAMI_EW_ABI
+
+int fami_scale_pairs_f32(const float* in, float* out, long n, float sx, float sy, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(in && out && n > 0, "fami_scale_pairs_f32", "bad argument");
+  hipLaunchKernelGGL(scale_pairs_kernel, dim3(fami_cdiv(2 * n, 256)), dim3(256), 0, s, in, out, n, sx, sy, accumulate);
+  FAMI_CHECK_LAUNCH("fami_scale_pairs_f32");
+  return FAMI_OK;
+}
 
 int fami_incr_i64(long long* v, long n, hipStream_t s) {
   FAMI_REQUIRE(v && n > 0, "fami_incr_i64", "bad argument");

@@ -268,10 +268,25 @@ class Engine:
     _zero_arenas = {}
 
     def _zero_begin(self):
-        st = Engine._zero_arenas.setdefault(self.dev.index, {'buf': None, 'high': 0, 'retired': []})
+        # The arena belongs to the Engine created LAST on the device; an older Engine that is still alive (two forwards
+        # before one backward through runtime._EngineFn) takes fresh, separately cleared buffers from then on -- both
+        # backwards handing fami_bn_bwd2 the same dirty slices was a silent wrong-gradient bug.  An Engine
+        # on another stream than the previous owner's first waits for that stream's work so far (the previous owner's
+        # kernels may still be reading their slots); inside a capture the Trainer has synchronised the device already.
+        import weakref
+        st = Engine._zero_arenas.setdefault(self.dev.index, {'buf': None, 'high': 0, 'retired': [], 'owner': None,
+                                                             'stream': None})
+        capturing = torch.cuda.is_current_stream_capturing()
+        prev = st['stream']
+        if prev is not None and prev.cuda_stream != self.stream and not capturing:
+            ev = torch.cuda.Event()
+            ev.record(prev)
+            self._main.wait_event(ev)
+        st['owner'] = weakref.ref(self)
+        st['stream'] = None if capturing else self._main
         self._zst, self._zoff, self._zfilled = st, 0, 0
         cap = 0 if st['buf'] is None else st['buf'].numel() * 4
-        if st['high'] > cap and not torch.cuda.is_current_stream_capturing():
+        if st['high'] > cap and not capturing:
             if st['buf'] is not None:
                 st['retired'].append(st['buf'])
             st['buf'] = torch.empty((st['high'] * 5 // 4 + 1023) // 4, dtype=torch.float32, device=self.dev)
@@ -287,7 +302,7 @@ class Engine:
         st, off = self._zst, self._zoff
         self._zoff += nbytes
         st['high'] = max(st['high'], self._zoff)
-        if off + nbytes <= self._zfilled:
+        if off + nbytes <= self._zfilled and st['owner']() is self:
             return st['buf'][off // 4:(off + nbytes) // 4]
         t = torch.empty(nbytes // 4, dtype=torch.float32, device=self.dev)
         self._keep.append(t)
@@ -703,9 +718,28 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ alignment ops
-    def shift(self, x, t):
-        """kornia warp_affine with a pure translation t=[B,2]=(tx,ty) (Alignment_V15.py:133-135)."""
+    def scale_pairs(self, t, sx, sy):
+        """t [B,2] f32 -> t * (sx, sy) (gradient scaled the same way)."""
+        B = t.shape[0]
+        y = self.empty(B, 2)
+        self.call('fami_scale_pairs_f32', _p(t.data), _p(y), B, float(sx), float(sy), 0)
+        out = T(y, t.requires_grad, f32grad=True)
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                g, acc = self.gbuf(t)
+                self.call('fami_scale_pairs_f32', _p(out.grad), _p(g), B, float(sx), float(sy), acc)
+            self.record_bwd(bwd, ())
+        return out
+
+    def shift(self, x, t, align_corners=True):
+        """kornia warp_affine with a pure translation t=[B,2]=(tx,ty) (Alignment_V15.py:133-135).  align_corners=False:
+        the kornia <= 0.4 default -- the matrix is normalised for [0, W-1] but the sampling grid is built and read with
+        align_corners=False, which for a pure translation is exactly a shift by (tx*W/(W-1), ty*H/(H-1))."""
         B, H, W, C = x.shape
+        if not align_corners:
+            t = self.scale_pairs(t, W / max(W - 1, 1), H / max(H - 1, 1))
         y = self.like(x.data)
         self.acall('fami_shift_bilinear_fwd', _p(x.data), _p(t.data), _p(y), B, H, W, C)
         out = T(y, x.requires_grad or t.requires_grad)

@@ -46,6 +46,9 @@ class FlatAdam:
         self.v = torch.zeros_like(flat_param)
         self.betas, self.eps, self.wd = tuple(betas), eps, weight_decay
         self.lr = float(lr)
+        # the undecayed rate an LR schedule scales (torch stores it as param_groups[0]['initial_lr'] the first time a
+        # scheduler is attached; checkpoints carry it so a resumed MultiStepLR does not decay an already decayed rate)
+        self.initial_lr = float(lr)
         self.hyper_version = 0
         self.state = torch.tensor([0.0, lr, 1.0, 1.0], device=flat_param.device)   # step, lr, bc1, bc2
 
@@ -79,7 +82,16 @@ class MultiStepLR:
         self.opt = opt.opt if hasattr(opt, 'opt') else opt
         self.milestones = sorted(int(m) for m in milestones)
         self.gamma = float(gamma)
-        self.base_lr = float(self.opt.lr if base_lr is None else base_lr)
+        # torch's rule (lr_scheduler.LRScheduler.__init__): a fresh schedule (last_epoch == -1) adopts the optimizer's
+        # current rate as `initial_lr`; a resumed one REQUIRES the stored `initial_lr` -- never the current, already
+        # decayed `lr` (resuming at epoch 10 gave 1e-5 instead of 1e-4)
+        if base_lr is not None:
+            self.base_lr = float(base_lr)
+        elif int(last_epoch) == -1:
+            self.base_lr = float(self.opt.lr)
+        else:
+            self.base_lr = float(getattr(self.opt, 'initial_lr', self.opt.lr))
+        self.opt.initial_lr = self.base_lr
         self.last_epoch = int(last_epoch)
         self.step()          # like torch: construction performs the step to epoch last_epoch + 1
 

@@ -69,6 +69,9 @@ class Alignment_V15(EngineModule):
         img_w, img_h = m.get('IMAGE_SIZE', [288, 384])
         G = m.get('DCN_OFFSET_GROUPS', None) or (12 if C % 48 == 0 else C // 4)
         self.C, self.S, self.G = C, S, G
+        # kornia.warp_affine's align_corners at Alignment_V15.py:135 (the call passes none): True = pixel-exact translation
+        # (kornia >= 0.5 behaviour, this build's default), False = the kornia <= 0.4 default (translation scaled by W/(W-1))
+        self.warp_align_corners = bool(m.get('WARP_ALIGN_CORNERS', True))
         h5, w5 = _ceil_half(img_h // 4), _ceil_half(img_w // 4)
 
         self.feat_global_offset_layers = nn.Sequential(
@@ -161,7 +164,7 @@ class Alignment_V15(EngineModule):
                 eng.set_lane(i % 4)
             t = self._translation(eng, diffs[i])
             shifts.append(t)
-            aligned.append(eng.shift(sups[i], t))
+            aligned.append(eng.shift(sups[i], t, self.warp_align_corners))
         if forked:
             eng.join(min(S, 4))
             eng.apply_deferred_bn()

@@ -130,6 +130,9 @@ int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alp
 int fami_fill_f32(float* out, long n, float v, fami_stream_t stream);
 /* dst (=|+=) src : fp32 accumulation buffer folded into an activation-typed gradient */
 int fami_cast_add_f32(const float* src, float* dst, long n, int accumulate, fami_stream_t stream);
+/* out[i] (=|+=) in[i] * (sx, sy) over n (x, y) pairs: legacy kornia.warp_affine translation scaling and its gradient
+ * (kornia <= 0.4 default align_corners=False at Alignment_V15.py:135: a shift of t pixels samples at x - t*W/(W-1)). */
+int fami_scale_pairs_f32(const float* in, float* out, long n, float sx, float sy, int accumulate, fami_stream_t stream);
 int fami_incr_i64(long long* v, long n, fami_stream_t stream);
 /* v[i] += inc[i] : BatchNorm num_batches_tracked counters, all layers in one launch */
 int fami_add_i64(long long* v, const long long* inc, long n, fami_stream_t stream);

@@ -247,9 +247,10 @@ def ceil_half(v, n=5):
 class AlignmentOracle(nn.Module):
     """Alignment_V15 (Alignment_V15.py:24-183)."""
 
-    def __init__(self, cfg, train=True, num_sup=4, image_hw=(384, 288), dcn_groups=12):
+    def __init__(self, cfg, train=True, num_sup=4, image_hw=(384, 288), dcn_groups=12, warp_align_corners=True):
         super().__init__()
         self.is_train = train
+        self.warp_align_corners = warp_align_corners      # kornia.warp_affine's align_corners (ops.warp_translate)
         self.J = cfg['MODEL']['NUM_JOINTS']
         C = cfg['MODEL']['EXTRA']['STAGE2']['NUM_CHANNELS'][0]
         self.C, self.S = C, num_sup
@@ -285,7 +286,7 @@ class AlignmentOracle(nn.Module):
         for i in range(S):
             t = self.feat_global_offset_layers(fs[1 + i] - kf)
             shifts.append(t)
-            aligned.append(ops.warp_translate(fs[1 + i], t))
+            aligned.append(ops.warp_translate(fs[1 + i], t, self.warp_align_corners))
         agg_sup = self.sup_agg_block(torch.cat(aligned, 1))
         comb = self.combined_feat_layers(torch.cat([agg_sup, kf], 1))
         comb = self._dcn(1, comb, comb)

@@ -109,12 +109,19 @@ def deform_conv2d_gridsample(inp, offset, mask, weight, bias=None, stride=1, pad
 # --------------------------------------------------------------------------
 # global translation (kornia.geometry.warp_affine with M = [[1,0,tx],[0,1,ty]])
 # --------------------------------------------------------------------------
-def warp_translate(src, t):
+def warp_translate(src, t, align_corners=True):
     """out[b,c,y,x] = bilinear(src[b,c], y - ty, x - tx), zero padding, same
     size.  Call site Alignment_V15.py:133-135: M maps src->dst pixel coords, so
     the sampling position is M^-1 x_dst.  Pixel-exact (align_corners=True)
-    semantics fixed by this build.  t [B,2] = (tx, ty)."""
+    semantics fixed by this build.  t [B,2] = (tx, ty).
+    align_corners=False restates the kornia <= 0.4 default: warp_affine
+    normalises M with normal_transform_pixel (x -> 2x/(W-1) - 1), inverts it,
+    and feeds affine_grid / grid_sample with align_corners=False; for a pure
+    translation that samples at x - tx*W/(W-1) (cross-checked against that
+    very pipeline in warp_translate_legacy_gridsample)."""
     B, C, H, W = src.shape
+    if not align_corners:
+        t = t * torch.tensor([W / max(W - 1, 1), H / max(H - 1, 1)], dtype=t.dtype)
     ys = torch.arange(H, dtype=src.dtype).view(1, 1, 1, H, 1) - t[:, 1].view(B, 1, 1, 1, 1)
     xs = torch.arange(W, dtype=src.dtype).view(1, 1, 1, 1, W) - t[:, 0].view(B, 1, 1, 1, 1)
     py = ys.expand(B, 1, 1, H, W)
@@ -127,6 +134,19 @@ def warp_affine_like(src, M, dsize):
     to pure translations (what Alignment_V15.py:133-135 builds)."""
     assert tuple(dsize) == tuple(src.shape[2:])
     return warp_translate(src, torch.stack([M[:, 0, 2], M[:, 1, 2]], 1))
+
+
+def warp_translate_legacy_gridsample(src, t):
+    """kornia <= 0.4 warp_affine(src, M, dsize) for M = [[1,0,tx],[0,1,ty]] spelled with torch only:
+    normalize_homography with normal_transform_pixel, inverse, F.affine_grid + F.grid_sample, align_corners=False."""
+    B, C, H, W = src.shape
+    M = torch.eye(3, dtype=src.dtype).repeat(B, 1, 1)
+    M[:, 0, 2], M[:, 1, 2] = t[:, 0], t[:, 1]
+    Nm = torch.tensor([[2.0 / (W - 1), 0, -1], [0, 2.0 / (H - 1), -1], [0, 0, 1]], dtype=src.dtype)
+    dst_norm_trans_src_norm = Nm @ M @ torch.linalg.inv(Nm)
+    src_norm_trans_dst_norm = torch.linalg.inv(dst_norm_trans_src_norm)
+    grid = F.affine_grid(src_norm_trans_dst_norm[:, :2, :], [B, C, H, W], align_corners=False)
+    return F.grid_sample(src, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
 
 
 def warp_translate_gridsample(src, t):

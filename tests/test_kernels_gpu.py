@@ -246,19 +246,22 @@ def test_linear_chain(dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 48, 24, 18), (1, 16, 7, 9)])
-def test_shift_bilinear(dev, shape):
+@pytest.mark.parametrize("align_corners", [True, False], ids=['pixel_exact', 'kornia04_legacy'])
+def test_shift_bilinear(dev, shape, align_corners):
+    """align_corners False = MODEL.WARP_ALIGN_CORNERS False: the kornia <= 0.4 default at Alignment_V15.py:135 (oracle twin
+    pinned against that release's affine_grid / grid_sample pipeline in test_oracle.py)."""
     from oracle import ops as O
     from fami_pose_amd.engine import T
     torch.manual_seed(4)
     B = shape[0]
     src = torch.randn(*shape, requires_grad=True)
     t = torch.tensor([[1.3, -2.6], [-0.25, 3.0]][:B], requires_grad=True)
-    y = O.warp_translate(src, t)
+    y = O.warp_translate(src, t, align_corners)
     g = torch.randn_like(y)
     y.backward(g)
     eng = _eng(dev)
-    st, tt = T(nhwc(src.detach()).to(dev), True), T(t.detach().to(dev), True)
-    yt = eng.shift(st, tt)
+    st, tt = T(nhwc(src.detach()).to(dev), True), T(t.detach().to(dev), True, f32grad=True)
+    yt = eng.shift(st, tt, align_corners)
     assert relerr(nchw(yt.data), y) < 1e-5
     yt.grad = nhwc(g).to(dev)
     eng.backward()
@@ -400,6 +403,43 @@ def test_final_preds_golden(dev):
     preds, maxvals = FL.get_final_preds(torch.from_numpy(g['hm']).to(dev), g['center'], g['scale'])
     assert np.array_equal(maxvals.cpu().numpy(), g['maxvals'])
     assert np.abs(preds.cpu().numpy().astype(np.float64) - g['preds']).max() < 1e-3
+
+
+def test_two_live_engines_do_not_share_bn_slot_rows(dev):
+    """two recorded Engines alive at once (model(a); model(b); (la + lb).backward() through runtime._EngineFn).
+    The slot rows of the two-launch BatchNorm come from one per-device arena; both backwards used to receive the same
+    slices, and fami_bn_bwd2 adds into its rows without clearing them -> silently wrong gradients for the second
+    backward.  Now only the Engine created last owns the arena.  Reference: each Engine run alone."""
+    from fami_pose_amd.engine import Engine, T
+    torch.manual_seed(3)
+    bn = nn.BatchNorm2d(16).to(dev).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    xs = [torch.randn(2, 48, 48, 16, device=dev) for _ in range(2)]      # P*C above the one-launch kernel's limit
+    gs = [torch.randn(2, 48, 48, 16, device=dev) for _ in range(2)]
+
+    def fwd(i):
+        eng = Engine(dev)
+        x = T(xs[i].clone(), True)
+        y = eng.bn(x, bn, relu=True)
+        y.grad = gs[i].clone()
+        return eng, x
+
+    def bwd(eng, x):
+        eng.backward()
+        torch.cuda.synchronize(dev)
+        return x.grad.clone(), eng.param_grads[id(bn.weight)].clone(), eng.param_grads[id(bn.bias)].clone()
+
+    if not Engine(dev).bn2:
+        pytest.skip('two-launch BatchNorm disabled')
+    alone = []
+    for _ in range(2):                      # the first round also sizes the arena, so the second round really uses it
+        alone = [bwd(*fwd(i)) for i in range(2)]
+    ea, eb = fwd(0), fwd(1)
+    both = [bwd(*ea), bwd(*eb)]
+    for (gx0, gw0, gb0), (gx1, gw1, gb1) in zip(alone, both):
+        assert relerr(gx1, gx0) < 1e-6 and relerr(gw1, gw0) < 1e-6 and relerr(gb1, gb0) < 1e-6
 
 
 def test_shared_module_on_two_lanes(dev):

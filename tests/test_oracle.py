@@ -267,6 +267,26 @@ def test_warp_translate_vs_gridsample_and_integer_shift():
     assert torch.equal(oops.warp_affine_like(src, M, (12, 9)), out)
 
 
+def test_warp_translate_legacy_align_corners_false():
+    """MODEL.WARP_ALIGN_CORNERS False = kornia <= 0.4's default at Alignment_V15.py:135: the restatement (translation
+    scaled by W/(W-1), H/(H-1)) against that release's own pipeline spelled with torch (normalize_homography for
+    [0, W-1], inverse, affine_grid + grid_sample with align_corners=False), values and both gradients."""
+    gen = torch.Generator().manual_seed(13)
+    src = torch.randn(3, 8, 12, 9, generator=gen, dtype=torch.float64, requires_grad=True)
+    t = torch.tensor([[0.3, -1.7], [4.25, 2.5], [-3.6, 0.4]], dtype=torch.float64, requires_grad=True)
+    a = oops.warp_translate(src, t, align_corners=False)
+    b = oops.warp_translate_legacy_gridsample(src, t)
+    close(a.detach(), b.detach(), 1e-9)
+    g = torch.randn(a.shape, generator=gen, dtype=torch.float64)
+    ga = torch.autograd.grad((a * g).sum(), [src, t])
+    gb = torch.autograd.grad((b * g).sum(), [src, t])
+    close(ga[0], gb[0], 1e-9)
+    close(ga[1], gb[1], 1e-8)
+    # and it differs from the pixel-exact form by exactly the scaled shift
+    c = oops.warp_translate(src, t * torch.tensor([9 / 8, 12 / 11], dtype=torch.float64))
+    close(a.detach(), c.detach(), 1e-12)
+
+
 def test_g12_final_preds():
     """get_final_preds: argmax + quarter-pixel shift + inverse affine (heatmaps_process.py:47-73)."""
     g = gold('g12_final_preds.npz')

@@ -108,3 +108,46 @@ def test_parity_class_tiling_of_the_stride2_input_gradient(N, Ho, Wo, k, pad, di
             reach = [t for t in range(k * k) if (y + pad - (t // k) * dil) % 2 == 0 and (x + pad - (t % k) * dil) % 2 == 0]
             assert reach == mine, (y, x, reach, mine)
     assert (seen == 1).all()
+
+
+def test_resumed_schedule_does_not_decay_twice(tmp_path):
+    """a checkpoint written after the first milestone carries the DECAYED lr; the resumed MultiStepLR must scale
+    the stored `initial_lr`, as torch's does (KeyError there when the key is missing), not the decayed one."""
+    from types import SimpleNamespace
+    from fami_pose_amd.checkpoint import adam_state_dict, load_adam_state_dict
+    p = torch.nn.Parameter(torch.zeros(4))
+    ref_opt = torch.optim.Adam([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.MultiStepLR(ref_opt, [8, 12, 16], 0.1)
+    opt = FlatAdam(torch.zeros(4), lr=1e-3)
+    sched = MultiStepLR(opt, [8, 12, 16], 0.1)
+    for _ in range(10):
+        ref_opt.step()
+        ref.step()
+        sched.step()
+    tr = SimpleNamespace(opt=opt, table=[(p, 0, 4)])
+    sd = adam_state_dict(tr)
+    assert sd['param_groups'][0]['lr'] == pytest.approx(1e-4) and sd['param_groups'][0]['initial_lr'] == pytest.approx(1e-3)
+    # the reference resumes with torch's scheduler on OUR checkpoint: it needs `initial_lr`
+    p2 = torch.nn.Parameter(torch.zeros(4))
+    ref_opt2 = torch.optim.Adam([p2], lr=1e-3)
+    ref_sd = ref_opt2.state_dict()
+    ref_sd['param_groups'][0].update(lr=sd['param_groups'][0]['lr'], initial_lr=sd['param_groups'][0]['initial_lr'])
+    ref_opt2.load_state_dict(ref_sd)
+    ref2 = torch.optim.lr_scheduler.MultiStepLR(ref_opt2, [8, 12, 16], 0.1, last_epoch=10)
+    # our resume
+    opt2 = FlatAdam(torch.zeros(4), lr=1e-3)
+    load_adam_state_dict(SimpleNamespace(opt=opt2, table=[(p, 0, 4)]), sd)
+    assert opt2.lr == pytest.approx(1e-4) and opt2.initial_lr == pytest.approx(1e-3)
+    mine = MultiStepLR(opt2, [8, 12, 16], 0.1, last_epoch=10)
+    for epoch in range(11, 21):
+        # rel 1e-6: the checkpoint's lr went through the optimizer's device-resident fp32 state
+        assert mine.get_last_lr()[0] == pytest.approx(ref2.get_last_lr()[0], rel=1e-6), epoch
+        ref_opt2.step()
+        ref2.step()
+        mine.step()
+    # a torch-written checkpoint that has an initial_lr (the reference attaches its scheduler before saving)
+    osd = ref_opt.state_dict()
+    assert 'initial_lr' in osd['param_groups'][0]
+    opt3 = FlatAdam(torch.zeros(4), lr=1e-3)
+    load_adam_state_dict(SimpleNamespace(opt=opt3, table=[(p, 0, 4)]), osd)
+    assert MultiStepLR(opt3, [8, 12, 16], 0.1, last_epoch=10).get_last_lr()[0] == pytest.approx(1e-4)
