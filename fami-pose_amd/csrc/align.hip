@@ -857,6 +857,9 @@ __device__ __forceinline__ float dcn_fix_scale(const unsigned* amax_bits) {
   const float amax = __uint_as_float(*amax_bits);
   int e = 0;
   if (amax > 0.f) (void)frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+  // clamp: for max|dy| below ~2^-85 (heavily down-scaled losses) 2^(42-e) overflows fp32 and every product v*scale is
+  // inf / NaN; gradients that small keep 2^(42+80) of scale instead (still far inside their own fp32 resolution)
+  e = e < -80 ? -80 : (e > 100 ? 100 : e);
   return ldexpf(1.f, DCN_FIX_BITS - e);
 }
 __device__ __forceinline__ void fix_add(long long* a, float v, float scale) {

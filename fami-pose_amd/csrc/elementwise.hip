@@ -91,6 +91,24 @@ __global__ void scale_pairs_kernel(const float* __restrict__ in, float* __restri
   out[i] = acc ? out[i] + v : v;
 }
 
+// g *= f over the flat gradient arena (1 / (world * loss_scale)); raises *flag when any element is inf / NaN
+__global__ __launch_bounds__(256) void unscale_check_kernel(float* __restrict__ g, long n, float f, unsigned* __restrict__ flag) {
+  bool bad = false;
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = ld4(g + i * 4) * f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bad |= !(fabsf(v[t]) <= 3.4028235e38f);
+    st4(g + i * 4, v);
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = g[i] * f;
+    bad |= !(fabsf(v) <= 3.4028235e38f);
+    g[i] = v;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 template <typename T>
 __global__ void axpby_kernel(const T* a, const T* b, T* out, long n, float alpha, float beta, int vec) {
   const long n4 = vec ? n >> 2 : 0;
@@ -220,8 +238,16 @@ __global__ void pool_relu_bwd_kernel(const T* __restrict__ dy, const T* __restri
 }
 
 // state = {step, lr, bc1, bc2}
-__global__ void adam_prep_kernel(float* state, float beta1, float beta2) {
+// flag (optional): raised by fami_unscale_check_f32 when the gradient arena holds an inf / NaN (an fp16 overflow under the
+// static loss scale).  The step is then SKIPPED: the step count does not advance, bc1 = 0 tells adam_kernel to return, and
+// the flag is cleared for the next step -- one overflow no longer poisons m, v and the parameters for good.
+__global__ void adam_prep_kernel(float* state, float beta1, float beta2, unsigned* flag) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (flag && *flag) {
+      *flag = 0u;
+      state[2] = 0.f;
+      return;
+    }
     const float t = state[0] + 1.f;
     state[0] = t;
     state[2] = 1.f - powf(beta1, t);
@@ -232,6 +258,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             float* __restrict__ v, long n, const float* __restrict__ state, float beta1,
                             float beta2, float eps, float wd) {
   const float lr = state[1], bc1 = state[2], bc2s = sqrtf(state[3]);
+  if (bc1 == 0.f) return;   // skipped step (non-finite gradients, see adam_prep_kernel); bc1 > 0 from step 1 on otherwise
   const float step_size = lr / bc1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i];
@@ -410,8 +437,21 @@ int fami_add_i64(long long* v, const long long* inc, long n, hipStream_t s) {
 // state (device float[4]) = {step, lr, 1-beta1^step, 1-beta2^step}; prep increments step
 int fami_adam_prep_f32(float* state, float beta1, float beta2, hipStream_t s) {
   FAMI_REQUIRE(state, "fami_adam_prep_f32", "bad argument");
-  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2);
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, (unsigned*)nullptr);
   FAMI_CHECK_LAUNCH("fami_adam_prep_f32");
+  return FAMI_OK;
+}
+// the same, skipping the step when *flag != 0 (and clearing the flag): see fami_unscale_check_f32
+int fami_adam_prep_checked_f32(float* state, float beta1, float beta2, unsigned* flag, hipStream_t s) {
+  FAMI_REQUIRE(state && flag, "fami_adam_prep_checked_f32", "bad argument");
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, flag);
+  FAMI_CHECK_LAUNCH("fami_adam_prep_checked_f32");
+  return FAMI_OK;
+}
+int fami_unscale_check_f32(float* g, long n, float f, unsigned* flag, hipStream_t s) {
+  FAMI_REQUIRE(g && flag && n > 0, "fami_unscale_check_f32", "bad argument");
+  hipLaunchKernelGGL(unscale_check_kernel, dim3(fami_ew_grid((n + 3) / 4)), dim3(256), 0, s, g, n, f, flag);
+  FAMI_CHECK_LAUNCH("fami_unscale_check_f32");
   return FAMI_OK;
 }
 int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* state, float beta1, float beta2,

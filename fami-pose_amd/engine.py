@@ -148,9 +148,18 @@ class Engine:
     def _enter_wlane(self):
         """Route the following calls to the weight-gradient stream, ordered after the current lane's work so far."""
         if self._wstream is None:
-            if self.dev not in Engine._wgrad_pool:
-                Engine._wgrad_pool[self.dev] = torch.cuda.Stream(self.dev)
-            self._wstream = Engine._wgrad_pool[self.dev]
+            # same aliasing hazard as _lanes(): torch hands streams out of a 32-entry round-robin pool, so the cached
+            # stream can BE this step's main / capture stream or one of its side lanes -- re-pick until distinct
+            taken = {self._main.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])}
+            ws = Engine._wgrad_pool.get(self.dev)
+            tries = 0
+            while (ws is None or ws.cuda_stream in taken) and tries < 64:
+                ws = torch.cuda.Stream(self.dev)
+                tries += 1
+            if ws.cuda_stream in taken:
+                raise RuntimeError('could not obtain a distinct weight-gradient stream')
+            Engine._wgrad_pool[self.dev] = ws
+            self._wstream = ws
         ev = torch.cuda.Event()
         ev.record(self._lane_stream())
         self._wstream.wait_event(ev)

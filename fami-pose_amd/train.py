@@ -63,9 +63,13 @@ class FlatAdam:
             self.betas, self.eps, self.wd = new
             self.hyper_version += 1
 
-    def step(self):
+    def step(self, flag=None):
+        """flag: device u32 raised by fami_unscale_check_f32 on non-finite gradients -> the step is skipped."""
         s = _stream(self.p.device)
-        lib().call('fami_adam_prep_f32', _p(self.state), self.betas[0], self.betas[1], s)
+        if flag is None:
+            lib().call('fami_adam_prep_f32', _p(self.state), self.betas[0], self.betas[1], s)
+        else:
+            lib().call('fami_adam_prep_checked_f32', _p(self.state), self.betas[0], self.betas[1], _p(flag), s)
         lib().call('fami_adam_f32', _p(self.p), _p(self.grad), _p(self.m), _p(self.v), self.p.numel(), _p(self.state),
                    self.betas[0], self.betas[1], self.eps, self.wd, s)
 
@@ -262,6 +266,8 @@ class Trainer:
         self.loss_scale = float(loss_scale if loss_scale is not None else
                                 (8192.0 if self.act_dtype == torch.float16 else 1.0))
         self.flat, self.table = flatten_parameters(model)
+        # overflow guard of the static loss scale: a device flag raised by the unscale pass, consumed by the optimizer
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.dev) if self.loss_scale != 1.0 else None
         self.opt = FlatAdam(self.flat, lr=lr)
         self.grad = self.opt.grad
         self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
@@ -396,7 +402,10 @@ class Trainer:
     def _unscale(self):
         """gradient arena *= 1 / (world * loss_scale): the data-parallel mean and the static loss scale in one pass."""
         f = 1.0 / ((self.world if self.ddp else 1) * self.loss_scale)
-        if f != 1.0:
+        if self.overflow is not None:
+            # static loss scaling (fp16): the same pass also looks for inf / NaN; Adam then skips the step
+            lib().call('fami_unscale_check_f32', _p(self.grad), self.grad.numel(), f, _p(self.overflow), _stream(self.dev))
+        elif f != 1.0:
             lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), f, 0.0, _stream(self.dev))
 
     def _eager_step(self, kf_x, sup_x, target, weight):
@@ -406,7 +415,7 @@ class Trainer:
         else:
             outs = self._forward_backward(kf_x, sup_x, target, weight)
         self._unscale()
-        self.opt.step()
+        self.opt.step(self.overflow)
         return outs
 
     # ------------------------------------------------------------------ hipGraph capture / replay
@@ -434,7 +443,7 @@ class Trainer:
             with torch.cuda.graph(g):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
                 self._unscale()
-                self.opt.step()
+                self.opt.step(self.overflow)
             plan = [('graph', g)]
         elif self.ddp_plan == 'serial':
             # graph 1 = forward + backward, then the bucketed all-reduce of the flat gradient arena (RCCL, outside any
@@ -450,7 +459,7 @@ class Trainer:
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=pool, capture_error_mode='thread_local'):
                 self._unscale()
-                self.opt.step()
+                self.opt.step(self.overflow)
             plan.append(('graph', g2))
         else:
             outs, plan = self._capture_overlap(st)
@@ -501,7 +510,7 @@ class Trainer:
             g2.capture_begin(pool=pool, capture_error_mode='thread_local')
             try:
                 self._unscale()
-                self.opt.step()
+                self.opt.step(self.overflow)
             finally:
                 g2.capture_end()
             plan.append(('graph', g2))

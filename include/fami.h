@@ -145,6 +145,11 @@ int fami_pool_relu_bwd_f32(const float* dy, const float* y, float* out, int N, i
 int fami_adam_prep_f32(float* state4, float beta1, float beta2, fami_stream_t stream);
 int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* state4, float beta1,
                   float beta2, float eps, float weight_decay, fami_stream_t stream);
+/* fp16 static loss scaling with an overflow guard (the reference trains in fp32 and has no counterpart; BASELINE config 5):
+ * fami_unscale_check_f32 multiplies the gradient arena by f and raises *flag (device u32) on any inf / NaN;
+ * fami_adam_prep_checked_f32 then skips the whole Adam step (no step count, no moment update) and clears the flag. */
+int fami_unscale_check_f32(float* g, long n, float f, unsigned* flag, fami_stream_t stream);
+int fami_adam_prep_checked_f32(float* state4, float beta1, float beta2, unsigned* flag, fami_stream_t stream);
 
 /* ---- temporal alignment ----------------------------------------------------------------------
  * fami_shift_bilinear_*: kornia.geometry.warp_affine(src, [[1,0,tx],[0,1,ty]], dsize) at

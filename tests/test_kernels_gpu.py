@@ -394,6 +394,43 @@ def test_adam_matches_torch(dev):
     assert relerr(flat, ref.data) < 1e-6
 
 
+def test_adam_skips_a_step_with_nonfinite_gradients(dev):
+    """Static loss scaling (fp16 mode) with the overflow guard: fami_unscale_check_f32 unscales the arena and raises the
+    device flag on inf / NaN; the optimizer then leaves parameters, both moments and the step count untouched and clears
+    the flag, and the next finite step continues exactly like torch's Adam that never saw the bad step."""
+    from fami_pose_amd._lib import lib
+    from fami_pose_amd.train import FlatAdam
+    torch.manual_seed(9)
+    p = torch.randn(1003)
+    ref = nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    flat = p.clone().to(dev)
+    ad = FlatAdam(flat, lr=1e-3)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    scale = 8192.0
+    for it in range(6):
+        g = torch.randn(1003)
+        bad = it in (1, 4)
+        gd = (g * scale).to(dev)
+        if bad:
+            gd[(17, 1002)[it == 4]] = float('inf') if it == 1 else float('nan')
+        else:
+            ref.grad = g.clone()
+            opt.step()
+        ad.grad.copy_(gd)
+        before = (flat.clone(), ad.m.clone(), ad.v.clone(), ad.state[0].item())
+        lib().call('fami_unscale_check_f32', ad.grad.data_ptr(), ad.grad.numel(), 1.0 / scale, flag.data_ptr(), st)
+        assert flag.item() == (1 if bad else 0)
+        ad.step(flag)
+        assert flag.item() == 0
+        if bad:
+            assert torch.equal(flat, before[0]) and torch.equal(ad.m, before[1]) and torch.equal(ad.v, before[2])
+            assert ad.state[0].item() == before[3]
+    assert ad.state[0].item() == 4.0
+    assert relerr(flat, ref.data) < 1e-6
+
+
 def test_final_preds_golden(dev):
     """On-device get_final_preds against the reference-generated golden (tests/golden/g12): fp32 arithmetic vs the
     reference's float64 affine -> 1e-3 image pixels on coordinates up to ~1e3."""
