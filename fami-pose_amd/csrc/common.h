@@ -125,6 +125,26 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row ends with the total.
+// quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror: four v_add_f32 with DPP modifiers, no LDS traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
+// ---- BatchNorm slot rows (norm.hip two-launch forms; filled by the convolution epilogues of conv.hip when fused) ----
+// slots = [BN_NS_MAX][2][C] fp64 sums (zero on entry) followed by [C] fp32 pivots (the value the forward sums are shifted
+// by; written by the producer, so every consumer workgroup reads the same one).
+#define BN_NS_MAX 8
+static inline int bn_slots(int C) { return C <= 96 ? 8 : (C <= 192 ? 4 : 2); }
+static inline long bn_slots_bytes(int C) { return (long)BN_NS_MAX * 2 * C * 8 + (long)((C + 3) & ~3) * 4; }
+__host__ __device__ static inline float* bn_slots_pivot(void* slots, int C) {
+  return reinterpret_cast<float*>(reinterpret_cast<double*>(slots) + (long)BN_NS_MAX * 2 * C);
+}
+
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own 4 MB L2:
 // with the natural order, neighbouring pixel tiles -- which share their 3x3 halo rows -- sit in 8 different L2s and
 // every input row is fetched from the fabric by several of them.  This remap hands XCD x the x-th contiguous eighth

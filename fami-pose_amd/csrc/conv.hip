@@ -22,7 +22,66 @@
 #include "common.h"
 #include <type_traits>
 
+// Optional BatchNorm work in a convolution's epilogue (reference semantics
+// posetimation/layers/basic_model.py:34-63: every conv is followed by a train-mode BatchNorm).  The output tile is in
+// registers anyway, so the statistics pass over the tensor -- one launch and one HBM read per BatchNorm, forward and
+// backward -- is folded in: per-channel partial sums of the workgroup's pixels go into the fp64 slot rows of the
+// two-launch BatchNorm (common.h; norm.hip's apply passes fold the rows in their prologue), by global_atomic_add_f64.
+//   mode 1 (forward conv -> BN):  sum (y - K), sum (y - K)^2 of the values as stored; K[c] = pivot_src[c] (the running
+//                                 mean: any value near the mean conditions the variance) or 0; the first pixel tile
+//                                 stores K behind the slot rows for the consumer.
+//   mode 2 (input gradient -> the BN that produced this conv's input):  the epilogue holds dL/d(BN output) complete
+//                                 (this launch is its last contribution), so dz = relu-mask(dy) is stored instead of dy
+//                                 and sum dz, sum dz*xhat are taken; mask from the BN output (relu 1) or recomputed from
+//                                 its input exactly as the forward apply pass computes it (relu 2).
+struct EpiBN {
+  double* slots;           // null: plain epilogue
+  int ns, mode, relu, C;   // C = channels of the output tensor (row length of the slot rows)
+  const float* pivot_src;  // mode 1
+  const void* z;           // mode 2: BN input  [P][C] (activation storage type)
+  const void* yr;          // mode 2, relu 1: BN output
+  const float *mean, *invstd, *gamma, *beta;
+};
+static inline EpiBN epi_none() {
+  EpiBN e;
+  e.slots = nullptr; e.ns = 1; e.mode = 0; e.relu = 0; e.C = 0; e.pivot_src = nullptr; e.z = nullptr; e.yr = nullptr;
+  e.mean = e.invstd = e.gamma = e.beta = nullptr;
+  return e;
+}
+// The EpiBN block of a kernel's argument struct, read in the EPILOGUE through the kernarg segment pointer instead of
+// through the by-value parameter: the compiler preloads every referenced kernel argument into SGPRs at the top of the
+// kernel and keeps it there (+28 SGPRs through the main loop, one resident workgroup per CU less on the dgrad form).
+// The empty asm makes the pointer opaque, so the loads cannot be hoisted above it.  `off` = offsetof(Args, e) (the
+// argument struct is the kernel's only parameter: it starts at byte 0 of the segment).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) EpiBN* EpiPtr;   // constant address space: the field reads stay scalar loads
+__device__ __forceinline__ EpiPtr epi_late(unsigned off) {
+  const __attribute__((address_space(4))) char* k =
+      (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off;
+  asm volatile("" : "+s"(k) : : "memory");
+  return (EpiPtr)k;
+}
+#else
+typedef const EpiBN* EpiPtr;
+__device__ inline EpiPtr epi_late(unsigned) { return nullptr; }
+#endif
+
+// the forward apply pass's scale / shift (norm.hip bn_scale_shift): the recomputed ReLU mask must match it bit for bit
+__device__ __forceinline__ void epi_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sf) {
+  sc = invstd * gamma;
+  sf = __builtin_fmaf(-mean, sc, beta);
+}
+
+// v rounded to storage type H and widened again (what a later pass over the stored tensor would read)
+template <typename H>
+__device__ __forceinline__ f32x4 ld4_round(f32x4 v) {
+  if constexpr (sizeof(H) == 4) return v;
+  else return __builtin_convertvector(__builtin_convertvector(v, H __attribute__((ext_vector_type(4)))), f32x4);
+}
+
 struct ConvArgs {
+  EpiBN e;              // read late (epi_late); `emode` below is the one field the top of the kernel looks at
+  int emode;            // 0 | e.mode when e.slots is set
   const float* x;       // GEMM input activation  [N,Hi,Wi,Ci]
   const float* wp;      // packed weights [taps][KC][NTt][64][4]
   float* y;             // GEMM output activation [N,Ho,Wo,Co]
@@ -129,7 +188,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     cb = c & 1;
     crem = rem;
   }
-  if (KS == 1 && !active) return;
+  const int emode = p.emode;   // kernel argument: uniform
+  if (KS == 1 && !active && !emode) return;      // (with statistics the wave still meets the others at the barrier)
   const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
 
@@ -388,6 +448,85 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
     const int co = (ntg0 + nt) * 16 + row;
     bv[nt] = (p.bias && co < p.Co) ? p.bias[co] : 0.f;
   }
+  if (emode) {
+    // EpiBN: a lane owns ONE channel per tile here, so the per-channel sums are register accumulations over its pixels;
+    // channel tile by channel tile, so one tile's parameters are live at a time
+    EpiPtr e = epi_late(__builtin_offsetof(ConvArgs, e));
+    __shared__ float ered[4][NT * 32];
+    const float* ez = reinterpret_cast<const float*>(e->z);
+    const float* eyr = reinterpret_cast<const float*>(e->yr);
+    const int erelu = e->relu, eC = e->C;
+    double* srow = e->slots + (long)((KS == 1 ? bx : tix) % e->ns) * 2 * eC;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = (ntg0 + nt) * 16 + row;
+      const int cc = min(co, p.Co - 1);
+      float es = 0.f, eq = 0.f, ek = 0.f, emu = 0.f, eis = 0.f, esc = 0.f, esf = 0.f;
+      if (emode == 1) {
+        ek = e->pivot_src ? e->pivot_src[cc] : 0.f;
+      } else {
+        emu = e->mean[cc];
+        eis = e->invstd[cc];
+        epi_scale_shift(emu, eis, e->gamma[cc], e->beta[cc], esc, esf);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int pm_mine = pv[mt] ? (pn[mt] * p.Ho + py[mt]) * p.Wo + px[mt] : -1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int m = m0 + mt * 16 + kq * 4 + r;
+          if (par) m = __shfl(pm_mine, kq * 4 + r);
+          if (m < 0 || m >= p.P || !active || co >= p.Co) continue;
+          const long idx = (long)m * p.Co + co;
+          float v = acc[mt][nt][r] + bv[nt];
+          if (p.accumulate) v += p.y[idx];
+          if (emode == 1) {
+            const float d = v - ek;
+            es += d;
+            eq = __builtin_fmaf(d, d, eq);
+          } else {
+            const float zz = ez[idx];
+            bool keep = true;
+            if (erelu == 1) keep = eyr[idx] > 0.f;
+            else if (erelu == 2) keep = __builtin_fmaf(zz, esc, esf) > 0.f;
+            v = keep ? v : 0.f;
+            es += v;
+            eq = __builtin_fmaf(v, (zz - emu) * eis, eq);
+          }
+          p.y[idx] = v;
+        }
+      }
+      // lanes l, l^16, l^32, l^48 hold the same channel: fold them, then the waves of the workgroup through LDS
+      es += __shfl_xor(es, 16, 64);
+      es += __shfl_xor(es, 32, 64);
+      eq += __shfl_xor(eq, 16, 64);
+      eq += __shfl_xor(eq, 32, 64);
+      if (KS == 1) {
+        if (kq == 0) {
+          ered[wave][nt * 32 + row] = es;
+          ered[wave][nt * 32 + 16 + row] = eq;
+        }
+      } else if (kq == 0 && co < p.Co) {   // KS > 1: only the k-part-0 waves get here, each adds its own sums
+        unsafeAtomicAdd(srow + co, (double)es);
+        unsafeAtomicAdd(srow + eC + co, (double)eq);
+        if (emode == 1 && tix == 0) bn_slots_pivot(e->slots, eC)[co] = ek;
+      }
+    }
+    if (KS == 1) {
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < NT * 32) {
+        const int nt = t >> 5, st = (t >> 4) & 1;
+        const int co = (ntg0 + nt) * 16 + (t & 15);
+        if (co < p.Co) {
+          const float v = (ered[0][t] + ered[1][t]) + (ered[2][t] + ered[3][t]);
+          unsafeAtomicAdd(srow + st * eC + co, (double)v);
+          if (emode == 1 && st == 0 && bx == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // par: the flat output pixel of tile row j lives in lane j (any kq): fetch it from there
@@ -574,6 +713,8 @@ __global__ __launch_bounds__(256) void conv_igemm32_f32(ConvArgs p) {
 // the epilogue is one 8-byte (bf16) or 16-byte (f32) store per tile instead of four scattered scalars.
 // K is walked tap-major in chunks of 32 channels; a lane's fragment is 8 consecutive channels = one 16-byte load.
 struct ConvArgsH {
+  EpiBN e;
+  int emode;
   const void* x;     // GEMM input activation  [N,Hi,Wi,Ci] (16-bit storage type H)
   const void* wp;    // packed weights [taps][KC][NTt][64][8] (H)
   void* y;           // GEMM output activation [N,Ho,Wo,Co], H or f32 (out_f32)
@@ -702,7 +843,8 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
     cb = c & 1;
     crem = rem;
   }
-  if (KS == 1 && !active) return;
+  const int emode = p.emode;   // kernel argument: uniform
+  if (KS == 1 && !active && !emode) return;      // (with statistics the wave still meets the others at the barrier)
   const int ntg0 = by * NT;
   const int HoWo = p.Ho * p.Wo;
 
@@ -867,6 +1009,105 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
 
   // epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel): 4 consecutive channels per lane
   const bool cvec = (p.Co & 3) == 0;
+  if (emode) {
+    // EpiBN (host guarantees Co % 4 == 0 and 16-bit output): channel tile by channel tile so only one tile's
+    // parameters are live; a lane holds 4 channels of one pixel, the 16 pixels of a tile row are one DPP row
+    EpiPtr e = epi_late(__builtin_offsetof(ConvArgsH, e));
+    __shared__ float ered[4][NT * 32];
+    const H* ez = reinterpret_cast<const H*>(e->z);
+    const H* eyr = reinterpret_cast<const H*>(e->yr);
+    const int erelu = e->relu, eC = e->C;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      const bool cok = co0 < p.Co;
+      const int cc = cok ? co0 : 0;
+      f32x4 es = z4, eq = z4, ek = z4, emu = z4, eis = z4, esc = z4, esf = z4, bias4 = z4;
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + cc);
+      if (emode == 1) {
+        if (e->pivot_src) ek = *reinterpret_cast<const f32x4*>(e->pivot_src + cc);
+      } else {
+        emu = *reinterpret_cast<const f32x4*>(e->mean + cc);
+        eis = *reinterpret_cast<const f32x4*>(e->invstd + cc);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + cc), be = *reinterpret_cast<const f32x4*>(e->beta + cc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a, b;
+          epi_scale_shift(emu[r], eis[r], ga[r], be[r], a, b);
+          esc[r] = a;
+          esf[r] = b;
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = par ? (pv[mt] ? (pn[mt] * p.Ho + py[mt]) * p.Wo + px[mt] : p.P) : m0 + mt * 16 + col;
+        if (m >= p.P || !cok || !active) continue;
+        f32x4 v = acc[mt][nt] + bias4;
+        const long idx = (long)m * p.Co + co0;
+        H* yp = reinterpret_cast<H*>(p.y) + idx;
+        if (p.accumulate) v += ld4(yp);
+        if (emode == 2) {
+          const f32x4 zz = ld4(ez + idx);
+          f32x4 yy = z4;
+          if (erelu == 1) yy = ld4(eyr + idx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool keep = true;
+            if (erelu == 1) keep = yy[r] > 0.f;
+            else if (erelu == 2) keep = __builtin_fmaf(zz[r], esc[r], esf[r]) > 0.f;
+            v[r] = keep ? v[r] : 0.f;
+          }
+          st4(yp, v);
+          const f32x4 g = ld4_round<H>(v);        // the sums see the gradient as stored
+          es += g;
+          eq += g * ((zz - emu) * eis);
+        } else {
+          st4(yp, v);
+          const f32x4 d = ld4_round<H>(v) - ek;   // statistics of the tensor as stored
+          es += d;
+          eq += d * d;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        es[r] = row16_sum(es[r]);
+        eq[r] = row16_sum(eq[r]);
+      }
+      if (KS == 1) {
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ered[wave][nt * 32 + kq * 4 + r] = es[r];
+            ered[wave][nt * 32 + 16 + kq * 4 + r] = eq[r];
+          }
+        }
+      } else if (col == 0 && cok) {
+        double* srow = e->slots + (long)(tix % e->ns) * 2 * eC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsafeAtomicAdd(srow + co0 + r, (double)es[r]);
+          unsafeAtomicAdd(srow + eC + co0 + r, (double)eq[r]);
+          if (emode == 1 && tix == 0) bn_slots_pivot(e->slots, eC)[co0 + r] = ek[r];
+        }
+      }
+    }
+    if (KS == 1) {
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < NT * 32) {
+        const int nt = t >> 5, st = (t >> 4) & 1, c16 = t & 15;
+        const int co = (ntg0 + nt) * 16 + c16;
+        if (co < p.Co) {
+          const float v = (ered[0][t] + ered[1][t]) + (ered[2][t] + ered[3][t]);
+          double* srow = e->slots + (long)(bx % e->ns) * 2 * eC;
+          unsafeAtomicAdd(srow + st * eC + co, (double)v);
+          if (emode == 1 && st == 0 && bx == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = par ? (pv[mt] ? (pn[mt] * p.Ho + py[mt]) * p.Wo + px[mt] : p.P) : m0 + mt * 16 + col;
@@ -925,6 +1166,8 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
 // channels of one pixel -> one 16-byte (f32) / 8-byte (bf16) store.  dgrad = the same kernel with the tap shift
 // negated and the mode-1 weight image.
 struct ConvLdsArgs {
+  EpiBN e;
+  int emode;
   const void* x;      // [N,H,W,Ci]
   const void* wp;     // packed weights (pack_w_kernel / pack_w_bf16_kernel layout)
   void* y;            // [N,H,W,Co]
@@ -1155,6 +1398,91 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(ConvLdsArgs p) {
 
   // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
   const long pix0 = ((long)img * p.H + y0) * p.W;
+  const int emode = p.emode;
+  if (emode) {
+    // EpiBN (see conv_igemm_h): per channel tile, the wave's row tiles are summed in registers, the 16 pixel lanes by
+    // DPP, the four waves through the (now idle) LDS; 16-bit or f32 storage output (not the f32 heatmap form)
+    EpiPtr e = epi_late(__builtin_offsetof(ConvLdsArgs, e));
+    float* ered = reinterpret_cast<float*>(smem);   // [4][NT*32]; every wave is past the last slab's barrier
+    const T* ez = reinterpret_cast<const T*>(e->z);
+    const T* eyr = reinterpret_cast<const T*>(e->yr);
+    const int erelu = e->relu, eC = e->C;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      f32x4 es = z4, eq = z4, ek = z4, emu = z4, eis = z4, esc = z4, esf = z4, bias4 = z4;
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co0);
+      if (emode == 1) {
+        if (e->pivot_src) ek = *reinterpret_cast<const f32x4*>(e->pivot_src + co0);
+      } else {
+        emu = *reinterpret_cast<const f32x4*>(e->mean + co0);
+        eis = *reinterpret_cast<const f32x4*>(e->invstd + co0);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + co0), be = *reinterpret_cast<const f32x4*>(e->beta + co0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a, b;
+          epi_scale_shift(emu[r], eis[r], ga[r], be[r], a, b);
+          esc[r] = a;
+          esf[r] = b;
+        }
+      }
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int mt = sl < 2 ? wave + 4 * sl : 8;
+        const int j = mt * 16 + col;
+        if (sl == 2 && !(has2 && nt == nt2)) continue;
+        if (mt >= ntile || j >= npix) continue;
+        f32x4 v = (sl < 2 ? acc[sl < 2 ? sl : 0][nt] : acc2) + bias4;
+        const long idx = (pix0 + j) * p.Co + co0;
+        T* yp = reinterpret_cast<T*>(p.y) + idx;
+        if (p.accumulate) v += ld4(yp);
+        if (emode == 2) {
+          const f32x4 zz = ld4(ez + idx);
+          f32x4 yy = z4;
+          if (erelu == 1) yy = ld4(eyr + idx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool keep = true;
+            if (erelu == 1) keep = yy[r] > 0.f;
+            else if (erelu == 2) keep = __builtin_fmaf(zz[r], esc[r], esf[r]) > 0.f;
+            v[r] = keep ? v[r] : 0.f;
+          }
+          st4(yp, v);
+          const f32x4 g = ld4_round<T>(v);
+          es += g;
+          eq += g * ((zz - emu) * eis);
+        } else {
+          st4(yp, v);
+          const f32x4 d = ld4_round<T>(v) - ek;
+          es += d;
+          eq += d * d;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        es[r] = row16_sum(es[r]);
+        eq[r] = row16_sum(eq[r]);
+      }
+      if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ered[wave * (NT * 32) + nt * 32 + kq * 4 + r] = es[r];
+          ered[wave * (NT * 32) + nt * 32 + 16 + kq * 4 + r] = eq[r];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NT * 32) {
+      const int nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
+      const int co = (ntg0 + nt) * 16 + c16;
+      const float v = (ered[tid] + ered[NT * 32 + tid]) + (ered[2 * NT * 32 + tid] + ered[3 * NT * 32 + tid]);
+      double* srow = e->slots + (long)(bxl % e->ns) * 2 * eC;
+      unsafeAtomicAdd(srow + st * eC + co, (double)v);
+      if (emode == 1 && st == 0 && bxl == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+    }
+    return;
+  }
   auto store = [&](int mt, int nt, f32x4 v) {
     const int j = mt * 16 + col;
     if (mt >= ntile || j >= npix) return;
@@ -2146,7 +2474,8 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
   a.par = (mode == 1 && a.sh == 1 && g_par) ? 1 : 0;
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
-  if (vec && g_use32 && (g_force_mt == 0 || g_force_mt == 32) && pack32_elems(a.Ci, a.Co, a.kh * a.kw) > 0 &&
+  // (the 32x32-tile kernel has no EpiBN epilogue: a fused call takes the 16x16 kernels)
+  if (vec && !a.e.slots && g_use32 && (g_force_mt == 0 || g_force_mt == 32) && pack32_elems(a.Ci, a.Co, a.kh * a.kw) > 0 &&
       (long)a.kh * a.kw * fami_cdiv(a.Ci, 8) * fami_cdiv(a.Co, 32) * 1024 < (1L << 31))
     return run_igemm32(a, mode, s, name);
   int NT = pick_nt(a.NTt);
@@ -2201,7 +2530,7 @@ static int g_wgrad_lin = 1;      // fami_conv_tune_wgrad_lds(50 / 51): linear-ad
 template <typename T>
 static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
-                           const char* name) {
+                           const char* name, const EpiBN& epi = epi_none()) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
   // default: bf16 from 96 input channels up (per launch: 192 ch 18.8 vs 30.3 us, 384 ch 27.8 vs 32.4, 96 ch equal,
   // 48 ch 23.9 vs 21.8 -> direct; tools/bench_xcd.py with KNOB=lds), f32 never (slower on every shape)
@@ -2234,6 +2563,7 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt; a.sgn = sgn;
   a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32; a.simz = 0;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0;
   const dim3 grid(N * a.bands, Co / (16 * NT));
   const int KSC = a.CHP / KSTEP;
   bool launched = false;
@@ -2355,15 +2685,38 @@ int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, in
 }
 
 // y[N,Ho,Wo,Co] = conv(x[N,H,W,Ci], W) (+bias) (+addend) (relu) ; wp packed with mode 0
+static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, const float* bias, const float* addend,
+                             float* y, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                             int relu, int accumulate, const EpiBN& e, hipStream_t s);
 int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* addend, float* y, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                         int accumulate, hipStream_t s) {
-  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_fwd_f32", "bad argument");
+  return conv_fwd_f32_impl("fami_conv2d_fwd_f32", x, wp, bias, addend, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil, relu,
+                           accumulate, epi_none(), s);
+}
+// the same (no addend / relu / accumulate: a BatchNorm follows) with the BatchNorm statistics of y taken in the
+// epilogue: `slots` = fami_bn_slots_bytes(Co) bytes, zero on entry, handed to fami_bn_apply_slots_f32 /
+// fami_bn_finalize_slots_f32 afterwards; pivot_src [Co] (the running mean) or null
+int fami_conv2d_fwd_stats_f32(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci,
+                              int Co, int kh, int kw, int stride, int pad, int dil, void* slots, const float* pivot_src,
+                              hipStream_t s) {
+  FAMI_REQUIRE(slots, "fami_conv2d_fwd_stats_f32", "null slots");
+  EpiBN e = epi_none();
+  e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Co); e.mode = 1; e.C = Co; e.pivot_src = pivot_src;
+  return conv_fwd_f32_impl("fami_conv2d_fwd_stats_f32", x, wp, bias, nullptr, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil,
+                           0, 0, e, s);
+}
+}  // extern "C"
+static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, const float* bias, const float* addend,
+                             float* y, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                             int relu, int accumulate, const EpiBN& e, hipStream_t s) {
+  FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
-    fami_set_error("fami_conv2d_fwd_f32", "unsupported geometry");
+    fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
   ConvArgs a;
+  a.e = e; a.emode = e.slots ? e.mode : 0;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias; a.addend = addend;
   a.N = N; a.Hi = H; a.Wi = W; a.Ci = Ci;
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
@@ -2371,25 +2724,52 @@ int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, cons
   a.KC = fami_cdiv(Ci, 16); a.NTt = fami_cdiv(Co, 16); a.relu = relu; a.accumulate = accumulate;
   const long P = (long)N * a.Ho * a.Wo;
   const long xb = (long)N * H * W * Ci * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_fwd_f32", "tensor >= 2 GiB");
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
-    const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, "fami_conv2d_fwd_f32");
+    const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, nm, e);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
-  return run_igemm(a, 0, s, "fami_conv2d_fwd_f32");
+  return run_igemm(a, 0, s, nm);
 }
+extern "C" {
 
 // dx[N,H,W,Ci] = conv^T(dy[N,Ho,Wo,Co], W) (+addend) ; wp packed with mode 1
+static int conv_dgrad_f32_impl(const char* nm, const float* dy, const float* wp, const float* addend, float* dx, int N,
+                               int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               const EpiBN& e, hipStream_t s);
 int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend, float* dx, int N, int H, int W,
                           int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                           hipStream_t s) {
-  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "fami_conv2d_dgrad_f32", "bad argument");
+  return conv_dgrad_f32_impl("fami_conv2d_dgrad_f32", dy, wp, addend, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil,
+                             accumulate, epi_none(), s);
+}
+// the same as the LAST contribution to dx = dL/d(output of a train-mode BatchNorm(+ReLU) with input z): stores
+// dz = relu-mask(dx) instead of dx and adds sum dz, sum dz*xhat into `slots` (zero on entry) for
+// fami_bn_bwd_apply_slots_f32.  relu: 0 none, 1 mask from the BatchNorm output yrelu, 2 recomputed from z.
+int fami_conv2d_dgrad_bnstats_f32(const float* dy, const float* wp, float* dx, int N, int H, int W, int Ci, int Co,
+                                  int kh, int kw, int stride, int pad, int dil, int accumulate, const float* z,
+                                  const float* yrelu, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int relu, void* slots, hipStream_t s) {
+  FAMI_REQUIRE(slots && z && mean && invstd && gamma && beta && (relu != 1 || yrelu) && relu >= 0 && relu <= 2,
+               "fami_conv2d_dgrad_bnstats_f32", "bad argument");
+  EpiBN e = epi_none();
+  e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Ci); e.mode = 2; e.relu = relu; e.C = Ci;
+  e.z = z; e.yr = yrelu; e.mean = mean; e.invstd = invstd; e.gamma = gamma; e.beta = beta;
+  return conv_dgrad_f32_impl("fami_conv2d_dgrad_bnstats_f32", dy, wp, nullptr, dx, N, H, W, Ci, Co, kh, kw, stride, pad,
+                             dil, accumulate, e, s);
+}
+}  // extern "C"
+static int conv_dgrad_f32_impl(const char* nm, const float* dy, const float* wp, const float* addend, float* dx, int N,
+                               int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               const EpiBN& e, hipStream_t s) {
+  FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
-    fami_set_error("fami_conv2d_dgrad_f32", "unsupported geometry");
+    fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
   ConvArgs a;
+  a.e = e; a.emode = e.slots ? e.mode : 0;
   a.x = dy; a.wp = wp; a.y = dx; a.bias = nullptr; a.addend = addend;
   a.N = N; a.Hi = out_dim(H, kh, stride, pad, dil); a.Wi = out_dim(W, kw, stride, pad, dil); a.Ci = Co;
   a.Ho = H; a.Wo = W; a.Co = Ci;
@@ -2397,15 +2777,16 @@ int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend,
   a.KC = fami_cdiv(Co, 16); a.NTt = fami_cdiv(Ci, 16); a.relu = 0; a.accumulate = accumulate;
   const long P = (long)N * H * W;
   const long xb = (long)N * a.Hi * a.Wi * Co * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
-  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), "fami_conv2d_dgrad_f32", "tensor >= 2 GiB");
+  FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
     // dgrad of a stride-1 "same" conv is the same conv on dy with the taps mirrored: GEMM K = Co, N = Ci
-    const int rc = try_conv3x3_lds<float>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 1, s, "fami_conv2d_dgrad_f32");
+    const int rc = try_conv3x3_lds<float>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 1, s, nm, e);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
-  return run_igemm(a, 1, s, "fami_conv2d_dgrad_f32");
+  return run_igemm(a, 1, s, nm);
 }
+extern "C" {
 
 struct WgradPlan { int MT, NT, ciBlocks, coBlocks, psplit, chunk, pertap, w8; long P; };
 static bool wgrad_lin_ok(int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
@@ -2788,13 +3169,18 @@ static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, 
 template <typename HT>
 static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const float* bias, void* y, int N, int H, int W,
                            int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,
-                           int out_f32, hipStream_t s) {
+                           int out_f32, hipStream_t s, const EpiBN& e = epi_none()) {
   FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
     fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
+  if (e.slots && (out_f32 || relu || (Co & 3))) {
+    fami_set_error(nm, "fused BatchNorm statistics need a 16-bit output, no ReLU and Co % 4 == 0");
+    return FAMI_ESHAPE;
+  }
   ConvArgsH a;
+  a.e = e; a.emode = e.slots ? e.mode : 0;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.Hi = H; a.Wi = W; a.Ci = Ci;
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
@@ -2805,7 +3191,7 @@ static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const floa
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm);
+    const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm, e);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
   return run_igemm_h<HT>(a, 0, s, nm);
@@ -2814,13 +3200,19 @@ static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const floa
 // dx[N,H,W,Ci] (=|+=) conv_transpose(dy[N,Ho,Wo,Co]) ; wp packed with mode 1
 template <typename HT>
 static int conv_dgrad_h_impl(const char* nm, const HT* dy, const HT* wp, HT* dx, int N, int H, int W, int Ci, int Co,
-                             int kh, int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {
+                             int kh, int kw, int stride, int pad, int dil, int accumulate, hipStream_t s,
+                             const EpiBN& e = epi_none()) {
   FAMI_REQUIRE(dy && wp && dx && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
     fami_set_error(nm, "unsupported geometry");
     return FAMI_ESHAPE;
   }
+  if (e.slots && (Ci & 3)) {
+    fami_set_error(nm, "fused BatchNorm statistics need Ci % 4 == 0");
+    return FAMI_ESHAPE;
+  }
   ConvArgsH a;
+  a.e = e; a.emode = e.slots ? e.mode : 0;
   a.x = dy; a.wp = wp; a.y = dx; a.bias = nullptr;
   a.N = N; a.Hi = out_dim(H, kh, stride, pad, dil); a.Wi = out_dim(W, kw, stride, pad, dil); a.Ci = Co;
   a.Ho = H; a.Wo = W; a.Co = Ci;
@@ -2831,7 +3223,7 @@ static int conv_dgrad_h_impl(const char* nm, const HT* dy, const HT* wp, HT* dx,
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const int rc = try_conv3x3_lds<HT>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, nm);
+    const int rc = try_conv3x3_lds<HT>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, nm, e);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
   return run_igemm_h<HT>(a, 1, s, nm);
@@ -2885,6 +3277,28 @@ long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
                               int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {                   \
     return conv_dgrad_h_impl<HT>("fami_conv2d_dgrad_" #sfx, dy, wp, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil,     \
                                  accumulate, s);                                                                       \
+  }                                                                                                                    \
+  /* fused BatchNorm statistics, see the _f32 forms */                                                                \
+  int fami_conv2d_fwd_stats_##sfx(const HT* x, const HT* wp, const float* bias, HT* y, int N, int H, int W, int Ci,    \
+                                  int Co, int kh, int kw, int stride, int pad, int dil, void* slots,                   \
+                                  const float* pivot_src, hipStream_t s) {                                             \
+    FAMI_REQUIRE(slots, "fami_conv2d_fwd_stats_" #sfx, "null slots");                                                  \
+    EpiBN e = epi_none();                                                                                              \
+    e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Co); e.mode = 1; e.C = Co; e.pivot_src = pivot_src;    \
+    return conv_fwd_h_impl<HT>("fami_conv2d_fwd_stats_" #sfx, x, wp, bias, y, N, H, W, Ci, Co, kh, kw, stride, pad,    \
+                               dil, 0, 0, 0, s, e);                                                                    \
+  }                                                                                                                    \
+  int fami_conv2d_dgrad_bnstats_##sfx(const HT* dy, const HT* wp, HT* dx, int N, int H, int W, int Ci, int Co,         \
+                                      int kh, int kw, int stride, int pad, int dil, int accumulate, const HT* z,       \
+                                      const HT* yrelu, const float* mean, const float* invstd, const float* gamma,     \
+                                      const float* beta, int relu, void* slots, hipStream_t s) {                       \
+    FAMI_REQUIRE(slots && z && mean && invstd && gamma && beta && (relu != 1 || yrelu) && relu >= 0 && relu <= 2,      \
+                 "fami_conv2d_dgrad_bnstats_" #sfx, "bad argument");                                                   \
+    EpiBN e = epi_none();                                                                                              \
+    e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Ci); e.mode = 2; e.relu = relu; e.C = Ci;              \
+    e.z = z; e.yr = yrelu; e.mean = mean; e.invstd = invstd; e.gamma = gamma; e.beta = beta;                           \
+    return conv_dgrad_h_impl<HT>("fami_conv2d_dgrad_bnstats_" #sfx, dy, wp, dx, N, H, W, Ci, Co, kh, kw, stride, pad,  \
+                                 dil, accumulate, s, e);                                                               \
   }
 FAMI_CONV_H_ABI(bf16, bf16_t)
 FAMI_CONV_H_ABI(f16, f16_t)

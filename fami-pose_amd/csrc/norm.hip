@@ -114,6 +114,32 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, const T* _
   }
 }
 
+// mean / invstd (+ running statistics) from slot rows a convolution epilogue filled (fuse terms: the cross-resolution sum
+// kernel applies the normalisation itself and only needs the two vectors)
+__global__ void bn_finalize_slots_kernel(const double* __restrict__ slots, int NS, const float* __restrict__ pivot, long P,
+                                         int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                                         float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < NS; ++k) {
+    s += slots[(long)k * 2 * C + c];
+    q += slots[(long)k * 2 * C + C + c];
+  }
+  const double invP = 1.0 / (double)P;
+  const double dm = s * invP;
+  double var = q * invP - dm * dm;
+  if (var < 0.0) var = 0.0;
+  const double mu = (double)pivot[c] + dm;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
 // running statistics from an already finalised (mean, invstd): lets BatchNorm calls that SHARE a module run concurrently
 // on several streams without touching the running buffers, and applies their updates afterwards in call order
 // (Alignment_V15.py:125-135 applies one regressor to every supporting frame, updating frame by frame).
@@ -299,8 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // (the caller hands out slices of an arena it clears once per step).  fp64 adds in arrival order: the sums are
 // reproducible to ~1e-16 relative, i.e. the fp32 mean / invstd almost always bit for bit, but not guaranteed -- the
 // three-launch forms above stay for the deterministic mode.
-#define BN_NS_MAX 8
-static inline int bn_slots(int C) { return C <= 96 ? 8 : (C <= 192 ? 4 : 2); }
+// (BN_NS_MAX, bn_slots, bn_slots_bytes, bn_slots_pivot live in common.h: the convolution epilogues fill the same rows)
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_partial2_kernel(const T* __restrict__ x, double* __restrict__ slots, int NS,
@@ -358,7 +383,9 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
                                                         const T* __restrict__ residual, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ invstd,
                                                         float* running_mean, float* running_var, long P, int C,
-                                                        int relu, float momentum, float eps) {
+                                                        int relu, float momentum, float eps, const float* pivot) {
+  // pivot: null = the sums were shifted by the first pixel x[0][c] (bn_partial2_kernel); else the [C] pivots the
+  // convolution epilogue that filled the slots wrote behind them (conv.hip, EpiBN mode 1)
   extern __shared__ float sm[];  // [2][C]: scale, shift
   for (int c = threadIdx.x; c < C; c += 256) {
     double s = 0.0, q = 0.0;
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_apply2_kernel(const T* __restrict__ x,
     const double dm = s * invP;                       // mean of (x - pivot)
     double var = q * invP - dm * dm;
     if (var < 0.0) var = 0.0;
-    const double mu = (double)ld1(x + c) + dm;
+    const double mu = (double)(pivot ? pivot[c] : ld1(x + c)) + dm;
     const float muf = (float)mu;
     const float isf = (float)(1.0 / sqrt(var + (double)eps));
     if (blockIdx.x == 0) {
@@ -833,13 +860,13 @@ static inline int bn_apply_grid(long P, int C) {
 template <typename T>
 static int bn_train_fwd2_impl(const T* x, const T* residual, T* y, const float* gamma, const float* beta, float* mean,
                               float* invstd, float* running_mean, float* running_var, long P, int C, int relu,
-                              float momentum, float eps, void* slots, hipStream_t s, const char* nm) {
+                              float momentum, float eps, void* slots, int pre, hipStream_t s, const char* nm) {
   FAMI_REQUIRE(x && y && gamma && beta && mean && invstd && slots, nm, "null pointer");
   if (!bn_shape_ok(P, C)) {
     fami_set_error(nm, "C must be a multiple of 4, <= 1024");
     return FAMI_ESHAPE;
   }
-  if (bn_small_ok(P, C)) {
+  if (bn_small_ok(P, C) && !pre) {
     hipLaunchKernelGGL(bn_small_fwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, x, residual, y, gamma, beta, mean, invstd,
                        running_mean, running_var, P, C, relu, momentum, eps);
     FAMI_CHECK_LAUNCH(nm);
@@ -847,12 +874,14 @@ static int bn_train_fwd2_impl(const T* x, const T* residual, T* y, const float* 
   }
   const int G = bn_grid(P, C), NS = bn_slots(C);
   const int rows = 256 / (C >> 2);
-  hipLaunchKernelGGL(bn_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x,
-                     reinterpret_cast<double*>(slots), NS, P, C);
-  FAMI_CHECK_LAUNCH(nm);
+  if (!pre) {   // pre: the producing convolution's epilogue has filled the slot rows and the pivots already
+    hipLaunchKernelGGL(bn_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x,
+                       reinterpret_cast<double*>(slots), NS, P, C);
+    FAMI_CHECK_LAUNCH(nm);
+  }
   hipLaunchKernelGGL(bn_apply2_kernel<T>, dim3(bn_apply_grid(P, C)), dim3(256), (size_t)2 * C * sizeof(float), s, x,
                      reinterpret_cast<const double*>(slots), NS, gamma, beta, residual, y, mean, invstd, running_mean,
-                     running_var, P, C, relu, momentum, eps);
+                     running_var, P, C, relu, momentum, eps, pre ? bn_slots_pivot(slots, C) : (const float*)nullptr);
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
@@ -860,7 +889,7 @@ static int bn_train_fwd2_impl(const T* x, const T* residual, T* y, const float* 
 template <typename T>
 static int bn_bwd2_impl(const T* dy, const T* x, const T* y, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, T* dx, float* dgamma, float* dbeta, T* dres, long P, int C, int relu,
-                        int acc_dx, int acc_param, int acc_dres, void* slots, hipStream_t s, const char* nm) {
+                        int acc_dx, int acc_param, int acc_dres, void* slots, int pre, hipStream_t s, const char* nm) {
   FAMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && slots, nm, "null pointer");
   FAMI_REQUIRE(relu != 1 || y, nm, "relu = 1 needs y");
   FAMI_REQUIRE(relu >= 0 && relu <= 2, nm, "relu must be 0, 1 (mask from y) or 2 (mask recomputed from x)");
@@ -868,7 +897,7 @@ static int bn_bwd2_impl(const T* dy, const T* x, const T* y, const float* mean, 
     fami_set_error(nm, "C must be a multiple of 4, <= 1024");
     return FAMI_ESHAPE;
   }
-  if (bn_small_ok(P, C)) {  // the one-launch kernel takes its mask from y
+  if (bn_small_ok(P, C) && !pre) {  // the one-launch kernel takes its mask from y
     FAMI_REQUIRE(relu != 2 || y, nm, "small tensors take the ReLU mask from y");
     hipLaunchKernelGGL(bn_small_bwd_kernel<T>, dim3(C / 4), dim3(256), 0, s, dy, x, y, mean, invstd, gamma, dx, dgamma,
                        dbeta, dres, P, C, relu ? 1 : 0, acc_dx, acc_param, acc_dres);
@@ -877,9 +906,11 @@ static int bn_bwd2_impl(const T* dy, const T* x, const T* y, const float* mean, 
   }
   const int G = bn_grid(P, C), NS = bn_slots(C);
   const int rows = 256 / (C >> 2);
-  hipLaunchKernelGGL(bn_bwd_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y, mean,
-                     invstd, gamma, beta, reinterpret_cast<double*>(slots), NS, P, C, relu);
-  FAMI_CHECK_LAUNCH(nm);
+  if (!pre) {   // pre: the input-gradient convolution that produced dy summed dz and dz*xhat in its epilogue
+    hipLaunchKernelGGL(bn_bwd_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y, mean,
+                       invstd, gamma, beta, reinterpret_cast<double*>(slots), NS, P, C, relu);
+    FAMI_CHECK_LAUNCH(nm);
+  }
   hipLaunchKernelGGL(bn_bwd_apply2_kernel<T>, dim3(bn_apply_grid(P, C)), dim3(256), (size_t)2 * C * sizeof(float), s, dy, x,
                      y, mean, invstd, gamma, beta, reinterpret_cast<const double*>(slots), NS, dx, dgamma, dbeta, dres, P,
                      C, relu, acc_dx, acc_param, acc_dres);
@@ -905,7 +936,8 @@ static int channel_sum_impl(const T* x, long P, int C, float* out, int accumulat
 extern "C" {
 
 long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
-long fami_bn_slots_bytes(int C) { return (long)BN_NS_MAX * 2 * C * (long)sizeof(double); }
+long fami_bn_slots_bytes(int C) { return bn_slots_bytes(C); }
+int fami_bn_is_small(long P, int C) { return bn_small_ok(P, C) ? 1 : 0; }
 long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
 
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
@@ -914,6 +946,15 @@ int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, 
   hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var, mean,
                      invstd, C, eps);
   FAMI_CHECK_LAUNCH("fami_bn_eval_stats_f32");
+  return FAMI_OK;
+}
+
+int fami_bn_finalize_slots_f32(void* slots, long P, int C, float* mean, float* invstd, float* running_mean,
+                               float* running_var, float momentum, float eps, hipStream_t s) {
+  FAMI_REQUIRE(slots && mean && invstd && C > 0 && P > 0, "fami_bn_finalize_slots_f32", "bad argument");
+  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, reinterpret_cast<const double*>(slots),
+                     bn_slots(C), bn_slots_pivot(slots, C), P, C, mean, invstd, running_mean, running_var, momentum, eps);
+  FAMI_CHECK_LAUNCH("fami_bn_finalize_slots_f32");
   return FAMI_OK;
 }
 
@@ -957,13 +998,29 @@ int fami_bn_running_update_f32(float* running_mean, float* running_var, const fl
                                float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,     \
                                int relu, float momentum, float eps, void* slots, hipStream_t s) {                      \
     return bn_train_fwd2_impl<T>(x, residual, y, gamma, beta, mean, invstd, running_mean, running_var, P, C, relu,     \
-                                 momentum, eps, slots, s, "fami_bn_train_fwd2_" #sfx);                                 \
+                                 momentum, eps, slots, 0, s, "fami_bn_train_fwd2_" #sfx);                              \
+  }                                                                                                                    \
+  /* the same with the statistics pass already done: `slots` was filled by fami_conv2d_fwd_stats_* (sums + pivots) */  \
+  int fami_bn_apply_slots_##sfx(const T* x, const T* residual, T* y, const float* gamma, const float* beta,            \
+                                float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,    \
+                                int relu, float momentum, float eps, void* slots, hipStream_t s) {                     \
+    return bn_train_fwd2_impl<T>(x, residual, y, gamma, beta, mean, invstd, running_mean, running_var, P, C, relu,     \
+                                 momentum, eps, slots, 1, s, "fami_bn_apply_slots_" #sfx);                             \
+  }                                                                                                                    \
+  /* backward apply pass alone: `slots` was filled by fami_conv2d_dgrad_bnstats_* (sums of dz and dz*xhat); dy holds  */\
+  /* dz (the ReLU mask is applied already), so no mask is taken here                                                  */\
+  int fami_bn_bwd_apply_slots_##sfx(const T* dz, const T* x, const float* mean, const float* invstd,                   \
+                                    const float* gamma, const float* beta, T* dx, float* dgamma, float* dbeta,         \
+                                    T* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,      \
+                                    hipStream_t s) {                                                                   \
+    return bn_bwd2_impl<T>(dz, x, (const T*)nullptr, mean, invstd, gamma, beta, dx, dgamma, dbeta, dres, P, C, 0,      \
+                           acc_dx, acc_param, acc_dres, slots, 1, s, "fami_bn_bwd_apply_slots_" #sfx);                 \
   }                                                                                                                    \
   int fami_bn_bwd2_##sfx(const T* dy, const T* x, const T* y, const float* mean, const float* invstd,                  \
                          const float* gamma, const float* beta, T* dx, float* dgamma, float* dbeta, T* dres, long P,   \
                          int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, hipStream_t s) {       \
     return bn_bwd2_impl<T>(dy, x, y, mean, invstd, gamma, beta, dx, dgamma, dbeta, dres, P, C, relu, acc_dx,           \
-                           acc_param, acc_dres, slots, s, "fami_bn_bwd2_" #sfx);                                       \
+                           acc_param, acc_dres, slots, 0, s, "fami_bn_bwd2_" #sfx);                                    \
   }                                                                                                                    \
   /* out[c] (=|+=) sum_p x[p][c] */                                                                      \
   int fami_channel_sum_##sfx(const T* x, long P, int C, float* out, int accumulate, float* ws, hipStream_t s) {        \

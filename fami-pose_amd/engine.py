@@ -37,7 +37,7 @@ def _sfx(t):
 class T:
     """Engine tensor: NHWC (or 2-D) storage + lazily allocated gradient.  `f32grad`: the gradient is fp32
     regardless of the activation dtype (dense [M,K] tensors of the translation regressor)."""
-    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad')
+    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad', 'uses', 'lanes', 'bnrec', 'nofuse')
 
     def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0, f32grad=False):
         self.data = data
@@ -45,6 +45,10 @@ class T:
         self.requires_grad = requires_grad
         self.parent, self.n0, self.n1 = parent, n0, n1
         self.f32grad = f32grad
+        self.uses = 0          # recorded consumers whose backward has not run yet (Engine.record_bwd / backward)
+        self.lanes = None      # stream lanes of those consumers
+        self.bnrec = None      # set on the output of a train-mode BatchNorm: what a fused backward statistics pass needs
+        self.nofuse = parent is not None     # batch-slice views and their parents receive gradients through slices
 
     @property
     def shape(self):
@@ -97,6 +101,18 @@ class Engine:
         # two-launch BatchNorm (fami_bn_train_fwd2 / fami_bn_bwd2: fp64 slot atomics, finalize folded into the apply pass).
         # Sums arrive in atomic order, so the deterministic mode keeps the three-launch forms.
         self.bn2 = (not self.deterministic) and os.environ.get('FAMI_BN2', '1') != '0'
+        # BatchNorm statistics folded into the neighbouring convolutions' epilogues (conv.hip EpiBN): the forward
+        # statistics into the producing convolution, the backward statistics into the input-gradient convolution that
+        # makes the last contribution to the BatchNorm output's gradient.  FAMI_FUSE_BN = 0 | fwd | bwd | 1 (both).
+        # Default 0: measured on MI355X (profiles/r03_fused_bn.txt) the epilogue costs what the removed pass cost --
+        # per launch +2..5 us on the forward convolution against a 4..6 us statistics kernel, +4..10 us on the input
+        # gradient (it has to read the BatchNorm input tile) against 4..9 us -- and inside the step the stand-alone
+        # statistics kernels were already hidden behind the other stream lanes: f32 62.2 -> 63.0 ms, bf16 32.9 -> 34.6 ms
+        # (fwd only: 32.8).  Kept as a tested option.
+        fz = os.environ.get('FAMI_FUSE_BN', '0')
+        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
+        self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
+        self.nfused = {'fwd': 0, 'bwd': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.sync_stream()
         self._zero_begin()
 
@@ -221,17 +237,27 @@ class Engine:
             return False
         self._do_fork(n)
         if self.record:
-            self.tape.append((lambda: self._do_join(n), (), 0))
+            self.tape.append((lambda: self._do_join(n), (), 0, ()))
         return True
 
     def join(self, n):
         """Lane 0 continues after lanes 1..n-1; the backward of a join is a fork."""
         self._do_join(n)
         if self.record:
-            self.tape.append((lambda: self._do_fork(n), (), 0))
+            self.tape.append((lambda: self._do_fork(n), (), 0, ()))
 
-    def record_bwd(self, fn, params):
-        self.tape.append((fn, params, self.lane))
+    def record_bwd(self, fn, params, inputs=()):
+        """inputs: the engine tensors this op's backward contributes gradient to.  Counting them lets a backward closure
+        know whether it makes the LAST contribution to a tensor (T.uses == 0 while it runs)."""
+        for t in inputs:
+            if t is None:
+                continue
+            t.uses += 1
+            if t.lanes is None:
+                t.lanes = {self.lane}
+            else:
+                t.lanes.add(self.lane)
+        self.tape.append((fn, params, self.lane, inputs))
 
     def call(self, name, *args):
         self.L.call(name, *args, self.stream)
@@ -443,15 +469,22 @@ class Engine:
             self.call('fami_nchw_to_nhwc' + _sfx(g), _p(g_nchw.contiguous()), _p(g), N, C, H, W)
 
     # ------------------------------------------------------------------ conv / bn
-    def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False):
-        """nn.Conv2d.  out_f32: write fp32 even in bf16 mode (heatmap-producing layers)."""
+    def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, stats=None):
+        """nn.Conv2d.  out_f32: write fp32 even in bf16 mode (heatmap-producing layers).  stats = (slots, pivot_src):
+        the statistics pass of the BatchNorm that follows runs in the epilogue (fami_conv2d_fwd_stats_*)."""
         N, H, W, Ci = x.shape
         Co, Ci2, kh, kw = weight.shape
         assert Ci2 == Ci, (x.shape, weight.shape)
         Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         wp = self.packed(weight, 0)
-        if self.half:
+        if stats is not None:
+            assert not relu and not out_f32
+            y = self.act(N, Ho, Wo, Co)
+            self.acall('fami_conv2d_fwd_stats', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
+                       N, H, W, Ci, Co, kh, kw, stride, pad, dil, _p(stats[0]), _p(stats[1]))
+            self.nfused['fwd'] += 1
+        elif self.half:
             y = self.empty(N, Ho, Wo, Co) if out_f32 else self.act(N, Ho, Wo, Co)
             self.acall('fami_conv2d_fwd', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
                       N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0, int(out_f32))
@@ -484,15 +517,45 @@ class Engine:
                 if x.requires_grad:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
-                    if self.half:
+                    rec = x.bnrec
+                    if (rec is not None and self.fuse_bn_bwd and x.uses == 0 and not x.nofuse and x.lanes is not None
+                            and len(x.lanes) == 1 and not x.f32grad):
+                        # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
+                        # the epilogue applies the ReLU mask and takes the two sums of the BatchNorm backward
+                        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Ci))
+                        self.acall('fami_conv2d_dgrad_bnstats', _p(dy), _p(wpd), _p(gx), *geo, acc, _p(rec['z']),
+                                   _p(rec['y'] if rec['rmode'] == 1 else None), _p(rec['mean']), _p(rec['invstd']),
+                                   _p(rec['gamma']), _p(rec['beta']), rec['rmode'], _p(slots))
+                        rec['pre_bwd'] = slots
+                        self.nfused['bwd'] += 1
+                    elif self.half:
                         self.acall('fami_conv2d_dgrad', _p(dy), _p(wpd), _p(gx), *geo, acc)
                     else:
                         self.call('fami_conv2d_dgrad_f32', _p(dy), _p(wpd), None, _p(gx), *geo, acc)
-            self.record_bwd(bwd, [weight, bias])
+            self.record_bwd(bwd, [weight, bias], (x,))
         return out
 
-    def bn(self, x, bn, relu=False, residual=None):
-        """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update."""
+    def bn_fusable(self, P, C):
+        """Can the statistics passes of a train-mode BatchNorm over [P, C] run in a convolution epilogue?"""
+        return C % 4 == 0 and 4 <= C <= 1024 and not self.L.cdll.fami_bn_is_small(P, C)
+
+    def conv_bn(self, x, conv, bn, relu=False, residual=None):
+        """nn.Conv2d -> nn.BatchNorm2d (-> + residual) (-> ReLU): basic_model.py:34-63, basic_layer.py:25-26.  With a
+        train-mode BatchNorm over a large enough tensor the statistics pass is the convolution's epilogue."""
+        N, H, W, _ = x.shape
+        Co, _, kh, kw = conv.weight.shape
+        st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
+        Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
+        Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
+        if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
+            slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+            z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
+            return self.bn(z, bn, relu=relu, residual=residual, pre=slots)
+        return self.bn(self.conv(x, conv.weight, conv.bias, st, pd, dl), bn, relu=relu, residual=residual)
+
+    def bn(self, x, bn, relu=False, residual=None, pre=None):
+        """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update.
+        pre: slot rows the producing convolution's epilogue has filled (Engine.conv_bn): apply pass only."""
         shp = x.shape
         C = shp[-1]
         P = x.data.numel() // C
@@ -504,16 +567,23 @@ class Engine:
                 self._lane_guard(('running statistics', id(bn)))
             mom = 0.1 if bn.momentum is None else bn.momentum
             bn2 = self.bn2
-            ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if bn2 else self.ws(self.L.cdll.fami_bn_workspace(C))
-            self.acall('fami_bn_train_fwd2' if bn2 else 'fami_bn_train_fwd', _p(x.data),
-                       _p(None if residual is None else residual.data), _p(y),
-                       _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
-                       _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
-                       int(relu), float(mom), float(bn.eps), _p(ws))
+            if pre is not None:
+                self.acall('fami_bn_apply_slots', _p(x.data), _p(None if residual is None else residual.data), _p(y),
+                           _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
+                           _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
+                           int(relu), float(mom), float(bn.eps), _p(pre))
+            else:
+                ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if bn2 else self.ws(self.L.cdll.fami_bn_workspace(C))
+                self.acall('fami_bn_train_fwd2' if bn2 else 'fami_bn_train_fwd', _p(x.data),
+                           _p(None if residual is None else residual.data), _p(y),
+                           _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
+                           _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
+                           int(relu), float(mom), float(bn.eps), _p(ws))
             if deferred:
                 self.defer_bn.append((bn, mean, invstd, P, float(mom)))
             self.bn_trained.append(bn)
         else:
+            assert pre is None
             self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd), C,
                       float(bn.eps))
             self.acall('fami_bn_apply', _p(x.data), _p(mean), _p(invstd), _p(bn.weight.data), _p(bn.bias.data),
@@ -523,6 +593,12 @@ class Engine:
         out = T(y, rg)
         if rg:
             training = bn.training
+            # ReLU mask in backward: from y when a residual was added, else recomputed from x (one tensor read less)
+            rmode = (1 if residual is not None else 2) if relu else 0
+            rec = None
+            if training and self.bn2 and self.bn_fusable(P, C):
+                rec = out.bnrec = {'z': x.data, 'y': y, 'mean': mean, 'invstd': invstd, 'gamma': bn.weight.data,
+                                   'beta': bn.bias.data, 'rmode': rmode, 'pre_bwd': None}
 
             def bwd():
                 if out.grad is None:
@@ -538,9 +614,12 @@ class Engine:
                 gr, accr = (None, 0)
                 if residual is not None and residual.requires_grad:
                     gr, accr = self.gbuf(residual)
-                if self.bn2:
-                    # ReLU mask: from y when a residual was added, else recomputed from x (one tensor read less per pass)
-                    rmode = (1 if residual is not None else 2) if relu else 0
+                if rec is not None and rec['pre_bwd'] is not None:
+                    # out.grad holds dz (mask applied) and the slot rows the two sums: fami_conv2d_dgrad_bnstats_*
+                    self.acall('fami_bn_bwd_apply_slots', _p(out.grad), _p(x.data), _p(mean), _p(invstd),
+                               _p(bn.weight.data), _p(bn.bias.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, accx, accp,
+                               accr, _p(rec['pre_bwd']))
+                elif self.bn2:
                     self.acall('fami_bn_bwd2', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
                                _p(bn.weight.data), _p(bn.bias.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, rmode, accx,
                                accp, accr, _p(self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C))))
@@ -549,14 +628,28 @@ class Engine:
                     self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
                                _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
                                _p(ws))
-            self.record_bwd(bwd, [bn.weight, bn.bias])
+            self.record_bwd(bwd, [bn.weight, bn.bias], (x, residual))
         return out
 
     # ------------------------------------------------------------------ fuse (hrnet.py:159-168)
-    def fuse_term(self, x, bn, shift):
+    def conv_fuse_term(self, x, conv, bn, shift):
+        """conv -> fuse term (hrnet.py:99-143: every cross-resolution path ends in conv + BatchNorm): the term's statistics
+        come out of the convolution's epilogue when the tensor is large enough."""
+        N, H, W, _ = x.shape
+        Co, _, kh, kw = conv.weight.shape
+        st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
+        Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
+        Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
+        if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
+            slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+            z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
+            return self.fuse_term(z, bn, shift, pre=slots)
+        return self.fuse_term(self.conv(x, conv.weight, conv.bias, st, pd, dl), bn, shift)
+
+    def fuse_term(self, x, bn, shift, pre=None):
         """One term of a HighResolutionModule fuse sum (hrnet.py:151-172): its BatchNorm statistics now, its backward as
         its own tape entry on the CURRENT lane -- all terms fed by branch j run on lane j, so the gradient of x_j is
-        accumulated by one stream.  -> handle for Engine.fuse."""
+        accumulated by one stream.  -> handle for Engine.fuse.  pre: slot rows filled by the producing convolution."""
         C = x.shape[-1]
         h = {'x': x, 'bn': bn, 'shift': shift, 'stats': None, 'out': None}
         if bn is not None:
@@ -564,10 +657,14 @@ class Engine:
             mean, invstd = self.empty(C), self.empty(C)
             if bn.training:
                 self._lane_guard(('running statistics', id(bn)))
-                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
                 mom = 0.1 if bn.momentum is None else bn.momentum
-                self.acall('fami_bn_stats', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
-                           _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
+                if pre is not None:
+                    self.call('fami_bn_finalize_slots_f32', _p(pre), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                              _p(bn.running_var), float(mom), float(bn.eps))
+                else:
+                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                    self.acall('fami_bn_stats', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
+                               _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
                 self.bn_trained.append(bn)
             else:
                 self.call('fami_bn_eval_stats_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
@@ -605,7 +702,7 @@ class Engine:
                     self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> shift, W >> shift, C, shift, 1)
                     self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
                                _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
-            self.record_bwd(bwd, [bn.weight, bn.bias] if bn is not None else [])
+            self.record_bwd(bwd, [bn.weight, bn.bias] if bn is not None else [], (x,))
         return h
 
     def fuse(self, handles):
@@ -636,6 +733,7 @@ class Engine:
         (gbuf creates the parent's buffer then), so the parent is not zero-filled up front: without a seed the
         producer's backward is skipped, as autograd skips a branch whose .grad is None (kf_hm made the
         final layer's weight gradient and a dgrad of zeros run every step)."""
+        x.nofuse = True         # gradients reach x through its slices: no "last contribution" bookkeeping on it
         if x.requires_grad and not terminal and all(x is not p for p in self._sliced):
             self._sliced.append(x)
         return T(x.data[n0:n1], x.requires_grad, parent=x, n0=n0, n1=n1)
@@ -652,7 +750,7 @@ class Engine:
                     if t.requires_grad:
                         g, acc = self.gbuf(t)
                         self.acall('fami_axpby', _p(out.grad), _p(g) if acc else None, _p(g), g.numel(), sgn, 1.0)
-            self.record_bwd(bwd, ())
+            self.record_bwd(bwd, (), (a, b))
         return out
 
     def concat(self, xs):
@@ -678,7 +776,7 @@ class Engine:
                         g, acc = self.gbuf(x)
                         self.acall('fami_copy_channels', _p(out.grad), _p(g), P, Ct, o, c, 0, c, acc)
                     o += c
-            self.record_bwd(bwd, ())
+            self.record_bwd(bwd, (), tuple(xs))
         return out
 
     def flatten_chw(self, x):
@@ -698,7 +796,7 @@ class Engine:
                     self.acall('fami_axpby', _p(tmp), _p(g), _p(g), g.numel(), 1.0, 1.0)
                 else:
                     self.acall('fami_nchw_to_nhwc', _p(out.grad), _p(g), N, C, H, W)
-            self.record_bwd(bwd, ())
+            self.record_bwd(bwd, (), (x,))
         return out
 
     def linear(self, x, lin):
@@ -723,7 +821,7 @@ class Engine:
                         gb, _ = self.pgrad(lin.bias)
                 self.call('fami_linear_bwd_f32', _p(out.grad), _p(x.data), _p(lin.weight.data), _p(gx), _p(gw),
                           _p(gb), M, K, Nn, accx, accp)
-            self.record_bwd(bwd, [lin.weight, lin.bias])
+            self.record_bwd(bwd, [lin.weight, lin.bias], (x,))
         return out
 
     # ------------------------------------------------------------------ alignment ops
@@ -739,7 +837,7 @@ class Engine:
                     return
                 g, acc = self.gbuf(t)
                 self.call('fami_scale_pairs_f32', _p(out.grad), _p(g), B, float(sx), float(sy), acc)
-            self.record_bwd(bwd, ())
+            self.record_bwd(bwd, (), (t,))
         return out
 
     def shift(self, x, t, align_corners=True):
@@ -765,7 +863,7 @@ class Engine:
                 ws = self.ws(self.L.cdll.fami_shift_workspace(B))
                 self.acall('fami_shift_bilinear_bwd', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
                            W, C, accs, acct, _p(ws))
-            self.record_bwd(bwd, ())
+            self.record_bwd(bwd, (), (x, t))
         return out
 
     def dcn(self, x, off, msk, weight, bias, G, pad=3, dil=3):
@@ -825,7 +923,7 @@ class Engine:
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
-            self.record_bwd(bwd, [weight, bias])
+            self.record_bwd(bwd, [weight, bias], (x, off, msk))
         return out
 
     # ------------------------------------------------------------------ MI estimators (Alignment_V15.py:250-277)
@@ -857,7 +955,7 @@ class Engine:
         remaining = None
         if on_params_done is not None:
             remaining = {}
-            for _, ps, _lane in self.tape:
+            for _, ps, _lane, _ins in self.tape:
                 for p in ps:
                     if p is not None and p.requires_grad:
                         remaining[id(p)] = remaining.get(id(p), 0) + 1
@@ -865,9 +963,12 @@ class Engine:
             if par.grad is None:
                 par.grad = self.fill(self.new_grad(par))
         pending = []
-        for fn, ps, lane in reversed(self.tape):
+        for fn, ps, lane, ins in reversed(self.tape):
             if lane != self.lane:
                 self.set_lane(lane)
+            for t in ins:
+                if t is not None:
+                    t.uses -= 1
             fn()
             if remaining is not None and ps:
                 for p in ps:

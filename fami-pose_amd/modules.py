@@ -32,11 +32,10 @@ class conv_bn_relu(nn.Module):
         self.has_relu = has_relu
 
     def run(self, eng, x):
-        y = run_conv(eng, self.conv, x)
         if self.bn is not None:
-            return eng.bn(y, self.bn, relu=self.has_relu)
+            return eng.conv_bn(x, self.conv, self.bn, relu=self.has_relu)
         assert not self.has_relu
-        return y
+        return run_conv(eng, self.conv, x)
 
 
 class BasicBlock(nn.Module):
@@ -53,9 +52,9 @@ class BasicBlock(nn.Module):
     def run(self, eng, x):
         res = x
         if self.downsample is not None:
-            res = eng.bn(run_conv(eng, self.downsample[0], x), self.downsample[1])
-        y = eng.bn(run_conv(eng, self.conv1, x), self.bn1, relu=True)
-        return eng.bn(run_conv(eng, self.conv2, y), self.bn2, relu=True, residual=res)
+            res = eng.conv_bn(x, self.downsample[0], self.downsample[1])
+        y = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
+        return eng.conv_bn(y, self.conv2, self.bn2, relu=True, residual=res)
 
 
 class Bottleneck(nn.Module):
@@ -74,10 +73,10 @@ class Bottleneck(nn.Module):
     def run(self, eng, x):
         res = x
         if self.downsample is not None:
-            res = eng.bn(run_conv(eng, self.downsample[0], x), self.downsample[1])
-        y = eng.bn(run_conv(eng, self.conv1, x), self.bn1, relu=True)
-        y = eng.bn(run_conv(eng, self.conv2, y), self.bn2, relu=True)
-        return eng.bn(run_conv(eng, self.conv3, y), self.bn3, relu=True, residual=res)
+            res = eng.conv_bn(x, self.downsample[0], self.downsample[1])
+        y = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = eng.conv_bn(y, self.conv2, self.bn2, relu=True)
+        return eng.conv_bn(y, self.conv3, self.bn3, relu=True, residual=res)
 
 
 def _shortcut(cin, cout):
@@ -106,7 +105,7 @@ def _cbr(cin, cout, k, stride, relu=True):
 
 
 def run_cbr(eng, seq, x):
-    return eng.bn(run_conv(eng, seq[0], x), seq[1], relu=len(seq) > 2)
+    return eng.conv_bn(x, seq[0], seq[1], relu=len(seq) > 2)
 
 
 class HighResolutionModule(nn.Module):
@@ -165,13 +164,13 @@ class HighResolutionModule(nn.Module):
                 if j == i:
                     handles[i][j] = eng.fuse_term(ys[j], None, 0)
                 elif j > i:
-                    handles[i][j] = eng.fuse_term(run_conv(eng, row[j][0], ys[j]), row[j][1], j - i)
+                    handles[i][j] = eng.conv_fuse_term(ys[j], row[j][0], row[j][1], j - i)
                 else:
                     z = ys[j]
                     chain = row[j]
                     for k in range(len(chain) - 1):
                         z = run_cbr(eng, chain[k], z)
-                    handles[i][j] = eng.fuse_term(run_conv(eng, chain[-1][0], z), chain[-1][1], 0)
+                    handles[i][j] = eng.conv_fuse_term(z, chain[-1][0], chain[-1][1], 0)
         if forked:
             eng.join(nb)
         return [eng.fuse(hs) for hs in handles]
@@ -229,8 +228,8 @@ class HRNetBody(nn.Module):
 
     def run(self, eng, x):
         """x: engine tensor [N,H,W,3] -> (heatmap T [N,H/4,W/4,J], stage-4 outputs, pre-stage-4 inputs)."""
-        x = eng.bn(run_conv(eng, self.conv1, x), self.bn1, relu=True)
-        x = eng.bn(run_conv(eng, self.conv2, x), self.bn2, relu=True)
+        x = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
+        x = eng.conv_bn(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:
             x = blk.run(eng, x)
         ys = [x]

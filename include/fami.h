@@ -68,6 +68,21 @@ int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, cons
 int fami_conv2d_dgrad_f32(const float* dy, const float* wp, const float* addend, float* dx, int N, int H, int W,
                           int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                           fami_stream_t stream);
+/* Convolution with the statistics pass of the train-mode BatchNorm that follows it (basic_model.py:34-63: every conv of
+ * a block feeds nn.BatchNorm2d) folded into the epilogue: per-channel sums of (y - pivot), (y - pivot)^2 go into the fp64
+ * slot rows of fami_bn_slots_bytes(Co) bytes (ZERO on entry), pivot = pivot_src[c] (the running mean; NULL = 0) is
+ * stored behind the rows.  Consumers: fami_bn_apply_slots_* / fami_bn_finalize_slots_f32.
+ * fami_conv2d_dgrad_bnstats_*: the input-gradient convolution that makes the LAST contribution to dx = dL/d(output of a
+ * train-mode BatchNorm [+ReLU] whose input was z): stores dz = relu-mask(dx) instead of dx and adds sum dz, sum dz*xhat
+ * into `slots` (fami_bn_slots_bytes(Ci), ZERO on entry) for fami_bn_bwd_apply_slots_*.  relu: 0 none, 1 mask from the
+ * BatchNorm output yrelu, 2 mask recomputed from z (forward run by fami_bn_train_fwd2 / fami_bn_apply_slots). */
+int fami_conv2d_fwd_stats_f32(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci,
+                              int Co, int kh, int kw, int stride, int pad, int dil, void* slots, const float* pivot_src,
+                              fami_stream_t stream);
+int fami_conv2d_dgrad_bnstats_f32(const float* dy, const float* wp, float* dx, int N, int H, int W, int Ci, int Co,
+                                  int kh, int kw, int stride, int pad, int dil, int accumulate, const float* z,
+                                  const float* yrelu, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int relu, void* slots, fami_stream_t stream);
 long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
 /* dw[Co,Ci,kh,kw] (OIHW, =|+=) */
 int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
@@ -110,6 +125,20 @@ int fami_bn_train_fwd2_f32(const float* x, const float* residual, float* y, cons
 int fami_bn_bwd2_f32(const float* dy, const float* x, const float* y, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta, float* dres, long P,
                      int C, int relu, int acc_dx, int acc_param, int acc_dres, void* slots, fami_stream_t stream);
+/* The apply passes alone, for slot rows a convolution epilogue has filled (fami_conv2d_fwd_stats_* /
+ * fami_conv2d_dgrad_bnstats_*): one launch per BatchNorm pass instead of two.  dz: the gradient with the ReLU mask
+ * already applied.  fami_bn_is_small: tensors the one-launch small-tensor kernel takes (no point fusing those).
+ * fami_bn_finalize_slots_f32: mean / invstd / running update only (HighResolutionModule fuse terms, hrnet.py:151-172). */
+int fami_bn_is_small(long P, int C);
+int fami_bn_apply_slots_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
+                            float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
+                            int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd_apply_slots_f32(const float* dz, const float* x, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                                float* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,
+                                fami_stream_t stream);
+int fami_bn_finalize_slots_f32(void* slots, long P, int C, float* mean, float* invstd, float* running_mean,
+                               float* running_var, float momentum, float eps, fami_stream_t stream);
 long fami_channel_sum_workspace(int C);
 /* out[c] (=|+=) sum_p x[p][c] : bias gradients of the biased convs */
 int fami_channel_sum_f32(const float* x, long P, int C, float* out, int accumulate, float* ws, fami_stream_t stream);
@@ -265,6 +294,20 @@ int fami_conv2d_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const floa
 int fami_conv2d_dgrad_bf16(const fami_bf16_t* dy, const fami_bf16_t* wp, fami_bf16_t* dx, int N, int H, int W, int Ci,
                            int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                            fami_stream_t stream);
+int fami_conv2d_fwd_stats_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const float* bias, fami_bf16_t* y, int N, int H, int W,
+                               int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void* slots,
+                               const float* pivot_src, fami_stream_t stream);
+int fami_conv2d_dgrad_bnstats_bf16(const fami_bf16_t* dy, const fami_bf16_t* wp, fami_bf16_t* dx, int N, int H, int W, int Ci,
+                                   int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                   const fami_bf16_t* z, const fami_bf16_t* yrelu, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, int relu, void* slots, fami_stream_t stream);
+int fami_bn_apply_slots_bf16(const fami_bf16_t* x, const fami_bf16_t* residual, fami_bf16_t* y, const float* gamma,
+                             const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
+                             long P, int C, int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd_apply_slots_bf16(const fami_bf16_t* dz, const fami_bf16_t* x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, fami_bf16_t* dx, float* dgamma, float* dbeta,
+                                 fami_bf16_t* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,
+                                 fami_stream_t stream);
 int fami_conv2d_wgrad_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
                            int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                            int accumulate, fami_stream_t stream);
@@ -346,6 +389,20 @@ int fami_conv2d_fwd_f16(const fami_f16_t* x, const fami_f16_t* wp, const float* 
 int fami_conv2d_dgrad_f16(const fami_f16_t* dy, const fami_f16_t* wp, fami_f16_t* dx, int N, int H, int W, int Ci,
                            int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                            fami_stream_t stream);
+int fami_conv2d_fwd_stats_f16(const fami_f16_t* x, const fami_f16_t* wp, const float* bias, fami_f16_t* y, int N, int H, int W,
+                               int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void* slots,
+                               const float* pivot_src, fami_stream_t stream);
+int fami_conv2d_dgrad_bnstats_f16(const fami_f16_t* dy, const fami_f16_t* wp, fami_f16_t* dx, int N, int H, int W, int Ci,
+                                   int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                   const fami_f16_t* z, const fami_f16_t* yrelu, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, int relu, void* slots, fami_stream_t stream);
+int fami_bn_apply_slots_f16(const fami_f16_t* x, const fami_f16_t* residual, fami_f16_t* y, const float* gamma,
+                             const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
+                             long P, int C, int relu, float momentum, float eps, void* slots, fami_stream_t stream);
+int fami_bn_bwd_apply_slots_f16(const fami_f16_t* dz, const fami_f16_t* x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, fami_f16_t* dx, float* dgamma, float* dbeta,
+                                 fami_f16_t* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,
+                                 fami_stream_t stream);
 int fami_conv2d_wgrad_f16(const fami_f16_t* x, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
                            int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                            int accumulate, fami_stream_t stream);

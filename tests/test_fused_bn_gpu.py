@@ -1,0 +1,128 @@
+"""BatchNorm statistics folded into the convolution epilogues (conv.hip EpiBN; Engine.conv_bn, the fused branch of
+Engine.conv's backward) against (a) the same graph with the stand-alone statistics passes and (b) torch fp32 autograd
+of the reference's blocks (posetimation/layers/basic_model.py:25-63 BasicBlock, hrnet.py:724-762 stride-2 transition):
+outputs, running statistics, input gradient, every weight / BatchNorm-parameter gradient.  All three storage types,
+direct and LDS-staged convolution routes.  Tolerances: f32 vs torch 2e-5 (relative to the tensor's max), fused vs
+unfused 5e-6 (same arithmetic, different summation order of the statistics).  16-bit: two valid evaluation orders of a
+chain of five BatchNorms differ by many storage ulps after the backward pass (one flipped rounding early on is amplified
+by every normalisation behind it), so the fused run is held to the f32 engine run instead: its error may be at most
+1.5x the unfused 16-bit run's own error plus a floor of one storage ulp of the tensor's maximum."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
+
+
+@pytest.fixture(params=[0, 1], ids=['direct', 'lds'])
+def lds_mode(request):
+    from fami_pose_amd._lib import lib
+    lib().cdll.fami_conv_tune_lds(request.param)
+    yield request.param
+    lib().cdll.fami_conv_tune_lds(-1)
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+class RefBlock(nn.Module):           # basic_model.py:25-63
+    def __init__(self, c):
+        super().__init__()
+        self.conv1, self.bn1 = nn.Conv2d(c, c, 3, 1, 1, bias=False), nn.BatchNorm2d(c)
+        self.conv2, self.bn2 = nn.Conv2d(c, c, 3, 1, 1, bias=False), nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        return torch.relu(self.bn2(self.conv2(y)) + x)
+
+
+class RefNet(nn.Module):
+    def __init__(self, c, c2):
+        super().__init__()
+        self.a, self.b = RefBlock(c), RefBlock(c)
+        self.down = nn.Sequential(nn.Conv2d(c, c2, 3, 2, 1, bias=False), nn.BatchNorm2d(c2), nn.ReLU())
+        self.last = nn.Conv2d(c2, 8, 1, bias=True)
+
+    def forward(self, x):
+        return self.last(self.down(self.b(self.a(x))))
+
+
+def _run(dev, ref, x, gy, dtype, fuse):
+    """the same graph on the HIP engine -> dict of results (fp32, on the host)"""
+    from fami_pose_amd.engine import Engine, T
+    from fami_pose_amd.modules import BasicBlock, _cbr, run_cbr
+    net = RefNet(ref.a.conv1.in_channels, ref.down[0].out_channels)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(dev).train()
+    blocks = []
+    for rb in (net.a, net.b):
+        b = BasicBlock(rb.conv1.in_channels, rb.conv1.in_channels)
+        b.conv1, b.bn1, b.conv2, b.bn2 = rb.conv1, rb.bn1, rb.conv2, rb.bn2
+        blocks.append(b)
+    eng = Engine(dev, dtype=dtype)
+    if not fuse:
+        eng.fuse_bn_fwd = eng.fuse_bn_bwd = False
+    xt = T(x.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype), True)
+    h = xt
+    for b in blocks:
+        h = b.run(eng, h)
+    h = run_cbr(eng, net.down, h)
+    y = eng.conv(h, net.last.weight, net.last.bias, 1, 0, 1)
+    y.grad = gy.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype)
+    eng.backward()
+    torch.cuda.synchronize(dev)
+    out = {'y': y.data.float().permute(0, 3, 1, 2), 'dx': xt.grad.float().permute(0, 3, 1, 2)}
+    for n, p in net.named_parameters():
+        out['g.' + n] = eng.param_grads[id(p)].float()
+    for n, b in net.named_buffers():
+        if b.dtype.is_floating_point:
+            out['b.' + n] = b.float()
+    return {k: v.detach().cpu().clone() for k, v in out.items()}, eng.nfused
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 24, 18, 96), (3, 96, 13, 11, 192), (2, 192, 12, 10, 384), (2, 64, 23, 20, 64)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+def test_fused_bn_statistics(dev, shape, dt, lds_mode):
+    N, C, H, W, C2 = shape
+    torch.manual_seed(sum(shape))
+    ref = RefNet(C, C2).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_(0, 0.2)           # the epilogue's pivot: neither zero nor the batch mean
+    x = torch.randn(N, C, H, W) + 0.5
+    gy = torch.randn(N, 8, (H + 1) // 2, (W + 1) // 2)
+    dtype = DT[dt]
+    fused, nf = _run(dev, ref, x, gy, dtype, True)
+    plain, npl = _run(dev, ref, x, gy, dtype, False)
+    # 5 BatchNorms forward; backward: a.bn1, a.bn2 (residual: last contribution = b.conv1's input gradient), b.bn1,
+    # b.bn2 (-> down conv, stride 2: parity-class input gradient), down.bn (-> 1x1 conv) -- the last one only when its
+    # quarter-size tensor is above the one-launch small-tensor kernel's limit (P * C > 32768)
+    n_exp = 5 if N * ((H + 1) // 2) * ((W + 1) // 2) * C2 > 32768 else 4
+    assert nf == {'fwd': n_exp, 'bwd': n_exp} and npl == {'fwd': 0, 'bwd': 0}
+    if dt == 'f32':
+        for k in fused:
+            assert relerr(fused[k], plain[k]) < 5e-6, (k, relerr(fused[k], plain[k]))
+    else:
+        ref32, _ = _run(dev, ref, x, gy, torch.float32, False)
+        ulp = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dt]
+        for k in fused:
+            ef, ep = relerr(fused[k], ref32[k]), relerr(plain[k], ref32[k])
+            assert ef < 1.5 * ep + ulp, (k, ef, ep)
+    if dt == 'f32':
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(gy)
+        assert relerr(fused['y'], yr) < 2e-5 and relerr(fused['dx'], xr.grad) < 2e-5
+        for n, p in ref.named_parameters():
+            assert relerr(fused['g.' + n], p.grad) < 5e-5, n
+        for n, b in ref.named_buffers():
+            if b.dtype.is_floating_point:
+                assert relerr(fused['b.' + n], b) < 1e-5, n
