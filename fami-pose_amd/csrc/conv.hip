@@ -22,62 +22,7 @@
 #include "common.h"
 #include <type_traits>
 
-// Optional BatchNorm work in a convolution's epilogue (reference semantics
-// posetimation/layers/basic_model.py:34-63: every conv is followed by a train-mode BatchNorm).  The output tile is in
-// registers anyway, so the statistics pass over the tensor -- one launch and one HBM read per BatchNorm, forward and
-// backward -- is folded in: per-channel partial sums of the workgroup's pixels go into the fp64 slot rows of the
-// two-launch BatchNorm (common.h; norm.hip's apply passes fold the rows in their prologue), by global_atomic_add_f64.
-//   mode 1 (forward conv -> BN):  sum (y - K), sum (y - K)^2 of the values as stored; K[c] = pivot_src[c] (the running
-//                                 mean: any value near the mean conditions the variance) or 0; the first pixel tile
-//                                 stores K behind the slot rows for the consumer.
-//   mode 2 (input gradient -> the BN that produced this conv's input):  the epilogue holds dL/d(BN output) complete
-//                                 (this launch is its last contribution), so dz = relu-mask(dy) is stored instead of dy
-//                                 and sum dz, sum dz*xhat are taken; mask from the BN output (relu 1) or recomputed from
-//                                 its input exactly as the forward apply pass computes it (relu 2).
-struct EpiBN {
-  double* slots;           // null: plain epilogue
-  int ns, mode, relu, C;   // C = channels of the output tensor (row length of the slot rows)
-  const float* pivot_src;  // mode 1
-  const void* z;           // mode 2: BN input  [P][C] (activation storage type)
-  const void* yr;          // mode 2, relu 1: BN output
-  const float *mean, *invstd, *gamma, *beta;
-};
-static inline EpiBN epi_none() {
-  EpiBN e;
-  e.slots = nullptr; e.ns = 1; e.mode = 0; e.relu = 0; e.C = 0; e.pivot_src = nullptr; e.z = nullptr; e.yr = nullptr;
-  e.mean = e.invstd = e.gamma = e.beta = nullptr;
-  return e;
-}
-// The EpiBN block of a kernel's argument struct, read in the EPILOGUE through the kernarg segment pointer instead of
-// through the by-value parameter: the compiler preloads every referenced kernel argument into SGPRs at the top of the
-// kernel and keeps it there (+28 SGPRs through the main loop, one resident workgroup per CU less on the dgrad form).
-// The empty asm makes the pointer opaque, so the loads cannot be hoisted above it.  `off` = offsetof(Args, e) (the
-// argument struct is the kernel's only parameter: it starts at byte 0 of the segment).
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) EpiBN* EpiPtr;   // constant address space: the field reads stay scalar loads
-__device__ __forceinline__ EpiPtr epi_late(unsigned off) {
-  const __attribute__((address_space(4))) char* k =
-      (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off;
-  asm volatile("" : "+s"(k) : : "memory");
-  return (EpiPtr)k;
-}
-#else
-typedef const EpiBN* EpiPtr;
-__device__ inline EpiPtr epi_late(unsigned) { return nullptr; }
-#endif
-
-// the forward apply pass's scale / shift (norm.hip bn_scale_shift): the recomputed ReLU mask must match it bit for bit
-__device__ __forceinline__ void epi_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sf) {
-  sc = invstd * gamma;
-  sf = __builtin_fmaf(-mean, sc, beta);
-}
-
-// v rounded to storage type H and widened again (what a later pass over the stored tensor would read)
-template <typename H>
-__device__ __forceinline__ f32x4 ld4_round(f32x4 v) {
-  if constexpr (sizeof(H) == 4) return v;
-  else return __builtin_convertvector(__builtin_convertvector(v, H __attribute__((ext_vector_type(4)))), f32x4);
-}
+#include "conv_epi.h"
 
 struct ConvArgs {
   EpiBN e;              // read late (epi_late); `emode` below is the one field the top of the kernel looks at
@@ -2532,6 +2477,13 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                            const char* name, const EpiBN& epi = epi_none()) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
+  if constexpr (SZ == 2) {
+    if (g_use_lds != 0) {   // fami_conv_tune_lds(0) still forces the direct kernels
+      const int rc = fami_try_conv3x3_t4(std::is_same<T, f16_t>::value ? 1 : 0, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu,
+                                         accumulate, out_f32, s, name, epi);
+      if (rc != 0) return rc;
+    }
+  }
   // default: bf16 from 96 input channels up (per launch: 192 ch 18.8 vs 30.3 us, 384 ch 27.8 vs 32.4, 96 ch equal,
   // 48 ch 23.9 vs 21.8 -> direct; tools/bench_xcd.py with KNOB=lds), f32 never (slower on every shape)
   const int use = g_use_lds < 0 ? (SZ == 2 && Ci >= 96 ? 1 : 0) : g_use_lds;
@@ -2620,8 +2572,13 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
 // -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
+  if (on == 10 || on == 11 || on >= 100) {   // register-blocked 16-bit kernel (conv_t4.hip): 10 / 11 off / on;
+    fami_conv_t4_tune(on);                   // 100 + tiles per band (100 = heuristic)
+    return FAMI_OK;
+  }
   g_use_lds = on < 0 ? -1 : (on ? 1 : 0);
   g_lds_sim = on == 2;
+  if (on < 0) fami_conv_t4_tune(-1);
   return FAMI_OK;
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)

@@ -1,0 +1,68 @@
+// Shared by the convolution translation units (conv.hip, conv_t4.hip): the optional BatchNorm work of an epilogue.
+#pragma once
+#include "common.h"
+
+// Optional BatchNorm work in a convolution's epilogue (reference semantics
+// posetimation/layers/basic_model.py:34-63: every conv is followed by a train-mode BatchNorm).  The output tile is in
+// registers anyway, so the statistics pass over the tensor -- one launch and one HBM read per BatchNorm, forward and
+// backward -- is folded in: per-channel partial sums of the workgroup's pixels go into the fp64 slot rows of the
+// two-launch BatchNorm (common.h; norm.hip's apply passes fold the rows in their prologue), by global_atomic_add_f64.
+//   mode 1 (forward conv -> BN):  sum (y - K), sum (y - K)^2 of the values as stored; K[c] = pivot_src[c] (the running
+//                                 mean: any value near the mean conditions the variance) or 0; the first pixel tile
+//                                 stores K behind the slot rows for the consumer.
+//   mode 2 (input gradient -> the BN that produced this conv's input):  the epilogue holds dL/d(BN output) complete
+//                                 (this launch is its last contribution), so dz = relu-mask(dy) is stored instead of dy
+//                                 and sum dz, sum dz*xhat are taken; mask from the BN output (relu 1) or recomputed from
+//                                 its input exactly as the forward apply pass computes it (relu 2).
+struct EpiBN {
+  double* slots;           // null: plain epilogue
+  int ns, mode, relu, C;   // C = channels of the output tensor (row length of the slot rows)
+  const float* pivot_src;  // mode 1
+  const void* z;           // mode 2: BN input  [P][C] (activation storage type)
+  const void* yr;          // mode 2, relu 1: BN output
+  const float *mean, *invstd, *gamma, *beta;
+};
+static inline EpiBN epi_none() {
+  EpiBN e;
+  e.slots = nullptr; e.ns = 1; e.mode = 0; e.relu = 0; e.C = 0; e.pivot_src = nullptr; e.z = nullptr; e.yr = nullptr;
+  e.mean = e.invstd = e.gamma = e.beta = nullptr;
+  return e;
+}
+// The EpiBN block of a kernel's argument struct, read in the EPILOGUE through the kernarg segment pointer instead of
+// through the by-value parameter: the compiler preloads every referenced kernel argument into SGPRs at the top of the
+// kernel and keeps it there (+28 SGPRs through the main loop, one resident workgroup per CU less on the dgrad form).
+// The empty asm makes the pointer opaque, so the loads cannot be hoisted above it.  `off` = offsetof(Args, e) (the
+// argument struct is the kernel's only parameter: it starts at byte 0 of the segment).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) EpiBN* EpiPtr;   // constant address space: the field reads stay scalar loads
+__device__ __forceinline__ EpiPtr epi_late(unsigned off) {
+  const __attribute__((address_space(4))) char* k =
+      (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off;
+  asm volatile("" : "+s"(k) : : "memory");
+  return (EpiPtr)k;
+}
+#else
+typedef const EpiBN* EpiPtr;
+__device__ inline EpiPtr epi_late(unsigned) { return nullptr; }
+#endif
+
+// the forward apply pass's scale / shift (norm.hip bn_scale_shift): the recomputed ReLU mask must match it bit for bit
+__device__ __forceinline__ void epi_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sf) {
+  sc = invstd * gamma;
+  sf = __builtin_fmaf(-mean, sc, beta);
+}
+
+// v rounded to storage type H and widened again (what a later pass over the stored tensor would read)
+template <typename H>
+__device__ __forceinline__ f32x4 ld4_round(f32x4 v) {
+  if constexpr (sizeof(H) == 4) return v;
+  else return __builtin_convertvector(__builtin_convertvector(v, H __attribute__((ext_vector_type(4)))), f32x4);
+}
+
+
+// conv_t4.hip: register-blocked LDS 3x3 kernel for the 16-bit storage types.  half_kind: 0 bf16, 1 fp16.
+// Returns 1 if launched, 0 if the shape is not eligible, < 0 on error.
+int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                        int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi);
+void fami_conv_t4_tune(int on);

@@ -1,0 +1,336 @@
+// Register-blocked LDS-staged 3x3 convolution (stride 1, pad 1) for bf16 / fp16 storage: forward and input gradient of the
+// HRNet branch convolutions (posetimation/backbones/hrnet.py:17-172 via layers/basic_model.py:25-63) in the 16-bit modes.
+#include "conv_epi.h"
+
+// ------------------------------------------------------------------ register-blocked LDS 3x3 for 16-bit storage ("t4")
+// Round-3 replacement of conv3x3_lds_kernel for the 16-bit modes.  In the graph-mode trace of the bf16 step
+// (profiles/r03_trace_*) the 96 / 192 / 384-channel branch convolutions ran 31-40 us per 5.7 GFLOP launch -- 10x off
+// both rooflines -- and were 20 % of the step's kernel time.  That kernel read one 1 KiB LDS fragment per MFMA (the LDS
+// peak of 256 B/clk/CU exactly), synchronised the workgroup once per tap row and staged every channel chunk
+// synchronously.  This one
+//   * register-blocks up to 4 pixel tiles x NT channel tiles per wave: (4 + NT) fragments feed 4*NT MFMAs
+//     (0.58 KiB of LDS traffic per MFMA at NT = 3);
+//   * stages a 32-channel chunk of the activation patch AND the nine taps' weight fragments of that chunk in one
+//     go, so the workgroup meets twice per chunk (not per tap row) with 9 * 4 * NT MFMAs per wave in between;
+//   * fetches the next chunk's patch and weights into registers before it starts multiplying the current one;
+//   * keeps the patch with a zero border column on either side (row stride W + 2): a tap is a wave-uniform LDS
+//     offset and needs no per-lane mask, and a pixel tile may straddle image rows, so a band is any run of up to 256
+//     consecutive pixels of a frame (no row alignment, no ninth-tile special case);
+//   * needs 27 KiB (weights) + <= 41 KiB (patch) of LDS: two or three workgroups per CU, and workgroups of DIFFERENT
+//     stream lanes can share a CU (the old kernel took 150 KiB).
+// MFMA A = weights (rows = 16 output channels), B = activations (cols = 16 pixels), as in the kernels above.
+struct ConvT4Args {
+  EpiBN e;
+  int emode;
+  const void* x;      // [N,H,W,Ci]
+  const void* wp;     // packed weights [tap][KC][NTt][64][8]
+  void* y;            // [N,H,W,Co]
+  const float* bias;  // [Co] or null
+  int N, H, W, Ci, Co;
+  int BT, bands;      // 16-pixel tiles per band (<= 16), bands per frame
+  int PW, PS;         // patch row length in positions (W + 2), bytes per position (80)
+  int KC, NTt;
+  int sgn, relu, accumulate, out_f32;
+  int patch_bytes;
+};
+
+#define T4_THREADS 512   // 8 waves: the staging registers per thread halve, 2 pixel tiles x NT channel tiles per wave
+#define T4_WAVES (T4_THREADS / 64)
+#define T4_MT (16 / T4_WAVES)   // pixel tiles per wave (a band has <= 16)
+#define T4_PMAX 5   // most 16-byte patch pieces per thread and chunk (<= 640 positions x 4 pieces / 512 threads); template PM <= it
+
+template <typename H, int NT, int PM>
+__global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel(ConvT4Args p) {
+  typedef typename H16<H>::x8 frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int WPC = 9 * NT * 64;               // 16-byte weight pieces per chunk
+  constexpr int WR = (WPC + T4_THREADS - 1) / T4_THREADS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  int bxl, byl;
+  xcd_tile(1, bxl, byl);   // neighbouring bands (shared halo rows) on one XCD's L2
+  const int img = bxl / p.bands, bnd = bxl - img * p.bands;
+  const int HW = p.H * p.W;
+  const int p0 = bnd * p.BT * 16, p1 = min(p0 + p.BT * 16, HW);
+  const int ntile = (p1 - p0 + 15) >> 4;
+  const int y0 = p0 / p.W, y1 = (p1 - 1) / p.W;
+  const int npos = (y1 - y0 + 3) * p.PW;          // patch rows y0-1 .. y1+1, columns -1 .. W
+  const int ntg0 = byl * NT;
+  char* patch = smem;
+  char* wbuf = smem + p.patch_bytes;
+  const int mtw = (ntile - wave + T4_WAVES - 1) / T4_WAVES;   // pixel tiles of this wave: wave, wave + 8, ... (wave-uniform)
+
+  int base[T4_MT];
+#pragma unroll
+  for (int mt = 0; mt < T4_MT; ++mt) {
+    const int pp = min(p0 + (wave + T4_WAVES * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
+    const int ry = pp / p.W, rx = pp - ry * p.W;
+    base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + kq * 16;
+  }
+  f32x4 acc[T4_MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < T4_MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // chunk-invariant part of the patch staging: global byte offset of this thread's pieces (-1: zero border / outside)
+  const char* xg = reinterpret_cast<const char*>(p.x);
+  const char* wg = reinterpret_cast<const char*>(p.wp);
+  const int npiece = npos * 4;
+  int goff[PM];
+#pragma unroll
+  for (int u = 0; u < PM; ++u) {
+    const int i = tid + u * T4_THREADS;
+    goff[u] = -1;
+    if (i < npiece) {
+      const int pos = i >> 2, pc = i & 3;
+      const int r = pos / p.PW, c = pos - r * p.PW;
+      const int gy = y0 - 1 + r, gx = c - 1;
+      if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        goff[u] = (((img * p.H + gy) * p.W + gx) * p.Ci + pc * 8) * 2;
+    }
+  }
+  const int nchunk = (p.Ci + 31) >> 5;
+  u32x4 pr[PM], wr[WR];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int u = 0; u < PM; ++u) {
+      pr[u] = u32x4{0u, 0u, 0u, 0u};
+      const int pc = (tid + u * T4_THREADS) & 3;
+      if (goff[u] >= 0 && c * 32 + pc * 8 < p.Ci) pr[u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < WR; ++u) {
+      const int i = tid + u * T4_THREADS;
+      wr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (i < WPC) {
+        const int blk = i >> 6, l = i & 63;        // blk = tap*NT + nt
+        const int tap = blk / NT, nt = blk - tap * NT;
+        wr[u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
+      }
+    }
+  };
+  fetch(0);
+  for (int c = 0; c < nchunk; ++c) {
+    if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
+#pragma unroll
+    for (int u = 0; u < PM; ++u) {
+      const int i = tid + u * T4_THREADS;
+      if (i < npiece) *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = pr[u];
+    }
+#pragma unroll
+    for (int u = 0; u < WR; ++u) {
+      const int i = tid + u * T4_THREADS;
+      if (i < WPC) *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[u];
+    }
+    __syncthreads();
+    if (c + 1 < nchunk) fetch(c + 1);   // in flight while this chunk is multiplied
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+      frag a[T4_MT], w[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wbuf + (tap * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+      for (int mt = 0; mt < T4_MT; ++mt)
+        if (mt < mtw) a[mt] = *reinterpret_cast<const frag*>(patch + base[mt] + toff);
+#pragma unroll
+      for (int mt = 0; mt < T4_MT; ++mt) {
+        if (mt < mtw) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<H>::mfma(w[nt], a[mt], acc[mt][nt]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
+  const long pix0 = (long)img * HW + p0;
+  const int emode = p.emode;
+  if (emode) {
+    // EpiBN (see conv_igemm_h): channel tile by channel tile; the wave's tiles in registers, the 16 pixel lanes by DPP,
+    // the four waves through the (now idle) LDS
+    EpiPtr e = epi_late(__builtin_offsetof(ConvT4Args, e));
+    __syncthreads();                                    // every wave is done with the last chunk's LDS
+    float* ered = reinterpret_cast<float*>(smem);       // [waves][NT*32]
+    const H* ez = reinterpret_cast<const H*>(e->z);
+    const H* eyr = reinterpret_cast<const H*>(e->yr);
+    const int erelu = e->relu, eC = e->C;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      f32x4 es = z4, eq = z4, ek = z4, emu = z4, eis = z4, esc = z4, esf = z4, bias4 = z4;
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co0);
+      if (emode == 1) {
+        if (e->pivot_src) ek = *reinterpret_cast<const f32x4*>(e->pivot_src + co0);
+      } else {
+        emu = *reinterpret_cast<const f32x4*>(e->mean + co0);
+        eis = *reinterpret_cast<const f32x4*>(e->invstd + co0);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + co0), be = *reinterpret_cast<const f32x4*>(e->beta + co0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a, b;
+          epi_scale_shift(emu[r], eis[r], ga[r], be[r], a, b);
+          esc[r] = a;
+          esf[r] = b;
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < T4_MT; ++mt) {
+        const int j = (wave + T4_WAVES * mt) * 16 + col;
+        if (mt >= mtw || p0 + j >= p1) continue;
+        f32x4 v = acc[mt][nt] + bias4;
+        const long idx = (pix0 + j) * p.Co + co0;
+        H* yp = reinterpret_cast<H*>(p.y) + idx;
+        if (p.accumulate) v += ld4(yp);
+        if (emode == 2) {
+          const f32x4 zz = ld4(ez + idx);
+          f32x4 yy = z4;
+          if (erelu == 1) yy = ld4(eyr + idx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool keep = true;
+            if (erelu == 1) keep = yy[r] > 0.f;
+            else if (erelu == 2) keep = __builtin_fmaf(zz[r], esc[r], esf[r]) > 0.f;
+            v[r] = keep ? v[r] : 0.f;
+          }
+          st4(yp, v);
+          const f32x4 g = ld4_round<H>(v);
+          es += g;
+          eq += g * ((zz - emu) * eis);
+        } else {
+          st4(yp, v);
+          const f32x4 d = ld4_round<H>(v) - ek;
+          es += d;
+          eq += d * d;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        es[r] = row16_sum(es[r]);
+        eq[r] = row16_sum(eq[r]);
+      }
+      if (col == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ered[wave * (NT * 32) + nt * 32 + kq * 4 + r] = es[r];
+          ered[wave * (NT * 32) + nt * 32 + 16 + kq * 4 + r] = eq[r];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NT * 32) {
+      const int nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
+      const int co = (ntg0 + nt) * 16 + c16;
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < T4_WAVES; ++wv) v += ered[wv * (NT * 32) + tid];
+      double* srow = e->slots + (long)(bxl % e->ns) * 2 * eC;
+      unsafeAtomicAdd(srow + st * eC + co, (double)v);
+      if (emode == 1 && st == 0 && bxl == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < T4_MT; ++mt) {
+    const int j = (wave + T4_WAVES * mt) * 16 + col;
+    if (mt >= mtw || p0 + j >= p1) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      f32x4 v = acc[mt][nt];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+      if (p.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      const long idx = (pix0 + j) * p.Co + co0;
+      if (p.out_f32) {
+        float* yp = reinterpret_cast<float*>(p.y) + idx;
+        if (p.accumulate) v += ld4(yp);
+        st4(yp, v);
+      } else {
+        H* yp = reinterpret_cast<H*>(p.y) + idx;
+        if (p.accumulate) v += ld4(yp);
+        st4(yp, v);
+      }
+    }
+  }
+}
+
+// ---- register-blocked LDS kernel (16-bit): plan + launch.  Returns 1 if launched, 0 if not eligible, <0 on error.
+static int g_use_t4 = 1;   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
+static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
+template <typename HT>
+static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
+                          int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const char* name,
+                          const EpiBN& epi) {
+  if (!g_use_t4 || (Ci % 8) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  int NT = 0;
+  if (Co % 48 == 0) NT = 3;
+  else if (Co % 64 == 0) NT = 4;
+  if (!NT) return 0;
+  const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
+  // tiles per band: the largest of the candidates that still gives >= 480 workgroups (two per CU); the low-resolution
+  // branches cannot, they take the count that fills the most CUs with at least 4 tiles (one per wave)
+  const int cand[8] = {16, 14, 12, 10, 8, 6, 5, 4};
+  // positions a band of bt tiles can need (any start): rows touched + halo rows, W + 2 columns
+  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
+  const long pos_cap = (long)(NT == 3 ? 4 : T4_PMAX) * T4_THREADS / 4;   // staging registers (NT = 3: the 128-VGPR build)
+  int BT = 0;
+  for (int i = 0; i < 8 && !BT; ++i)
+    if (positions(cand[i]) <= pos_cap && (long)N * ((FT + cand[i] - 1) / cand[i]) * cblocks >= 480) BT = cand[i];
+  if (!BT) BT = 4;
+  if (g_t4_bt > 0) BT = g_t4_bt;
+  if (BT > FT) BT = FT;
+  if (BT > 16 || positions(BT) > pos_cap) return 0;
+  ConvT4Args a;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0;
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
+  a.PW = W + 2; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  const long npos = positions(BT);
+  a.patch_bytes = (int)(npos * a.PS);
+  const size_t wbytes = (size_t)9 * NT * 1024;
+  size_t lds = (size_t)a.patch_bytes + wbytes;
+  if (lds < (size_t)T4_WAVES * NT * 32 * 4) lds = (size_t)T4_WAVES * NT * 32 * 4;
+  if (lds > 100 * 1024) return 0;
+  const dim3 grid(N * a.bands, cblocks);
+  const int PM = (int)((npos * 4 + T4_THREADS - 1) / T4_THREADS);
+  bool ok = false;
+#define FAMI_T4_CASE(nt, pm)                                                                                              \
+  if (NT == nt && PM <= pm && !ok) {                                                                                      \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<HT, nt, pm>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_t4_kernel<HT, nt, pm>), grid, dim3(T4_THREADS), lds, s, a);                               \
+    ok = true;                                                                                                            \
+  }
+  FAMI_T4_CASE(3, 3) FAMI_T4_CASE(3, 4) FAMI_T4_CASE(3, 5) FAMI_T4_CASE(4, 3) FAMI_T4_CASE(4, 4) FAMI_T4_CASE(4, 5)
+#undef FAMI_T4_CASE
+  if (!ok) return 0;
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    fami_set_error(name, hipGetErrorString(err));
+    return FAMI_EHIP;
+  }
+  return 1;
+}
+
+
+int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                        int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi) {
+  if (half_kind == 1)
+    return try_conv3x3_t4<f16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+  return try_conv3x3_t4<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+}
+void fami_conv_t4_tune(int on) {
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; }
+  else if (on == 10 || on == 11) g_use_t4 = on - 10;
+  else if (on >= 100) g_t4_bt = on - 100;
+}

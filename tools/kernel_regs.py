@@ -7,7 +7,7 @@ import sys
 import tempfile
 import os
 
-so = sys.argv.pop(1) if len(sys.argv) > 1 and sys.argv[1].endswith('.so') else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'fami-pose_amd', 'libfami_hip.so')
+so = sys.argv.pop(1) if len(sys.argv) > 1 and sys.argv[1].endswith(('.so', '.o')) else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'fami-pose_amd', 'libfami_hip.so')
 data = open(so, 'rb').read()
 magic = b'__CLANG_OFFLOAD_BUNDLE__'
 pos, rows = 0, []
