@@ -2583,6 +2583,10 @@ int fami_conv_tune_lds(int on) {
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
 int fami_conv_tune_wgrad_lds(int on) {
+  if (on >= 20000) {         // round-3 16-bit kernel (conv_wg16.hip): 20000 / 20001 off / on, 20100 + tiles per run,
+    fami_wgrad16_tune(on - 20000);   // 21000 + workgroup target
+    return FAMI_OK;
+  }
   if (on >= 1000) {
     g_wgrad_ps = on - 1000;
     return FAMI_OK;
@@ -2596,6 +2600,7 @@ int fami_conv_tune_wgrad_lds(int on) {
     return FAMI_OK;
   }
   if (on < 0) {  // defaults
+    fami_wgrad16_tune(-1);
     g_wgrad_lds = 1;
     g_wgrad_lds_f32 = 2;
     g_wgrad_nsub = 2;
@@ -2867,6 +2872,10 @@ long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, in
     const long nl = (long)f.G * Co * Ci * 9 * (long)sizeof(float);
     if (nl > need) need = nl;
   }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
+    const long nl = fami_wgrad16_slabs(N, H, W, Ci, Co) * Co * Ci * 9 * (long)sizeof(float);
+    if (nl > need) need = nl;
+  }
   return need;
 }
 
@@ -3076,6 +3085,16 @@ template <typename HT>
 static int wgrad_h_impl(const char* nm, const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                         hipStream_t s) {
+  if (g_wgrad_lds && x && dy && dw && workspace && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
+    // round-3 kernel (conv_wg16.hip): pipelined staging, padded patch, 8 waves
+    const int G = fami_try_wgrad16(std::is_same<HT, f16_t>::value ? 1 : 0, x, dy, workspace, ws_bytes, N, H, W, Ci, Co, s, nm);
+    if (G < 0) return G;
+    if (G > 0) {
+      launch_reduce_taps(workspace, dw, Co, Ci, 9, G, accumulate, s);
+      FAMI_CHECK_LAUNCH(nm);
+      return FAMI_OK;
+    }
+  }
   const WgradLdsPlan l = g_wgrad_lds ? wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
     const long need = (long)l.G * Co * Ci * 9 * (long)sizeof(float);

@@ -66,3 +66,10 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi);
 void fami_conv_t4_tune(int on);
+
+// conv_wg16.hip: 16-bit weight gradient of the 3x3 stride-1 pad-1 convolutions.  fami_try_wgrad16 -> number of partial
+// slabs [G][9][Ci][Co] written to `part` (reduce them with the caller's slab reduce), 0 = not eligible, < 0 = error.
+long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co);
+int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
+                     int Co, hipStream_t s, const char* name);
+void fami_wgrad16_tune(int on);
