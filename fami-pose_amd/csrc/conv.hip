@@ -21,6 +21,7 @@
 // dgrad is the same kernel with the transposed position map (MODE 1).
 #include "common.h"
 #include <type_traits>
+#include <string.h>
 
 #include "conv_epi.h"
 
@@ -1865,15 +1866,18 @@ __global__ __launch_bounds__(1024) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) 
     }
 }
 
+// ---- slab reduces.  The bodies are device functions shared by the one-reduce kernels and the batched kernel
+// (wgrad_reduce_batch_kernel: up to 16 reduces of a backward pass in ONE launch -- 303 launches per step were 4.6-4.9 %
+// of the kernel time and sat between every weight gradient and the next kernel of its stream lane), so a deferred reduce
+// sums in exactly the order the immediate one does.
+//
 // slabs [psplit][tap][ci][co] -> dw OIHW (=|+=).  64 outputs x 16 slab groups per block: the reduction is
 // latency-bound (each output owns a strided column), so parallelism comes from splitting the slab axis.
-__global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __restrict__ part,
-                                                                 float* __restrict__ dw, int Co, int Ci, int taps,
-                                                                 int psplit, int accumulate) {
-  __shared__ float sm[1024];
+__device__ __forceinline__ void reduce_taps_body(const float* __restrict__ part, float* __restrict__ dw, int Co, int Ci,
+                                                 int taps, int psplit, int accumulate, int bid, float* sm /* [1024] */) {
   const long n = (long)taps * Ci * Co;
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + o;
+  const long i = (long)bid * 64 + o;
   float s0 = 0.f, s1 = 0.f;
   if (i < n) {
     int k = g;
@@ -1896,17 +1900,21 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __
     *d = accumulate ? *d + s : s;
   }
 }
+__global__ __launch_bounds__(1024) void wgrad_reduce_taps_kernel(const float* __restrict__ part,
+                                                                 float* __restrict__ dw, int Co, int Ci, int taps,
+                                                                 int psplit, int accumulate) {
+  __shared__ float sm[1024];
+  reduce_taps_body(part, dw, Co, Ci, taps, psplit, accumulate, blockIdx.x, sm);
+}
 
 // same reduction with 16-byte loads: a thread owns 4 consecutive output channels of one (tap, ci), 2^sg slab groups per
 // block walk the slab axis with four independent partial sums (Co % 4 == 0; summation order is fixed)
-__global__ __launch_bounds__(256) void wgrad_reduce_taps4_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                 int Co, int Ci, int taps, int psplit, int accumulate,
-                                                                 int sg) {
-  __shared__ f32x4 sm[256];
+__device__ __forceinline__ void reduce_taps4_body(const float* __restrict__ part, float* __restrict__ dw, int Co, int Ci,
+                                                  int taps, int psplit, int accumulate, int sg, int bid, f32x4* sm /* [256] */) {
   const int SG = 1 << sg, cols = 256 >> sg;
   const int o = threadIdx.x & (cols - 1), g = threadIdx.x >> (8 - sg);
   const long n4 = (long)taps * Ci * Co / 4;
-  const long i = (long)blockIdx.x * cols + o;
+  const long i = (long)bid * cols + o;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 s0 = z, s1 = z, s2 = z, s3 = z;
   if (i < n4) {
@@ -1945,16 +1953,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_taps4_kernel(const float* __
     }
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_taps4_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int Co, int Ci, int taps, int psplit, int accumulate,
+                                                                 int sg) {
+  __shared__ f32x4 sm[256];
+  reduce_taps4_body(part, dw, Co, Ci, taps, psplit, accumulate, sg, blockIdx.x, sm);
+}
 
 static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
                                hipStream_t s);
 
 // dw[i] (=|+=) sum_k part[k][i]; 64 outputs x 4 slab groups per block so the serial chain is psplit/4 long
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           long n, int psplit, int accumulate) {
-  __shared__ float sm[256];
+__device__ __forceinline__ void reduce_plain_body(const float* __restrict__ part, float* __restrict__ dw, long n,
+                                                  int psplit, int accumulate, int bid, float* sm /* [256] */) {
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + o;
+  const long i = (long)bid * 64 + o;
   float s = 0.f;
   if (i < n)
     for (int k = g; k < psplit; k += 4) s += part[(long)k * n + i];
@@ -1964,6 +1977,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     s = sm[o] + sm[64 + o] + sm[128 + o] + sm[192 + o];
     dw[i] = accumulate ? dw[i] + s : s;
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           long n, int psplit, int accumulate) {
+  __shared__ float sm[256];
+  reduce_plain_body(part, dw, n, psplit, accumulate, blockIdx.x, sm);
+}
+
+// One deferred reduce.  kind 0: plain [psplit][n] -> dw[n] ; 1: taps layout, 16-byte loads (sg) ; 2: taps layout, scalar.
+struct ReduceDesc {
+  const float* part;
+  float* dw;
+  int Co, Ci, taps, psplit, accumulate, kind, sg, blocks;
+};
+#define FAMI_REDUCE_BATCH 16
+struct ReduceBatch { ReduceDesc d[FAMI_REDUCE_BATCH]; };
+// blockIdx.y = entry, blockIdx.x = block of that entry's own grid (the launch takes the largest); 1024 threads: the
+// scalar taps form uses all of them, the other two forms the first 256
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(ReduceBatch b) {
+  __shared__ f32x4 sm[256];   // 4 KiB: [1024] floats for the scalar taps form
+  const ReduceDesc& d = b.d[blockIdx.y];
+  if ((int)blockIdx.x >= d.blocks) return;
+  if (d.kind == 2) {
+    reduce_taps_body(d.part, d.dw, d.Co, d.Ci, d.taps, d.psplit, d.accumulate, blockIdx.x, reinterpret_cast<float*>(sm));
+    return;
+  }
+  if (threadIdx.x >= 256) return;   // (no barrier is shared with the upper waves: they leave before any)
+  if (d.kind == 1) reduce_taps4_body(d.part, d.dw, d.Co, d.Ci, d.taps, d.psplit, d.accumulate, d.sg, blockIdx.x, sm);
+  else reduce_plain_body(d.part, d.dw, (long)d.Co * d.Ci * d.taps, d.psplit, d.accumulate, blockIdx.x, reinterpret_cast<float*>(sm));
 }
 
 // ------------------------------------------------------------------ bf16 wgrad on the bf16 matrix core
@@ -2308,17 +2349,44 @@ static int pick_small(int tiles) {  // wgrad tile counts in {4,3,2,1}
   return best;
 }
 
-static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
-                               hipStream_t s) {
+// A weight-gradient call made through fami_conv2d_wgrad_defer_* records its reduce here instead of launching it
+static thread_local ReduceDesc* g_defer = nullptr;
+static ReduceDesc reduce_desc_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate) {
+  ReduceDesc d;
+  d.part = part; d.dw = dw; d.Co = Co; d.Ci = Ci; d.taps = taps; d.psplit = psplit; d.accumulate = accumulate;
   const long n = (long)Co * Ci * taps;
   if (Co % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) {
     int sg = 0;
     while (sg < 4 && (8 << sg) <= psplit) ++sg;  // up to 16 slab groups, each at least 4 slabs deep
-    const int cols = 256 >> sg;
-    hipLaunchKernelGGL(wgrad_reduce_taps4_kernel, dim3(fami_cdiv(n / 4, cols)), dim3(256), 0, s, part, dw, Co, Ci, taps, psplit, accumulate, sg);
+    d.kind = 1; d.sg = sg; d.blocks = fami_cdiv(n / 4, 256 >> sg);
   } else {
-    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(fami_cdiv(n, 64)), dim3(1024), 0, s, part, dw, Co, Ci, taps, psplit, accumulate);
+    d.kind = 2; d.sg = 0; d.blocks = fami_cdiv(n, 64);
   }
+  return d;
+}
+static void launch_reduce_taps(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
+                               hipStream_t s) {
+  const ReduceDesc d = reduce_desc_taps(part, dw, Co, Ci, taps, psplit, accumulate);
+  if (g_defer) {
+    *g_defer = d;
+    return;
+  }
+  if (d.kind == 1)
+    hipLaunchKernelGGL(wgrad_reduce_taps4_kernel, dim3(d.blocks), dim3(256), 0, s, part, dw, Co, Ci, taps, psplit, accumulate, d.sg);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3(d.blocks), dim3(1024), 0, s, part, dw, Co, Ci, taps, psplit, accumulate);
+}
+static void launch_reduce_plain(const float* part, float* dw, int Co, int Ci, int taps, int psplit, int accumulate,
+                                hipStream_t s) {
+  const long n = (long)Co * Ci * taps;
+  if (g_defer) {
+    ReduceDesc d;
+    d.part = part; d.dw = dw; d.Co = Co; d.Ci = Ci; d.taps = taps; d.psplit = psplit; d.accumulate = accumulate;
+    d.kind = 0; d.sg = 0; d.blocks = fami_cdiv(n, 64);
+    *g_defer = d;
+    return;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, part, dw, n, psplit, accumulate);
 }
 
 static int g_lin_conv = 1;  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
@@ -2906,7 +2974,6 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
   const long xb = (long)N * H * W * Ci * (long)sizeof(T), yb = q.P * Co * (long)sizeof(T);
   FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), nm, "tensor >= 2 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-  const long n = (long)Co * Ci * kh * kw;
   if (q.pertap) {
     const dim3 grid(q.w8 ? q.psplit + (q.psplit + 7) / 8 : q.psplit, q.ciBlocks * q.coBlocks), block(q.w8 ? 512 * q.w8 : kh * kw * 64);
     const size_t lin_lds = q.w8 == 2 ? (size_t)8 * q.MT * q.NT * 1024 : 0;
@@ -2960,7 +3027,7 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
     return FAMI_ESHAPE;
   }
   FAMI_CHECK_LAUNCH(nm);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, workspace, dw, n, q.psplit, accumulate);
+  launch_reduce_plain(workspace, dw, Co, Ci, kh * kw, q.psplit, accumulate, s);
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
@@ -3077,6 +3144,44 @@ int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* wor
   }
   return wgrad_impl<float>(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s,
                            "fami_conv2d_wgrad_f32");
+}
+}  // extern "C"
+
+extern "C" {
+// Deferred slab reduce: the weight-gradient kernel is launched now, its reduce is described in desc_out (a HOST buffer of
+// FAMI_REDUCE_DESC_LONGS longs, opaque) and launched later -- up to 16 at a time -- by fami_wgrad_reduce_batch.  The
+// workspace must stay untouched until then.  Two deferred reduces into the same dw must not share a batch when the
+// second accumulates (the caller flushes in between).
+int fami_conv2d_wgrad_defer_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                                int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                                long* desc_out, hipStream_t s) {
+  FAMI_REQUIRE(desc_out, "fami_conv2d_wgrad_defer_f32", "null descriptor");
+  ReduceDesc d;
+  d.part = nullptr;
+  g_defer = &d;
+  const int rc = fami_conv2d_wgrad_f32(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s);
+  g_defer = nullptr;
+  if (rc != FAMI_OK) return rc;
+  FAMI_REQUIRE(d.part, "fami_conv2d_wgrad_defer_f32", "no reduce recorded");
+  memcpy(desc_out, &d, sizeof(d));
+  return FAMI_OK;
+}
+int fami_wgrad_reduce_desc_longs(void) { return (int)((sizeof(ReduceDesc) + sizeof(long) - 1) / sizeof(long)); }
+int fami_wgrad_reduce_batch(const long* descs, int n, hipStream_t s) {
+  FAMI_REQUIRE(descs && n > 0, "fami_wgrad_reduce_batch", "bad argument");
+  const int stride = fami_wgrad_reduce_desc_longs();
+  for (int i0 = 0; i0 < n; i0 += FAMI_REDUCE_BATCH) {
+    const int m = n - i0 < FAMI_REDUCE_BATCH ? n - i0 : FAMI_REDUCE_BATCH;
+    ReduceBatch b;
+    int maxb = 1;
+    for (int i = 0; i < m; ++i) {
+      memcpy(&b.d[i], descs + (long)(i0 + i) * stride, sizeof(ReduceDesc));
+      if (b.d[i].blocks > maxb) maxb = b.d[i].blocks;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(maxb, m), dim3(1024), 0, s, b);
+    FAMI_CHECK_LAUNCH("fami_wgrad_reduce_batch");
+  }
+  return FAMI_OK;
 }
 }  // extern "C"
 
@@ -3231,6 +3336,21 @@ long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
                               hipStream_t s) {                                                                         \
     return wgrad_h_impl<HT>("fami_conv2d_wgrad_" #sfx, x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw,        \
                             stride, pad, dil, accumulate, s);                                                          \
+  }                                                                                                                    \
+  int fami_conv2d_wgrad_defer_##sfx(const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,      \
+                                    int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,        \
+                                    int accumulate, long* desc_out, hipStream_t s) {                                   \
+    FAMI_REQUIRE(desc_out, "fami_conv2d_wgrad_defer_" #sfx, "null descriptor");                                        \
+    ReduceDesc d;                                                                                                      \
+    d.part = nullptr;                                                                                                  \
+    g_defer = &d;                                                                                                      \
+    const int rc = wgrad_h_impl<HT>("fami_conv2d_wgrad_defer_" #sfx, x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co,  \
+                                    kh, kw, stride, pad, dil, accumulate, s);                                          \
+    g_defer = nullptr;                                                                                                 \
+    if (rc != FAMI_OK) return rc;                                                                                      \
+    FAMI_REQUIRE(d.part, "fami_conv2d_wgrad_defer_" #sfx, "no reduce recorded");                                       \
+    memcpy(desc_out, &d, sizeof(d));                                                                                   \
+    return FAMI_OK;                                                                                                    \
   }                                                                                                                    \
   int fami_pack_conv_weights_batch_##sfx(const float* params, HT* packed, const void* desc, int n, hipStream_t s) {    \
     FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_" #sfx, "bad argument");\

@@ -273,16 +273,18 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   else if (Co % 64 == 0) NT = 4;
   if (!NT) return 0;
   const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
-  // tiles per band: the largest of the candidates that still gives >= 480 workgroups (two per CU); the low-resolution
-  // branches cannot, they take the count that fills the most CUs with at least 4 tiles (one per wave)
-  const int cand[8] = {16, 14, 12, 10, 8, 6, 5, 4};
-  // positions a band of bt tiles can need (any start): rows touched + halo rows, W + 2 columns
+  // tiles per band.  Measured (tools/bench_t4.py, profiles/r03_bench_t4.txt): 12 tiles (192 pixels) is the best or equal
+  // on every branch shape -- 16.1 / 13.0 / 13.7 us at 48 / 96 / 192 channels against 19-21 us with 6-8 tiles (the weight
+  // slab is re-staged per band) and 23 us with 16 at 48 channels (staging registers spill); a frame smaller than that
+  // (12x9 maps: 7 tiles) is one band: 19.3 us against 25-28 with 4-6 tiles (waves without a tile idle).  More workgroups
+  // than that do not help even where the grid is below one workgroup per CU: other stream lanes fill the rest.
+  const int cand[8] = {12, 10, 8, 6, 5, 4, 3, 2};
   auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
   const long pos_cap = (long)(NT == 3 ? 4 : T4_PMAX) * T4_THREADS / 4;   // staging registers (NT = 3: the 128-VGPR build)
   int BT = 0;
   for (int i = 0; i < 8 && !BT; ++i)
-    if (positions(cand[i]) <= pos_cap && (long)N * ((FT + cand[i] - 1) / cand[i]) * cblocks >= 480) BT = cand[i];
-  if (!BT) BT = 4;
+    if (positions(cand[i]) <= pos_cap) BT = cand[i];
+  if (!BT) return 0;
   if (g_t4_bt > 0) BT = g_t4_bt;
   if (BT > FT) BT = FT;
   if (BT > 16 || positions(BT) > pos_cap) return 0;

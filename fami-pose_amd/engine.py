@@ -113,6 +113,13 @@ class Engine:
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.nfused = {'fwd': 0, 'bwd': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
+        # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
+        # 16 at a time per stream (fami_wgrad_reduce_batch) at the joins / bucket boundaries / the end of backward --
+        # 303 tiny launches per step otherwise sit between every weight gradient and the next kernel of its lane
+        self.defer_reduce = os.environ.get('FAMI_DEFER_REDUCE', '1') != '0'
+        self._red = {}                 # raw stream -> [ctypes descriptor buffers]
+        self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
+        self._red_longs = self.L.cdll.fami_wgrad_reduce_desc_longs()
         self.sync_stream()
         self._zero_begin()
 
@@ -187,6 +194,7 @@ class Engine:
     def sync_wgrad_lane(self):
         """Lane 0 continues after every weight-gradient kernel enqueued so far (before an all-reduce / the optimizer)."""
         if self._wdirty:
+            self.flush_reduces(self._wstream.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(self._wstream)
             self._main.wait_event(ev)
@@ -209,6 +217,7 @@ class Engine:
 
     def _do_fork(self, n):
         side = self._lanes(n)
+        self.flush_reduces()
         ev = torch.cuda.Event()
         ev.record(self._main)
         for i in range(n - 1):
@@ -218,6 +227,7 @@ class Engine:
 
     def _do_join(self, n):
         side = self._lanes(n)
+        self.flush_reduces()               # every lane's pending reduces go out on their own streams before the join events
         for i in range(n - 1):
             ev = torch.cuda.Event()
             ev.record(side[i])
@@ -261,6 +271,40 @@ class Engine:
 
     def call(self, name, *args):
         self.L.call(name, *args, self.stream)
+
+    # ------------------------------------------------------------------ weight gradients with deferred slab reduces
+    def wgrad(self, x_data, dy, g, geo, acc):
+        """dW (=|+=) of one convolution: the partial-slab kernel now, its reduce batched with the stream's others."""
+        nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
+        ws = self.ws(nb)
+        if not self.defer_reduce:
+            self.acall('fami_conv2d_wgrad', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+            return
+        st = self.stream
+        dws = self._red_dw.setdefault(st, set())
+        if g.data_ptr() in dws:            # a second reduce into the same gradient must follow the first
+            self.flush_reduces(st)
+            dws = self._red_dw.setdefault(st, set())
+        desc = (ctypes.c_long * self._red_longs)()
+        self.acall('fami_conv2d_wgrad_defer', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc, desc)
+        self._red.setdefault(st, []).append(desc)
+        dws.add(g.data_ptr())
+        if len(self._red[st]) >= 16:
+            self.flush_reduces(st)
+
+    def flush_reduces(self, stream=None):
+        """Launch the pending reduces of one raw stream (default: every stream), each batch on its own stream."""
+        for st in ([stream] if stream is not None else list(self._red)):
+            items = self._red.get(st)
+            if not items:
+                continue
+            n = len(items)
+            flat = (ctypes.c_long * (self._red_longs * n))()
+            for i, d in enumerate(items):
+                flat[i * self._red_longs:(i + 1) * self._red_longs] = d[:]
+            self.L.call('fami_wgrad_reduce_batch', flat, n, st)
+            self._red[st] = []
+            self._red_dw[st] = set()
 
     def empty(self, *shape, dtype=torch.float32):
         t = torch.empty(shape, dtype=dtype, device=self.dev)
@@ -505,9 +549,7 @@ class Engine:
                 saved = self._enter_wlane() if (self.use_wlane and need_w) else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
-                    nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
-                    ws = self.ws(nb)
-                    self.acall('fami_conv2d_wgrad', _p(x.data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                    self.wgrad(x.data, dy, g, geo, acc)
                 if self.rq(bias):
                     g, acc = self.pgrad(bias)
                     ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
@@ -918,8 +960,7 @@ class Engine:
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)
-                    ws = self.ws(self.L.cdll.fami_conv2d_wgrad_workspace(*geo))
-                    self.acall('fami_conv2d_wgrad', _p(col), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
+                    self.wgrad(col, dy, g, geo, acc)
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
@@ -979,9 +1020,11 @@ class Engine:
             # bucket hooks only fire from lane 0 outside a forked region: by then every lane's gradient
             # kernels are ordered before whatever the hook enqueues on the main stream
             if pending and on_params_done is not None and self._forked == 0 and self.lane == 0:
+                self.flush_reduces()       # the completed parameters' gradients must be final before the hook reads them
                 on_params_done(pending)
                 pending = []
         self.set_lane(0)
+        self.flush_reduces()
         self.sync_wgrad_lane()
         if pending and on_params_done is not None:
             on_params_done(pending)

@@ -84,6 +84,15 @@ int fami_conv2d_dgrad_bnstats_f32(const float* dy, const float* wp, float* dx, i
                                   const float* yrelu, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, int relu, void* slots, fami_stream_t stream);
 long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+/* Deferred slab reduce (the weight-gradient kernels write per-workgroup partial slabs; the reference's autograd has no
+ * counterpart): fami_conv2d_wgrad_defer_* launches the kernel and describes its reduce in desc_out -- a HOST buffer of
+ * fami_wgrad_reduce_desc_longs() longs -- and fami_wgrad_reduce_batch launches up to 16 described reduces per kernel
+ * launch (descs: n consecutive descriptors on the host).  Same summation order as the immediate reduce. */
+int fami_wgrad_reduce_desc_longs(void);
+int fami_wgrad_reduce_batch(const long* descs, int n, fami_stream_t stream);
+int fami_conv2d_wgrad_defer_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N,
+                                int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                                int accumulate, long* desc_out, fami_stream_t stream);
 /* dw[Co,Ci,kh,kw] (OIHW, =|+=) */
 int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
@@ -308,6 +317,9 @@ int fami_bn_bwd_apply_slots_bf16(const fami_bf16_t* dz, const fami_bf16_t* x, co
                                  const float* gamma, const float* beta, fami_bf16_t* dx, float* dgamma, float* dbeta,
                                  fami_bf16_t* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,
                                  fami_stream_t stream);
+int fami_conv2d_wgrad_defer_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
+                                 int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                                 int accumulate, long* desc_out, fami_stream_t stream);
 int fami_conv2d_wgrad_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
                            int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                            int accumulate, fami_stream_t stream);
@@ -403,6 +415,9 @@ int fami_bn_bwd_apply_slots_f16(const fami_f16_t* dz, const fami_f16_t* x, const
                                  const float* gamma, const float* beta, fami_f16_t* dx, float* dgamma, float* dbeta,
                                  fami_f16_t* dres, long P, int C, int acc_dx, int acc_param, int acc_dres, void* slots,
                                  fami_stream_t stream);
+int fami_conv2d_wgrad_defer_f16(const fami_f16_t* x, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
+                                 int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                                 int accumulate, long* desc_out, fami_stream_t stream);
 int fami_conv2d_wgrad_f16(const fami_f16_t* x, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
                            int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                            int accumulate, fami_stream_t stream);

@@ -64,8 +64,9 @@ def _run(dev, ref, x, gy, dtype, fuse):
         b.conv1, b.bn1, b.conv2, b.bn2 = rb.conv1, rb.bn1, rb.conv2, rb.bn2
         blocks.append(b)
     eng = Engine(dev, dtype=dtype)
-    if not fuse:
-        eng.fuse_bn_fwd = eng.fuse_bn_bwd = False
+    if not eng.bn2:
+        pytest.skip('two-launch BatchNorm disabled')
+    eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # the fusion is opt-in (FAMI_FUSE_BN): switch it per engine
     xt = T(x.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype), True)
     h = xt
     for b in blocks:

@@ -442,6 +442,39 @@ def test_final_preds_golden(dev):
     assert np.abs(preds.cpu().numpy().astype(np.float64) - g['preds']).max() < 1e-3
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_deferred_slab_reduces_are_bitwise_the_immediate_ones(dev, dt):
+    """Engine.wgrad defers the slab reduce of every weight-gradient kernel and launches them 16 at a time
+    (fami_wgrad_reduce_batch: one kernel, blockIdx.y = reduce).  Same device code, same summation order: bit-identical to
+    the immediate reduces -- across the three reduce forms (taps layout with 16-byte loads, taps layout scalar for
+    Co % 4 != 0, plain 1x1), more than one batch, and two convolutions SHARING a weight (the second accumulates, so the
+    engine must flush in between)."""
+    from fami_pose_amd.engine import Engine, T
+    dtype = {'f32': torch.float32, 'bf16': torch.bfloat16}[dt]
+    torch.manual_seed(21)
+    specs = [(48, 48, 3, 1, 1), (48, 17, 3, 1, 1), (48, 96, 1, 1, 0), (48, 96, 3, 2, 1), (16, 16, 3, 1, 1), (48, 17, 1, 1, 0)] * 4
+    convs = [nn.Conv2d(ci, co, k, st, pd, bias=False).to(dev) for ci, co, k, st, pd in specs[:6]]
+    xs = {c: torch.randn(2, 20, 18, c, device=dev).to(dtype) for c in (48, 16)}
+
+    def run(defer):
+        eng = Engine(dev, dtype=dtype)
+        eng.defer_reduce = defer
+        outs = []
+        for rep in range(4):                       # 24 convolutions: two batches; every weight is used four times
+            for cv, (ci, co, k, st, pd) in zip(convs, specs):
+                outs.append(eng.conv(T(xs[ci], False), cv.weight, None, st, pd, 1))
+        for i, y in enumerate(outs):
+            g = torch.Generator(device='cpu').manual_seed(100 + i)
+            y.grad = torch.randn(y.shape, generator=g).to(dev).to(dtype)
+        eng.backward()
+        torch.cuda.synchronize(dev)
+        return [eng.param_grads[id(cv.weight)].clone() for cv in convs]
+
+    a, b = run(False), run(True)
+    for ga, gb in zip(a, b):
+        assert torch.equal(ga, gb)
+
+
 def test_two_live_engines_do_not_share_bn_slot_rows(dev):
     """two recorded Engines alive at once (model(a); model(b); (la + lb).backward() through runtime._EngineFn).
     The slot rows of the two-launch BatchNorm come from one per-device arena; both backwards used to receive the same
