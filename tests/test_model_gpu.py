@@ -109,10 +109,13 @@ def test_g3_hrnet_w32_config1_golden(dev):
         assert f.double().abs().sum().item() == pytest.approx(float(g['feat%d_abssum' % i]), rel=1e-4)
 
 
-@pytest.mark.parametrize('S,hw,B', [(2, (384, 288), 2), (7, (128, 96), 2), (1, (256, 192), 2)])
+@pytest.mark.parametrize('S,hw,B', [(2, (192, 144), 2), (7, (128, 96), 1), (1, (256, 192), 1)])
 def test_model_vs_oracle(dev, S, hw, B):
-    """BASELINE configs[1] (3-frame W48 384x288) and generalised heads (7 / 1 supporting frames, other input sizes)
-    against the CPU oracle: forward, loss, and gradients of head, DCN, translation regressor and backbone."""
+    """BASELINE configs[1]'s graph (3-frame W48) and generalised heads (7 / 1 supporting frames, other input sizes)
+    against the CPU oracle: forward, loss, and gradients of head, DCN, translation regressor and backbone -- every
+    parameter, arbitrated by an fp64 evaluation.  (Sizes keep the fp64 CPU pass short: the full 384x288 resolution is
+    held to the oracle by test_train_gpu.py::test_bench_workload_train_step_matches_the_oracle at the bench's own batch
+    and by the reference-generated golden g9; the GPU suite has to fit the driver's time limit.)"""
     H, W = hw
     model, orc = _pair(48, S, hw, 'train', 3 + S)
     model = model.to(dev)
@@ -232,12 +235,14 @@ def test_baseline_configs_4_5_forward(dev, width, S, hw, B):
         assert not worse, worse[:10]
 
 
-def test_full_size_properties(dev):
-    """BASELINE's full per-GPU batch (4 five-frame 384x288 clips): properties that need no CPU reference."""
-    model, _ = _pair(48, 4, (384, 288), fp.VAL_PHASE, 21)
+@pytest.mark.parametrize('S,B', [(4, 4), (2, 8)], ids=['config3_5frame_b4', 'config2_3frame_b8'])
+def test_full_size_properties(dev, S, B):
+    """BASELINE's full per-GPU batches -- 4 five-frame clips (the bench workload) and config 2 as stated: 8 three-frame
+    clips, fp32 -- at 384x288: properties that need no CPU reference."""
+    model, _ = _pair(48, S, (384, 288), fp.VAL_PHASE, 21)
     model = model.to(dev)
     gen = torch.Generator().manual_seed(77)
-    kf, sup = torch.randn(4, 3, 384, 288, generator=gen).to(dev), torch.randn(4, 12, 384, 288, generator=gen).to(dev)
+    kf, sup = torch.randn(B, 3, 384, 288, generator=gen).to(dev), torch.randn(B, 3 * S, 384, 288, generator=gen).to(dev)
     with torch.no_grad():
         a = model(kf, sup)
         b = model(kf, sup)
@@ -246,7 +251,7 @@ def test_full_size_properties(dev):
     assert (one[0] - a[0][2:3]).abs().max().item() < 1e-4
     assert (one[1] - a[1][2:3]).abs().max().item() < 1e-4
     assert np.array_equal(_argmax(one[0]), _argmax(a[0][2:3]))
-    assert torch.isfinite(a[0]).all() and a[0].shape == (4, 17, 96, 72)
+    assert torch.isfinite(a[0]).all() and a[0].shape == (B, 17, 96, 72)
 
 
 def test_trainer_step_matches_oracle_adam(dev):
@@ -333,7 +338,7 @@ def test_half_mode_vs_oracle(dev, mode):
     The 1e-3 / bit-exact-argmax contract belongs to the fp32 mode, tested above; the 16-bit kernels are held
     individually to 1e-2 / 1.5e-3 in tests/test_kernels_half_gpu.py."""
     tdt, floor, ltol = (torch.bfloat16, 1e-2, 0.1) if mode == 'bf16' else (torch.float16, 2e-3, 0.02)
-    S, H, W, B = 4, 384, 288, 2
+    S, H, W, B = (4, 384, 288, 2) if mode == 'bf16' else (4, 256, 192, 2)   # (the fp16 CPU emulation is 2x slower per pixel)
     model, orc = _pair(48, S, (H, W), 'train', 31)
     model = model.to(dev).set_compute_dtype(mode)
     gen = torch.Generator().manual_seed(131)

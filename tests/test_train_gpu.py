@@ -233,3 +233,48 @@ def test_evaluate_loop_accumulates_like_the_reference(dev, tmp_path):
     (path,) = written
     data = json.load(open(path))['annolist']
     assert [el['imgnum'][0] for el in data] == [1, 2, 3, 4] and data[2]['annorect'][0]['score'] == [0]      # frame 3: dummy
+
+
+def test_bench_workload_train_step_matches_the_oracle(dev):
+    """The headline workload itself (bench.py: HRNet-W48, 4 supporting frames, 384x288, batch 4 per GPU, train phase with
+    MI, on-device Gaussian targets, fp32): one Trainer.step against the CPU oracle's forward on the same inputs --
+    heatmaps <= 1e-3 absolute (north_star), argmax keypoint indices bit-exact, loss to 1e-4 relative -- and, with the
+    deterministic DCN backward, two hipGraph-replayed steps bitwise equal to two eager steps (parameters and both Adam
+    moments)."""
+    from fami_pose_amd.train import Trainer
+    Sx, Hx, Wx, Bx = 4, 384, 288, 4
+    orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(48), True, Sx, (Hx, Wx)), 31)
+    gen = torch.Generator().manual_seed(19970808)
+    kf, sup = torch.randn(Bx, 3, Hx, Wx, generator=gen), torch.randn(Bx, 3 * Sx, Hx, Wx, generator=gen)
+    joints = torch.rand(Bx, 17, 2, generator=gen) * torch.tensor([Wx, Hx], dtype=torch.float32)
+    vis = (torch.rand(Bx, 17, generator=gen) < 0.8).float()
+    tg = np.zeros((Bx, 17, Hx // 4, Wx // 4), np.float32)
+    tw = np.zeros((Bx, 17, 1), np.float32)
+    for b in range(Bx):
+        j3 = np.concatenate([joints[b].numpy(), np.zeros((17, 1), np.float32)], 1)
+        v3 = np.repeat(vis[b].numpy()[:, None], 3, 1)
+        tg[b], tw[b] = oops.generate_heatmaps(j3, v3, 3, np.array([Wx, Hx]), np.array([Wx // 4, Hx // 4]), 17)
+    with torch.no_grad():
+        f0, k0, mi0 = orc(kf, sup)
+        l0 = oops.total_loss(f0, torch.from_numpy(tg), torch.from_numpy(tw), mi0).item()
+    args = tuple(t.to(dev) for t in (kf, sup, joints, vis))
+
+    def trainer(use_graph):
+        m = fp.build_model(fp.default_cfg(48, image_size=(Wx, Hx), num_sup=Sx), 'train')
+        m.load_state_dict(orc.state_dict())
+        m.set_deterministic(True)
+        return Trainer(m.to(dev), lr=1e-3, use_graph=use_graph, targets_from_joints=True)
+
+    te = trainer(False)
+    outs = te.step(*args)
+    final, kf_hm = outs[0].cpu(), outs[1].cpu()
+    assert (final - f0).abs().max().item() < 1e-3 and (kf_hm - k0).abs().max().item() < 1e-3
+    am = lambda t: t.reshape(Bx, 17, -1).argmax(2).numpy()
+    assert np.array_equal(am(final), am(f0)) and np.array_equal(am(kf_hm), am(k0))
+    assert te.loss_value() == pytest.approx(l0, rel=1e-4)
+    te.step(*args)
+    tg_ = trainer(True)
+    for _ in range(2):
+        tg_.step(*args)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(te.flat, tg_.flat) and torch.equal(te.opt.m, tg_.opt.m) and torch.equal(te.opt.v, tg_.opt.v)
