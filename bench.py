@@ -69,6 +69,16 @@ def pmc_traffic(key):
 TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
 
 
+def in_step(dtype):
+    """What the committed rocprofv3 kernel trace of this round says about the step as a whole (profiles/in_step.json,
+    written by tools/in_step_summary.py from the trace of `bench.py --dtype <dtype>` in graph mode): launches per step,
+    the dominant kernel's average duration INSIDE the step, the share of the step's wall time with no kernel in flight."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'in_step.json'))).get(dtype)
+    except Exception:
+        return None
+
+
 def _time_launches(launch, s, reps):
     for _ in range(5):
         launch()
@@ -111,12 +121,21 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
     ach = flops / (ms * 1e-3) / 1e12
     peak = PEAK_BF16_MFMA_TFLOPS if half else PEAK_F32_MFMA_TFLOPS
     # the library's default route for this shape: direct implicit GEMM (both dtypes at < 96 channels)
-    kname = ('conv_igemm_h<%s>' % dtype) if half else 'conv_igemm_f32'
-    key = {'f32': 'conv_igemm_f32', 'bf16': 'conv3x3_lds_bf16'}.get(dtype)
-    return {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
-            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
-            "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
+    # the library's default route for this shape: f32 = direct implicit GEMM (linear-address form), 16-bit = the
+    # register-blocked LDS kernel of conv_t4.hip
+    kname = ('conv3x3_t4_kernel<%s>' % dtype) if half else 'conv_igemm_f32'
+    key = {'f32': 'conv_igemm_f32', 'bf16': 'conv3x3_t4_bf16'}.get(dtype)
+    out = {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
+           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+           "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
+           "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
+    rec = in_step(dtype)
+    if rec and N == 20 and C == 48 and H == 96 and rec.get('dominant_avg_us'):
+        # the same launch inside the training step (committed trace; other stream lanes contend for the chip)
+        out["in_step_avg_us"] = rec['dominant_avg_us']
+        out["frac_in_step"] = round(flops / (rec['dominant_avg_us'] * 1e-6) / 1e12 / peak, 4)
+        out["in_step_source"] = rec.get('source')
+    return out
 
 
 def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
@@ -170,7 +189,8 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
     achb = nb / (msb * 1e-3) / 1e9
     bwd = {"bound": "hbm", "kernel": "dcn_bwd_kernel (%dch, %d groups, %dx%d, B=%d, %s; 64-bit fixed-point LDS scatter, f32 atomic flush)" % (C, G, H, W, B, dtype),
            "achieved": round(achb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achb / PEAK_HBM_GBS, 4),
-           "traffic": None, "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
+           "traffic": pmc_traffic('dcn_bwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
+           "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
     # the deterministic (64-bit fixed-point) form of the same backward: zero + |dy| max + kernel + conversion pass
     gxd = torch.empty(B, H, W, C, device=dev, dtype=tdt)
     ws = torch.empty(L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C) // 4 + 4, device=dev)
@@ -349,17 +369,25 @@ def main():
             trainer.step(kf, sup, joints, vis)
         barrier()
         dt = time.perf_counter() - t0
+        rank_ms = None
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
+            # every rank's own wall time of the timed region: a straggler shows as max >> min (value uses the max)
+            ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(ts, torch.tensor([dt], device=dev, dtype=torch.float64))
+            per = [t.item() for t in ts]
+            dt = max(per)
+            rank_ms = [round(v / steps * 1e3, 3) for v in per]
         loss = trainer.loss_value()
-        info = {"pck_final": round(trainer.accuracy()[0][1], 4), "pck_kf_backbone": round(trainer.accuracy()[1][1], 4)}
+        info = {"pck_final": round(trainer.accuracy()[0][1], 4), "pck_kf_backbone": round(trainer.accuracy()[1][1], 4),
+                "conv_flops_per_step": int(trainer.conv_flops)}
+        if rank_ms is not None:
+            info.update({"rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms), "rank_ms_per_step": rank_ms})
         if world > 1:
             info.update({"dist_ranks": dist.get_world_size(), "dist_backend": dist.get_backend(),
                          "ddp_plan": plan_name, "ddp_plan_fallbacks": plan_notes, "bucket_mb": args.bucket_mb,
                          "buckets": len(trainer.reducer.ranges()),
-                         "gradient_bytes": int(trainer.grad.numel() * 4), **trainer.plan_summary(),
+                         "gradient_bytes": int(trainer.grad.numel() * 4),
+                         "gradient_payload": os.environ.get('FAMI_DDP_PAYLOAD', 'f32'), **trainer.plan_summary(),
                          "allreduce_ms_standalone": round(trainer.measure_allreduce_ms(), 3)})
         del trainer, model
         torch.cuda.empty_cache()
@@ -370,8 +398,8 @@ def main():
     other = None
     if args.also and args.also != primary and world == 1:      # the extra dtype line is a single-GPU report
         o_steps = max(3, min(args.steps, 20))
-        o_dt, o_loss, _ = timed_run(args.also, o_steps, max(2, min(args.warmup, 5)))
-        other = (args.also, o_dt, o_loss, o_steps)
+        o_dt, o_loss, o_info = timed_run(args.also, o_steps, max(2, min(args.warmup, 5)))
+        other = (args.also, o_dt, o_loss, o_steps, o_info)
     args.dtype = primary
     frozen = None
     if world == 1 and not args.freeze_backbone and not args.no_frozen:
@@ -399,9 +427,21 @@ def main():
         C, Hf, Wf = args.width, args.img_h // 4, args.img_w // 4
         G = 12 if C % 48 == 0 else C // 4
         out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype, C=C, H=Hf, W=Wf)
+
+        def step_roofline(dtype, flops, ms):
+            # every nn.Conv2d FLOP of the step (forward + input gradient + weight gradient, counted by the engine as the
+            # launches are enqueued) over the measured step time, against the dtype's dense MFMA peak
+            peak = PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+            r = {"bound": "mfma", "conv_flops_per_step": int(flops), "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
+                 "peak": peak, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
+            rec = in_step(dtype)
+            if rec:
+                r.update({k: rec[k] for k in ('launches_per_step', 'idle_share', 'kernel_time_ms_per_step', 'source') if k in rec})
+            return r
+        out["roofline_step"] = step_roofline(args.dtype, info["conv_flops_per_step"], dt / args.steps * 1e3)   # per rank
         out["roofline_dcn"], out["roofline_dcn_bwd"] = dcn_roofline(dev, args.batch, args.dtype, C=C, G=G, H=Hf, W=Wf)
         if other is not None:
-            o_dtype, o_dt, o_loss, o_steps = other
+            o_dtype, o_dt, o_loss, o_steps, o_info = other
             out["also_" + o_dtype] = {
                 "note": "same workload with %s activation storage / conv MFMA (fp32 accumulation, master weights, "
                         "losses); not the parity-gated configuration" % o_dtype if o_dtype != 'f32' else
@@ -409,6 +449,7 @@ def main():
                 "value": round(args.batch * world * o_steps / o_dt, 3), "unit": "clips/s", "steps": o_steps,
                 "ms_per_step": round(o_dt / o_steps * 1e3, 3), "loss": round(o_loss, 6),
                 "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype, C=C, H=Hf, W=Wf),
+                "roofline_step": step_roofline(o_dtype, o_info["conv_flops_per_step"], o_dt / o_steps * 1e3),
                 "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype, C=C, G=G, H=Hf, W=Wf)[0]}
         if frozen is not None:
             f_dt, f_loss, f_steps = frozen

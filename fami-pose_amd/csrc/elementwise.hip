@@ -317,6 +317,19 @@ static int axpby_impl(const T* a, const T* b, T* out, long n, float alpha, float
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
+// dst[i] = (float)src[i]: the 16-bit gradient payload of the data-parallel exchange widened back into the fp32 arena
+template <typename T>
+__global__ void widen_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = ld1(src + i);
+}
+template <typename T>
+static int widen_impl(const T* src, float* dst, long n, hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(src && dst && n > 0, nm, "bad argument");
+  hipLaunchKernelGGL(widen_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, src, dst, n);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
 template <typename T>
 static int cast_add_impl(const float* src, T* dst, long n, int accumulate, hipStream_t s, const char* nm) {
   FAMI_REQUIRE(src && dst && n > 0, nm, "bad argument");
@@ -392,6 +405,9 @@ extern "C" {
   }                                                                                                                    \
   int fami_cast_add_##sfx(const float* src, T* dst, long n, int accumulate, hipStream_t s) {                           \
     return cast_add_impl<T>(src, dst, n, accumulate, s, "fami_cast_add_" #sfx);                                        \
+  }                                                                                                                    \
+  int fami_widen_##sfx(const T* src, float* dst, long n, hipStream_t s) {                                              \
+    return widen_impl<T>(src, dst, n, s, "fami_widen_" #sfx);                                                          \
   }                                                                                                                    \
   int fami_fill_##sfx(T* out, long n, float v, hipStream_t s) { return fill_impl<T>(out, n, v, s, "fami_fill_" #sfx); }\
   /* term k: x[k] [N, H>>shift[k], W>>shift[k], C]; mean[k]==null => identity term.  Arrays of length nterms (<=4). */ \

@@ -113,6 +113,7 @@ class Engine:
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.nfused = {'fwd': 0, 'bwd': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
+        self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
         # 16 at a time per stream (fami_wgrad_reduce_batch) at the joins / bucket boundaries / the end of backward --
         # 303 tiny launches per step otherwise sit between every weight gradient and the next kernel of its lane
@@ -522,6 +523,8 @@ class Engine:
         Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         wp = self.packed(weight, 0)
+        flops = 2 * N * Ho * Wo * Ci * Co * kh * kw
+        self.conv_flops += flops
         if stats is not None:
             assert not relu and not out_f32
             y = self.act(N, Ho, Wo, Co)
@@ -550,6 +553,7 @@ class Engine:
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     self.wgrad(x.data, dy, g, geo, acc)
+                    self.conv_flops += flops
                 if self.rq(bias):
                     g, acc = self.pgrad(bias)
                     ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
@@ -557,6 +561,7 @@ class Engine:
                 if saved is not None:
                     self.stream = saved
                 if x.requires_grad:
+                    self.conv_flops += flops
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
                     rec = x.bnrec

@@ -186,7 +186,15 @@ class BucketReducer:
     gradient contribution has been enqueued; once every parameter overlapping a slice is complete the slice
     is handed to `on_bucket(lo, hi)` (an async all-reduce, or a graph cut during capture)."""
 
-    def __init__(self, grad, table, bucket_elems, process_group=None):
+    def __init__(self, grad, table, bucket_elems, process_group=None, payload=None, cast=None, widen=None):
+        """payload: None (the fp32 slices themselves are reduced in place) or a 16-bit torch dtype: a slice is cast into a
+        16-bit mirror of the arena, the mirror slice is all-reduced (half the bytes over xGMI: 129 MB instead of 258.6 MB
+        per step for W48) and widened back into the fp32 arena in wait().  cast(src_f32, dst_16) / widen(src_16, dst_f32):
+        the device kernels of the caller (Trainer: fami_cast_add_* / fami_widen_*); default = torch copies (CPU tests)."""
+        self.payload = payload
+        self._cast = cast or (lambda src, dst: dst.copy_(src))
+        self._widen = widen or (lambda src, dst: dst.copy_(src))
+        self._mirror = None
         self.grad = grad
         self.offset = {id(p): (o, n) for p, o, n in table}
         self.total = grad.numel()
@@ -230,13 +238,23 @@ class BucketReducer:
             self._next += 1
 
     def allreduce(self, lo, hi):
-        wk = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self.works.append(wk)
+        if self.payload is None:
+            wk = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.works.append((wk, None))
+            return wk
+        if self._mirror is None:
+            self._mirror = torch.empty(self.total, dtype=self.payload, device=self.grad.device)
+        buf = self._mirror[lo:hi]
+        self._cast(self.grad[lo:hi], buf)
+        wk = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self.works.append((wk, (lo, hi)))
         return wk
 
     def wait(self):
-        for wk in self.works:
+        for wk, rng in self.works:
             wk.wait()
+            if rng is not None:
+                self._widen(self._mirror[rng[0]:rng[1]], self.grad[rng[0]:rng[1]])
         self.works = []
 
 
@@ -280,7 +298,14 @@ class Trainer:
         # force_ddp: run the bucketed all-reduce path even with one rank (exercises the hooks / RCCL stream ordering
         # on a single GPU; an all-reduce over one rank is the identity)
         self.ddp = self.world > 1 or (force_ddp and dist.is_initialized())
-        self.reducer = BucketReducer(self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg)
+        # FAMI_DDP_PAYLOAD = f32 (default) | bf16 | f16: gradient bytes on the wire (the sum over ranks is then taken in
+        # that type; master gradients, the 1/world scale and Adam stay fp32)
+        pay = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[os.environ.get('FAMI_DDP_PAYLOAD', 'f32')]
+        sfx = {torch.bfloat16: 'bf16', torch.float16: 'f16'}.get(pay)
+        self.reducer = BucketReducer(
+            self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg, payload=pay,
+            cast=lambda src, dst: lib().call('fami_cast_add_' + sfx, _p(src), _p(dst), src.numel(), 0, _stream(self.dev)),
+            widen=lambda src, dst: lib().call('fami_widen_' + sfx, _p(src), _p(dst), src.numel(), _stream(self.dev)))
         self.reducer.world = self.world
         self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype)
         # data-parallel launch plan: 'overlap' (default) = hipGraph segments cut at the bucket boundaries with each
@@ -389,6 +414,7 @@ class Trainer:
         if packed_bwd is not None:
             eng.wait_main(packed_bwd)
         eng.backward(on_params_done=hook)
+        self.conv_flops = eng.conv_flops        # nn.Conv2d FLOPs of one step (forward + both gradients; reporting)
         if on_bucket is not None:
             self._flushing = True
             try:
@@ -398,6 +424,7 @@ class Trainer:
         return outs
 
     _flushing = False
+    conv_flops = 0
 
     def _unscale(self):
         """gradient arena *= 1 / (world * loss_scale): the data-parallel mean and the static loss scale in one pass."""

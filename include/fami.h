@@ -168,6 +168,9 @@ int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alp
 int fami_fill_f32(float* out, long n, float v, fami_stream_t stream);
 /* dst (=|+=) src : fp32 accumulation buffer folded into an activation-typed gradient */
 int fami_cast_add_f32(const float* src, float* dst, long n, int accumulate, fami_stream_t stream);
+/* dst[i] = (float)src[i] (fami_widen_bf16 / _f16: the 16-bit gradient payload of the data-parallel all-reduce widened
+ * back into the fp32 gradient arena; the _f32 instance is a copy) */
+int fami_widen_f32(const float* src, float* dst, long n, fami_stream_t stream);
 /* out[i] (=|+=) in[i] * (sx, sy) over n (x, y) pairs: legacy kornia.warp_affine translation scaling and its gradient
  * (kornia <= 0.4 default align_corners=False at Alignment_V15.py:135: a shift of t pixels samples at x - t*W/(W-1)). */
 int fami_scale_pairs_f32(const float* in, float* out, long n, float sx, float sy, int accumulate, fami_stream_t stream);
@@ -354,6 +357,7 @@ int fami_copy_channels_bf16(const fami_bf16_t* src, fami_bf16_t* dst, long P, in
                             int dst_off, int Cc, int accumulate, fami_stream_t stream);
 int fami_axpby_bf16(const fami_bf16_t* a, const fami_bf16_t* b, fami_bf16_t* out, long n, float alpha, float beta,
                     fami_stream_t stream);
+int fami_widen_bf16(const fami_bf16_t* src, float* dst, long n, fami_stream_t stream);
 int fami_cast_add_bf16(const float* src, fami_bf16_t* dst, long n, int accumulate, fami_stream_t stream);
 int fami_fill_bf16(fami_bf16_t* out, long n, float v, fami_stream_t stream);
 int fami_fuse_sum_bf16(int nterms, const fami_bf16_t* const* x, const float* const* mean, const float* const* invstd,
@@ -452,6 +456,7 @@ int fami_copy_channels_f16(const fami_f16_t* src, fami_f16_t* dst, long P, int C
                             int dst_off, int Cc, int accumulate, fami_stream_t stream);
 int fami_axpby_f16(const fami_f16_t* a, const fami_f16_t* b, fami_f16_t* out, long n, float alpha, float beta,
                     fami_stream_t stream);
+int fami_widen_f16(const fami_f16_t* src, float* dst, long n, fami_stream_t stream);
 int fami_cast_add_f16(const float* src, fami_f16_t* dst, long n, int accumulate, fami_stream_t stream);
 int fami_fill_f16(fami_f16_t* out, long n, float v, fami_stream_t stream);
 int fami_fuse_sum_f16(int nterms, const fami_f16_t* const* x, const float* const* mean, const float* const* invstd,

@@ -72,6 +72,18 @@ def _worker(rank, world, port, q):
         mean = grad / world
         assert torch.allclose(mean, torch.stack(both).mean(0), atol=1e-6)
 
+        # 16-bit payload (FAMI_DDP_PAYLOAD=bf16): the wire carries bf16 slices, the sum is taken in bf16, the arena stays
+        # fp32 -- exactly round(round(g0) + round(g1)) per element, i.e. within 2^-8 of the fp32 sum's magnitude
+        grad16 = local.clone()
+        red16 = BucketReducer(grad16, table, bucket_elems=128, payload=torch.bfloat16)
+        hook16 = red16.begin()
+        for i in range(len(sizes) - 1, -1, -1):
+            hook16([params[i]])
+        red16.wait()
+        want16 = (both[0].to(torch.bfloat16) + both[1].to(torch.bfloat16)).float()
+        assert torch.equal(grad16, want16)
+        assert (grad16 - want).abs().max() <= 2.0 ** -7 * want.abs().max()
+
         # parameter / buffer broadcast from rank 0 (what Trainer.broadcast_parameters does with the flat arena)
         flat = torch.full((total,), float(rank + 1))
         dist.broadcast(flat, src=0)
