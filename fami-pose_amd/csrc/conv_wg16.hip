@@ -18,10 +18,20 @@
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// two transposing reads (4 K-values each, one 64-bit register pair) -> one 8-value MFMA fragment.  Assembled from DWORDS:
+// built element by element from the 16-bit lanes the compiler emitted a v_perm / shift-or per half-word -- with 14 reads
+// per K step the kernel was instruction-issue bound (SQ_ACTIVE_INST_ANY 45 % of the wave cycles, profiles/r03_pmc_wgrad16)
+template <typename X8>
+__device__ __forceinline__ X8 frag_of(s16x4 lo, s16x4 hi) {
+  const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+  const u32x4 t = {a.x, a.y, b.x, b.y};
+  return __builtin_bit_cast(X8, t);
+}
 
 #define WG16_THREADS 512
 #define WG16_WAVES 8
-#define WG16_PM 10   // 16-byte staging pieces per thread and run
+#define WG16_XSWEEPS 8   // patch positions per thread and run (512 / (2*CIT) positions per sweep: >= 85)
 
 struct Wg16Args {
   const void* x;    // [N,H,W,Ci]
@@ -51,9 +61,6 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   int g, byl;
   xcd_tile(1, g, byl);
   const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
-  char* xt = smem;                      // patch [(rows + 2) * PW][xps]
-  char* yt = smem + p.xbytes;           // [BT*16][yps]
-  char* zrow = yt + p.BT * 16 * p.yps;  // 32 zero bytes
   const int HW = p.H * p.W;
 
   // pairs of this wave: q = wave + 8*i -> (ci tile, tap); LDS offset of the pair relative to a pixel's own position
@@ -75,83 +82,113 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 
   const char* xg = reinterpret_cast<const char*>(p.x) + (long)cib * (CIT * 32);
   const char* yg = reinterpret_cast<const char*>(p.dy) + (long)cob * (COT * 32);
-  u32x4 pr[WG16_PM];
-  // geometry of run b (wave-uniform): frame, first / last pixel in the frame, first patch row
-  auto run_geo = [&](int b, int& img, int& q0, int& q1, int& y0, int& nx) {
+  // ---- staging plan, computed ONCE per thread: the kernel was instruction-issue bound (SQ_ACTIVE_INST_ANY 45 % of the
+  // wave cycles), and the per-piece index arithmetic of every run's fetch (two divisions per 16-byte piece) was half of it.
+  // A thread owns piece xpc of patch positions xp0, xp0 + XS, ... and piece ypc of dY pixels yp0, yp0 + YS, ...: its patch
+  // (row, column) per sweep does not depend on the run, so a run's fetch is one add and two compares per piece.
+  constexpr int XS = WG16_THREADS / XPC, YS = WG16_THREADS / YPC;     // positions / pixels per sweep
+  constexpr int NXS = WG16_XSWEEPS, NYS = (256 + YS - 1) / YS;
+  const int xpc = tid % XPC, xp0 = tid / XPC, ypc = tid % YPC, yp0 = tid / YPC;
+  const bool xthr = xp0 < XS, ythr = yp0 < YS;                        // the last threads of the block own no piece
+  int xrow[NXS], xgo[NXS];   // patch row of the sweep's position; global byte offset relative to the run's first patch row
+  {
+    int r = xp0 / p.PW, c = xp0 - r * p.PW;
+    const int dr = XS / p.PW, dc = XS - dr * p.PW;
+#pragma unroll
+    for (int u = 0; u < NXS; ++u) {
+      const bool colok = c >= 1 && c <= p.W;                          // columns 0 and W + 1 are the zero border
+      xrow[u] = (xthr && colok) ? r : 0x40000000;                     // never a valid row
+      xgo[u] = ((r * p.W + c - 1) * p.Ci) * 2 + xpc * 16;
+      c += dc;
+      r += dr;
+      if (c >= p.PW) {
+        c -= p.PW;
+        r += 1;
+      }
+    }
+  }
+  const int ygo = (yp0 * p.Co) * 2 + ypc * 16;
+  u32x4 prx[NXS], pry[NYS];
+  // geometry of run b (wave-uniform): frame, first / last pixel in the frame, first patch row, patch rows
+  auto run_geo = [&](int b, int& img, int& q0, int& q1, int& y0, int& nrow) {
     img = b / p.bpf;
     q0 = (b - img * p.bpf) * p.BT * 16;
     q1 = min(q0 + p.BT * 16, HW);
     y0 = q0 / p.W;
-    const int y1 = (q1 - 1) / p.W;
-    nx = (y1 - y0 + 3) * p.PW * XPC;   // patch pieces
+    nrow = (q1 - 1) / p.W - y0 + 3;
   };
   auto fetch = [&](int b) {
-    int img, q0, q1, y0, nx;
-    run_geo(b, img, q0, q1, y0, nx);
-    const int ny = (q1 - q0) * YPC;
+    int img, q0, q1, y0, nrow;
+    run_geo(b, img, q0, q1, y0, nrow);
+    const char* xr = xg + ((long)(img * p.H + y0 - 1) * p.W) * p.Ci * 2;   // first patch row (may lie above the image)
 #pragma unroll
-    for (int u = 0; u < WG16_PM; ++u) {
-      const int i = tid + u * WG16_THREADS;
-      pr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < nx) {
-        const int pos = i / XPC, pc = i - pos * XPC;
-        const int r = pos / p.PW, c = pos - r * p.PW;
-        const int gy = y0 - 1 + r, gx = c - 1;
-        if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-          pr[u] = *reinterpret_cast<const u32x4*>(xg + ((long)(img * p.H + gy) * p.W + gx) * p.Ci * 2 + pc * 16);
-      } else if (i < nx + ny) {
-        const int k = i - nx;
-        const int px = k / YPC, pc = k - px * YPC;
-        pr[u] = *reinterpret_cast<const u32x4*>(yg + ((long)img * HW + q0 + px) * p.Co * 2 + pc * 16);
-      }
+    for (int u = 0; u < NXS; ++u) {
+      prx[u] = u32x4{0u, 0u, 0u, 0u};
+      if (xrow[u] < nrow && (unsigned)(y0 - 1 + xrow[u]) < (unsigned)p.H) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+    }
+    const char* yr = yg + ((long)img * HW + q0) * p.Co * 2;
+    const int M = q1 - q0;
+#pragma unroll
+    for (int u = 0; u < NYS; ++u) {
+      pry[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ythr && yp0 + u * YS < M) pry[u] = *reinterpret_cast<const u32x4*>(yr + ygo + (long)u * YS * p.Co * 2);
     }
   };
+  // Two LDS buffers: while run b is multiplied out of one, run b+1's registers (fetched at the top of the run) are
+  // written into the other between the two halves of the K loop -- the global-load latency and the LDS stores sit
+  // behind MFMAs, and the workgroup meets once per run.  dY rows past the run's last pixel are stored as zeros, so the
+  // partial last K step needs no select on the dY side.
+  const int yrows = ((p.BT * 16 + 31) >> 5) << 5;     // dY rows of a buffer: whole K steps (the tail rows are zeros)
+  const int bufsz = p.xbytes + yrows * p.yps;         // one buffer: patch + dY rows (16-byte multiple)
+  auto stash = [&](int b, char* buf) {                 // registers of run b -> LDS
+    int img, q0, q1, y0, nrow;
+    run_geo(b, img, q0, q1, y0, nrow);
+    const int npos = nrow * p.PW;
+#pragma unroll
+    for (int u = 0; u < NXS; ++u)
+      if (xthr && xp0 + u * XS < npos) *reinterpret_cast<u32x4*>(buf + (xp0 + u * XS) * p.xps + xpc * 16) = prx[u];
+#pragma unroll
+    for (int u = 0; u < NYS; ++u)
+      if (ythr && yp0 + u * YS < yrows) *reinterpret_cast<u32x4*>(buf + p.xbytes + (yp0 + u * YS) * p.yps + ypc * 16) = pry[u];
+  };
   const int b0 = g * p.nsub;
-  if (b0 < p.NB) fetch(b0);
+  if (b0 < p.NB) {
+    fetch(b0);
+    stash(b0, smem);
+  }
+  __syncthreads();
+  const int dyq = 32 / p.W, dxr = 32 - dyq * p.W;
   for (int sub = 0; sub < p.nsub; ++sub) {
     const int b = b0 + sub;
     if (b >= p.NB) break;
-    int img, q0, q1, y0, nx;
-    run_geo(b, img, q0, q1, y0, nx);
-    const int M = q1 - q0, ny = M * YPC;
-    if (sub > 0) __syncthreads();   // the previous run has been consumed
-#pragma unroll
-    for (int u = 0; u < WG16_PM; ++u) {
-      const int i = tid + u * WG16_THREADS;
-      if (i < nx) {
-        const int pos = i / XPC, pc = i - pos * XPC;
-        *reinterpret_cast<u32x4*>(xt + pos * p.xps + pc * 16) = pr[u];
-      } else if (i < nx + ny) {
-        const int k = i - nx;
-        const int px = k / YPC, pc = k - px * YPC;
-        *reinterpret_cast<u32x4*>(yt + px * p.yps + pc * 16) = pr[u];
-      }
-    }
-    if (tid < 2) *reinterpret_cast<u32x4*>(zrow + tid * 16) = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    if (sub + 1 < p.nsub && b + 1 < p.NB) fetch(b + 1);   // in flight while this run is multiplied
+    int img, q0, q1, y0, nrow;
+    run_geo(b, img, q0, q1, y0, nrow);
+    const int M = q1 - q0;
+    char* xt = smem + (sub & 1) * bufsz;
+    const bool more = sub + 1 < p.nsub && b + 1 < p.NB;
+    if (more) fetch(b + 1);   // in flight while the first half of this run is multiplied
 
     // this lane's two pixels of the current K step (local index pl = ks*32 + kq*8 + h*4 + rsel): image coordinates kept
-    // incrementally (a K step advances a pixel by 32: dyq rows + dxr columns, one conditional carry)
-    int py[2], pxx[2];
+    // incrementally (a K step advances a pixel by 32: dyq rows + dxr columns, one conditional carry); the dY address
+    // advances by 32 rows per step
+    int py[2], pxx[2], pl[2], ya[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int q = q0 + kq * 8 + h * 4 + rsel;
+      pl[h] = kq * 8 + h * 4 + rsel;
+      const int q = q0 + pl[h];
       py[h] = q / p.W;
       pxx[h] = q - py[h] * p.W;
+      ya[h] = p.xbytes + pl[h] * p.yps + piece * 8;
     }
-    const int dyq = 32 / p.W, dxr = 32 - dyq * p.W;
     const int ksteps = (M + 31) >> 5;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      int pl[2], xb[2];
-      bool pin[2];
+    auto kstep = [&]() {
+      int xb[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        pl[h] = ks * 32 + kq * 8 + h * 4 + rsel;
-        pin[h] = pl[h] < M;
-        // patch position of the pixel; pixels past the run contribute through a zero dY row, so X may be anything in range
-        const int yy = pin[h] ? py[h] - y0 + 1 : 1, xx = pin[h] ? pxx[h] + 1 : 1;
-        xb[h] = (yy * p.PW + xx) * p.xps;
+        // pixels past the run meet a zero dY row; their X address only has to stay inside the patch
+        const bool pin = pl[h] < M;
+        xb[h] = pin ? ((py[h] - y0 + 1) * p.PW + pxx[h] + 1) * p.xps : (p.PW + 1) * p.xps;
+        pl[h] += 32;
         pxx[h] += dxr;
         py[h] += dyq;
         if (pxx[h] >= p.W) {
@@ -162,24 +199,27 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
       hx8 bfr[COT];
 #pragma unroll
       for (int c = 0; c < COT; ++c) {
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(pin[0] ? yt + pl[0] * p.yps + c * 32 + piece * 8 : zrow + piece * 8));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(pin[1] ? yt + pl[1] * p.yps + c * 32 + piece * 8 : zrow + piece * 8));
-        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfr[c] = __builtin_bit_cast(hx8, t);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[0] + c * 32));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[1] + c * 32));
+        bfr[c] = frag_of<hx8>(lo, hi);
       }
+      ya[0] += 32 * p.yps;
+      ya[1] += 32 * p.yps;
 #pragma unroll
       for (int i = 0; i < NPW; ++i) {
         if (ptap[i] < 0) continue;   // wave-uniform
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[0] + poff[i]));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[1] + poff[i]));
-        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const hx8 afr = __builtin_bit_cast(hx8, t);
+        const hx8 afr = frag_of<hx8>(lo, hi);
 #pragma unroll
         for (int c = 0; c < COT; ++c) acc[i][c] = H16<H>::mfma(afr, bfr[c], acc[i][c]);
       }
-    }
+    };
+    const int kh = (ksteps + 1) >> 1;
+    for (int ks = 0; ks < kh; ++ks) kstep();
+    if (more) stash(b + 1, smem + ((sub + 1) & 1) * bufsz);
+    for (int ks = kh; ks < ksteps; ++ks) kstep();
+    __syncthreads();   // this buffer is free, the other one is complete
   }
 
   // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [g][tap][ci][co]
@@ -218,9 +258,8 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co) {
   for (int i = 0; i < 6 && !q.BT; ++i) {
     const int bt = g_wg16_bt > 0 ? g_wg16_bt : cand[i];
     const long npos = (long)((bt * 16 + W - 2) / W + 3) * (W + 2);
-    const long pieces = npos * 2 * q.CIT + (long)bt * 16 * 2 * q.COT;
-    const size_t lds = (size_t)npos * q.xps + (size_t)bt * 16 * q.yps + 32;
-    if (pieces <= (long)WG16_PM * WG16_THREADS && lds <= 76 * 1024) {
+    const size_t lds = 2 * ((size_t)npos * q.xps + (size_t)((bt * 16 + 31) / 32 * 32) * q.yps);   // two buffers
+    if (npos <= (long)WG16_XSWEEPS * (WG16_THREADS / (2 * q.CIT)) && bt * 16 <= 256 && lds <= 150 * 1024) {
       q.BT = bt > FT ? FT : bt;
       q.xbytes = (int)(npos * q.xps);
       q.lds = lds;
@@ -262,7 +301,7 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
   if (q.CIT == cit && q.COT == cot) {                                                                                     \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad16_kernel<HT, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad16_kernel<HT, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
       attr = true;                                                                                                        \
     }                                                                                                                     \
     hipLaunchKernelGGL((conv_wgrad16_kernel<HT, cit, cot>), grid, dim3(WG16_THREADS), q.lds, s, a);                       \

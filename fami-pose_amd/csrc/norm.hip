@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
 #define BN_SMALL_P 16384
 // one workgroup per 4 channels is serial over pixels: measured slower than the three-launch path for everything but
 // tiny tensors (the translation regressor's 16-channel maps below 24x18), where launch count is all that matters
-static inline bool bn_small_ok(long P, int C) { return P * C <= 32768; }
+static long g_bn_small_elems = 32768;   // fami_bn_tune_small: tensors up to this many elements take the one-launch kernels
+static inline bool bn_small_ok(long P, int C) { return P * C <= g_bn_small_elems; }
 
 __device__ __forceinline__ f32x4 block_sum4(f32x4 v, float* sm) {  // sm: 4 * 4 floats
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -937,6 +938,7 @@ extern "C" {
 
 long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
 long fami_bn_slots_bytes(int C) { return bn_slots_bytes(C); }
+int fami_bn_tune_small(long elems) { g_bn_small_elems = elems < 0 ? 32768 : elems; return FAMI_OK; }
 int fami_bn_is_small(long P, int C) { return bn_small_ok(P, C) ? 1 : 0; }
 long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
 

@@ -139,6 +139,8 @@ int fami_bn_bwd2_f32(const float* dy, const float* x, const float* y, const floa
  * already applied.  fami_bn_is_small: tensors the one-launch small-tensor kernel takes (no point fusing those).
  * fami_bn_finalize_slots_f32: mean / invstd / running update only (HighResolutionModule fuse terms, hrnet.py:151-172). */
 int fami_bn_is_small(long P, int C);
+/* benchmarks: element count up to which a tensor takes the one-launch small-tensor kernels (< 0: default 32768) */
+int fami_bn_tune_small(long elems);
 int fami_bn_apply_slots_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
                             float* mean, float* invstd, float* running_mean, float* running_var, long P, int C,
                             int relu, float momentum, float eps, void* slots, fami_stream_t stream);

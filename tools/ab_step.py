@@ -21,6 +21,8 @@ for st in states:
             os.environ[k] = v
         elif k == 'tile':                     # tile=mt:nt:ks -> fami_conv_tune(mt, nt, ks)
             L.fami_conv_tune(*[int(t) for t in v.split(':')])
+        elif k == 'bnsmall':
+            L.fami_bn_tune_small(int(v))
         else:
             getattr(L, 'fami_conv_tune_' + k)(int(v))
     tr = Trainer(bench.build(args, dev), lr=1e-3, use_mi=os.environ.get('AB_NO_MI') != '1', use_graph=True, targets_from_joints=True)
