@@ -14,6 +14,7 @@
 //   * 8 waves per workgroup: 27 pairs at 48 input channels are 4+4+4+3+3+3+3+3 instead of 7+7+7+6 (48 instead of 84
 //     accumulator registers), twice the loads in flight per workgroup.
 #include "conv_epi.h"
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -181,7 +182,11 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
       ya[h] = p.xbytes + pl[h] * p.yps + piece * 8;
     }
     const int ksteps = (M + 31) >> 5;
-    auto kstep = [&]() {
+    // one K step with NP live pairs (compile-time: the per-pair "is this slot used" branch kept every pair's LDS reads
+    // behind the previous pair's MFMAs -- ds_read x2, s_waitcnt, 3 MFMAs, four times over).  All fragments of the step
+    // are requested first, then multiplied.
+    auto kstep = [&](auto npc) {
+      constexpr int NP = decltype(npc)::value;
       int xb[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -196,29 +201,33 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
           py[h] += 1;
         }
       }
-      hx8 bfr[COT];
+      hx8 bfr[COT], afr[NP];
 #pragma unroll
       for (int c = 0; c < COT; ++c) {
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[0] + c * 32));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[1] + c * 32));
         bfr[c] = frag_of<hx8>(lo, hi);
       }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[0] + poff[i]));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[1] + poff[i]));
+        afr[i] = frag_of<hx8>(lo, hi);
+      }
       ya[0] += 32 * p.yps;
       ya[1] += 32 * p.yps;
 #pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        if (ptap[i] < 0) continue;   // wave-uniform
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[0] + poff[i]));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[1] + poff[i]));
-        const hx8 afr = frag_of<hx8>(lo, hi);
+      for (int i = 0; i < NP; ++i)
 #pragma unroll
-        for (int c = 0; c < COT; ++c) acc[i][c] = H16<H>::mfma(afr, bfr[c], acc[i][c]);
-      }
+        for (int c = 0; c < COT; ++c) acc[i][c] = H16<H>::mfma(afr[i], bfr[c], acc[i][c]);
     };
+    const bool full = ptap[NPW - 1] >= 0;   // wave-uniform: does this wave use its last pair slot?
     const int kh = (ksteps + 1) >> 1;
-    for (int ks = 0; ks < kh; ++ks) kstep();
+    if (full) { for (int ks = 0; ks < kh; ++ks) kstep(std::integral_constant<int, NPW>()); }
+    else { for (int ks = 0; ks < kh; ++ks) kstep(std::integral_constant<int, (NPW > 1 ? NPW - 1 : 1)>()); }
     if (more) stash(b + 1, smem + ((sub + 1) & 1) * bufsz);
-    for (int ks = kh; ks < ksteps; ++ks) kstep();
+    if (full) { for (int ks = kh; ks < ksteps; ++ks) kstep(std::integral_constant<int, NPW>()); }
+    else { for (int ks = kh; ks < ksteps; ++ks) kstep(std::integral_constant<int, (NPW > 1 ? NPW - 1 : 1)>()); }
     __syncthreads();   // this buffer is free, the other one is complete
   }
 
