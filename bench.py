@@ -153,7 +153,7 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
     y = torch.empty(B, H, W, C, device=dev, dtype=tdt)
     wp = torch.empty(L.cdll.fami_dcn_packed_weight_elems(C, C, 3, 3, G), device=dev)
     s = torch.cuda.current_stream(dev)
-    L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
+    L.call('fami_dcn_pack_weight_' + dtype, w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
 
     def launch():
         L.call('fami_dcn_fwd_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(),

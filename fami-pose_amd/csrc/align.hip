@@ -165,6 +165,7 @@ struct DcnArgs {
   const T* off;       // [B,Ho,Wo,2*G*K]
   const T* msk;       // [B,Ho,Wo,G*K]   (may be null => mask 1)
   const float* wp;    // packed [KS][NTt][64][4]
+  const void* wp16;   // 16-bit image [ceil(KS/2)][NTt][64][8] (16-bit modes: contraction on the 16x16x32 matrix core)
   const float* bias;  // [Co] or null
   T* y;               // [B,Ho,Wo,Co]
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil;
@@ -197,6 +198,29 @@ __global__ void dcn_pack_w_kernel(const float* __restrict__ w, float* __restrict
       v = w[((long)co * C + g * cg + q * 4 + t) * K + tap];
     }
     wp[i] = v;
+  }
+}
+
+// 16-bit image of the same matrix for the 16x16x32 matrix-core instruction (bf16 / fp16 modes): a lane's 8 K-values are
+// its sample block of 16-step 2s (j < 4) and of 16-step 2s+1 (j >= 4) -- the two blocks the lane gathers per 32-step.
+template <typename H>
+__global__ void dcn_pack_w16_kernel(const float* __restrict__ w, H* __restrict__ wp, int Co, int C, int K, int cg, int KS32,
+                                    int NTt) {
+  const long total = (long)KS32 * NTt * 512;
+  const int CK = C * K, G = C / cg, q4 = cg >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long r = i >> 9;
+    const int nt = (int)(r % NTt), s32 = (int)(r / NTt);
+    const int kidx = ((2 * s32 + (j >> 2)) * 4 + (lane >> 4)) * 4 + (j & 3);
+    const int co = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (kidx < CK && co < Co) {
+      const int item = kidx >> 2, q = item % q4, tg = item / q4;
+      const int g = tg % G, tap = tg / G;
+      v = w[((long)co * C + g * cg + q * 4 + (j & 3)) * K + tap];
+    }
+    wp[i] = (H)v;
   }
 }
 
@@ -441,50 +465,92 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int ks0 = wave; ks0 < KS16; ks0 += 4 * PF) {
-    f32x4 bw[PF][NT];
-    f32x4 a[PF][4];
-    float w1[PF][4];  // mask*wy0, mask*wy1, wx0, wx1 (validity folded in)
+  // one sample block (4 channels of one tap / group) of this lane's pixel: the four corner loads and the folded weights
+  auto gather = [&](int ks, f32x4 (&a)[4], float (&w1)[4]) {
+    const int4 te = tapt[min(ks, KS16 - 1) * 4 + kq];
+    const bool ok = valid && ks < KS16 && (ks * 4 + kq) * 4 < CK;
+    const f32x2 ov = ld2(myoff + te.w * 2);
+    const float mv = p.msk ? ld1(mymsk + te.w) : 1.f;
+    const float py = (float)(oy0 + te.y) + ov.x;
+    const float px = (float)(ox0 + te.z) + ov.y;
+    const float fy = floorf(py), fx = floorf(px);
+    const float ly = py - fy, lx = px - fx;
+    const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, Hf1), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, Wf1);
+    const int y1 = y0 + 1, x1 = x0 + 1;
+    w1[0] = (ok && (unsigned)y0 <= (unsigned)Hm1) ? (1.f - ly) * mv : 0.f;  // modulation folded into the row weights
+    w1[1] = (ok && (unsigned)y1 <= (unsigned)Hm1) ? ly * mv : 0.f;
+    w1[2] = (unsigned)x0 <= (unsigned)Wm1 ? 1.f - lx : 0.f;
+    w1[3] = (unsigned)x1 <= (unsigned)Wm1 ? lx : 0.f;
+    const unsigned r0 = xoff + __umul24(min(max(y0, 0), Hm1), WCb), r1 = xoff + __umul24(min(max(y1, 0), Hm1), WCb);
+    const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)te.x, c1 = __umul24(min(max(x1, 0), Wm1), Cb) + (unsigned)te.x;
+    a[0] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0)));
+    a[1] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
+    a[2] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0)));
+    a[3] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
+  };
+  // corner order of the oracle's sum
+  auto blend = [&](const f32x4 (&a)[4], const float (&w1)[4]) {
+    return ((a[0] * (w1[0] * w1[2]) + a[1] * (w1[0] * w1[3])) + a[2] * (w1[1] * w1[2])) + a[3] * (w1[1] * w1[3]);
+  };
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit modes: the contraction runs on v_mfma_f32_16x16x32_{bf16,f16} -- the MATRIX pipe -- so the gather's address
+    // and bilinear arithmetic (vector pipe) overlaps it; with the exact-f32 MFMA (which IS the vector ALUs on gfx950) the
+    // two added up (profiles/r02_probe_mfma_valu_overlap.txt).  A lane's two sample blocks of a 32-step (16-steps 2s and
+    // 2s+1) are rounded to the storage type and form its 8 K-values; dcn_pack_w16_kernel orders the weights to match.
+    typedef typename H16<T>::x8 hx8;
+    typedef T hx4 __attribute__((ext_vector_type(4)));
+    const int KS32 = (KS16 + 1) >> 1;
+    const T* w16 = reinterpret_cast<const T*>(p.wp16);
+    for (int s0 = wave; s0 < KS32; s0 += 4 * PF) {
+      f32x4 a0[PF][4], a1[PF][4];
+      float wa[PF][4], wb[PF][4];
+      hx8 bw[PF][NT];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int ks = ks0 + 4 * i;
-      if (ks < KS16) {
-        const int4 te = tapt[ks * 4 + kq];
-        const bool ok = valid && (ks * 4 + kq) * 4 < CK;
-        const f32x2 ov = ld2(myoff + te.w * 2);
-        const float mv = p.msk ? ld1(mymsk + te.w) : 1.f;
-        const float py = (float)(oy0 + te.y) + ov.x;
-        const float px = (float)(ox0 + te.z) + ov.y;
-        const float fy = floorf(py), fx = floorf(px);
-        const float ly = py - fy, lx = px - fx;
-        const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, Hf1), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, Wf1);
-        const int y1 = y0 + 1, x1 = x0 + 1;
-        w1[i][0] = (ok && (unsigned)y0 <= (unsigned)Hm1) ? (1.f - ly) * mv : 0.f;  // modulation folded into the row weights
-        w1[i][1] = (ok && (unsigned)y1 <= (unsigned)Hm1) ? ly * mv : 0.f;
-        w1[i][2] = (unsigned)x0 <= (unsigned)Wm1 ? 1.f - lx : 0.f;
-        w1[i][3] = (unsigned)x1 <= (unsigned)Wm1 ? lx : 0.f;
-        const unsigned r0 = xoff + __umul24(min(max(y0, 0), Hm1), WCb), r1 = xoff + __umul24(min(max(y1, 0), Hm1), WCb);
-        const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)te.x, c1 = __umul24(min(max(x1, 0), Wm1), Cb) + (unsigned)te.x;
-        a[i][0] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0)));
-        a[i][1] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
-        a[i][2] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0)));
-        a[i][3] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
-        const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bw[i][nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      if (ks0 + 4 * i < KS16) {
-        // corner order of the oracle's sum
-        const f32x4 v = ((a[i][0] * (w1[i][0] * w1[i][2]) + a[i][1] * (w1[i][0] * w1[i][3])) + a[i][2] * (w1[i][1] * w1[i][2])) +
-                        a[i][3] * (w1[i][1] * w1[i][3]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int i = 0; i < PF; ++i) {       // PF 32-steps in flight: 8 * PF corner loads per lane before the first blend
+        const int s32 = s0 + 4 * i;
+        if (s32 < KS32) {
+          gather(2 * s32, a0[i], wa[i]);
+          gather(2 * s32 + 1, a1[i], wb[i]);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], bw[i][nt][t], acc[nt], 0, 0, 0);
+            bw[i][nt] = *reinterpret_cast<const hx8*>(w16 + ((long)s32 * p.NTt + nt) * 512 + lane * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        if (s0 + 4 * i < KS32) {
+          const hx4 v0 = __builtin_convertvector(blend(a0[i], wa[i]), hx4), v1 = __builtin_convertvector(blend(a1[i], wb[i]), hx4);
+          const hx8 av = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = H16<T>::mfma(av, bw[i][nt], acc[nt]);
+        }
+      }
+    }
+  } else {
+    for (int ks0 = wave; ks0 < KS16; ks0 += 4 * PF) {
+      f32x4 bw[PF][NT];
+      f32x4 a[PF][4];
+      float w1[PF][4];  // mask*wy0, mask*wy1, wx0, wx1 (validity folded in)
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int ks = ks0 + 4 * i;
+        if (ks < KS16) {
+          gather(ks, a[i], w1[i]);
+          const float* wb = p.wp + ((long)ks * p.NTt) * 256 + lane * 4;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bw[i][nt] = *reinterpret_cast<const f32x4*>(wb + (long)nt * 256);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        if (ks0 + 4 * i < KS16) {
+          const f32x4 v = blend(a[i], w1[i]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], bw[i][nt][t], acc[nt], 0, 0, 0);
+        }
       }
     }
   }
@@ -1389,6 +1455,10 @@ static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, size_t ld
     dcn_fwd_direct_launch<T, NT, 1, 7>(a, grid, lds_direct, s);
 }
 
+static inline long dcn_f32_image_elems(int Co, int C, int kh, int kw, int G) {
+  const long nt = fami_cdiv(Co, 16);
+  return (long)fami_cdiv((long)C * kh * kw, 16) * nt * 256 + (long)fami_cdiv((long)G * kh * kw, 16) * 4 * nt * 256;
+}
 template <typename T>
 static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp, const float* bias, T* y, int B, int H,
                         int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s,
@@ -1398,6 +1468,8 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   a.x = x; a.off = off; a.msk = msk; a.wp = wp; a.bias = bias; a.y = y;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
   a.stride = stride; a.pad = pad; a.dil = dil;
+  // the 16-bit image follows the two fp32 images (fami_dcn_packed_weight_elems); written by fami_dcn_pack_weight_bf16/_f16
+  a.wp16 = wp + dcn_f32_image_elems(Co, C, kh, kw, G);
   a.Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
   a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   a.cg = C / G;
@@ -1559,16 +1631,28 @@ static int dcn_bwd_det_impl(const T* x, const T* off, const T* msk, const T* dy,
   return FAMI_OK;
 }
 
+extern "C" int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s);
+template <typename H>
+static int dcn_pack_w16_impl(const char* nm, const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
+  const int rc = fami_dcn_pack_weight_f32(w_oihw, wp, Co, C, kh, kw, G, s);
+  if (rc != FAMI_OK) return rc;
+  const int K = kh * kw, KS32 = fami_cdiv(fami_cdiv((long)C * K, 16), 2), NTt = fami_cdiv(Co, 16);
+  H* w16 = reinterpret_cast<H*>(wp + dcn_f32_image_elems(Co, C, kh, kw, G));
+  hipLaunchKernelGGL(dcn_pack_w16_kernel<H>, dim3(fami_ew_grid((long)KS32 * NTt * 512)), dim3(256), 0, s, w_oihw, w16, Co, C, K, C / G, KS32, NTt);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
 extern "C" {
 
 long fami_dcn_bwd_det_workspace(int B, int H, int W, int C) { return (long)B * H * W * C * 8 + 16; }
 
 long fami_shift_workspace(int B) { return (long)B * 256 * 2 * (long)sizeof(float); }
 
-// two images: tap-major (dcn_fwd_kernel / dcn_fwd_direct_kernel) followed by quad-group order (dcn_fwd_win_kernel)
+// two fp32 images: tap-major (dcn_fwd_kernel / dcn_fwd_direct_kernel) followed by quad-group order (dcn_fwd_win_kernel);
+// behind them the 16-bit tap-major image of the 16-bit modes (256 floats' worth per 32-step and channel tile)
 long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G) {
   const long nt = fami_cdiv(Co, 16);
-  return (long)fami_cdiv((long)C * kh * kw, 16) * nt * 256 + (long)fami_cdiv((long)G * kh * kw, 16) * 4 * nt * 256;
+  return dcn_f32_image_elems(Co, C, kh, kw, G) + (long)fami_cdiv(fami_cdiv((long)C * kh * kw, 16), 2) * nt * 256;
 }
 
 // forward weight image (fp32 for both activation types: the contraction runs on the exact f32 MFMA)
@@ -1582,6 +1666,13 @@ int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int 
   hipLaunchKernelGGL(dcn_pack_wq_kernel, dim3(fami_ew_grid((long)NQ * 4 * NTt * 256)), dim3(256), 0, s, w_oihw, wp + total, Co, C, K, G, NQ, NTt);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_f32/quad");
   return FAMI_OK;
+}
+// the fp32 images plus the 16-bit image the bf16 / fp16 forward contracts with (wp: fami_dcn_packed_weight_elems floats)
+int fami_dcn_pack_weight_bf16(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
+  return dcn_pack_w16_impl<bf16_t>("fami_dcn_pack_weight_bf16", w_oihw, wp, Co, C, kh, kw, G, s);
+}
+int fami_dcn_pack_weight_f16(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G, hipStream_t s) {
+  return dcn_pack_w16_impl<f16_t>("fami_dcn_pack_weight_f16", w_oihw, wp, Co, C, kh, kw, G, s);
 }
 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;

@@ -920,7 +920,7 @@ class Engine:
         K = kh * kw
         n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
         wp = self.empty(n)
-        self.call('fami_dcn_pack_weight_f32', _p(weight.data), _p(wp), Co, C, kh, kw, G)
+        self.acall('fami_dcn_pack_weight', _p(weight.data), _p(wp), Co, C, kh, kw, G)   # 16-bit modes: + the 16-bit image
         y = self.act(B, H, W, Co)
         self.acall('fami_dcn_fwd', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
                    C, Co, G, kh, kw, 1, pad, dil)

@@ -208,6 +208,12 @@ int fami_shift_bilinear_bwd_f32(const float* gout, const float* src, const float
 long fami_dcn_packed_weight_elems(int Co, int C, int kh, int kw, int G);
 int fami_dcn_pack_weight_f32(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G,
                              fami_stream_t stream);
+/* the same plus the 16-bit image the bf16 / fp16 forward contracts with on the 16x16x32 matrix-core instruction (the gather's
+ * vector arithmetic then overlaps the contraction); wp: fami_dcn_packed_weight_elems floats in every case */
+int fami_dcn_pack_weight_bf16(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G,
+                              fami_stream_t stream);
+int fami_dcn_pack_weight_f16(const float* w_oihw, float* wp, int Co, int C, int kh, int kw, int G,
+                             fami_stream_t stream);
 int fami_dcn_fwd_f32(const float* x, const float* off, const float* msk, const float* wp, const float* bias, float* y,
                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,
                      fami_stream_t stream);

@@ -51,7 +51,7 @@ else:
     y = torch.randn(B, H, W, C, device=dev).to(tdt)
     if kind == 'dcn':
         wp = torch.empty(L.cdll.fami_dcn_packed_weight_elems(C, C, 3, 3, G), device=dev)
-        L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, st)
+        L.call('fami_dcn_pack_weight_' + dt, w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, st)
         fn = lambda: L.call('fami_dcn_fwd_' + dt, x.data_ptr(), off.data_ptr(), msk.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, st)
     else:
         wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
