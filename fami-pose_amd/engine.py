@@ -104,12 +104,14 @@ class Engine:
         # BatchNorm statistics folded into the neighbouring convolutions' epilogues (conv.hip EpiBN): the forward
         # statistics into the producing convolution, the backward statistics into the input-gradient convolution that
         # makes the last contribution to the BatchNorm output's gradient.  FAMI_FUSE_BN = 0 | fwd | bwd | 1 (both).
-        # Default 0: measured on MI355X (profiles/r03_fused_bn.txt) the epilogue costs what the removed pass cost --
-        # per launch +2..5 us on the forward convolution against a 4..6 us statistics kernel, +4..10 us on the input
+        # Default fwd.  Measured on MI355X (profiles/r03_fused_bn.txt): per launch the epilogue costs about what the removed
+        # pass cost -- +2..5 us on the forward convolution against a 4..6 us statistics kernel, +4..10 us on the input
         # gradient (it has to read the BatchNorm input tile) against 4..9 us -- and inside the step the stand-alone
-        # statistics kernels were already hidden behind the other stream lanes: f32 62.2 -> 63.0 ms, bf16 32.9 -> 34.6 ms
-        # (fwd only: 32.8).  Kept as a tested option.
-        fz = os.environ.get('FAMI_FUSE_BN', '0')
+        # statistics kernels were mostly hidden behind the other stream lanes.  Whole step, interleaved A/B with the
+        # round-3 kernels: forward fusion f32 62.7 -> 62.3 ms, bf16 29.1 -> 29.0 ms (neutral, ~250 launches and as many
+        # tensor reads fewer per step: on); backward fusion bf16 29.1 -> 29.3 ms, both 28.7 -> 29.1 ms (off, kept as a
+        # tested option).
+        fz = os.environ.get('FAMI_FUSE_BN', 'fwd')
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.nfused = {'fwd': 0, 'bwd': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
