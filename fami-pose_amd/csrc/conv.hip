@@ -2545,12 +2545,11 @@ static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, voi
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                            const char* name, const EpiBN& epi = epi_none()) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
-  if constexpr (SZ == 2) {
-    if (g_use_lds != 0) {   // fami_conv_tune_lds(0) still forces the direct kernels
-      const int rc = fami_try_conv3x3_t4(std::is_same<T, f16_t>::value ? 1 : 0, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu,
-                                         accumulate, out_f32, s, name, epi);
-      if (rc != 0) return rc;
-    }
+  if (g_use_lds != 0) {   // fami_conv_tune_lds(0) still forces the direct kernels
+    // register-blocked LDS kernel (conv_t4.hip): every storage type since round 3
+    const int rc = fami_try_conv3x3_t4(std::is_same<T, float>::value ? 2 : (std::is_same<T, f16_t>::value ? 1 : 0), x, wp, bias, y,
+                                       N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+    if (rc != 0) return rc;
   }
   // default: bf16 from 96 input channels up (per launch: 192 ch 18.8 vs 30.3 us, 384 ch 27.8 vs 32.4, 96 ch equal,
   // 48 ch 23.9 vs 21.8 -> direct; tools/bench_xcd.py with KNOB=lds), f32 never (slower on every shape)
@@ -2640,7 +2639,7 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
 // -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
-  if (on == 10 || on == 11 || on >= 100) {   // register-blocked 16-bit kernel (conv_t4.hip): 10 / 11 off / on;
+  if (on == 10 || on == 11 || on == 20 || on == 21 || on >= 100) {   // register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
     fami_conv_t4_tune(on);                   // 100 + tiles per band (100 = heuristic)
     return FAMI_OK;
   }

@@ -60,7 +60,7 @@ __device__ __forceinline__ f32x4 ld4_round(f32x4 v) {
 }
 
 
-// conv_t4.hip: register-blocked LDS 3x3 kernel for the 16-bit storage types.  half_kind: 0 bf16, 1 fp16.
+// conv_t4.hip: register-blocked LDS 3x3 kernel for the 16-bit storage types.  half_kind: 0 bf16, 1 fp16, 2 f32.
 // Returns 1 if launched, 0 if the shape is not eligible, < 0 on error.
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,

@@ -34,6 +34,23 @@ struct ConvT4Args {
   int patch_bytes;
 };
 
+// storage-type traits: a fragment is 16 bytes per lane in every case -- 8 K-values of a 32-channel chunk for the 16-bit
+// types (one v_mfma_f32_16x16x32), 4 K-values of a 16-channel chunk for f32 (four v_mfma_f32_16x16x4_f32, exact f32:
+// the K order (lane >> 4) * 4 + t is the same permutation on both operands, as in conv_igemm_f32).  A chunk is 64 bytes
+// of a pixel either way, so the staging, the patch layout and the weight slabs (1 KiB blocks) are shared.
+template <typename T> struct T4Traits {
+  typedef typename H16<T>::x8 frag;
+  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) { return H16<T>::mfma(w, a, acc); }
+};
+template <> struct T4Traits<float> {
+  typedef f32x4 frag;
+  __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[t], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
 #define T4_THREADS 512   // 8 waves: the staging registers per thread halve, 2 pixel tiles x NT channel tiles per wave
 #define T4_WAVES (T4_THREADS / 64)
 #define T4_MT (16 / T4_WAVES)   // pixel tiles per wave (a band has <= 16)
@@ -41,7 +58,8 @@ struct ConvT4Args {
 
 template <typename H, int NT, int PM>
 __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel(ConvT4Args p) {
-  typedef typename H16<H>::x8 frag;
+  typedef typename T4Traits<H>::frag frag;
+  constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // bytes per element, channels per chunk / per piece
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WPC = 9 * NT * 64;               // 16-byte weight pieces per chunk
   constexpr int WR = (WPC + T4_THREADS - 1) / T4_THREADS;
@@ -88,17 +106,17 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
       const int r = pos / p.PW, c = pos - r * p.PW;
       const int gy = y0 - 1 + r, gx = c - 1;
       if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-        goff[u] = (((img * p.H + gy) * p.W + gx) * p.Ci + pc * 8) * 2;
+        goff[u] = (((img * p.H + gy) * p.W + gx) * p.Ci + pc * PCN) * SZ;
     }
   }
-  const int nchunk = (p.Ci + 31) >> 5;
+  const int nchunk = (p.Ci + CHN - 1) / CHN;
   u32x4 pr[PM], wr[WR];
   auto fetch = [&](int c) {
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
       pr[u] = u32x4{0u, 0u, 0u, 0u};
       const int pc = (tid + u * T4_THREADS) & 3;
-      if (goff[u] >= 0 && c * 32 + pc * 8 < p.Ci) pr[u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
+      if (goff[u] >= 0 && c * CHN + pc * PCN < p.Ci) pr[u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
@@ -139,7 +157,7 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
       for (int mt = 0; mt < T4_MT; ++mt) {
         if (mt < mtw) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<H>::mfma(w[nt], a[mt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = T4Traits<H>::mma(w[nt], a[mt], acc[mt][nt]);
         }
       }
     }
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       const long idx = (pix0 + j) * p.Co + co0;
-      if (p.out_f32) {
+      if (p.out_f32 || SZ == 4) {
         float* yp = reinterpret_cast<float*>(p.y) + idx;
         if (p.accumulate) v += ld4(yp);
         st4(yp, v);
@@ -261,13 +279,17 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
 }
 
 // ---- register-blocked LDS kernel (16-bit): plan + launch.  Returns 1 if launched, 0 if not eligible, <0 on error.
-static int g_use_t4 = 1;   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
+static int g_use_t4 = 1;
+static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance off / on.  Off by default: per launch it wins where
+                               // the launch fills the chip (below), inside the f32 step it does not (61.2 vs 61.7 ms, and 61.4 vs 60.9
+                               // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 template <typename HT>
 static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                           int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const char* name,
                           const EpiBN& epi) {
-  if (!g_use_t4 || (Ci % 8) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  if (!g_use_t4 || ((Ci * (int)sizeof(HT)) % 16) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  if (sizeof(HT) == 4 && !g_use_t4_f32) return 0;
   int NT = 0;
   if (Co % 48 == 0) NT = 3;
   else if (Co % 64 == 0) NT = 4;
@@ -288,6 +310,12 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   if (g_t4_bt > 0) BT = g_t4_bt;
   if (BT > FT) BT = FT;
   if (BT > 16 || positions(BT) > pos_cap) return 0;
+  // f32: measured per launch (DT=f32 tools/bench_t4.py, profiles/r03_bench_t4_f32.txt) against the direct implicit GEMM:
+  // 48->48 @96x72 57.0 vs 66.9 us, 192->48 199 vs 219, 96->48 equal, but 68.9 vs 57.6 (96 ch @48x36), 68.4 vs 56.1 (192
+  // ch), 95 vs 60 (384 ch): with 16-channel chunks the low-resolution branches are 6-24 barrier-separated chunks on
+  // fewer workgroups than CUs, and the exact-f32 MFMA has no second pipe to hide the gaps under.  The f32 instance
+  // therefore takes only launches that fill the chip (>= 600 workgroups: the 96x72 maps) with 48-wide channel blocks.
+  if (sizeof(HT) == 4 && g_t4_bt == 0 && !((long)N * ((FT + BT - 1) / BT) * cblocks >= 600 && NT == 3)) return 0;
   ConvT4Args a;
   a.e = epi; a.emode = epi.slots ? epi.mode : 0;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
@@ -327,12 +355,15 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi) {
+  if (half_kind == 2)
+    return try_conv3x3_t4<float>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
   if (half_kind == 1)
     return try_conv3x3_t4<f16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
   return try_conv3x3_t4<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
 }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; }
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
+  else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;
 }

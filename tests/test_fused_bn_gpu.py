@@ -20,6 +20,8 @@ DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}
 def lds_mode(request):
     from fami_pose_amd._lib import lib
     lib().cdll.fami_conv_tune_lds(request.param)
+    if request.param:
+        lib().cdll.fami_conv_tune_lds(21)                   # ... including the (opt-in) f32 instance of the register-blocked kernel
     yield request.param
     lib().cdll.fami_conv_tune_lds(-1)
 

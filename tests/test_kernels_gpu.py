@@ -14,6 +14,8 @@ def lds_mode(request):
     """Run the convolution cases on the direct kernels and with the LDS-staged 3x3 kernel enabled."""
     from fami_pose_amd._lib import lib
     lib().cdll.fami_conv_tune_lds(request.param)
+    if request.param:
+        lib().cdll.fami_conv_tune_lds(21)                   # ... including the (opt-in) f32 instance of the register-blocked kernel
     lib().cdll.fami_conv_tune_wgrad_lds(request.param)      # 'direct' also takes the scalar-operand weight-gradient kernels
     yield request.param
     lib().cdll.fami_conv_tune_lds(-1)
