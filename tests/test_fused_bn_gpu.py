@@ -22,6 +22,7 @@ def lds_mode(request):
     lib().cdll.fami_conv_tune_lds(request.param)
     if request.param:
         lib().cdll.fami_conv_tune_lds(21)                   # ... including the (opt-in) f32 instance of the register-blocked kernel
+        lib().cdll.fami_conv_tune_lds(112)                  # (explicit tiles per band: the f32 instance otherwise only takes chip-filling launches)
     yield request.param
     lib().cdll.fami_conv_tune_lds(-1)
 
