@@ -1,6 +1,7 @@
 // Register-blocked LDS-staged 3x3 convolution (stride 1, pad 1) for bf16 / fp16 storage: forward and input gradient of the
 // HRNet branch convolutions (posetimation/backbones/hrnet.py:17-172 via layers/basic_model.py:25-63) in the 16-bit modes.
 #include "conv_epi.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ register-blocked LDS 3x3 for 16-bit storage ("t4")
 // Round-3 replacement of conv3x3_lds_kernel for the 16-bit modes.  In the graph-mode trace of the bf16 step
@@ -144,23 +145,27 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
     }
     __syncthreads();
     if (c + 1 < nchunk) fetch(c + 1);   // in flight while this chunk is multiplied
+    // the nine taps of this chunk for a wave with MW live pixel tiles (compile-time: a per-tile "is it live" branch cut the
+    // loop into 3-MFMA blocks, each behind its own LDS wait -- now a tap's fragments are requested while the previous
+    // tap's MFMAs issue)
+    auto taps = [&](auto mwc) {
+      constexpr int MW = decltype(mwc)::value;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
-      frag a[T4_MT], w[NT];
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+        frag a[MW], w[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wbuf + (tap * NT + nt) * 1024 + lane * 16);
+        for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wbuf + (tap * NT + nt) * 1024 + lane * 16);
 #pragma unroll
-      for (int mt = 0; mt < T4_MT; ++mt)
-        if (mt < mtw) a[mt] = *reinterpret_cast<const frag*>(patch + base[mt] + toff);
+        for (int mt = 0; mt < MW; ++mt) a[mt] = *reinterpret_cast<const frag*>(patch + base[mt] + toff);
 #pragma unroll
-      for (int mt = 0; mt < T4_MT; ++mt) {
-        if (mt < mtw) {
+        for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = T4Traits<H>::mma(w[nt], a[mt], acc[mt][nt]);
-        }
       }
-    }
+    };
+    if (mtw >= T4_MT) taps(std::integral_constant<int, T4_MT>());
+    else if (mtw == 1) taps(std::integral_constant<int, 1>());
   }
 
   // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
