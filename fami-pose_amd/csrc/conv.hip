@@ -38,6 +38,7 @@ struct ConvArgs {
   int KC, NTt, relu, accumulate, P;
   unsigned x_bytes, wp_bytes;  // buffer-descriptor extents (out-of-range lanes read 0)
   int xcd;                     // 1: XCD-contiguous tile order (xcd_tile)
+  int prio;                    // > 0: raise the waves' issue priority (s_setprio): f32 MFMA kernels against concurrent memory-bound lanes
   int par;                     // stride-2 dgrad (f32): waves own pixels of ONE parity class and walk only its taps
 };
 
@@ -101,6 +102,10 @@ __global__ void pack_w_kernel(const float* __restrict__ w, float* __restrict__ w
 // instead of one v_add per load and a channel-tail test.
 template <int MT, int NT, int MODE, int VEC, int KS, int ST, int LIN = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p) {
+  // The exact-f32 MFMA issues on the vector ALUs (gfx950): a BatchNorm / elementwise kernel of another stream lane that is
+  // resident on the same SIMD takes its VALU slots out of this kernel's matrix rate (in-step 77 us against 67 us alone).
+  // With a raised priority the arbiter serves these waves first; the memory-bound lanes fill the remaining slots.
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * MT * NT * 256 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the K-loop bookkeeping scalar
@@ -511,6 +516,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NT, int MODE, int KS>
 __global__ __launch_bounds__(256) void conv_igemm32_f32(ConvArgs p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);   // see conv_igemm_f32
   __shared__ float red[KS > 1 ? (4 - 4 / KS) * NT * 1024 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1483,6 +1489,7 @@ struct WgradArgs {
   unsigned x_bytes, dy_bytes;
   int xcd;
   int psplit, w8;   // linear-address kernel: number of pixel chunks; 8-wave workgroups (3x3 only)
+  int prio;         // > 0: s_setprio (see ConvArgs)
 };
 
 // dW[tap][ci][co] = sum_pixels X[pix@tap][ci] * dY[pix][co]; MFMA rows = ci, cols = co, K = pixels.
@@ -1721,6 +1728,7 @@ __global__ __launch_bounds__(576) void conv_wgrad_taps_f32(WgradArgs<T> p) {
 //    groups at W = 72); the others take a wave-uniform branch to the per-lane test.
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(1024) void conv_wgrad_taps_lin_f32(WgradArgs<T> p) {
+  if (p.prio) __builtin_amdgcn_s_setprio(3);   // see conv_igemm_f32
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c16 = lane & 15, kq = lane >> 4;
@@ -2389,6 +2397,7 @@ static void launch_reduce_plain(const float* part, float* dw, int Co, int Ci, in
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, part, dw, n, psplit, accumulate);
 }
 
+static int g_prio = 0;      // fami_conv_tune_stages(120 / 121): s_setprio in the f32 MFMA kernels off / on
 static int g_lin_conv = 1;  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
 static int g_par = 1;       // fami_conv_tune_stages(110 / 111): parity-class stride-2 input gradient off / on
 // pixel tiles of MT*16 pixels: all of them, or (stride-2 dgrad by parity class) the sum over the four classes
@@ -2446,6 +2455,7 @@ static int g_xcd = -1;  // fami_conv_tune_xcd: 0 natural tile order, 1 XCD-conti
 
 static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
+  a.prio = g_prio;
   const long n16 = pack16_elems(a.Ci, a.Co, a.kh * a.kw);
   a.wp = a.wp + n16;
   a.KC = fami_cdiv(a.Ci, 8);
@@ -2485,6 +2495,7 @@ static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
 
 static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
   a.xcd = g_xcd < 0 ? 1 : g_xcd;
+  a.prio = g_prio;
   a.par = (mode == 1 && a.sh == 1 && g_par) ? 1 : 0;
   const int vec = (a.Ci % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0);
   // (the 32x32-tile kernel has no EpiBN epilogue: a fused call takes the 16x16 kernels)
@@ -2686,6 +2697,10 @@ int fami_conv_tune_xcd(int mode) {
   return FAMI_OK;
 }
 int fami_conv_tune_stages(int stages) {
+  if (stages == 120 || stages == 121) {   // s_setprio in the f32 MFMA kernels off / on
+    g_prio = stages - 120;
+    return FAMI_OK;
+  }
   if (stages == 110 || stages == 111) {   // benchmarks / tests: parity-class stride-2 input gradient off / on
     g_par = stages - 110;
     return FAMI_OK;
@@ -2969,7 +2984,7 @@ static int wgrad_impl(const T* x, const T* dy, float* dw, float* workspace, long
   a.N = N; a.H = H; a.W = W; a.Ci = Ci;
   a.Ho = out_dim(H, kh, stride, pad, dil); a.Wo = out_dim(W, kw, stride, pad, dil); a.Co = Co;
   a.kh = kh; a.kw = kw; a.sh = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil;
-  a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks; a.xcd = g_xcd_w;
+  a.P = (int)q.P; a.chunk = q.chunk; a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks; a.xcd = g_xcd_w; a.prio = g_prio;
   const long xb = (long)N * H * W * Ci * (long)sizeof(T), yb = q.P * Co * (long)sizeof(T);
   FAMI_REQUIRE(xb < (1L << 31) && yb < (1L << 31), nm, "tensor >= 2 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
