@@ -109,7 +109,7 @@ def test_g3_hrnet_w32_config1_golden(dev):
         assert f.double().abs().sum().item() == pytest.approx(float(g['feat%d_abssum' % i]), rel=1e-4)
 
 
-@pytest.mark.parametrize('S,hw,B', [(2, (192, 128), 2), (7, (128, 96), 1), (1, (256, 192), 1)])
+@pytest.mark.parametrize('S,hw,B', [(2, (192, 128), 2), (7, (128, 96), 2), (1, (256, 192), 1)])
 def test_model_vs_oracle(dev, S, hw, B):
     """BASELINE configs[1]'s graph (3-frame W48) and generalised heads (7 / 1 supporting frames, other input sizes)
     against the CPU oracle: forward, loss, and gradients of head, DCN, translation regressor and backbone -- every
