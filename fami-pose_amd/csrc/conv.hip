@@ -2954,8 +2954,8 @@ long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, in
     const long nl = (long)f.G * Co * Ci * 9 * (long)sizeof(float);
     if (nl > need) need = nl;
   }
-  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const long nl = fami_wgrad16_slabs(N, H, W, Ci, Co) * Co * Ci * 9 * (long)sizeof(float);
+  if (kh == kw) {
+    const long nl = fami_wgrad16_slabs(N, H, W, Ci, Co, kh, stride, pad, dil) * Co * Ci * kh * kw * (long)sizeof(float);
     if (nl > need) need = nl;
   }
   return need;
@@ -3204,12 +3204,13 @@ template <typename HT>
 static int wgrad_h_impl(const char* nm, const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                         hipStream_t s) {
-  if (g_wgrad_lds && x && dy && dw && workspace && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    // round-3 kernel (conv_wg16.hip): pipelined staging, padded patch, 8 waves
-    const int G = fami_try_wgrad16(std::is_same<HT, f16_t>::value ? 1 : 0, x, dy, workspace, ws_bytes, N, H, W, Ci, Co, s, nm);
+  if (g_wgrad_lds && x && dy && dw && workspace && kh == kw) {
+    // round-3 kernel (conv_wg16.hip): pipelined staging, padded patch, 8 waves; 1x1 / 3x3, stride 1 / 2, any dilation
+    const int G = fami_try_wgrad16(std::is_same<HT, f16_t>::value ? 1 : 0, x, dy, workspace, ws_bytes, N, H, W, Ci, Co, kh, stride,
+                                   pad, dil, s, nm);
     if (G < 0) return G;
     if (G > 0) {
-      launch_reduce_taps(workspace, dw, Co, Ci, 9, G, accumulate, s);
+      launch_reduce_taps(workspace, dw, Co, Ci, kh * kw, G, accumulate, s);
       FAMI_CHECK_LAUNCH(nm);
       return FAMI_OK;
     }

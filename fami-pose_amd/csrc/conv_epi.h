@@ -67,9 +67,9 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
                         const char* name, const EpiBN& epi);
 void fami_conv_t4_tune(int on);
 
-// conv_wg16.hip: 16-bit weight gradient of the 3x3 stride-1 pad-1 convolutions.  fami_try_wgrad16 -> number of partial
+// conv_wg16.hip: 16-bit weight gradient of the centred k x k convolutions (k = 1 | 3, stride 1 | 2, any dilation).  fami_try_wgrad16 -> number of partial
 // slabs [G][9][Ci][Co] written to `part` (reduce them with the caller's slab reduce), 0 = not eligible, < 0 = error.
-long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co);
+long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil);
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
-                     int Co, hipStream_t s, const char* name);
+                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name);
 void fami_wgrad16_tune(int on);

@@ -36,24 +36,27 @@ __device__ __forceinline__ X8 frag_of(s16x4 lo, s16x4 hi) {
 
 struct Wg16Args {
   const void* x;    // [N,H,W,Ci]
-  const void* dy;   // [N,H,W,Co]
-  float* part;      // [G][9][Ci][Co]
+  const void* dy;   // [N,Ho,Wo,Co]
+  float* part;      // [G][taps][Ci][Co]
   int N, H, W, Ci, Co;
+  int Ho, Wo;       // output map (= H, W for the stride-1 same-size convolutions)
+  int st, dil, pad; // stride (1 | 2), dilation, padding (= dil for 3x3, 0 for 1x1: the kernel is centred)
   int BT;           // 16-pixel tiles per run (<= 16)
   int bpf;          // runs per frame
   int nsub;         // runs per workgroup (accumulators persist)
   int NB;           // runs in total (N * bpf)
   int ciBlocks, coBlocks;
-  int PW;           // W + 2
+  int PW;           // W + 2 * pad: patch row length in positions
   int xps, yps;     // LDS bytes per patch position / per dY pixel
   int xbytes;       // LDS bytes reserved for the patch
 };
 
-template <typename H, int CIT, int COT>
+template <typename H, int CIT, int COT, int TAPS>
 __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) {
   typedef typename H16<H>::x8 hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPW = (CIT * 9 + WG16_WAVES - 1) / WG16_WAVES;   // (ci tile, tap) pairs per wave
+  constexpr int KW = TAPS == 9 ? 3 : 1;
+  constexpr int NPW = (CIT * TAPS + WG16_WAVES - 1) / WG16_WAVES;   // (ci tile, tap) pairs per wave
   constexpr int XPC = CIT * 2, YPC = COT * 2;                     // 16-byte pieces per position / pixel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,18 +65,20 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   int g, byl;
   xcd_tile(1, g, byl);
   const int cob = byl % p.coBlocks, cib = byl / p.coBlocks;
-  const int HW = p.H * p.W;
+  const int HW = p.Ho * p.Wo;   // output pixels of a frame: the runs and the K dimension walk these
 
   // pairs of this wave: q = wave + 8*i -> (ci tile, tap); LDS offset of the pair relative to a pixel's own position
   int poff[NPW], ptap[NPW], pci[NPW];
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int q = wave + WG16_WAVES * i;
-    const bool ok = q < CIT * 9;
-    pci[i] = ok ? q / 9 : 0;
-    ptap[i] = ok ? q - pci[i] * 9 : -1;
-    const int t = ok ? ptap[i] : 4;
-    poff[i] = ((t / 3 - 1) * p.PW + (t % 3 - 1)) * p.xps + pci[i] * 32 + piece * 8;
+    const bool ok = q < CIT * TAPS;
+    pci[i] = ok ? q / TAPS : 0;
+    ptap[i] = ok ? q - pci[i] * TAPS : -1;
+    const int t = ok ? ptap[i] : 0;
+    // the patch starts at input row st*y0 - pad, column -pad: tap (ky, kx) of output pixel (y, x) sits at patch row
+    // st*(y - y0) + ky*dil, column st*x + kx*dil
+    poff[i] = ((t / KW) * p.dil * p.PW + (t % KW) * p.dil) * p.xps + pci[i] * 32 + piece * 8;
   }
   f32x4 acc[NPW][COT];
 #pragma unroll
@@ -97,9 +102,9 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     const int dr = XS / p.PW, dc = XS - dr * p.PW;
 #pragma unroll
     for (int u = 0; u < NXS; ++u) {
-      const bool colok = c >= 1 && c <= p.W;                          // columns 0 and W + 1 are the zero border
+      const bool colok = c >= p.pad && c < p.W + p.pad;               // the pad columns on either side are the zero border
       xrow[u] = (xthr && colok) ? r : 0x40000000;                     // never a valid row
-      xgo[u] = ((r * p.W + c - 1) * p.Ci) * 2 + xpc * 16;
+      xgo[u] = ((r * p.W + c - p.pad) * p.Ci) * 2 + xpc * 16;
       c += dc;
       r += dr;
       if (c >= p.PW) {
@@ -109,30 +114,42 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     }
   }
   const int ygo = (yp0 * p.Co) * 2 + ypc * 16;
+  // output-channel tail of the last block (Co % 16 != 0: 216 / 108-channel offset and mask predictors): a piece holds 8
+  // channels; a piece with only 4 left is an 8-byte load, pieces past Co stay zero
+  const int yc0 = cob * (COT * 16) + ypc * 8;
+  const int ykind = yc0 + 8 <= p.Co ? 2 : (yc0 + 4 <= p.Co ? 1 : 0);
   u32x4 prx[NXS], pry[NYS];
   // geometry of run b (wave-uniform): frame, first / last pixel in the frame, first patch row, patch rows
   auto run_geo = [&](int b, int& img, int& q0, int& q1, int& y0, int& nrow) {
     img = b / p.bpf;
     q0 = (b - img * p.bpf) * p.BT * 16;
     q1 = min(q0 + p.BT * 16, HW);
-    y0 = q0 / p.W;
-    nrow = (q1 - 1) / p.W - y0 + 3;
+    y0 = q0 / p.Wo;
+    nrow = p.st * ((q1 - 1) / p.Wo - y0) + 2 * p.pad + 1;
   };
   auto fetch = [&](int b) {
     int img, q0, q1, y0, nrow;
     run_geo(b, img, q0, q1, y0, nrow);
-    const char* xr = xg + ((long)(img * p.H + y0 - 1) * p.W) * p.Ci * 2;   // first patch row (may lie above the image)
+    const int r0 = p.st * y0 - p.pad;                                       // first patch row (may lie above the image)
+    const char* xr = xg + ((long)(img * p.H + r0) * p.W) * p.Ci * 2;
 #pragma unroll
     for (int u = 0; u < NXS; ++u) {
       prx[u] = u32x4{0u, 0u, 0u, 0u};
-      if (xrow[u] < nrow && (unsigned)(y0 - 1 + xrow[u]) < (unsigned)p.H) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+      if (xrow[u] < nrow && (unsigned)(r0 + xrow[u]) < (unsigned)p.H) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
     }
     const char* yr = yg + ((long)img * HW + q0) * p.Co * 2;
     const int M = q1 - q0;
 #pragma unroll
     for (int u = 0; u < NYS; ++u) {
       pry[u] = u32x4{0u, 0u, 0u, 0u};
-      if (ythr && yp0 + u * YS < M) pry[u] = *reinterpret_cast<const u32x4*>(yr + ygo + (long)u * YS * p.Co * 2);
+      if (ythr && yp0 + u * YS < M) {
+        const char* src = yr + ygo + (long)u * YS * p.Co * 2;
+        if (ykind == 2) pry[u] = *reinterpret_cast<const u32x4*>(src);
+        else if (ykind == 1) {
+          const u32x2 h2 = *reinterpret_cast<const u32x2*>(src);
+          pry[u] = u32x4{h2.x, h2.y, 0u, 0u};
+        }
+      }
     }
   };
   // Two LDS buffers: while run b is multiplied out of one, run b+1's registers (fetched at the top of the run) are
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     stash(b0, smem);
   }
   __syncthreads();
-  const int dyq = 32 / p.W, dxr = 32 - dyq * p.W;
+  const int dyq = 32 / p.Wo, dxr = 32 - dyq * p.Wo;
   for (int sub = 0; sub < p.nsub; ++sub) {
     const int b = b0 + sub;
     if (b >= p.NB) break;
@@ -177,8 +194,8 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     for (int h = 0; h < 2; ++h) {
       pl[h] = kq * 8 + h * 4 + rsel;
       const int q = q0 + pl[h];
-      py[h] = q / p.W;
-      pxx[h] = q - py[h] * p.W;
+      py[h] = q / p.Wo;
+      pxx[h] = q - py[h] * p.Wo;
       ya[h] = p.xbytes + pl[h] * p.yps + piece * 8;
     }
     const int ksteps = (M + 31) >> 5;
@@ -192,12 +209,12 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
       for (int h = 0; h < 2; ++h) {
         // pixels past the run meet a zero dY row; their X address only has to stay inside the patch
         const bool pin = pl[h] < M;
-        xb[h] = pin ? ((py[h] - y0 + 1) * p.PW + pxx[h] + 1) * p.xps : (p.PW + 1) * p.xps;
+        xb[h] = pin ? (p.st * (py[h] - y0) * p.PW + p.st * pxx[h]) * p.xps : 0;
         pl[h] += 32;
         pxx[h] += dxr;
         py[h] += dyq;
-        if (pxx[h] >= p.W) {
-          pxx[h] -= p.W;
+        if (pxx[h] >= p.Wo) {
+          pxx[h] -= p.Wo;
           py[h] += 1;
         }
       }
@@ -232,13 +249,14 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   }
 
   // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [g][tap][ci][co]
-  float* slab = p.part + (long)g * 9 * p.Ci * p.Co;
+  float* slab = p.part + (long)g * TAPS * p.Ci * p.Co;
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     if (ptap[i] < 0) continue;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
       const int co = cob * (COT * 16) + c * 16 + l16;
+      if (co >= p.Co) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = cib * (CIT * 16) + pci[i] * 16 + kq * 4 + r;
@@ -249,24 +267,38 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 }
 
 // ------------------------------------------------------------------ host side
-struct Wg16Plan { int ok, CIT, COT, BT, bpf, nsub, G; size_t lds; int xps, yps, xbytes; };
-static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0;
-static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co) {
+// Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
+// every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
+struct Wg16Plan { int ok, CIT, COT, taps, BT, bpf, nsub, G, Ho, Wo, ciBlocks, coBlocks; size_t lds; int xps, yps, xbytes; };
+static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0, g_wg16_general = 1;
+static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg16Plan q;
   q.ok = 0;
-  if (!g_wg16 || (Ci % 16) || (Co % 16)) return q;
+  if (!g_wg16 || (Ci % 16) || (Co % 4) || !(k == 1 || k == 3) || !(st == 1 || st == 2) || pad != dil * (k - 1) / 2) return q;
+  if (!g_wg16_general && !(k == 3 && st == 1 && dil == 1 && Co % 16 == 0)) return q;
+  q.taps = k * k;
+  q.Ho = (H + 2 * pad - dil * (k - 1) - 1) / st + 1;
+  q.Wo = (W + 2 * pad - dil * (k - 1) - 1) / st + 1;
   q.CIT = Ci % 48 == 0 ? 3 : (Ci % 32 == 0 ? 2 : 1);
-  q.COT = Co % 48 == 0 ? 3 : (Co % 32 == 0 ? 2 : 1);
-  const int HW = H * W, FT = (HW + 15) / 16;
-  const long blocks = (long)(Ci / (16 * q.CIT)) * (Co / (16 * q.COT));
+  q.COT = Co > 32 ? 3 : (Co > 16 ? 2 : 1);
+  if (Co % 48 != 0 && Co % 32 == 0 && Co <= 64) q.COT = 2;
+  q.ciBlocks = Ci / (16 * q.CIT);
+  q.coBlocks = (Co + 16 * q.COT - 1) / (16 * q.COT);
+  const int HW = q.Ho * q.Wo, FT = (HW + 15) / 16;
+  const long blocks = (long)q.ciBlocks * q.coBlocks;
+  // every channel block re-stages the pixels: the wide 1x1 convolutions of stage 1 on the full-resolution map (64 -> 256,
+  // 256 -> 64 @96x72: 12 blocks x 138 240 pixels) measured 105-110 us against 80 us for the scalar-operand kernel
+  if (k == 1 && (long)N * HW * blocks > 500000) return q;
   // LDS rows are unpadded (see conv_wgrad_h_kernel): the 4 pixel rows of a transposing read are 32 * CIT bytes apart
   q.xps = 32 * q.CIT;
   q.yps = 32 * q.COT;
-  const int cand[6] = {16, 14, 12, 10, 8, 4};
+  const int PW = W + 2 * pad;
+  const int cand[8] = {16, 14, 12, 10, 8, 6, 4, 2};
   q.BT = 0;
-  for (int i = 0; i < 6 && !q.BT; ++i) {
+  for (int i = 0; i < 8 && !q.BT; ++i) {
     const int bt = g_wg16_bt > 0 ? g_wg16_bt : cand[i];
-    const long npos = (long)((bt * 16 + W - 2) / W + 3) * (W + 2);
+    const long orows = (bt * 16 + q.Wo - 2) / q.Wo + 1;                 // output rows a run can touch
+    const long npos = (st * (orows - 1) + 2 * pad + 1) * (long)PW;       // patch positions
     const size_t lds = 2 * ((size_t)npos * q.xps + (size_t)((bt * 16 + 31) / 32 * 32) * q.yps);   // two buffers
     if (npos <= (long)WG16_XSWEEPS * (WG16_THREADS / (2 * q.CIT)) && bt * 16 <= 256 && lds <= 150 * 1024) {
       q.BT = bt > FT ? FT : bt;
@@ -278,7 +310,7 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co) {
   if (!q.BT) return q;
   q.bpf = (FT + q.BT - 1) / q.BT;
   const long NB = (long)N * q.bpf;
-  // runs per workgroup: the kernel holds 140-190 VGPRs x 8 waves, i.e. ONE workgroup per CU at a time -- one workgroup
+  // runs per workgroup: the kernel holds 140-230 VGPRs x 8 waves, i.e. ONE workgroup per CU at a time -- one workgroup
   // more than 256 costs a whole second round (A: 270 workgroups 41.7 us, 180 workgroups 30.5 us; tools/bench_wg16.py)
   const long target = g_wg16_target > 0 ? g_wg16_target : 256;
   long G = target / blocks;
@@ -286,53 +318,56 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co) {
   if (G < 1) G = 1;
   q.nsub = (int)((NB + G - 1) / G);
   q.G = (int)((NB + q.nsub - 1) / q.nsub);
-  q.ok = (long)N * HW < (1L << 31) && q.G < 65536;
+  q.ok = (long)N * HW < (1L << 31) && (long)N * H * W * Ci * 2 < (1L << 31) && q.G < 65536 && blocks < 65536;
   return q;
 }
 
-long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co) {
-  const Wg16Plan q = wg16_plan(N, H, W, Ci, Co);
+long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
+  const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   return q.ok ? q.G : 0;
 }
 
 template <typename HT>
 static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* part, int N, int H, int W, int Ci, int Co,
-                       hipStream_t s) {
+                       int st, int pad, int dil, hipStream_t s) {
   Wg16Args a;
   a.x = x; a.dy = dy; a.part = part;
-  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ho = q.Ho; a.Wo = q.Wo; a.st = st; a.dil = dil; a.pad = pad;
   a.BT = q.BT; a.bpf = q.bpf; a.nsub = q.nsub; a.NB = N * q.bpf;
-  a.ciBlocks = Ci / (16 * q.CIT); a.coBlocks = Co / (16 * q.COT);
-  a.PW = W + 2; a.xps = q.xps; a.yps = q.yps; a.xbytes = q.xbytes;
+  a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
+  a.PW = W + 2 * pad; a.xps = q.xps; a.yps = q.yps; a.xbytes = q.xbytes;
   const dim3 grid(q.G, a.ciBlocks * a.coBlocks);
   bool ok = false;
-#define FAMI_WG16_CASE(cit, cot)                                                                                          \
-  if (q.CIT == cit && q.COT == cot) {                                                                                     \
+#define FAMI_WG16_CASE(cit, cot, TP)                                                                                    \
+  if (q.CIT == cit && q.COT == cot && q.taps == TP) {                                                                   \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad16_kernel<HT, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad16_kernel<HT, cit, cot, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((conv_wgrad16_kernel<HT, cit, cot>), grid, dim3(WG16_THREADS), q.lds, s, a);                       \
+    hipLaunchKernelGGL((conv_wgrad16_kernel<HT, cit, cot, TP>), grid, dim3(WG16_THREADS), q.lds, s, a);                 \
     ok = true;                                                                                                            \
   }
-  FAMI_WG16_CASE(1, 1) FAMI_WG16_CASE(1, 2) FAMI_WG16_CASE(1, 3) FAMI_WG16_CASE(2, 1) FAMI_WG16_CASE(2, 2) FAMI_WG16_CASE(2, 3)
-  FAMI_WG16_CASE(3, 1) FAMI_WG16_CASE(3, 2) FAMI_WG16_CASE(3, 3)
+#define FAMI_WG16_ROW(TP)                                                                                               \
+  FAMI_WG16_CASE(1, 1, TP) FAMI_WG16_CASE(1, 2, TP) FAMI_WG16_CASE(1, 3, TP) FAMI_WG16_CASE(2, 1, TP)             \
+  FAMI_WG16_CASE(2, 2, TP) FAMI_WG16_CASE(2, 3, TP) FAMI_WG16_CASE(3, 1, TP) FAMI_WG16_CASE(3, 2, TP) FAMI_WG16_CASE(3, 3, TP)
+  FAMI_WG16_ROW(9) FAMI_WG16_ROW(1)
+#undef FAMI_WG16_ROW
 #undef FAMI_WG16_CASE
   return ok ? 1 : 0;
 }
 
-// -> number of partial slabs written to `part` ([G][9][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
+// -> number of partial slabs written to `part` ([G][k*k][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
-                     int Co, hipStream_t s, const char* name) {
-  const Wg16Plan q = wg16_plan(N, H, W, Ci, Co);
+                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name) {
+  const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   if (!q.ok || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return 0;
-  if (ws_bytes < (long)q.G * Co * Ci * 9 * (long)sizeof(float)) {
+  if (ws_bytes < (long)q.G * Co * Ci * k * k * (long)sizeof(float)) {
     fami_set_error(name, "workspace too small");
     return FAMI_EARG;
   }
-  const int rc = half_kind == 1 ? wg16_launch<f16_t>(q, x, dy, part, N, H, W, Ci, Co, s)
-                                : wg16_launch<bf16_t>(q, x, dy, part, N, H, W, Ci, Co, s);
+  const int rc = half_kind == 1 ? wg16_launch<f16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s)
+                                : wg16_launch<bf16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s);
   if (!rc) return 0;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
@@ -341,10 +376,12 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
   }
   return q.G;
 }
-// benchmarks / tests: 0 / 1 off / on, 100 + bt forces the tiles per run, 1000 + n the workgroup target, < 0 defaults
+// benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
+// tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_bt = 0; g_wg16_target = 0; }
+  if (on < 0) { g_wg16 = 1; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; }
   else if (on <= 1) g_wg16 = on;
+  else if (on <= 3) g_wg16_general = on - 2;
   else if (on >= 1000) g_wg16_target = on - 1000;
   else if (on >= 100) g_wg16_bt = on - 100;
 }
