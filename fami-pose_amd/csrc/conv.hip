@@ -2554,14 +2554,15 @@ static int g_wgrad_lin = 1;      // fami_conv_tune_wgrad_lds(50 / 51): linear-ad
 template <typename T>
 static int try_conv3x3_lds(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                            int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
-                           const char* name, const EpiBN& epi = epi_none()) {
+                           const char* name, const EpiBN& epi = epi_none(), const XBN& xbn = xbn_none()) {
   constexpr int SZ = (int)sizeof(T), KSTEP = LdsTraits<T>::KSTEP;
   if (g_use_lds != 0) {   // fami_conv_tune_lds(0) still forces the direct kernels
     // register-blocked LDS kernel (conv_t4.hip): every storage type since round 3
     const int rc = fami_try_conv3x3_t4(std::is_same<T, float>::value ? 2 : (std::is_same<T, f16_t>::value ? 1 : 0), x, wp, bias, y,
-                                       N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+                                       N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
     if (rc != 0) return rc;
   }
+  if (xbn.on) return 0;   // only the register-blocked kernel applies a BatchNorm to its input
   // default: bf16 from 96 input channels up (per launch: 192 ch 18.8 vs 30.3 us, 384 ch 27.8 vs 32.4, 96 ch equal,
   // 48 ch 23.9 vs 21.8 -> direct; tools/bench_xcd.py with KNOB=lds), f32 never (slower on every shape)
   const int use = g_use_lds < 0 ? (SZ == 2 && Ci >= 96 ? 1 : 0) : g_use_lds;
@@ -2940,6 +2941,12 @@ static WgradLdsPlan wgrad_lds_plan_f32(int N, int H, int W, int Ci, int Co, int 
   return q;
 }
 
+// 1 if a 16-bit 3x3 stride-1 pad-1 convolution of this shape can take its input un-normalised (fami_conv2d_fwd_xbn_* and
+// fami_conv2d_wgrad_defer_xbn_* would both run)
+int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co) {
+  return (g_use_lds != 0 && g_wgrad_lds && fami_conv_t4_eligible16(N, H, W, Ci, Co) &&
+          fami_wgrad16_slabs(N, H, W, Ci, Co, 3, 1, 1, 1) > 0) ? 1 : 0;
+}
 long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
   if (!geom_ok(kh, kw, stride, pad, dil)) return -1;
   const WgradPlan q = wgrad_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil);
@@ -3203,17 +3210,21 @@ int fami_wgrad_reduce_batch(const long* descs, int n, hipStream_t s) {
 template <typename HT>
 static int wgrad_h_impl(const char* nm, const HT* x, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                        hipStream_t s) {
+                        hipStream_t s, const XBN& xbn = xbn_none()) {
   if (g_wgrad_lds && x && dy && dw && workspace && kh == kw) {
     // round-3 kernel (conv_wg16.hip): pipelined staging, padded patch, 8 waves; 1x1 / 3x3, stride 1 / 2, any dilation
     const int G = fami_try_wgrad16(std::is_same<HT, f16_t>::value ? 1 : 0, x, dy, workspace, ws_bytes, N, H, W, Ci, Co, kh, stride,
-                                   pad, dil, s, nm);
+                                   pad, dil, s, nm, xbn);
     if (G < 0) return G;
     if (G > 0) {
       launch_reduce_taps(workspace, dw, Co, Ci, kh * kw, G, accumulate, s);
       FAMI_CHECK_LAUNCH(nm);
       return FAMI_OK;
     }
+  }
+  if (xbn.on) {
+    fami_set_error(nm, "input BatchNorm needs the conv_wg16 kernel (ask fami_conv2d_xbn_ok first)");
+    return FAMI_ESHAPE;
   }
   const WgradLdsPlan l = g_wgrad_lds ? wgrad_lds_plan(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   if (l.ok && x && dy && dw && workspace && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
@@ -3265,7 +3276,7 @@ static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, 
 template <typename HT>
 static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const float* bias, void* y, int N, int H, int W,
                            int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, int accumulate,
-                           int out_f32, hipStream_t s, const EpiBN& e = epi_none()) {
+                           int out_f32, hipStream_t s, const EpiBN& e = epi_none(), const XBN& xbn = xbn_none()) {
   FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
     fami_set_error(nm, "unsupported geometry");
@@ -3287,8 +3298,12 @@ static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const floa
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
-    const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm, e);
+    const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
+  if (xbn.on) {
+    fami_set_error(nm, "input BatchNorm needs the register-blocked 3x3 kernel (ask fami_conv2d_xbn_ok first)");
+    return FAMI_ESHAPE;
   }
   return run_igemm_h<HT>(a, 0, s, nm);
 }
@@ -3388,6 +3403,45 @@ long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
                               int kw, int stride, int pad, int dil, int accumulate, hipStream_t s) {                   \
     return conv_dgrad_h_impl<HT>("fami_conv2d_dgrad_" #sfx, dy, wp, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil,     \
                                  accumulate, s);                                                                       \
+  }                                                                                                                    \
+  /* BatchNorm (+ReLU) of the INPUT applied while it is staged (XBN, conv_epi.h): x is the pre-normalisation tensor z.  */ \
+  /* fwd: statistics of z come from xslots (filled by fami_conv2d_fwd_stats_*), mean / invstd / running statistics are */ \
+  /* published; slots / pivot_src (optional) request the statistics of y for the BatchNorm that follows.               */ \
+  int fami_conv2d_fwd_xbn_##sfx(const HT* z, const HT* wp, const float* bias, HT* y, int N, int H, int W, int Ci,      \
+                                int Co, void* slots, const float* pivot_src, const void* xslots, long xP,             \
+                                const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,                 \
+                                float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps,                \
+                                hipStream_t s) {                                                                       \
+    FAMI_REQUIRE(xslots && xgamma && xbeta && xmean && xinvstd && xP > 0, "fami_conv2d_fwd_xbn_" #sfx, "bad argument");\
+    EpiBN e = epi_none();                                                                                              \
+    if (slots) {                                                                                                       \
+      e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Co); e.mode = 1; e.C = Co; e.pivot_src = pivot_src;  \
+    }                                                                                                                  \
+    XBN xb = xbn_none();                                                                                               \
+    xb.on = 1; xb.slots = reinterpret_cast<const double*>(xslots); xb.ns = bn_slots(Ci); xb.C = Ci; xb.P = xP;         \
+    xb.gamma = xgamma; xb.beta = xbeta; xb.mean = xmean; xb.invstd = xinvstd; xb.running_mean = xrunning_mean;         \
+    xb.running_var = xrunning_var; xb.momentum = xmomentum; xb.eps = xeps;                                             \
+    return conv_fwd_h_impl<HT>("fami_conv2d_fwd_xbn_" #sfx, z, wp, bias, y, N, H, W, Ci, Co, 3, 3, 1, 1, 1, 0, 0, 0,   \
+                               s, e, xb);                                                                              \
+  }                                                                                                                    \
+  int fami_conv2d_wgrad_defer_xbn_##sfx(const HT* z, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,  \
+                                        int H, int W, int Ci, int Co, int accumulate, long* desc_out,                  \
+                                        const float* xmean, const float* xinvstd, const float* xgamma,                 \
+                                        const float* xbeta, hipStream_t s) {                                           \
+    FAMI_REQUIRE(desc_out && xmean && xinvstd && xgamma && xbeta, "fami_conv2d_wgrad_defer_xbn_" #sfx, "bad argument");\
+    XBN xb = xbn_none();                                                                                               \
+    xb.on = 1; xb.C = Ci; xb.gamma = xgamma; xb.beta = xbeta; xb.mean = const_cast<float*>(xmean);                     \
+    xb.invstd = const_cast<float*>(xinvstd);                                                                           \
+    ReduceDesc d;                                                                                                      \
+    d.part = nullptr;                                                                                                  \
+    g_defer = &d;                                                                                                      \
+    const int rc = wgrad_h_impl<HT>("fami_conv2d_wgrad_defer_xbn_" #sfx, z, dy, dw, workspace, ws_bytes, N, H, W, Ci,  \
+                                    Co, 3, 3, 1, 1, 1, accumulate, s, xb);                                             \
+    g_defer = nullptr;                                                                                                 \
+    if (rc != FAMI_OK) return rc;                                                                                      \
+    FAMI_REQUIRE(d.part, "fami_conv2d_wgrad_defer_xbn_" #sfx, "no reduce recorded");                                   \
+    memcpy(desc_out, &d, sizeof(d));                                                                                   \
+    return FAMI_OK;                                                                                                    \
   }                                                                                                                    \
   /* fused BatchNorm statistics, see the _f32 forms */                                                                \
   int fami_conv2d_fwd_stats_##sfx(const HT* x, const HT* wp, const float* bias, HT* y, int N, int H, int W, int Ci,    \

@@ -60,16 +60,79 @@ __device__ __forceinline__ f32x4 ld4_round(f32x4 v) {
 }
 
 
+// Optional train-mode BatchNorm (+ReLU) applied to a convolution's INPUT while it is staged (conv_t4.hip forward,
+// conv_wg16.hip weight gradient): y = relu(fma(z, sc, sf)) with sc = invstd*gamma, sf = fma(-mean, sc, beta) -- the
+// arithmetic of norm.hip's apply pass, so the normalised tensor the reference materialises between conv1 and conv2 of a
+// BasicBlock (basic_model.py:34-63) never exists in HBM.  Forward (slots != null): mean / invstd are folded from the slot
+// rows the producing convolution's epilogue filled; workgroup (0, 0) stores them and advances the running statistics.
+// Weight gradient (slots == null): mean / invstd are read.
+struct XBN {
+  const double* slots;   // forward: statistics of z (EpiBN mode 1 rows + pivots); null: use mean / invstd as they are
+  const float *gamma, *beta;
+  float *mean, *invstd, *running_mean, *running_var;
+  long P;                // pixels the statistics were taken over
+  float momentum, eps;
+  int C, ns, on;         // channels of z, slot rows, 0 = no transform
+};
+static inline XBN xbn_none() {
+  XBN x;
+  x.slots = nullptr; x.gamma = x.beta = nullptr; x.mean = x.invstd = x.running_mean = x.running_var = nullptr;
+  x.P = 0; x.momentum = 0.f; x.eps = 0.f; x.C = 0; x.ns = 0; x.on = 0;
+  return x;
+}
+// scale / shift of channel c into (sc, sf); forward form also publishes mean / invstd / running statistics when `publish`
+__device__ __forceinline__ void xbn_channel(const XBN& x, int c, bool publish, float& sc, float& sf) {
+  float muf, isf;
+  if (x.slots) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < x.ns; ++k) {
+      s += x.slots[(long)k * 2 * x.C + c];
+      q += x.slots[(long)k * 2 * x.C + x.C + c];
+    }
+    const double invP = 1.0 / (double)x.P;
+    const double dm = s * invP;
+    double var = q * invP - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const double mu = (double)bn_slots_pivot(const_cast<double*>(x.slots), x.C)[c] + dm;
+    muf = (float)mu;
+    isf = (float)(1.0 / sqrt(var + (double)x.eps));
+    if (publish) {
+      x.mean[c] = muf;
+      x.invstd[c] = isf;
+      if (x.running_mean) {
+        const double unb = x.P > 1 ? var * (double)x.P / (double)(x.P - 1) : var;
+        x.running_mean[c] = (float)((1.0 - x.momentum) * x.running_mean[c] + x.momentum * mu);
+        x.running_var[c] = (float)((1.0 - x.momentum) * x.running_var[c] + x.momentum * unb);
+      }
+    }
+  } else {
+    muf = x.mean[c];
+    isf = x.invstd[c];
+  }
+  epi_scale_shift(muf, isf, x.gamma[c], x.beta[c], sc, sf);
+}
+// 8 staged 16-bit values (one 16-byte piece, channels c0 .. c0+7) -> relu(fma(v, sc, sf)), tables in LDS
+template <typename H>
+__device__ __forceinline__ u32x4 xbn_piece(u32x4 raw, const float* sc, const float* sf) {
+  typedef H hx8 __attribute__((ext_vector_type(8)));
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  f32x8 v = __builtin_convertvector(__builtin_bit_cast(hx8, raw), f32x8);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = fmaxf(__builtin_fmaf(v[j], sc[j], sf[j]), 0.f);
+  return __builtin_bit_cast(u32x4, __builtin_convertvector(v, hx8));
+}
+
 // conv_t4.hip: register-blocked LDS 3x3 kernel for the 16-bit storage types.  half_kind: 0 bf16, 1 fp16, 2 f32.
 // Returns 1 if launched, 0 if the shape is not eligible, < 0 on error.
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
-                        const char* name, const EpiBN& epi);
+                        const char* name, const EpiBN& epi, const XBN& xbn = xbn_none());
 void fami_conv_t4_tune(int on);
+int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co);
 
 // conv_wg16.hip: 16-bit weight gradient of the centred k x k convolutions (k = 1 | 3, stride 1 | 2, any dilation).  fami_try_wgrad16 -> number of partial
 // slabs [G][9][Ci][Co] written to `part` (reduce them with the caller's slab reduce), 0 = not eligible, < 0 = error.
 long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil);
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
-                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name);
+                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn = xbn_none());
 void fami_wgrad16_tune(int on);

@@ -23,6 +23,7 @@
 struct ConvT4Args {
   EpiBN e;
   int emode;
+  XBN xb;             // BatchNorm + ReLU applied to the input while it is staged (16-bit types; xb.on)
   const void* x;      // [N,H,W,Ci]
   const void* wp;     // packed weights [tap][KC][NTt][64][8]
   void* y;            // [N,H,W,Co]
@@ -131,12 +132,33 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
     }
   };
   fetch(0);
+  // XBN: per-channel scale / shift of the input's BatchNorm in LDS (behind the weight slab), computed while the first
+  // chunk's loads are in flight; workgroup (0, 0) publishes mean / invstd / running statistics
+  float* xsc = reinterpret_cast<float*>(wbuf + 9 * NT * 1024);
+  float* xsf = xsc + p.Ci;
+  const bool xon = SZ == 2 && p.xb.on;
+  if (xon) {
+    for (int ch = tid; ch < p.Ci; ch += T4_THREADS) {
+      float a, b;
+      xbn_channel(p.xb, ch, bxl == 0 && byl == 0, a, b);
+      xsc[ch] = a;
+      xsf[ch] = b;
+    }
+    __syncthreads();
+  }
   for (int c = 0; c < nchunk; ++c) {
     if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
       const int i = tid + u * T4_THREADS;
-      if (i < npiece) *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = pr[u];
+      if (i < npiece) {
+        u32x4 v = pr[u];
+        if constexpr (SZ == 2) {
+          const int ch0 = c * CHN + (i & 3) * PCN;      // border / outside pieces stay zero: the conv pads the NORMALISED tensor
+          if (xon && goff[u] >= 0 && ch0 < p.Ci) v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
+        }
+        *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = v;
+      }
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
@@ -292,7 +314,8 @@ static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per 
 template <typename HT>
 static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                           int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const char* name,
-                          const EpiBN& epi) {
+                          const EpiBN& epi, const XBN& xbn) {
+  if (xbn.on && (sizeof(HT) != 2 || (Ci % 8) != 0)) return 0;
   if (!g_use_t4 || ((Ci * (int)sizeof(HT)) % 16) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
   if (sizeof(HT) == 4 && !g_use_t4_f32) return 0;
   int NT = 0;
@@ -322,14 +345,14 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   // therefore takes only launches that fill the chip (>= 600 workgroups: the 96x72 maps) with 48-wide channel blocks.
   if (sizeof(HT) == 4 && g_t4_bt == 0 && !((long)N * ((FT + BT - 1) / BT) * cblocks >= 600 && NT == 3)) return 0;
   ConvT4Args a;
-  a.e = epi; a.emode = epi.slots ? epi.mode : 0;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
   a.PW = W + 2; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * a.PS);
   const size_t wbytes = (size_t)9 * NT * 1024;
-  size_t lds = (size_t)a.patch_bytes + wbytes;
+  size_t lds = (size_t)a.patch_bytes + wbytes + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   if (lds < (size_t)T4_WAVES * NT * 32 * 4) lds = (size_t)T4_WAVES * NT * 32 * 4;
   if (lds > 100 * 1024) return 0;
   const dim3 grid(N * a.bands, cblocks);
@@ -359,12 +382,32 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
-                        const char* name, const EpiBN& epi) {
+                        const char* name, const EpiBN& epi, const XBN& xbn) {
   if (half_kind == 2)
-    return try_conv3x3_t4<float>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+    return try_conv3x3_t4<float>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
   if (half_kind == 1)
-    return try_conv3x3_t4<f16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
-  return try_conv3x3_t4<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi);
+    return try_conv3x3_t4<f16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
+  return try_conv3x3_t4<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
+}
+// would a 16-bit 3x3 stride-1 pad-1 convolution [N,H,W,Ci] -> Co take this kernel (XBN callers ask before they decide not
+// to materialise the normalised input)?
+int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
+  if (!g_use_t4 || (Ci % 8) != 0) return 0;
+  const int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  if (!NT) return 0;
+  const int FT = (H * W + 15) / 16;
+  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
+  const long pos_cap = (long)(NT == 3 ? 4 : T4_PMAX) * T4_THREADS / 4;
+  const int cand[8] = {12, 10, 8, 6, 5, 4, 3, 2};
+  int BT = 0;
+  for (int i = 0; i < 8 && !BT; ++i)
+    if (positions(cand[i]) <= pos_cap) BT = cand[i];
+  if (!BT) return 0;
+  if (g_t4_bt > 0) BT = g_t4_bt;
+  if (BT > FT) BT = FT;
+  if (BT > 16 || positions(BT) > pos_cap) return 0;
+  const size_t lds = (size_t)positions(BT) * 80 + (size_t)9 * NT * 1024 + (size_t)2 * Ci * sizeof(float);
+  return lds <= 100 * 1024 ? 1 : 0;
 }
 void fami_conv_t4_tune(int on) {
   if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; }

@@ -35,6 +35,7 @@ __device__ __forceinline__ X8 frag_of(s16x4 lo, s16x4 hi) {
 #define WG16_XSWEEPS 8   // patch positions per thread and run (512 / (2*CIT) positions per sweep: >= 85)
 
 struct Wg16Args {
+  XBN xb;           // BatchNorm + ReLU applied to X while it is staged (the convolution's input was never materialised; xb.on)
   const void* x;    // [N,H,W,Ci]
   const void* dy;   // [N,Ho,Wo,Co]
   float* part;      // [G][taps][Ci][Co]
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   const int yc0 = cob * (COT * 16) + ypc * 8;
   const int ykind = yc0 + 8 <= p.Co ? 2 : (yc0 + 4 <= p.Co ? 1 : 0);
   u32x4 prx[NXS], pry[NYS];
+  unsigned xvalid = 0;   // bit u: sweep u's piece was loaded (a zero-border / outside piece stays zero under XBN)
   // geometry of run b (wave-uniform): frame, first / last pixel in the frame, first patch row, patch rows
   auto run_geo = [&](int b, int& img, int& q0, int& q1, int& y0, int& nrow) {
     img = b / p.bpf;
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 #pragma unroll
     for (int u = 0; u < NXS; ++u) {
       prx[u] = u32x4{0u, 0u, 0u, 0u};
-      if (xrow[u] < nrow && (unsigned)(r0 + xrow[u]) < (unsigned)p.H) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+      const bool ld = xrow[u] < nrow && (unsigned)(r0 + xrow[u]) < (unsigned)p.H;
+      if (ld) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+      xvalid = (xvalid & ~(1u << u)) | ((ld ? 1u : 0u) << u);
     }
     const char* yr = yg + ((long)img * HW + q0) * p.Co * 2;
     const int M = q1 - q0;
@@ -158,13 +162,29 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   // partial last K step needs no select on the dY side.
   const int yrows = ((p.BT * 16 + 31) >> 5) << 5;     // dY rows of a buffer: whole K steps (the tail rows are zeros)
   const int bufsz = p.xbytes + yrows * p.yps;         // one buffer: patch + dY rows (16-byte multiple)
+  // XBN: scale / shift of this workgroup's CIT*16 input channels in LDS behind the two buffers
+  float* xsc = reinterpret_cast<float*>(smem + 2 * bufsz);
+  float* xsf = xsc + CIT * 16;
+  if (p.xb.on) {
+    if (tid < CIT * 16) {
+      float a, b;
+      xbn_channel(p.xb, cib * (CIT * 16) + tid, false, a, b);
+      xsc[tid] = a;
+      xsf[tid] = b;
+    }
+    __syncthreads();
+  }
   auto stash = [&](int b, char* buf) {                 // registers of run b -> LDS
     int img, q0, q1, y0, nrow;
     run_geo(b, img, q0, q1, y0, nrow);
     const int npos = nrow * p.PW;
 #pragma unroll
     for (int u = 0; u < NXS; ++u)
-      if (xthr && xp0 + u * XS < npos) *reinterpret_cast<u32x4*>(buf + (xp0 + u * XS) * p.xps + xpc * 16) = prx[u];
+      if (xthr && xp0 + u * XS < npos) {
+        u32x4 v = prx[u];
+        if (p.xb.on && ((xvalid >> u) & 1u)) v = xbn_piece<H>(v, xsc + xpc * 8, xsf + xpc * 8);
+        *reinterpret_cast<u32x4*>(buf + (xp0 + u * XS) * p.xps + xpc * 16) = v;
+      }
 #pragma unroll
     for (int u = 0; u < NYS; ++u)
       if (ythr && yp0 + u * YS < yrows) *reinterpret_cast<u32x4*>(buf + p.xbytes + (yp0 + u * YS) * p.yps + ypc * 16) = pry[u];
@@ -299,7 +319,7 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
     const int bt = g_wg16_bt > 0 ? g_wg16_bt : cand[i];
     const long orows = (bt * 16 + q.Wo - 2) / q.Wo + 1;                 // output rows a run can touch
     const long npos = (st * (orows - 1) + 2 * pad + 1) * (long)PW;       // patch positions
-    const size_t lds = 2 * ((size_t)npos * q.xps + (size_t)((bt * 16 + 31) / 32 * 32) * q.yps);   // two buffers
+    const size_t lds = 2 * ((size_t)npos * q.xps + (size_t)((bt * 16 + 31) / 32 * 32) * q.yps) + 2 * 48 * sizeof(float);   // two buffers + the XBN table
     if (npos <= (long)WG16_XSWEEPS * (WG16_THREADS / (2 * q.CIT)) && bt * 16 <= 256 && lds <= 150 * 1024) {
       q.BT = bt > FT ? FT : bt;
       q.xbytes = (int)(npos * q.xps);
@@ -329,8 +349,9 @@ long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int 
 
 template <typename HT>
 static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* part, int N, int H, int W, int Ci, int Co,
-                       int st, int pad, int dil, hipStream_t s) {
+                       int st, int pad, int dil, hipStream_t s, const XBN& xbn) {
   Wg16Args a;
+  a.xb = xbn;
   a.x = x; a.dy = dy; a.part = part;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.Ho = q.Ho; a.Wo = q.Wo; a.st = st; a.dil = dil; a.pad = pad;
   a.BT = q.BT; a.bpf = q.bpf; a.nsub = q.nsub; a.NB = N * q.bpf;
@@ -359,15 +380,15 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
 
 // -> number of partial slabs written to `part` ([G][k*k][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
-                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name) {
+                     int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn) {
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   if (!q.ok || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return 0;
   if (ws_bytes < (long)q.G * Co * Ci * k * k * (long)sizeof(float)) {
     fami_set_error(name, "workspace too small");
     return FAMI_EARG;
   }
-  const int rc = half_kind == 1 ? wg16_launch<f16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s)
-                                : wg16_launch<bf16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s);
+  const int rc = half_kind == 1 ? wg16_launch<f16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s, xbn)
+                                : wg16_launch<bf16_t>(q, x, dy, part, N, H, W, Ci, Co, st, pad, dil, s, xbn);
   if (!rc) return 0;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {

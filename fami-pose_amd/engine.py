@@ -37,7 +37,7 @@ def _sfx(t):
 class T:
     """Engine tensor: NHWC (or 2-D) storage + lazily allocated gradient.  `f32grad`: the gradient is fp32
     regardless of the activation dtype (dense [M,K] tensors of the translation regressor)."""
-    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad', 'uses', 'lanes', 'bnrec', 'nofuse')
+    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad', 'uses', 'lanes', 'bnrec', 'nofuse', 'xbn')
 
     def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0, f32grad=False):
         self.data = data
@@ -49,6 +49,8 @@ class T:
         self.lanes = None      # stream lanes of those consumers
         self.bnrec = None      # set on the output of a train-mode BatchNorm: what a fused backward statistics pass needs
         self.nofuse = parent is not None     # batch-slice views and their parents receive gradients through slices
+        self.xbn = None        # set on a NOT materialised BatchNorm+ReLU output (Engine.conv_bn_relu_into): data is the
+                               # pre-normalisation tensor, the one consumer applies scale / shift / ReLU while staging it
 
     @property
     def shape(self):
@@ -114,7 +116,12 @@ class Engine:
         fz = os.environ.get('FAMI_FUSE_BN', 'fwd')
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
-        self.nfused = {'fwd': 0, 'bwd': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
+        # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
+        # XBN; 16-bit modes): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN=1 opts in.  Measured on
+        # MI355X (gpurun_out r03g, interleaved A/B of the bf16 step): 27.91 ms with, 27.70 ms without -- the transform moves
+        # into the staging path of kernels that are bound by exactly that path, so the step does not get shorter.
+        self.use_xbn = os.environ.get('FAMI_XBN', '0') != '0'
+        self.nfused = {'fwd': 0, 'bwd': 0, 'xbn': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
         # 16 at a time per stream (fami_wgrad_reduce_batch) at the joins / bucket boundaries / the end of backward --
@@ -276,10 +283,12 @@ class Engine:
         self.L.call(name, *args, self.stream)
 
     # ------------------------------------------------------------------ weight gradients with deferred slab reduces
-    def wgrad(self, x_data, dy, g, geo, acc):
-        """dW (=|+=) of one convolution: the partial-slab kernel now, its reduce batched with the stream's others."""
+    def wgrad(self, x_data, dy, g, geo, acc, xbn=None):
+        """dW (=|+=) of one convolution: the partial-slab kernel now, its reduce batched with the stream's others.
+        xbn: x_data is the input of a not materialised BatchNorm+ReLU (mean, invstd, gamma, beta)."""
         nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
         ws = self.ws(nb)
+        assert xbn is None or self.defer_reduce
         if not self.defer_reduce:
             self.acall('fami_conv2d_wgrad', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc)
             return
@@ -289,7 +298,11 @@ class Engine:
             self.flush_reduces(st)
             dws = self._red_dw.setdefault(st, set())
         desc = (ctypes.c_long * self._red_longs)()
-        self.acall('fami_conv2d_wgrad_defer', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc, desc)
+        if xbn is not None:
+            self.acall('fami_conv2d_wgrad_defer_xbn', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo[:5], acc, desc,
+                       *[_p(t) for t in xbn])
+        else:
+            self.acall('fami_conv2d_wgrad_defer', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc, desc)
         self._red.setdefault(st, []).append(desc)
         dws.add(g.data_ptr())
         if len(self._red[st]) >= 16:
@@ -527,7 +540,21 @@ class Engine:
         wp = self.packed(weight, 0)
         flops = 2 * N * Ho * Wo * Ci * Co * kh * kw
         self.conv_flops += flops
-        if stats is not None:
+        xb = x.xbn
+        if xb is not None:
+            # x.data is z of a BatchNorm+ReLU nobody materialised: this convolution is its one consumer
+            assert not relu and not out_f32 and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and not xb['used']
+            xb['used'] = True
+            bnm = xb['bn']
+            y = self.act(N, Ho, Wo, Co)
+            self.acall('fami_conv2d_fwd_xbn', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
+                       N, H, W, Ci, Co, _p(None if stats is None else stats[0]), _p(None if stats is None else stats[1]),
+                       _p(xb['slots']), xb['P'], _p(bnm.weight.data), _p(bnm.bias.data), _p(xb['mean']), _p(xb['invstd']),
+                       _p(bnm.running_mean), _p(bnm.running_var), float(xb['mom']), float(bnm.eps))
+            self.nfused['xbn'] += 1
+            if stats is not None:
+                self.nfused['fwd'] += 1
+        elif stats is not None:
             assert not relu and not out_f32
             y = self.act(N, Ho, Wo, Co)
             self.acall('fami_conv2d_fwd_stats', _p(x.data), _p(wp), _p(None if bias is None else bias.data), _p(y),
@@ -554,7 +581,8 @@ class Engine:
                 saved = self._enter_wlane() if (self.use_wlane and need_w) else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
-                    self.wgrad(x.data, dy, g, geo, acc)
+                    self.wgrad(x.data, dy, g, geo, acc,
+                               None if xb is None else (xb['mean'], xb['invstd'], xb['bn'].weight.data, xb['bn'].bias.data))
                     self.conv_flops += flops
                 if self.rq(bias):
                     g, acc = self.pgrad(bias)
@@ -601,6 +629,49 @@ class Engine:
             z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
             return self.bn(z, bn, relu=relu, residual=residual, pre=slots)
         return self.bn(self.conv(x, conv.weight, conv.bias, st, pd, dl), bn, relu=relu, residual=residual)
+
+    def conv_bn_relu_into(self, x, conv, bn, nxt):
+        """conv -> BatchNorm -> ReLU whose ONLY consumer is the 3x3 stride-1 convolution `nxt` (conv1 -> bn1 -> relu ->
+        conv2 of a BasicBlock, basic_model.py:34-63).  16-bit modes, train-mode statistics: the normalised tensor is never
+        written -- conv's epilogue takes the statistics, nxt's forward and weight-gradient kernels apply scale / shift /
+        ReLU while they stage z (conv_epi.h XBN), and the BatchNorm backward recomputes the ReLU mask from z.  Anything
+        else falls back to conv_bn(relu=True).  Opt-in (FAMI_XBN=1, see __init__)."""
+        N, H, W, _ = x.shape
+        Co, _, kh, kw = conv.weight.shape
+        st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
+        Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
+        Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
+        P = N * Ho * Wo
+        ok = (self.use_xbn and self.half and self.bn2 and self.defer_reduce and bn.training and self.fuse_bn_fwd
+              and self.defer_bn is None and bn.running_mean is not None and self.bn_fusable(P, Co)
+              and tuple(nxt.weight.shape[1:]) == (Co, 3, 3) and nxt.stride[0] == 1 and nxt.padding[0] == 1
+              and nxt.dilation[0] == 1 and self.L.cdll.fami_conv2d_xbn_ok(N, Ho, Wo, Co, nxt.weight.shape[0]))
+        if not ok:
+            return self.conv_bn(x, conv, bn, relu=True)
+        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+        z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
+        self._lane_guard(('running statistics', id(bn)))
+        mean, invstd = self.empty(Co), self.empty(Co)
+        self.bn_trained.append(bn)
+        need_p = self.rq(bn.weight)
+        out = T(z.data, z.requires_grad or need_p)
+        out.xbn = {'bn': bn, 'slots': slots, 'mean': mean, 'invstd': invstd, 'P': P,
+                   'mom': 0.1 if bn.momentum is None else bn.momentum, 'used': False}
+        if out.requires_grad:
+            def bwd():
+                if out.grad is None:
+                    return
+                gx, accx = self.gbuf(z) if z.requires_grad else (self.act(N, Ho, Wo, Co), 0)
+                gg = gb = None
+                accp = 0
+                if need_p:
+                    gg, accp = self.pgrad(bn.weight)
+                    gb, _ = self.pgrad(bn.bias)
+                self.acall('fami_bn_bwd2', _p(out.grad), _p(z.data), None, _p(mean), _p(invstd), _p(bn.weight.data),
+                           _p(bn.bias.data), _p(gx), _p(gg), _p(gb), None, P, Co, 2, accx, accp, 0,
+                           _p(self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))))
+            self.record_bwd(bwd, [bn.weight, bn.bias], (z,))
+        return out
 
     def bn(self, x, bn, relu=False, residual=None, pre=None):
         """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update.

@@ -53,7 +53,7 @@ class BasicBlock(nn.Module):
         res = x
         if self.downsample is not None:
             res = eng.conv_bn(x, self.downsample[0], self.downsample[1])
-        y = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
+        y = eng.conv_bn_relu_into(x, self.conv1, self.bn1, self.conv2)
         return eng.conv_bn(y, self.conv2, self.bn2, relu=True, residual=res)
 
 

@@ -139,6 +139,11 @@ int fami_bn_bwd2_f32(const float* dy, const float* x, const float* y, const floa
  * already applied.  fami_bn_is_small: tensors the one-launch small-tensor kernel takes (no point fusing those).
  * fami_bn_finalize_slots_f32: mean / invstd / running update only (HighResolutionModule fuse terms, hrnet.py:151-172). */
 int fami_bn_is_small(long P, int C);
+/* conv1 -> BatchNorm -> ReLU -> conv2 without the normalised tensor in HBM (16-bit modes; basic_model.py:34-63): conv2's
+ * forward (fami_conv2d_fwd_xbn_*) and weight gradient (fami_conv2d_wgrad_defer_xbn_*) take the PRE-normalisation tensor z
+ * and apply scale / shift / ReLU while they stage it into LDS.  fami_conv2d_xbn_ok: can a 3x3 stride-1 pad-1 convolution of
+ * this shape do that (both kernels eligible)? */
+int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co);
 /* benchmarks: element count up to which a tensor takes the one-launch small-tensor kernels (< 0: default 32768) */
 int fami_bn_tune_small(long elems);
 int fami_bn_apply_slots_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,
@@ -314,6 +319,14 @@ int fami_conv2d_fwd_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const floa
 int fami_conv2d_dgrad_bf16(const fami_bf16_t* dy, const fami_bf16_t* wp, fami_bf16_t* dx, int N, int H, int W, int Ci,
                            int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                            fami_stream_t stream);
+int fami_conv2d_fwd_xbn_bf16(const fami_bf16_t* z, const fami_bf16_t* wp, const float* bias, fami_bf16_t* y, int N, int H, int W,
+                             int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
+                             const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
+                             float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
+int fami_conv2d_wgrad_defer_xbn_bf16(const fami_bf16_t* z, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
+                                     int N, int H, int W, int Ci, int Co, int accumulate, long* desc_out,
+                                     const float* xmean, const float* xinvstd, const float* xgamma, const float* xbeta,
+                                     fami_stream_t stream);
 int fami_conv2d_fwd_stats_bf16(const fami_bf16_t* x, const fami_bf16_t* wp, const float* bias, fami_bf16_t* y, int N, int H, int W,
                                int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void* slots,
                                const float* pivot_src, fami_stream_t stream);
@@ -413,6 +426,14 @@ int fami_conv2d_fwd_f16(const fami_f16_t* x, const fami_f16_t* wp, const float* 
 int fami_conv2d_dgrad_f16(const fami_f16_t* dy, const fami_f16_t* wp, fami_f16_t* dx, int N, int H, int W, int Ci,
                            int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                            fami_stream_t stream);
+int fami_conv2d_fwd_xbn_f16(const fami_f16_t* z, const fami_f16_t* wp, const float* bias, fami_f16_t* y, int N, int H, int W,
+                             int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
+                             const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
+                             float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
+int fami_conv2d_wgrad_defer_xbn_f16(const fami_f16_t* z, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
+                                     int N, int H, int W, int Ci, int Co, int accumulate, long* desc_out,
+                                     const float* xmean, const float* xinvstd, const float* xgamma, const float* xbeta,
+                                     fami_stream_t stream);
 int fami_conv2d_fwd_stats_f16(const fami_f16_t* x, const fami_f16_t* wp, const float* bias, fami_f16_t* y, int N, int H, int W,
                                int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void* slots,
                                const float* pivot_src, fami_stream_t stream);

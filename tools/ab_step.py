@@ -34,7 +34,7 @@ for st in states:
             del os.environ[k]
 torch.cuda.synchronize()
 res = [[], []]
-for rnd in range(6):
+for rnd in range(int(os.environ.get('AB_ROUNDS', '6'))):
     for i, tr in enumerate(trainers):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(8):
