@@ -34,6 +34,7 @@ struct ConvT4Args {
   int KC, NTt;
   int sgn, relu, accumulate, out_f32;
   int patch_bytes;
+  long long* dbg;     // FAMI_T4_TRACE builds: phase timestamps of one workgroup (null otherwise)
 };
 
 // storage-type traits: a fragment is 16 bytes per lane in every case -- 8 K-values of a 32-channel chunk for the 16-bit
@@ -58,10 +59,46 @@ template <> struct T4Traits<float> {
 #define T4_MT (16 / T4_WAVES)   // pixel tiles per wave (a band has <= 16)
 #define T4_PMAX 5   // most 16-byte patch pieces per thread and chunk (<= 640 positions x 4 pieces / 512 threads); template PM <= it
 
-template <typename H, int NT, int PM>
-__global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel(ConvT4Args p) {
+// S3 (H = float only): f32 storage, products on the bf16 matrix pipe.  Every f32 operand is split while it is staged into
+// three bf16 terms, x = x0 + x1 + x2 EXACTLY (8 + 8 + 8 mantissa bits; bf16 has f32's exponent range), and the six products
+// x0w0, x1w0, x0w1, x2w0, x1w1, x0w2 are accumulated in fp32 -- the three dropped ones are below 2^-24 of the product.
+// Measured against fp64 (tools/probes/split_mfma.hip, MI355X): error <= the v_mfma_f32_16x16x4_f32 chain's at K = 448 and
+// K = 3456 (6.3e-7 vs 4.2e-7, 1.4e-6 vs 2.0e-6 of the result's maximum), i.e. this IS an f32 convolution, at 3 matrix-pipe
+// MFMAs (16 cycles each) per 16 channels where the exact-f32 MFMA spends 4 x 32 cycles on the VALU-rate pipe.
+// LDS: one array per plane, a row (a patch position or a weight row) is 16 channels bf16 = 32 bytes, unpadded.  A
+// ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, ...: eight rows at channel offset 0 and eight other rows at
+// offset 16 bytes -- with 32-byte rows those are the 16 distinct bank quads (the first layout, planes interleaved in
+// 112-byte rows, was 2-way conflicted on 7 lanes of every group: 54 us per launch at 48 channels, LDS-bound).
+// One v_mfma_f32_16x16x32_bf16 takes K = 16 channels of plane a next to 16 channels of plane b, i.e. two of the six
+// products: X(0|0) W(0|1) = x0w0 + x0w1, X(1|1) W(0|1) = x1w0 + x1w1, X(0|2) W(2|0) = x0w2 + x2w0 -- three activation
+// fragments per pixel tile and two weight fragments per channel tile (12 LDS reads per 18 MFMAs at 2 x 3 tiles; the
+// kernel is LDS-read bound before it is MFMA bound).
+#define T4_S3_ROW 32
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+struct T4Split { bf16x4v h[3]; };
+__device__ __forceinline__ T4Split t4_split(u32x4 raw) {
+  T4Split o;
+  const f32x4 v = __builtin_bit_cast(f32x4, raw);
+  o.h[0] = __builtin_convertvector(v, bf16x4v);
+  const f32x4 r1 = v - __builtin_convertvector(o.h[0], f32x4);      // exact
+  o.h[1] = __builtin_convertvector(r1, bf16x4v);
+  const f32x4 r2 = r1 - __builtin_convertvector(o.h[1], f32x4);     // exact, and representable in bf16
+  o.h[2] = __builtin_convertvector(r2, bf16x4v);
+  return o;
+}
+__device__ __forceinline__ void t4_split_store(char* dst, int plane_bytes, const T4Split& o) {
+  *reinterpret_cast<bf16x4v*>(dst) = o.h[0];
+  *reinterpret_cast<bf16x4v*>(dst + plane_bytes) = o.h[1];
+  *reinterpret_cast<bf16x4v*>(dst + 2 * plane_bytes) = o.h[2];
+}
+
+template <typename H, int NT, int PM, bool S3 = false>
+__global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t4_kernel(ConvT4Args p) {
   typedef typename T4Traits<H>::frag frag;
+  static_assert(!S3 || sizeof(H) == 4, "the split instance takes f32 storage");
   constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // bytes per element, channels per chunk / per piece
+  constexpr int WBLK = S3 ? 16 * T4_S3_ROW : 1024;                   // LDS bytes of one (tap, channel tile) weight block (S3: per plane)
+  constexpr int WPL = 9 * NT * WBLK;                                 // S3: bytes of one weight plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WPC = 9 * NT * 64;               // 16-byte weight pieces per chunk
   constexpr int WR = (WPC + T4_THREADS - 1) / T4_THREADS;
@@ -86,8 +123,13 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
   for (int mt = 0; mt < T4_MT; ++mt) {
     const int pp = min(p0 + (wave + T4_WAVES * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
     const int ry = pp / p.W, rx = pp - ry * p.W;
-    base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + kq * 16;
+    base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + (S3 ? 0 : kq * 16);
   }
+  // S3: per-lane byte offset of fragment m inside a row: K 0..15 (kq 0, 1) from one plane, K 16..31 (kq 2, 3) from another
+  const int s3h = kq >> 1, s3l = (kq & 1) * 16;
+  const int ppl = p.patch_bytes / 3;                                 // S3: bytes of one patch plane
+  const int xo0 = s3l, xo1 = ppl + s3l, xo2 = (s3h ? 2 : 0) * ppl + s3l;                 // X(0|0), X(1|1), X(0|2)
+  const int wo0 = (s3h ? 1 : 0) * WPL + s3l + col * T4_S3_ROW, wo1 = (s3h ? 0 : 2) * WPL + s3l + col * T4_S3_ROW;   // W(0|1), W(2|0)
   f32x4 acc[T4_MT][NT];
 #pragma unroll
   for (int mt = 0; mt < T4_MT; ++mt)
@@ -125,16 +167,28 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
       const int i = tid + u * T4_THREADS;
       wr[u] = u32x4{0u, 0u, 0u, 0u};
       if (i < WPC) {
-        const int blk = i >> 6, l = i & 63;        // blk = tap*NT + nt
+        const int blk = i >> 6;                    // blk = tap*NT + nt
+        // S3: thread j of a block takes the image's lane (k quarter j & 3, row j >> 2): consecutive threads then store
+        // consecutive 8-byte runs of a plane row
+        const int l = S3 ? (((i & 3) << 4) | ((i >> 2) & 15)) : (i & 63);
         const int tap = blk / NT, nt = blk - tap * NT;
         wr[u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
       }
     }
   };
   fetch(0);
+  // S3: the split of a chunk's pieces (10 VALU per element) is done in registers DURING the previous chunk's tap loop (a
+  // piece or two per tap, in the shadow of the MFMAs); between the barriers only the LDS stores remain
+  T4Split sp[S3 ? PM + WR : 1];
+  if constexpr (S3) {
+#pragma unroll
+    for (int u = 0; u < PM; ++u) sp[u] = t4_split(pr[u]);
+#pragma unroll
+    for (int u = 0; u < WR; ++u) sp[PM + u] = t4_split(wr[u]);
+  }
   // XBN: per-channel scale / shift of the input's BatchNorm in LDS (behind the weight slab), computed while the first
   // chunk's loads are in flight; workgroup (0, 0) publishes mean / invstd / running statistics
-  float* xsc = reinterpret_cast<float*>(wbuf + 9 * NT * 1024);
+  float* xsc = reinterpret_cast<float*>(wbuf + 9 * NT * WBLK);      // (16-bit instances only)
   float* xsf = xsc + p.Ci;
   const bool xon = SZ == 2 && p.xb.on;
   if (xon) {
@@ -146,8 +200,19 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
     }
     __syncthreads();
   }
+#ifdef FAMI_T4_TRACE
+  const bool trace = p.dbg && bxl == 300 && byl == 0 && lane == 0;
+#define T4_STAMP(k) if (trace) p.dbg[(wave * 32 + c) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define T4_STAMP(k)
+#endif
   for (int c = 0; c < nchunk; ++c) {
+    T4_STAMP(0);
+    // S3: this chunk's pieces are already split (sp), so the next chunk's loads go out before the LDS stores and have the
+    // store phase and most of the tap loop to land (they are consumed at taps 4 .. 8)
+    if constexpr (S3) { if (c + 1 < nchunk) fetch(c + 1); }
     if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
+    T4_STAMP(1);
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
       const int i = tid + u * T4_THREADS;
@@ -157,16 +222,23 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
           const int ch0 = c * CHN + (i & 3) * PCN;      // border / outside pieces stay zero: the conv pads the NORMALISED tensor
           if (xon && goff[u] >= 0 && ch0 < p.Ci) v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
         }
-        *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = v;
+        if constexpr (S3) t4_split_store(patch + (i >> 2) * T4_S3_ROW + (i & 3) * 8, ppl, sp[u]);
+        else *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = v;
       }
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
       const int i = tid + u * T4_THREADS;
-      if (i < WPC) *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[u];
+      if (i < WPC) {
+        // S3: row (i >> 2) & 15 of block i >> 6, channels (i & 3) * 4 .. + 3 of each plane (see fetch)
+        if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, sp[PM + u]);
+        else *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[u];
+      }
     }
+    T4_STAMP(2);
     __syncthreads();
-    if (c + 1 < nchunk) fetch(c + 1);   // in flight while this chunk is multiplied
+    T4_STAMP(3);
+    if constexpr (!S3) { if (c + 1 < nchunk) fetch(c + 1); }   // in flight while this chunk is multiplied
     // the nine taps of this chunk for a wave with MW live pixel tiles (compile-time: a per-tile "is it live" branch cut the
     // loop into 3-MFMA blocks, each behind its own LDS wait -- now a tap's fragments are requested while the previous
     // tap's MFMAs issue)
@@ -175,6 +247,35 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+        if constexpr (S3) {
+          bf16x8 a3[MW][3], w3[NT][2];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const char* wb = wbuf + (tap * NT + nt) * WBLK;
+            w3[nt][0] = *reinterpret_cast<const bf16x8*>(wb + wo0);
+            w3[nt][1] = *reinterpret_cast<const bf16x8*>(wb + wo1);
+          }
+#pragma unroll
+          for (int mt = 0; mt < MW; ++mt) {
+            const char* pb = patch + base[mt] + toff;
+            a3[mt][0] = *reinterpret_cast<const bf16x8*>(pb + xo0);
+            a3[mt][1] = *reinterpret_cast<const bf16x8*>(pb + xo1);
+            a3[mt][2] = *reinterpret_cast<const bf16x8*>(pb + xo2);
+          }
+#pragma unroll
+          for (int m = 2; m >= 0; --m)          // low-order products first
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], acc[mt][nt], 0, 0, 0);
+          // the next chunk's pieces (fetched at the top of this iteration) are split here, spread over taps 4 .. 8 (stale
+          // registers after the last chunk: harmless)
+#pragma unroll
+          for (int u = 0; u < PM + WR; ++u)
+            if (4 + (u * 5) / (PM + WR) == tap) sp[u] = t4_split(u < PM ? pr[u < PM ? u : 0] : wr[u >= PM ? u - PM : 0]);
+          continue;
+        }
         frag a[MW], w[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wbuf + (tap * NT + nt) * 1024 + lane * 16);
@@ -188,6 +289,13 @@ __global__ __launch_bounds__(T4_THREADS, NT == 3 ? 4 : 3) void conv3x3_t4_kernel
     };
     if (mtw >= T4_MT) taps(std::integral_constant<int, T4_MT>());
     else if (mtw == 1) taps(std::integral_constant<int, 1>());
+    else if constexpr (S3) {      // a wave without a pixel tile still stages its pieces of the next chunk
+#pragma unroll
+      for (int u = 0; u < PM; ++u) sp[u] = t4_split(pr[u]);
+#pragma unroll
+      for (int u = 0; u < WR; ++u) sp[PM + u] = t4_split(wr[u]);
+    }
+    T4_STAMP(4);
   }
 
   // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
@@ -311,6 +419,59 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // the launch fills the chip (below), inside the f32 step it does not (61.2 vs 61.7 ms, and 61.4 vs 60.9
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
+static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
+
+// ---- the split-product f32 instance: plan + launch
+static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
+                             int KC, int NTt, int sgn, int relu, int accumulate, hipStream_t s, const char* name,
+                             const EpiBN& epi) {
+  if (!g_use_t4 || !g_use_t4_s3 || (Ci % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  const int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  if (!NT) return 0;
+  const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
+  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
+  const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW, lds_cap = 160 * 1024;
+  const long pos_cap = (long)T4_PMAX * T4_THREADS / 4;
+  int BT = 0;
+  for (int bt = 16; bt >= 1 && !BT; --bt)
+    if (positions(bt) <= pos_cap && (size_t)positions(bt) * 3 * T4_S3_ROW + wbytes <= lds_cap) BT = bt;
+  if (!BT) return 0;
+  if (g_t4_bt > 0 && g_t4_bt <= BT) BT = g_t4_bt;
+  if (BT > FT) BT = FT;
+  ConvT4Args a;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn_none();
+  a.x = x; a.wp = wp; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
+  a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
+  const long npos = positions(BT);
+  a.patch_bytes = (int)(npos * 3 * a.PS);     // three planes
+  a.dbg = g_t4_dbg;
+  size_t lds = (size_t)a.patch_bytes + wbytes;
+  const dim3 grid(N * a.bands, cblocks);
+  const int PM = (int)((npos * 4 + T4_THREADS - 1) / T4_THREADS);
+  bool ok = false;
+#define FAMI_T4S3_CASE(nt, pm)                                                                                            \
+  if (NT == nt && PM <= pm && !ok) {                                                                                      \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, nt, pm, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true>), grid, dim3(T4_THREADS), lds, s, a);                      \
+    ok = true;                                                                                                            \
+  }
+  FAMI_T4S3_CASE(3, 3) FAMI_T4S3_CASE(3, 5) FAMI_T4S3_CASE(4, 3) FAMI_T4S3_CASE(4, 5)
+#undef FAMI_T4S3_CASE
+  if (!ok) return 0;
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    fami_set_error(name, hipGetErrorString(err));
+    return FAMI_EHIP;
+  }
+  return 1;
+}
+
 template <typename HT>
 static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                           int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const char* name,
@@ -351,6 +512,7 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   a.PW = W + 2; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * a.PS);
+  a.dbg = g_t4_dbg;
   const size_t wbytes = (size_t)9 * NT * 1024;
   size_t lds = (size_t)a.patch_bytes + wbytes + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   if (lds < (size_t)T4_WAVES * NT * 32 * 4) lds = (size_t)T4_WAVES * NT * 32 * 4;
@@ -383,6 +545,10 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
+  if (half_kind == 2 && !xbn.on) {
+    const int rc = try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi);
+    if (rc != 0) return rc;
+  }
   if (half_kind == 2)
     return try_conv3x3_t4<float>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
   if (half_kind == 1)
@@ -409,8 +575,10 @@ int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
   const size_t lds = (size_t)positions(BT) * 80 + (size_t)9 * NT * 1024 + (size_t)2 * Ci * sizeof(float);
   return lds <= 100 * 1024 ? 1 : 0;
 }
+extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; }
+  else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
   else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;

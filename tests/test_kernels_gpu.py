@@ -738,3 +738,49 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
             assert far.item() < 5e-6, mode
         finally:
             lib().cdll.fami_dcn_tune(513)
+
+
+@pytest.mark.parametrize("shape", [(20, 96, 72, 48, 48), (3, 48, 36, 96, 96), (2, 24, 18, 192, 192), (2, 12, 9, 384, 384),
+                                   (2, 33, 21, 64, 64), (2, 16, 12, 256, 48), (1, 5, 7, 20, 48), (2, 40, 30, 8, 128)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
+    """conv_t4.hip S3: f32 3x3 convolutions with every operand split into three bf16 terms (exactly) and six products on
+    the bf16 matrix pipe.  Against an fp64 reference its error has to be of the size of the exact-f32 MFMA path's own
+    rounding error (at most 2x + 1e-7 of the result's maximum), forward and input gradient, and far inside the 2e-5 the
+    f32 convolution tests allow."""
+    from fami_pose_amd._lib import lib
+    from fami_pose_amd.engine import T
+    N, H, W, Ci, Co = shape
+    torch.manual_seed(sum(shape))
+    conv = nn.Conv2d(Ci, Co, 3, 1, 1, bias=True).double()
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+    x = (torch.randn(N, Ci, H, W, dtype=torch.float64) + 0.5).requires_grad_(True)
+    # f32-representable operands: the fp64 reference and the kernels see the same numbers
+    with torch.no_grad():
+        x.copy_(x.float().double())
+        for p_ in conv.parameters():
+            p_.copy_(p_.float().double())
+    y = conv(x)
+    gy = torch.randn_like(y).float().double()
+    y.backward(gy)
+    cd = nn.Conv2d(Ci, Co, 3, 1, 1, bias=True).to(dev)
+    cd.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
+    res = {}
+    try:
+        for name, knob in (('exact', 30), ('split', 31)):
+            lib().cdll.fami_conv_tune_lds(knob)
+            eng = _eng(dev)
+            xt = T(nhwc(x.detach().float()).to(dev), True)
+            yt = eng.conv(xt, cd.weight, cd.bias, 1, 1, 1)
+            yt.grad = nhwc(gy.float()).to(dev)
+            eng.backward()
+            torch.cuda.synchronize(dev)
+            res[name] = (nchw(yt.data).double().cpu(), nchw(xt.grad).double().cpu())
+    finally:
+        lib().cdll.fami_conv_tune_lds(-1)
+    for i, ref in enumerate((y.detach(), x.grad)):
+        m = ref.abs().max().item()
+        ee, es = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split')]
+        assert es < 2 * ee + 1e-7 and es < 3e-6, (i, ee, es)
+    assert not torch.equal(res['exact'][0], res['split'][0])      # the two paths really are different kernels

@@ -16,7 +16,7 @@ def timeit(fn, reps=40):
 p = lambda t: None if t is None else t.data_ptr()
 DT = os.environ.get('DT', 'bf16')
 tdt = {'bf16': torch.bfloat16, 'f32': torch.float32}[DT]
-shapes = [(96, 72, 48, 48), (48, 36, 96, 96), (24, 18, 192, 192), (12, 9, 384, 384), (96, 72, 192, 48), (96, 72, 96, 48), (96, 72, 256, 48)]
+shapes = [(96, 72, 48, 48), (48, 36, 96, 96), (24, 18, 192, 192), (12, 9, 384, 384), (96, 72, 192, 48), (96, 72, 96, 48), (96, 72, 256, 48), (96, 72, 64, 64)]
 for (H, W, Ci, Co) in shapes:
     x = torch.randn(N, H, W, Ci, device=dev).to(tdt); y = torch.empty(N, H, W, Co, device=dev, dtype=tdt)
     dy = torch.randn(N, H, W, Co, device=dev).to(tdt); dx = torch.empty_like(x)
@@ -36,8 +36,15 @@ for (H, W, Ci, Co) in shapes:
     L.cdll.fami_conv_tune_lds(0); res.append(('direct', timeit(fwd), timeit(bwd)))
     L.cdll.fami_conv_tune_lds(1); L.cdll.fami_conv_tune_lds(10); res.append(('lds-r1', timeit(fwd), timeit(bwd)))
     L.cdll.fami_conv_tune_lds(11)
-    for bt in (0, 16, 12, 8, 6, 4):
-        L.cdll.fami_conv_tune_lds(100 + bt); res.append(('t4/bt%d' % bt, timeit(fwd), timeit(bwd)))
+    if DT == 'f32':   # exact-f32 MFMA instance of the register-blocked kernel, then the split-product instance (bf16 matrix pipe)
+        L.cdll.fami_conv_tune_lds(30); L.cdll.fami_conv_tune_lds(21); L.cdll.fami_conv_tune_lds(112)
+        res.append(('t4-exact/bt12', timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(31)
+        for bt in (0, 16, 14, 12, 10, 8, 6):
+            L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3/bt%d' % bt, timeit(fwd), timeit(bwd)))
+    else:
+        for bt in (0, 16, 12, 8, 6, 4):
+            L.cdll.fami_conv_tune_lds(100 + bt); res.append(('t4/bt%d' % bt, timeit(fwd), timeit(bwd)))
     L.cdll.fami_conv_tune_lds(-1)
     gf = 2.0 * N * H * W * Ci * Co * 9 / 1e9
     print(DT + ' %3dx%-3d %3d->%-3d %.2f GFLOP | ' % (H, W, Ci, Co, gf) + ' | '.join('%s %.1f/%.1f' % r for r in res), flush=True)

@@ -15,6 +15,8 @@ tdt = torch.bfloat16 if dt == 'bf16' else torch.float32
 st = s.cuda_stream
 for code in [c for c in os.environ.get('DCN_TUNE', '').split(',') if c]:      # e.g. DCN_TUNE=2 (window kernel), 2,95 (+ ablation bits)
     L.cdll.fami_dcn_tune(int(code))
+for code in [c for c in os.environ.get('LDS_TUNE', '').split(',') if c]:      # e.g. LDS_TUNE=112 (12 tiles per band), 30 (no split-product f32)
+    L.cdll.fami_conv_tune_lds(int(code))
 if os.environ.get('XCD'):
     L.cdll.fami_conv_tune_xcd(int(os.environ['XCD']))
 if kind in ('conv', 'dgrad', 'wgrad'):
