@@ -74,6 +74,12 @@ template <> struct T4Traits<float> {
 // fragments per pixel tile and two weight fragments per channel tile (12 LDS reads per 18 MFMAs at 2 x 3 tiles; the
 // kernel is LDS-read bound before it is MFMA bound).
 #define T4_S3_ROW 32
+// The low-order MFMAs (x1 w0 + x1 w1, x0 w2 + x2 w0) have their own accumulators: the high-order sum then takes one fp32
+// rounding per 16 channels instead of three.  Measured against fp64 (tools/probes/s3_check.py, 12 shapes): error 1.0-2.5x
+// the exact-f32 MFMA path's (3.0e-7 vs 1.6e-7 ... 1.26e-6 vs 5.0e-7 of the result's maximum); with one accumulator 2-4x.
+// (Splitting the next chunk in registers during the tap loop, so that only the LDS stores sit between the barriers, was
+// tried: 236 VGPRs, same time per launch and per step -- the split is not what the staging phase waits for.)
+#define T4_S3_ACC2 1
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 struct T4Split { bf16x4v h[3]; };
 __device__ __forceinline__ T4Split t4_split(u32x4 raw) {
@@ -135,6 +141,13 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   for (int mt = 0; mt < T4_MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[S3 && T4_S3_ACC2 ? T4_MT : 1][S3 && T4_S3_ACC2 ? NT : 1];
+  if constexpr (S3 && T4_S3_ACC2) {
+#pragma unroll
+    for (int mt = 0; mt < T4_MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // chunk-invariant part of the patch staging: global byte offset of this thread's pieces (-1: zero border / outside)
   const char* xg = reinterpret_cast<const char*>(p.x);
@@ -177,15 +190,6 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
     }
   };
   fetch(0);
-  // S3: the split of a chunk's pieces (10 VALU per element) is done in registers DURING the previous chunk's tap loop (a
-  // piece or two per tap, in the shadow of the MFMAs); between the barriers only the LDS stores remain
-  T4Split sp[S3 ? PM + WR : 1];
-  if constexpr (S3) {
-#pragma unroll
-    for (int u = 0; u < PM; ++u) sp[u] = t4_split(pr[u]);
-#pragma unroll
-    for (int u = 0; u < WR; ++u) sp[PM + u] = t4_split(wr[u]);
-  }
   // XBN: per-channel scale / shift of the input's BatchNorm in LDS (behind the weight slab), computed while the first
   // chunk's loads are in flight; workgroup (0, 0) publishes mean / invstd / running statistics
   float* xsc = reinterpret_cast<float*>(wbuf + 9 * NT * WBLK);      // (16-bit instances only)
@@ -208,9 +212,6 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
 #endif
   for (int c = 0; c < nchunk; ++c) {
     T4_STAMP(0);
-    // S3: this chunk's pieces are already split (sp), so the next chunk's loads go out before the LDS stores and have the
-    // store phase and most of the tap loop to land (they are consumed at taps 4 .. 8)
-    if constexpr (S3) { if (c + 1 < nchunk) fetch(c + 1); }
     if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
     T4_STAMP(1);
 #pragma unroll
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
           const int ch0 = c * CHN + (i & 3) * PCN;      // border / outside pieces stay zero: the conv pads the NORMALISED tensor
           if (xon && goff[u] >= 0 && ch0 < p.Ci) v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
         }
-        if constexpr (S3) t4_split_store(patch + (i >> 2) * T4_S3_ROW + (i & 3) * 8, ppl, sp[u]);
+        if constexpr (S3) t4_split_store(patch + (i >> 2) * T4_S3_ROW + (i & 3) * 8, ppl, t4_split(v));
         else *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = v;
       }
     }
@@ -231,14 +232,14 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
       const int i = tid + u * T4_THREADS;
       if (i < WPC) {
         // S3: row (i >> 2) & 15 of block i >> 6, channels (i & 3) * 4 .. + 3 of each plane (see fetch)
-        if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, sp[PM + u]);
+        if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, t4_split(wr[u]));
         else *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[u];
       }
     }
     T4_STAMP(2);
     __syncthreads();
     T4_STAMP(3);
-    if constexpr (!S3) { if (c + 1 < nchunk) fetch(c + 1); }   // in flight while this chunk is multiplied
+    if (c + 1 < nchunk) fetch(c + 1);   // in flight while this chunk is multiplied
     // the nine taps of this chunk for a wave with MW live pixel tiles (compile-time: a per-tile "is it live" branch cut the
     // loop into 3-MFMA blocks, each behind its own LDS wait -- now a tap's fragments are requested while the previous
     // tap's MFMAs issue)
@@ -268,12 +269,10 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
             for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], acc[mt][nt], 0, 0, 0);
-          // the next chunk's pieces (fetched at the top of this iteration) are split here, spread over taps 4 .. 8 (stale
-          // registers after the last chunk: harmless)
-#pragma unroll
-          for (int u = 0; u < PM + WR; ++u)
-            if (4 + (u * 5) / (PM + WR) == tap) sp[u] = t4_split(u < PM ? pr[u < PM ? u : 0] : wr[u >= PM ? u - PM : 0]);
+              {
+                f32x4& dst = (T4_S3_ACC2 && m > 0) ? acc2[T4_S3_ACC2 ? mt : 0][T4_S3_ACC2 ? nt : 0] : acc[mt][nt];
+                dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], dst, 0, 0, 0);
+              }
           continue;
         }
         frag a[MW], w[NT];
@@ -289,15 +288,15 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
     };
     if (mtw >= T4_MT) taps(std::integral_constant<int, T4_MT>());
     else if (mtw == 1) taps(std::integral_constant<int, 1>());
-    else if constexpr (S3) {      // a wave without a pixel tile still stages its pieces of the next chunk
-#pragma unroll
-      for (int u = 0; u < PM; ++u) sp[u] = t4_split(pr[u]);
-#pragma unroll
-      for (int u = 0; u < WR; ++u) sp[PM + u] = t4_split(wr[u]);
-    }
     T4_STAMP(4);
   }
 
+  if constexpr (S3 && T4_S3_ACC2) {
+#pragma unroll
+    for (int mt = 0; mt < T4_MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += acc2[mt][nt];
+  }
   // ---- epilogue: D row = kq*4 + r (output channel), col = lane&15 (pixel)
   const long pix0 = (long)img * HW + p0;
   const int emode = p.emode;
