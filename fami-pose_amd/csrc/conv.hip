@@ -2662,6 +2662,10 @@ int fami_conv_tune_lds(int on) {
 }
 // 0 routes bf16 weight gradients through the scalar-operand f32-MFMA kernels (benchmarks / tests)
 int fami_conv_tune_wgrad_lds(int on) {
+  if (on >= 30000) {         // split-product f32 kernel (conv_wgs3.hip): 30000 / 30001 off / on, 30100 + tiles per run,
+    fami_wgrad_s3_tune(on - 30000);  // 31000 + workgroup target
+    return FAMI_OK;
+  }
   if (on >= 20000) {         // round-3 16-bit kernel (conv_wg16.hip): 20000 / 20001 off / on, 20100 + tiles per run,
     fami_wgrad16_tune(on - 20000);   // 21000 + workgroup target
     return FAMI_OK;
@@ -2680,6 +2684,7 @@ int fami_conv_tune_wgrad_lds(int on) {
   }
   if (on < 0) {  // defaults
     fami_wgrad16_tune(-1);
+    fami_wgrad_s3_tune(-1);
     g_wgrad_lds = 1;
     g_wgrad_lds_f32 = 2;
     g_wgrad_nsub = 2;
@@ -2965,6 +2970,10 @@ long fami_conv2d_wgrad_workspace(int N, int H, int W, int Ci, int Co, int kh, in
     const long nl = fami_wgrad16_slabs(N, H, W, Ci, Co, kh, stride, pad, dil) * Co * Ci * kh * kw * (long)sizeof(float);
     if (nl > need) need = nl;
   }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
+    const long nl = fami_wgrad_s3_slabs(N, H, W, Ci, Co) * Co * Ci * 9 * (long)sizeof(float);
+    if (nl > need) need = nl;
+  }
   return need;
 }
 
@@ -3125,6 +3134,16 @@ extern "C" {
 int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                           hipStream_t s) {
+  if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && x && dy && dw && workspace) {
+    // split-product kernel on the bf16 matrix pipe (conv_wgs3.hip)
+    const int G = fami_try_wgrad_s3(x, dy, workspace, ws_bytes, N, H, W, Ci, Co, s, "fami_conv2d_wgrad_f32");
+    if (G < 0) return G;
+    if (G > 0) {
+      launch_reduce_taps(workspace, dw, Co, Ci, 9, G, accumulate, s);
+      FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
+      return FAMI_OK;
+    }
+  }
   WgradLdsPlan l = g_wgrad_lds_f32 ? wgrad_lds_plan_f32(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   // measured (tools/bench_wgrad.py f32): the staged kernel wins once the channel blocks alone give >= 64 workgroup
   // columns (384 channels: 136 vs 151 us); below that the per-tap scalar-operand kernel is faster (85 vs 105 us)

@@ -136,3 +136,10 @@ long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int 
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
                      int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn = xbn_none());
 void fami_wgrad16_tune(int on);
+
+// conv_wgs3.hip: f32 weight gradient of the 3x3 stride-1 pad-1 convolutions on the bf16 matrix pipe (operands split into
+// three bf16 terms, six products, fp32 accumulation).  Same contract as fami_try_wgrad16.
+long fami_wgrad_s3_slabs(int N, int H, int W, int Ci, int Co);
+int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_bytes, int N, int H, int W, int Ci, int Co,
+                      hipStream_t s, const char* name);
+void fami_wgrad_s3_tune(int on);

@@ -744,10 +744,10 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
                                    (2, 33, 21, 64, 64), (2, 16, 12, 256, 48), (1, 5, 7, 20, 48), (2, 40, 30, 8, 128)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
-    """conv_t4.hip S3: f32 3x3 convolutions with every operand split into three bf16 terms (exactly) and six products on
-    the bf16 matrix pipe.  Against an fp64 reference its error has to be of the size of the exact-f32 MFMA path's own
-    rounding error (at most 3x + 1e-7 of the result's maximum; measured 1.0-2.5x), forward and input gradient, and far
-    inside the 2e-5 the f32 convolution tests allow."""
+    """conv_t4.hip S3 / conv_wgs3.hip: f32 3x3 convolutions with every operand split into three bf16 terms (exactly) and
+    six products on the bf16 matrix pipe.  Against an fp64 reference its error has to be of the size of the exact-f32
+    MFMA path's own rounding error (at most 3x + 1e-7 of the result's maximum; measured 1.0-2.5x) -- forward, input
+    gradient and weight gradient -- and far inside the 2e-5 / 5e-5 the f32 convolution tests allow."""
     from fami_pose_amd._lib import lib
     from fami_pose_amd.engine import T
     N, H, W, Ci, Co = shape
@@ -770,17 +770,22 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
     try:
         for name, knob in (('exact', 30), ('split', 31)):
             lib().cdll.fami_conv_tune_lds(knob)
+            lib().cdll.fami_conv_tune_wgrad_lds(30000 + knob - 30)
             eng = _eng(dev)
             xt = T(nhwc(x.detach().float()).to(dev), True)
             yt = eng.conv(xt, cd.weight, cd.bias, 1, 1, 1)
             yt.grad = nhwc(gy.float()).to(dev)
             eng.backward()
             torch.cuda.synchronize(dev)
-            res[name] = (nchw(yt.data).double().cpu(), nchw(xt.grad).double().cpu())
+            res[name] = (nchw(yt.data).double().cpu(), nchw(xt.grad).double().cpu(),
+                         eng.param_grads[id(cd.weight)].double().cpu())
     finally:
         lib().cdll.fami_conv_tune_lds(-1)
-    for i, ref in enumerate((y.detach(), x.grad)):
+        lib().cdll.fami_conv_tune_wgrad_lds(-1)
+    for i, ref in enumerate((y.detach(), x.grad, conv.weight.grad)):
         m = ref.abs().max().item()
         ee, es = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split')]
         assert es < 3 * ee + 1e-7 and es < 3e-6, (i, ee, es)
     assert not torch.equal(res['exact'][0], res['split'][0])      # the two paths really are different kernels
+    if Ci % 16 == 0 and Co % 16 == 0:
+        assert not torch.equal(res['exact'][2], res['split'][2])
