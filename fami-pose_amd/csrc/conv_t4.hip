@@ -80,6 +80,12 @@ template <> struct T4Traits<float> {
 // (Splitting the next chunk in registers during the tap loop, so that only the LDS stores sit between the barriers, was
 // tried: 236 VGPRs, same time per launch and per step -- the split is not what the staging phase waits for.)
 #define T4_S3_ACC2 1
+// Where the time of a launch goes (48 -> 48 channels @96x72, 20 frames, 44 us; ablation builds of this kernel, MI355X):
+// two of the three MFMAs removed -12 us, weight stores removed -4.7, split arithmetic -3.3, global loads after chunk 0 -2,
+// patch stores -1.7; requesting a tap's fragments a whole tap ahead (below) and two 4-wave workgroups per CU instead of
+// one 8-wave workgroup changed nothing.  With 100 KiB of LDS per workgroup there is one workgroup and two waves per
+// SIMD on a CU, and the phases of a chunk (loads -> split -> LDS stores -> barrier -> LDS reads -> MFMAs) add up instead of
+// overlapping: MFMA floor 13.7 us + LDS reads 12 us + LDS stores 4 us + staging.
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 struct T4Split { bf16x4v h[3]; };
 __device__ __forceinline__ T4Split t4_split(u32x4 raw) {
@@ -98,8 +104,10 @@ __device__ __forceinline__ void t4_split_store(char* dst, int plane_bytes, const
   *reinterpret_cast<bf16x4v*>(dst + 2 * plane_bytes) = o.h[2];
 }
 
-template <typename H, int NT, int PM, bool S3 = false>
-__global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t4_kernel(ConvT4Args p) {
+// WV: waves per workgroup (8; a 4-wave S3 form with two workgroups per CU measured the same and is not instantiated).
+template <typename H, int NT, int PM, bool S3 = false, int WV = 8>
+__global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t4_kernel(ConvT4Args p) {
+  constexpr int THREADS = WV * 64;
   typedef typename T4Traits<H>::frag frag;
   static_assert(!S3 || sizeof(H) == 4, "the split instance takes f32 storage");
   constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // bytes per element, channels per chunk / per piece
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   constexpr int WPL = 9 * NT * WBLK;                                 // S3: bytes of one weight plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WPC = 9 * NT * 64;               // 16-byte weight pieces per chunk
-  constexpr int WR = (WPC + T4_THREADS - 1) / T4_THREADS;
+  constexpr int WR = (WPC + THREADS - 1) / THREADS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kq = lane >> 4;
@@ -122,12 +130,12 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   const int ntg0 = byl * NT;
   char* patch = smem;
   char* wbuf = smem + p.patch_bytes;
-  const int mtw = (ntile - wave + T4_WAVES - 1) / T4_WAVES;   // pixel tiles of this wave: wave, wave + 8, ... (wave-uniform)
+  const int mtw = (ntile - wave + WV - 1) / WV;   // pixel tiles of this wave: wave, wave + 8, ... (wave-uniform)
 
   int base[T4_MT];
 #pragma unroll
   for (int mt = 0; mt < T4_MT; ++mt) {
-    const int pp = min(p0 + (wave + T4_WAVES * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
+    const int pp = min(p0 + (wave + WV * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
     const int ry = pp / p.W, rx = pp - ry * p.W;
     base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + (S3 ? 0 : kq * 16);
   }
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   int goff[PM];
 #pragma unroll
   for (int u = 0; u < PM; ++u) {
-    const int i = tid + u * T4_THREADS;
+    const int i = tid + u * THREADS;
     goff[u] = -1;
     if (i < npiece) {
       const int pos = i >> 2, pc = i & 3;
@@ -172,12 +180,12 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
       pr[u] = u32x4{0u, 0u, 0u, 0u};
-      const int pc = (tid + u * T4_THREADS) & 3;
+      const int pc = (tid + u * THREADS) & 3;
       if (goff[u] >= 0 && c * CHN + pc * PCN < p.Ci) pr[u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
-      const int i = tid + u * T4_THREADS;
+      const int i = tid + u * THREADS;
       wr[u] = u32x4{0u, 0u, 0u, 0u};
       if (i < WPC) {
         const int blk = i >> 6;                    // blk = tap*NT + nt
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   float* xsf = xsc + p.Ci;
   const bool xon = SZ == 2 && p.xb.on;
   if (xon) {
-    for (int ch = tid; ch < p.Ci; ch += T4_THREADS) {
+    for (int ch = tid; ch < p.Ci; ch += THREADS) {
       float a, b;
       xbn_channel(p.xb, ch, bxl == 0 && byl == 0, a, b);
       xsc[ch] = a;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
     T4_STAMP(1);
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
-      const int i = tid + u * T4_THREADS;
+      const int i = tid + u * THREADS;
       if (i < npiece) {
         u32x4 v = pr[u];
         if constexpr (SZ == 2) {
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
-      const int i = tid + u * T4_THREADS;
+      const int i = tid + u * THREADS;
       if (i < WPC) {
         // S3: row (i >> 2) & 15 of block i >> 6, channels (i & 3) * 4 .. + 3 of each plane (see fetch)
         if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, t4_split(wr[u]));
@@ -245,24 +253,41 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
     // tap's MFMAs issue)
     auto taps = [&](auto mwc) {
       constexpr int MW = decltype(mwc)::value;
+      bf16x8 a3[S3 ? 2 : 1][MW][3], w3[S3 ? 2 : 1][NT][2];
+      auto s3_load_w = [&](int tap, bf16x8 (&w)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const char* wb = wbuf + (tap * NT + nt) * WBLK;
+          w[nt][0] = *reinterpret_cast<const bf16x8*>(wb + wo0);
+          w[nt][1] = *reinterpret_cast<const bf16x8*>(wb + wo1);
+        }
+      };
+      auto s3_load_a = [&](int tap, bf16x8 (&a)[MW][3]) {
+        const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+          const char* pb = patch + base[mt] + toff;
+          a[mt][0] = *reinterpret_cast<const bf16x8*>(pb + xo0);
+          a[mt][1] = *reinterpret_cast<const bf16x8*>(pb + xo1);
+          a[mt][2] = *reinterpret_cast<const bf16x8*>(pb + xo2);
+        }
+      };
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
         if constexpr (S3) {
-          bf16x8 a3[MW][3], w3[NT][2];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const char* wb = wbuf + (tap * NT + nt) * WBLK;
-            w3[nt][0] = *reinterpret_cast<const bf16x8*>(wb + wo0);
-            w3[nt][1] = *reinterpret_cast<const bf16x8*>(wb + wo1);
+          // fragments of tap t + 1 are requested before tap t is multiplied (two register sets): left to itself the
+          // scheduler issued a tap's twelve LDS reads one to three MFMAs ahead of their use and the wave sat in
+          // s_waitcnt lgkmcnt(0..1) before most MFMAs (2 waves per SIMD cannot cover that)
+          if (tap == 0) {
+            s3_load_w(0, w3[0]);
+            s3_load_a(0, a3[0]);
           }
-#pragma unroll
-          for (int mt = 0; mt < MW; ++mt) {
-            const char* pb = patch + base[mt] + toff;
-            a3[mt][0] = *reinterpret_cast<const bf16x8*>(pb + xo0);
-            a3[mt][1] = *reinterpret_cast<const bf16x8*>(pb + xo1);
-            a3[mt][2] = *reinterpret_cast<const bf16x8*>(pb + xo2);
+          if (tap < 8) {
+            s3_load_w(tap + 1, w3[(tap + 1) & 1]);
+            s3_load_a(tap + 1, a3[(tap + 1) & 1]);
           }
+          const int cur = tap & 1;
 #pragma unroll
           for (int m = 2; m >= 0; --m)          // low-order products first
 #pragma unroll
@@ -271,8 +296,17 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
               for (int nt = 0; nt < NT; ++nt)
               {
                 f32x4& dst = (T4_S3_ACC2 && m > 0) ? acc2[T4_S3_ACC2 ? mt : 0][T4_S3_ACC2 ? nt : 0] : acc[mt][nt];
-                dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[cur][nt][m == 2 ? 1 : 0], a3[cur][mt][m], dst, 0, 0, 0);
               }
+          if (tap < 8) {
+            // one LDS read behind each of the first MFMAs, the rest of the MFMAs after them
+#pragma unroll
+            for (int k = 0; k < 3 * MW + 2 * NT; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MW * NT - (3 * MW + 2 * NT), 0);
+          }
           continue;
         }
         frag a[MW], w[NT];
@@ -331,7 +365,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
       }
 #pragma unroll
       for (int mt = 0; mt < T4_MT; ++mt) {
-        const int j = (wave + T4_WAVES * mt) * 16 + col;
+        const int j = (wave + WV * mt) * 16 + col;
         if (mt >= mtw || p0 + j >= p1) continue;
         f32x4 v = acc[mt][nt] + bias4;
         const long idx = (pix0 + j) * p.Co + co0;
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
       const int co = (ntg0 + nt) * 16 + c16;
       float v = 0.f;
 #pragma unroll
-      for (int wv = 0; wv < T4_WAVES; ++wv) v += ered[wv * (NT * 32) + tid];
+      for (int wv = 0; wv < WV; ++wv) v += ered[wv * (NT * 32) + tid];
       double* srow = e->slots + (long)(bxl % e->ns) * 2 * eC;
       unsafeAtomicAdd(srow + st * eC + co, (double)v);
       if (emode == 1 && st == 0 && bxl == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(T4_THREADS, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x
   }
 #pragma unroll
   for (int mt = 0; mt < T4_MT; ++mt) {
-    const int j = (wave + T4_WAVES * mt) * 16 + col;
+    const int j = (wave + WV * mt) * 16 + col;
     if (mt >= mtw || p0 + j >= p1) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -430,7 +464,9 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   if (!NT) return 0;
   const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
   auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
-  const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW, lds_cap = 160 * 1024;
+  const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW;
+  const int WVs = 8;
+  const size_t lds_cap = 160 * 1024;
   const long pos_cap = (long)T4_PMAX * T4_THREADS / 4;
   int BT = 0;
   for (int bt = 16; bt >= 1 && !BT; --bt)
@@ -448,19 +484,19 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   a.dbg = g_t4_dbg;
   size_t lds = (size_t)a.patch_bytes + wbytes;
   const dim3 grid(N * a.bands, cblocks);
-  const int PM = (int)((npos * 4 + T4_THREADS - 1) / T4_THREADS);
+  const int PM = (int)((npos * 4 + WVs * 64 - 1) / (WVs * 64));
   bool ok = false;
-#define FAMI_T4S3_CASE(nt, pm)                                                                                            \
-  if (NT == nt && PM <= pm && !ok) {                                                                                      \
+#define FAMI_T4S3_CASE(nt, pm, wv)                                                                                        \
+  if (NT == nt && WVs == wv && PM <= pm && !ok) {                                                                         \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, nt, pm, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, nt, pm, true, wv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true>), grid, dim3(T4_THREADS), lds, s, a);                      \
+    hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true, wv>), grid, dim3(wv * 64), lds, s, a);                     \
     ok = true;                                                                                                            \
   }
-  FAMI_T4S3_CASE(3, 3) FAMI_T4S3_CASE(3, 5) FAMI_T4S3_CASE(4, 3) FAMI_T4S3_CASE(4, 5)
+  FAMI_T4S3_CASE(3, 3, 8) FAMI_T4S3_CASE(3, 5, 8) FAMI_T4S3_CASE(4, 3, 8) FAMI_T4S3_CASE(4, 5, 8)
 #undef FAMI_T4S3_CASE
   if (!ok) return 0;
   hipError_t err = hipGetLastError();
