@@ -119,16 +119,29 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
     ms = _time_launches(launch, s, reps)
     flops = 2.0 * N * H * W * C * 9 * C
     ach = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS if half else PEAK_F32_MFMA_TFLOPS
-    # the library's default route for this shape: direct implicit GEMM (both dtypes at < 96 channels)
-    # the library's default route for this shape: f32 = direct implicit GEMM (linear-address form), 16-bit = the
-    # register-blocked LDS kernel of conv_t4.hip
-    kname = ('conv3x3_t4_kernel<%s>' % dtype) if half else 'conv_igemm_f32'
-    key = {'f32': 'conv_igemm_f32', 'bf16': 'conv3x3_t4_bf16'}.get(dtype)
+    # the library's default route for this shape is the register-blocked LDS kernel of conv_t4.hip in every storage type.
+    # f32 storage: its split-product instance -- every f32 operand split exactly into three bf16 terms, six products per
+    # f32 product on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- so the peak that bounds it is a sixth of the dense
+    # bf16 MFMA peak; the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, peak 157.3) route is timed beside it.
+    split = (not half) and os.environ.get('FAMI_F32_SPLIT', '1') != '0'
+    peak = PEAK_BF16_MFMA_TFLOPS if half else (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS)
+    kname = ('conv3x3_t4_kernel<%s>' % dtype) if half else ('conv3x3_t4_kernel<float, split-product>' if split else 'conv_igemm_f32')
+    key = {'f32': 'conv3x3_t4_s3_f32' if split else 'conv_igemm_f32', 'bf16': 'conv3x3_t4_bf16'}.get(dtype)
     out = {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
            "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
+    if split:
+        out["peak_note"] = ("dense bf16 MFMA peak %.0f / 6 products per f32 product; achieved counts each f32 "
+                            "multiply-add once" % PEAK_BF16_MFMA_TFLOPS)
+        L.cdll.fami_conv_tune_lds(30)
+        try:
+            ms_x = _time_launches(launch, s, reps)
+        finally:
+            L.cdll.fami_conv_tune_lds(31)
+        out["exact_f32_mfma"] = {"kernel": "conv_igemm_f32 (v_mfma_f32_16x16x4_f32)", "avg_launch_us": round(ms_x * 1e3, 2),
+                                 "achieved": round(flops / (ms_x * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                                 "frac": round(flops / (ms_x * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     rec = in_step(dtype)
     if rec and N == 20 and C == 48 and H == 96 and rec.get('dominant_avg_us'):
         # the same launch inside the training step (committed trace; other stream lanes contend for the chip)
@@ -424,6 +437,12 @@ def main():
                        "hipgraph": use_graph, **({} if backend == 'nccl' or world == 1 else {"dist_backend": backend})},
             "loss": round(loss, 6), **info,
         }
+        if args.dtype == 'f32':
+            out["conv_arithmetic"] = (
+                "f32 storage and accumulation; 3x3 stride-1 convolutions (forward, input and weight gradient): each f32 "
+                "operand split exactly into three bf16 terms, six products on v_mfma_f32_16x16x32_bf16 (error vs fp64 1-2.5x "
+                "the exact-f32 MFMA path's, tests/test_kernels_gpu.py); all other convolutions v_mfma_f32_16x16x4_f32"
+                if os.environ.get('FAMI_F32_SPLIT', '1') != '0' else "f32 storage, v_mfma_f32_16x16x4_f32 everywhere")
         C, Hf, Wf = args.width, args.img_h // 4, args.img_w // 4
         G = 12 if C % 48 == 0 else C // 4
         out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype, C=C, H=Hf, W=Wf)
@@ -431,9 +450,14 @@ def main():
         def step_roofline(dtype, flops, ms):
             # every nn.Conv2d FLOP of the step (forward + input gradient + weight gradient, counted by the engine as the
             # launches are enqueued) over the measured step time, against the dtype's dense MFMA peak
-            peak = PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+            # (f32: the 3x3 stride-1 convolutions -- 90 % of those FLOPs -- run as six bf16 products per f32 product on the
+            # bf16 matrix pipe, hence a sixth of the dense bf16 peak; the fraction of the exact-f32 MFMA peak beside it)
+            split = dtype == 'f32' and os.environ.get('FAMI_F32_SPLIT', '1') != '0'
+            peak = (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS) if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
             r = {"bound": "mfma", "conv_flops_per_step": int(flops), "achieved": round(flops / (ms * 1e-3) / 1e12, 2),
                  "peak": peak, "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
+            if split:
+                r["frac_of_exact_f32_mfma_peak"] = round(flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             rec = in_step(dtype)
             if rec:
                 r.update({k: rec[k] for k in ('launches_per_step', 'idle_share', 'kernel_time_ms_per_step', 'source') if k in rec})

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     int py[2], pxx[2], pl[2], ya[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      pl[h] = kq * 8 + h * 4 + rsel;
+      pl[h] = kq * 4 + h * 16 + rsel;   // (any pixel <-> K-slot map serves as long as both operands use it; this one is bank-conflict free)
       const int q = q0 + pl[h];
       py[h] = q / p.Wo;
       pxx[h] = q - py[h] * p.Wo;
@@ -310,8 +310,10 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
   // 256 -> 64 @96x72: 12 blocks x 138 240 pixels) measured 105-110 us against 80 us for the scalar-operand kernel
   if (k == 1 && (long)N * HW * blocks > 500000) return q;
   // LDS rows are unpadded (see conv_wgrad_h_kernel): the 4 pixel rows of a transposing read are 32 * CIT bytes apart
-  q.xps = 32 * q.CIT;
-  q.yps = 32 * q.COT;
+  // a row is an odd number of 32-byte bank blocks (32-channel rows padded to 48): the eight pixel rows a transposing read's
+  // 32 lanes touch then hit eight distinct blocks (see the K-step's pixel map)
+  q.xps = q.CIT == 2 ? 96 : 32 * q.CIT;
+  q.yps = q.COT == 2 ? 96 : 32 * q.COT;
   const int PW = W + 2 * pad;
   const int cand[8] = {16, 14, 12, 10, 8, 6, 4, 2};
   q.BT = 0;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NPW = (CIT * 9 + WS3_WAVES - 1) / WS3_WAVES;   // (ci tile, tap) pairs per wave
   constexpr int XPC = CIT * 4, YPC = COT * 4;                   // 16-byte f32 pieces per position / pixel
-  constexpr int XPS = CIT * 32, YPS = COT * 32;                 // LDS bytes per position / pixel in one plane
+  constexpr int XPS = CIT == 2 ? 96 : CIT * 32, YPS = COT == 2 ? 96 : COT * 32;   // LDS bytes per position / pixel in one plane (an odd number of 32-byte blocks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, kq = lane >> 4;
@@ -167,11 +167,15 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
     const int M = q1 - q0;
     if (sub + 1 < p.nsub && b + 1 < p.NB) fetch(b + 1);   // in flight while this run is multiplied
 
-    // this lane's two pixels of the current K step (local index pl = ks*32 + kq*8 + h*4 + rsel), kept incrementally
+    // this lane's two pixels of the current K step (local index pl = ks*32 + h*16 + kq*4 + rsel), kept incrementally.
+    // The 32 lanes a transposing read serves together are two kq groups: with kq*8 + h*4 the second group's four pixel rows
+    // sat 8 rows = a multiple of 256 bytes behind the first's and hit the same banks (SQ_LDS_BANK_CONFLICT 38 % of the LDS
+    // cycles); rows kq*4 .. kq*4+3 of both groups are eight consecutive rows = eight distinct 32-byte bank blocks when a
+    // row is an odd number of them (16 or 48 channels; 32-channel rows are padded to 48)
     int py[2], pxx[2], pl[2], ya[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      pl[h] = kq * 8 + h * 4 + rsel;
+      pl[h] = kq * 4 + h * 16 + rsel;   // (any pixel <-> K-slot map serves as long as both operands use it; this one is bank-conflict free)
       const int q = q0 + pl[h];
       py[h] = q / p.W;
       pxx[h] = q - py[h] * p.W;
@@ -272,13 +276,14 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
     const long orows = (bt * 16) % W == 0 ? (bt * 16) / W : (bt * 16 + W - 2) / W + 1;
     const long npos = (orows + 2) * (long)PW;
     const int yrows = (bt * 16 + 31) / 32 * 32;
-    const size_t lds = 3 * ((size_t)npos * 32 * q.CIT + (size_t)yrows * 32 * q.COT);
+    const int xps = q.CIT == 2 ? 96 : 32 * q.CIT, yps = q.COT == 2 ? 96 : 32 * q.COT;
+    const size_t lds = 3 * ((size_t)npos * xps + (size_t)yrows * yps);
     const int nys = (yrows + YS - 1) / YS;      // the zero tail rows are stored too
     if (npos <= (long)WS3_NXS * XS && nys <= 7 && bt <= 16 && lds <= 158 * 1024) {
       q.BT = bt > FT ? FT : bt;
-      q.xpl = (int)(npos * 32 * q.CIT);
+      q.xpl = (int)(npos * xps);
       q.yrows = yrows;
-      q.ypl = yrows * 32 * q.COT;
+      q.ypl = yrows * yps;
       q.lds = lds;
       q.NYS = nys <= 4 ? 4 : 7;
     }

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-S, H, W, B = 2, 128, 96, 2
+S, H, W, B = 2, 96, 64, 2
 
 
 def _free_port():
