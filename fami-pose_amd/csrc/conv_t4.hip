@@ -453,6 +453,7 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_t4_s3_minwg = 0;  // fami_conv_tune_lds(2000 + n): the split-product instance only for launches of >= n workgroups (benchmarks)
 static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
 
 // ---- the split-product f32 instance: plan + launch
@@ -484,6 +485,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   a.dbg = g_t4_dbg;
   size_t lds = (size_t)a.patch_bytes + wbytes;
   const dim3 grid(N * a.bands, cblocks);
+  if ((long)N * a.bands * cblocks < g_t4_s3_minwg) return 0;
   const int PM = (int)((npos * 4 + WVs * 64 - 1) / (WVs * 64));
   bool ok = false;
 #define FAMI_T4S3_CASE(nt, pm, wv)                                                                                        \
@@ -612,8 +614,9 @@ int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
+  else if (on >= 2000) g_t4_s3_minwg = on - 2000;
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
   else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;

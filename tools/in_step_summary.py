@@ -5,7 +5,9 @@ step -- the numbers bench.py quotes next to its isolated-launch roofline.
 usage: python tools/in_step_summary.py <source tag> f32=trace_f32.pkl.gz bf16=trace_bf16.pkl.gz > profiles/in_step.json"""
 import gzip, json, pickle, sys
 
-DOMINANT = {'f32': ('conv_igemm_f32<1, 3, 0, 1, 1, 2, 1>', 552960), 'bf16': ('conv3x3_t4_kernel', 368640)}
+# (kernel-name substring, grid_x in threads) of the 3x3 convolutions on the 96x72 map with a 48-channel output block (f32: the
+# split-product instance, 27 bands of 16 tiles x 20 frames x 512 threads; bf16: 36 bands of 12 tiles)
+DOMINANT = {'f32': ('conv3x3_t4_kernel<float, 3, 5, true', 276480), 'bf16': ('conv3x3_t4_kernel', 368640)}
 out = {}
 tag = sys.argv[1]
 for arg in sys.argv[2:]:
