@@ -105,7 +105,8 @@ __device__ __forceinline__ void t4_split_store(char* dst, int plane_bytes, const
 }
 
 // WV: waves per workgroup (8; a 4-wave S3 form with two workgroups per CU measured the same and is not instantiated).
-template <typename H, int NT, int PM, bool S3 = false, int WV = 8>
+// MTT: pixel tiles per wave (2; the split-product instance also 3 / 4: bands of 24 / 32 tiles, fewer LDS fragment reads per MFMA)
+template <typename H, int NT, int PM, bool S3 = false, int WV = 8, int MTT = 2>
 __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t4_kernel(ConvT4Args p) {
   constexpr int THREADS = WV * 64;
   typedef typename T4Traits<H>::frag frag;
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   char* wbuf = smem + p.patch_bytes;
   const int mtw = (ntile - wave + WV - 1) / WV;   // pixel tiles of this wave: wave, wave + 8, ... (wave-uniform)
 
-  int base[T4_MT];
+  int base[MTT];
 #pragma unroll
-  for (int mt = 0; mt < T4_MT; ++mt) {
+  for (int mt = 0; mt < MTT; ++mt) {
     const int pp = min(p0 + (wave + WV * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
     const int ry = pp / p.W, rx = pp - ry * p.W;
     base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + (S3 ? 0 : kq * 16);
@@ -144,15 +145,15 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   const int ppl = p.patch_bytes / 3;                                 // S3: bytes of one patch plane
   const int xo0 = s3l, xo1 = ppl + s3l, xo2 = (s3h ? 2 : 0) * ppl + s3l;                 // X(0|0), X(1|1), X(0|2)
   const int wo0 = (s3h ? 1 : 0) * WPL + s3l + col * T4_S3_ROW, wo1 = (s3h ? 0 : 2) * WPL + s3l + col * T4_S3_ROW;   // W(0|1), W(2|0)
-  f32x4 acc[T4_MT][NT];
+  f32x4 acc[MTT][NT];
 #pragma unroll
-  for (int mt = 0; mt < T4_MT; ++mt)
+  for (int mt = 0; mt < MTT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 acc2[S3 && T4_S3_ACC2 ? T4_MT : 1][S3 && T4_S3_ACC2 ? NT : 1];
+  f32x4 acc2[S3 && T4_S3_ACC2 ? MTT : 1][S3 && T4_S3_ACC2 ? NT : 1];
   if constexpr (S3 && T4_S3_ACC2) {
 #pragma unroll
-    for (int mt = 0; mt < T4_MT; ++mt)
+    for (int mt = 0; mt < MTT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -253,7 +254,8 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     // tap's MFMAs issue)
     auto taps = [&](auto mwc) {
       constexpr int MW = decltype(mwc)::value;
-      bf16x8 a3[S3 ? 2 : 1][MW][3], w3[S3 ? 2 : 1][NT][2];
+      constexpr bool DB = MTT <= 2;                    // two fragment sets (a tap ahead) only where the registers allow
+      bf16x8 a3[S3 && DB ? 2 : 1][MW][3], w3[S3 && DB ? 2 : 1][NT][2];
       auto s3_load_w = [&](int tap, bf16x8 (&w)[NT][2]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -279,15 +281,15 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
           // fragments of tap t + 1 are requested before tap t is multiplied (two register sets): left to itself the
           // scheduler issued a tap's twelve LDS reads one to three MFMAs ahead of their use and the wave sat in
           // s_waitcnt lgkmcnt(0..1) before most MFMAs (2 waves per SIMD cannot cover that)
-          if (tap == 0) {
-            s3_load_w(0, w3[0]);
-            s3_load_a(0, a3[0]);
+          if (tap == 0 || !DB) {
+            s3_load_w(tap, w3[0]);
+            s3_load_a(tap, a3[0]);
           }
-          if (tap < 8) {
-            s3_load_w(tap + 1, w3[(tap + 1) & 1]);
-            s3_load_a(tap + 1, a3[(tap + 1) & 1]);
+          if (DB && tap < 8) {
+            s3_load_w(tap + 1, w3[DB ? (tap + 1) & 1 : 0]);
+            s3_load_a(tap + 1, a3[DB ? (tap + 1) & 1 : 0]);
           }
-          const int cur = tap & 1;
+          const int cur = DB ? tap & 1 : 0;
 #pragma unroll
           for (int m = 2; m >= 0; --m)          // low-order products first
 #pragma unroll
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
                 f32x4& dst = (T4_S3_ACC2 && m > 0) ? acc2[T4_S3_ACC2 ? mt : 0][T4_S3_ACC2 ? nt : 0] : acc[mt][nt];
                 dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[cur][nt][m == 2 ? 1 : 0], a3[cur][mt][m], dst, 0, 0, 0);
               }
-          if (tap < 8) {
+          if (DB && tap < 8) {
             // one LDS read behind each of the first MFMAs, the rest of the MFMAs after them
 #pragma unroll
             for (int k = 0; k < 3 * MW + 2 * NT; ++k) {
@@ -320,14 +322,16 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = T4Traits<H>::mma(w[nt], a[mt], acc[mt][nt]);
       }
     };
-    if (mtw >= T4_MT) taps(std::integral_constant<int, T4_MT>());
+    if (mtw >= MTT) taps(std::integral_constant<int, MTT>());
+    else if (MTT >= 4 && mtw == 3) taps(std::integral_constant<int, (MTT >= 4 ? 3 : 1)>());
+    else if (MTT >= 3 && mtw == 2) taps(std::integral_constant<int, (MTT >= 3 ? 2 : 1)>());
     else if (mtw == 1) taps(std::integral_constant<int, 1>());
     T4_STAMP(4);
   }
 
   if constexpr (S3 && T4_S3_ACC2) {
 #pragma unroll
-    for (int mt = 0; mt < T4_MT; ++mt)
+    for (int mt = 0; mt < MTT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += acc2[mt][nt];
   }
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
         }
       }
 #pragma unroll
-      for (int mt = 0; mt < T4_MT; ++mt) {
+      for (int mt = 0; mt < MTT; ++mt) {
         const int j = (wave + WV * mt) * 16 + col;
         if (mt >= mtw || p0 + j >= p1) continue;
         f32x4 v = acc[mt][nt] + bias4;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     return;
   }
 #pragma unroll
-  for (int mt = 0; mt < T4_MT; ++mt) {
+  for (int mt = 0; mt < MTT; ++mt) {
     const int j = (wave + WV * mt) * 16 + col;
     if (mt >= mtw || p0 + j >= p1) continue;
 #pragma unroll
@@ -453,6 +457,11 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
+static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
+                               // fragment reads per 27 MFMAs instead of 12 per 18; 256 VGPRs, 12-64 bytes of scratch): per launch 48 ch @96x72
+                               // 54 -> 51.5 us, 96 ch @48x36 56 -> 40.6, but 192 ch @24x18 55 -> 71 (hence the frame-size rule); f32 step
+                               // 53.5 -> 52.3 ms.  4 tiles per wave (and 3 with 64-wide channel blocks) spill hundreds of bytes: not built.
 static int g_t4_s3_minwg = 0;  // fami_conv_tune_lds(2000 + n): the split-product instance only for launches of >= n workgroups (benchmarks)
 static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
 
@@ -468,13 +477,19 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW;
   const int WVs = 8;
   const size_t lds_cap = 160 * 1024;
-  const long pos_cap = (long)T4_PMAX * T4_THREADS / 4;
+  // pixel tiles per wave: 2 (bands of <= 16 tiles), or 3 / 4 (<= 24 / 32) where the frame is large enough to use them
+  int MTs = NT == 3 ? g_t4_s3_mt : 2;       // (3 tiles x 4 channel tiles spill; 4 x 3 too)
+  if (MTs > 3) MTs = 3;
+  if (MTs > 2 && FT < g_t4_s3_mt_minft) MTs = 2;
+  const long pos_cap = (long)(MTs == 2 ? T4_PMAX : 7) * T4_THREADS / 4;
   int BT = 0;
-  for (int bt = 16; bt >= 1 && !BT; --bt)
+  for (int bt = 8 * MTs; bt >= 1 && !BT; --bt)
     if (positions(bt) <= pos_cap && (size_t)positions(bt) * 3 * T4_S3_ROW + wbytes <= lds_cap) BT = bt;
   if (!BT) return 0;
+  if (MTs > 2 && g_t4_bt == 0) BT = (FT + (FT + BT - 1) / BT - 1) / ((FT + BT - 1) / BT);   // same number of bands, equal sizes
   if (g_t4_bt > 0 && g_t4_bt <= BT) BT = g_t4_bt;
   if (BT > FT) BT = FT;
+  if (BT <= 16) MTs = 2;
   ConvT4Args a;
   a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn_none();
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
@@ -488,17 +503,18 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   if ((long)N * a.bands * cblocks < g_t4_s3_minwg) return 0;
   const int PM = (int)((npos * 4 + WVs * 64 - 1) / (WVs * 64));
   bool ok = false;
-#define FAMI_T4S3_CASE(nt, pm, wv)                                                                                        \
-  if (NT == nt && WVs == wv && PM <= pm && !ok) {                                                                         \
+#define FAMI_T4S3_CASE(nt, pm, mt)                                                                                        \
+  if (NT == nt && MTs == mt && PM <= pm && !ok) {                                                                         \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, nt, pm, true, wv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, nt, pm, true, 8, mt>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true, wv>), grid, dim3(wv * 64), lds, s, a);                     \
+    hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true, 8, mt>), grid, dim3(WVs * 64), lds, s, a);                 \
     ok = true;                                                                                                            \
   }
-  FAMI_T4S3_CASE(3, 3, 8) FAMI_T4S3_CASE(3, 5, 8) FAMI_T4S3_CASE(4, 3, 8) FAMI_T4S3_CASE(4, 5, 8)
+  FAMI_T4S3_CASE(3, 3, 2) FAMI_T4S3_CASE(3, 5, 2) FAMI_T4S3_CASE(4, 3, 2) FAMI_T4S3_CASE(4, 5, 2)
+  FAMI_T4S3_CASE(3, 5, 3) FAMI_T4S3_CASE(3, 7, 3)
 #undef FAMI_T4S3_CASE
   if (!ok) return 0;
   hipError_t err = hipGetLastError();
@@ -614,9 +630,10 @@ int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;
+  else if (on >= 52 && on <= 53) g_t4_s3_mt = on - 50;
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
   else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;

@@ -24,7 +24,7 @@ for st in states:
         elif k == 'bnsmall':
             L.fami_bn_tune_small(int(v))
         else:
-            getattr(L, 'fami_conv_tune_' + k)(int(v))
+            getattr(L, 'fami_conv_tune_' + k.split('#')[0])(int(v))      # 'lds#2=118': a second call of the same knob
     tr = Trainer(bench.build(args, dev), lr=1e-3, use_mi=os.environ.get('AB_NO_MI') != '1', use_graph=True, targets_from_joints=True)
     for _ in range(3):
         tr.step(kf, sup, joints, vis)

@@ -44,6 +44,14 @@ for (H, W, Ci, Co) in shapes:
         L.cdll.fami_conv_tune_lds(31)
         for bt in (0, 16, 14, 12, 10, 8):
             L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3/bt%d' % bt, timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(53)       # three pixel tiles per wave: bands of <= 24 tiles
+        for bt in (0, 24, 22, 20, 18):
+            L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3m3/bt%d' % bt, timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(52)
+        L.cdll.fami_conv_tune_lds(53)       # three pixel tiles per wave: bands of <= 24 tiles
+        for bt in (0, 24, 22, 20, 18):
+            L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3m3/bt%d' % bt, timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(52)
     else:
         for bt in (0, 16, 12, 8, 6, 4):
             L.cdll.fami_conv_tune_lds(100 + bt); res.append(('t4/bt%d' % bt, timeit(fwd), timeit(bwd)))

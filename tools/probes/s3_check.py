@@ -7,7 +7,7 @@ L = lib(); dev = torch.device('cuda:0'); st = torch.cuda.current_stream(dev).cud
 p = lambda t: None if t is None else t.data_ptr()
 shapes = [(2, 24, 18, 192, 192), (2, 16, 12, 256, 48), (2, 24, 18, 48, 48), (2, 12, 9, 96, 96), (2, 12, 9, 384, 384), (1, 5, 7, 20, 48),
           (2, 33, 21, 64, 64), (20, 96, 72, 48, 48), (2, 48, 36, 96, 96), (1, 24, 18, 16, 48), (1, 24, 18, 32, 48), (1, 24, 18, 48, 48), (1, 6, 5, 16, 48)]
-for bt in (0,):
+for bt in (0,) if not os.environ.get('S3_MT') else (0, 20):
     for (N, H, W, Ci, Co) in shapes:
         torch.manual_seed(1)
         x = torch.randn(N, H, W, Ci, device=dev); dy = torch.randn(N, H, W, Co, device=dev)
@@ -18,6 +18,8 @@ for bt in (0,):
         out = {}
         for knob in (30, 31):
             L.cdll.fami_conv_tune_lds(-1); L.cdll.fami_conv_tune_lds(knob); L.cdll.fami_conv_tune_lds(100 + bt)
+            if os.environ.get('S3_MT'): L.cdll.fami_conv_tune_lds(50 + int(os.environ['S3_MT']))
+            if os.environ.get('S3_MT'): L.cdll.fami_conv_tune_lds(50 + int(os.environ['S3_MT']))
             y = torch.zeros(N, H, W, Co, device=dev); dx = torch.zeros(N, H, W, Ci, device=dev)
             L.call('fami_conv2d_fwd_f32', p(x), p(wp0), None, None, p(y), *geo, 0, 0, st)
             L.call('fami_conv2d_dgrad_f32', p(dy), p(wp1), None, p(dx), *geo, 0, st)
