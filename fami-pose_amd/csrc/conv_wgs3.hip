@@ -268,9 +268,10 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
   const int HW = H * W, FT = (HW + 15) / 16, PW = W + 2;
   const long blocks = (long)q.ciBlocks * q.coBlocks;
   const int XS = WS3_THREADS / (4 * q.CIT), YS = WS3_THREADS / (4 * q.COT);
-  const int cand[9] = {16, 14, 12, 10, 8, 6, 4, 3, 2};
+  // (9 tiles = 144 pixels = whole rows of every map of the path (widths 72, 36, 18, 9): aligned runs carry one halo row less)
+  const int cand[10] = {16, 14, 12, 10, 9, 8, 6, 4, 3, 2};
   q.BT = 0;
-  for (int i = 0; i < 9 && !q.BT; ++i) {
+  for (int i = 0; i < 10 && !q.BT; ++i) {
     const int bt = g_wgs3_bt > 0 ? g_wgs3_bt : cand[i];
     // output rows a run can touch: runs of whole rows are aligned, any other length may straddle one row more
     const long orows = (bt * 16) % W == 0 ? (bt * 16) / W : (bt * 16 + W - 2) / W + 1;

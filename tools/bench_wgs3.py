@@ -32,7 +32,7 @@ for (H, W, Ci, Co) in SHAPES:
         return t
     L.cdll.fami_conv_tune_wgrad_lds(30000); res.append(('exact', run('exact')))
     L.cdll.fami_conv_tune_wgrad_lds(30001)
-    for bt in (0, 16, 12, 8, 6, 4):
+    for bt in (0, 9, 8, 6, 4):
         L.cdll.fami_conv_tune_wgrad_lds(30100 + bt); res.append(('s3/bt%d' % bt, run('split' if bt == 0 else None)))
     L.cdll.fami_conv_tune_wgrad_lds(30100)
     for tg in (192, 384, 512):
