@@ -2737,7 +2737,7 @@ int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, in
 // y[N,Ho,Wo,Co] = conv(x[N,H,W,Ci], W) (+bias) (+addend) (relu) ; wp packed with mode 0
 static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, const float* bias, const float* addend,
                              float* y, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                             int relu, int accumulate, const EpiBN& e, hipStream_t s);
+                             int relu, int accumulate, const EpiBN& e, hipStream_t s, const XBN& xbn = xbn_none());
 int fami_conv2d_fwd_f32(const float* x, const float* wp, const float* bias, const float* addend, float* y, int N,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
                         int accumulate, hipStream_t s) {
@@ -2756,10 +2756,27 @@ int fami_conv2d_fwd_stats_f32(const float* x, const float* wp, const float* bias
   return conv_fwd_f32_impl("fami_conv2d_fwd_stats_f32", x, wp, bias, nullptr, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil,
                            0, 0, e, s);
 }
+// f32 form of fami_conv2d_fwd_xbn_* (see the 16-bit entry points below): z is the PRE-normalisation input; the
+// split-product kernel applies BatchNorm + ReLU while it stages z
+int fami_conv2d_fwd_xbn_f32(const float* z, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci, int Co,
+                            void* slots, const float* pivot_src, const void* xslots, long xP, const float* xgamma,
+                            const float* xbeta, float* xmean, float* xinvstd, float* xrunning_mean, float* xrunning_var,
+                            float xmomentum, float xeps, hipStream_t s) {
+  FAMI_REQUIRE(xslots && xgamma && xbeta && xmean && xinvstd && xP > 0, "fami_conv2d_fwd_xbn_f32", "bad argument");
+  EpiBN e = epi_none();
+  if (slots) {
+    e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Co); e.mode = 1; e.C = Co; e.pivot_src = pivot_src;
+  }
+  XBN xb = xbn_none();
+  xb.on = 1; xb.slots = reinterpret_cast<const double*>(xslots); xb.ns = bn_slots(Ci); xb.C = Ci; xb.P = xP;
+  xb.gamma = xgamma; xb.beta = xbeta; xb.mean = xmean; xb.invstd = xinvstd; xb.running_mean = xrunning_mean;
+  xb.running_var = xrunning_var; xb.momentum = xmomentum; xb.eps = xeps;
+  return conv_fwd_f32_impl("fami_conv2d_fwd_xbn_f32", z, wp, bias, nullptr, y, N, H, W, Ci, Co, 3, 3, 1, 1, 1, 0, 0, e, s, xb);
+}
 }  // extern "C"
 static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, const float* bias, const float* addend,
                              float* y, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                             int relu, int accumulate, const EpiBN& e, hipStream_t s) {
+                             int relu, int accumulate, const EpiBN& e, hipStream_t s, const XBN& xbn) {
   FAMI_REQUIRE(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, nm, "bad argument");
   if (!geom_ok(kh, kw, stride, pad, dil)) {
     fami_set_error(nm, "unsupported geometry");
@@ -2777,8 +2794,12 @@ static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, co
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
-    const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, nm, e);
+    const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
+  if (xbn.on) {
+    fami_set_error(nm, "input BatchNorm needs the split-product 3x3 kernel (ask fami_conv2d_xbn_ok_f32 first)");
+    return FAMI_ESHAPE;
   }
   return run_igemm(a, 0, s, nm);
 }
@@ -3131,18 +3152,30 @@ static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
 
 extern "C" {
 
+static int wgrad_f32_entry(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                           hipStream_t s, const XBN& xbn);
 int fami_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                           hipStream_t s) {
+  return wgrad_f32_entry(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, accumulate, s, xbn_none());
+}
+static int wgrad_f32_entry(const float* x, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                           int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                           hipStream_t s, const XBN& xbn) {
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && x && dy && dw && workspace) {
     // split-product kernel on the bf16 matrix pipe (conv_wgs3.hip)
-    const int G = fami_try_wgrad_s3(x, dy, workspace, ws_bytes, N, H, W, Ci, Co, s, "fami_conv2d_wgrad_f32");
+    const int G = fami_try_wgrad_s3(x, dy, workspace, ws_bytes, N, H, W, Ci, Co, s, "fami_conv2d_wgrad_f32", xbn);
     if (G < 0) return G;
     if (G > 0) {
       launch_reduce_taps(workspace, dw, Co, Ci, 9, G, accumulate, s);
       FAMI_CHECK_LAUNCH("fami_conv2d_wgrad_f32/reduce");
       return FAMI_OK;
     }
+  }
+  if (xbn.on) {
+    fami_set_error("fami_conv2d_wgrad_defer_xbn_f32", "input BatchNorm needs the split-product kernel (ask fami_conv2d_xbn_ok_f32 first)");
+    return FAMI_ESHAPE;
   }
   WgradLdsPlan l = g_wgrad_lds_f32 ? wgrad_lds_plan_f32(N, H, W, Ci, Co, kh, kw, stride, pad, dil) : WgradLdsPlan{0};
   // measured (tools/bench_wgrad.py f32): the staged kernel wins once the channel blocks alone give >= 64 workgroup
@@ -3205,6 +3238,27 @@ int fami_conv2d_wgrad_defer_f32(const float* x, const float* dy, float* dw, floa
   FAMI_REQUIRE(d.part, "fami_conv2d_wgrad_defer_f32", "no reduce recorded");
   memcpy(desc_out, &d, sizeof(d));
   return FAMI_OK;
+}
+int fami_conv2d_wgrad_defer_xbn_f32(const float* z, const float* dy, float* dw, float* workspace, long ws_bytes, int N, int H,
+                                    int W, int Ci, int Co, int accumulate, long* desc_out, const float* xmean,
+                                    const float* xinvstd, const float* xgamma, const float* xbeta, hipStream_t s) {
+  FAMI_REQUIRE(desc_out && xmean && xinvstd && xgamma && xbeta, "fami_conv2d_wgrad_defer_xbn_f32", "bad argument");
+  XBN xb = xbn_none();
+  xb.on = 1; xb.C = Ci; xb.gamma = xgamma; xb.beta = xbeta; xb.mean = const_cast<float*>(xmean);
+  xb.invstd = const_cast<float*>(xinvstd);
+  ReduceDesc d;
+  d.part = nullptr;
+  g_defer = &d;
+  const int rc = wgrad_f32_entry(z, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, 3, 3, 1, 1, 1, accumulate, s, xb);
+  g_defer = nullptr;
+  if (rc != FAMI_OK) return rc;
+  FAMI_REQUIRE(d.part, "fami_conv2d_wgrad_defer_xbn_f32", "no reduce recorded");
+  memcpy(desc_out, &d, sizeof(d));
+  return FAMI_OK;
+}
+// f32 storage: both split-product kernels (conv_t4.hip S3, conv_wgs3.hip) would take the shape
+int fami_conv2d_xbn_ok_f32(int N, int H, int W, int Ci, int Co) {
+  return (g_use_lds != 0 && fami_conv_t4_eligible_s3(N, H, W, Ci, Co) && fami_wgrad_s3_slabs(N, H, W, Ci, Co) > 0) ? 1 : 0;
 }
 int fami_wgrad_reduce_desc_longs(void) { return (int)((sizeof(ReduceDesc) + sizeof(long) - 1) / sizeof(long)); }
 int fami_wgrad_reduce_batch(const long* descs, int n, hipStream_t s) {

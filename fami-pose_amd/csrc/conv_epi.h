@@ -129,6 +129,7 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
                         const char* name, const EpiBN& epi, const XBN& xbn = xbn_none());
 void fami_conv_t4_tune(int on);
 int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co);
+int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co);
 
 // conv_wg16.hip: 16-bit weight gradient of the centred k x k convolutions (k = 1 | 3, stride 1 | 2, any dilation).  fami_try_wgrad16 -> number of partial
 // slabs [G][9][Ci][Co] written to `part` (reduce them with the caller's slab reduce), 0 = not eligible, < 0 = error.
@@ -141,5 +142,5 @@ void fami_wgrad16_tune(int on);
 // three bf16 terms, six products, fp32 accumulation).  Same contract as fami_try_wgrad16.
 long fami_wgrad_s3_slabs(int N, int H, int W, int Ci, int Co);
 int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_bytes, int N, int H, int W, int Ci, int Co,
-                      hipStream_t s, const char* name);
+                      hipStream_t s, const char* name, const XBN& xbn = xbn_none());
 void fami_wgrad_s3_tune(int on);

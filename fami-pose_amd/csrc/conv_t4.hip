@@ -201,9 +201,9 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   fetch(0);
   // XBN: per-channel scale / shift of the input's BatchNorm in LDS (behind the weight slab), computed while the first
   // chunk's loads are in flight; workgroup (0, 0) publishes mean / invstd / running statistics
-  float* xsc = reinterpret_cast<float*>(wbuf + 9 * NT * WBLK);      // (16-bit instances only)
+  float* xsc = reinterpret_cast<float*>(wbuf + (S3 ? 3 : 1) * 9 * NT * WBLK);      // (16-bit and split-product instances)
   float* xsf = xsc + p.Ci;
-  const bool xon = SZ == 2 && p.xb.on;
+  const bool xon = (SZ == 2 || S3) && p.xb.on;
   if (xon) {
     for (int ch = tid; ch < p.Ci; ch += THREADS) {
       float a, b;
@@ -231,6 +231,14 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
         if constexpr (SZ == 2) {
           const int ch0 = c * CHN + (i & 3) * PCN;      // border / outside pieces stay zero: the conv pads the NORMALISED tensor
           if (xon && goff[u] >= 0 && ch0 < p.Ci) v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
+        } else if constexpr (S3) {
+          const int ch0 = c * CHN + (i & 3) * PCN;
+          if (xon && goff[u] >= 0 && ch0 < p.Ci) {      // f32 storage: exactly what the apply pass would have stored
+            f32x4 t = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = fmaxf(__builtin_fmaf(t[j], xsc[ch0 + j], xsf[ch0 + j]), 0.f);
+            v = __builtin_bit_cast(u32x4, t);
+          }
         }
         if constexpr (S3) t4_split_store(patch + (i >> 2) * T4_S3_ROW + (i & 3) * 8, ppl, t4_split(v));
         else *reinterpret_cast<u32x4*>(patch + (i >> 2) * p.PS + (i & 3) * 16) = v;
@@ -468,13 +476,13 @@ static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on th
 // ---- the split-product f32 instance: plan + launch
 static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                              int KC, int NTt, int sgn, int relu, int accumulate, hipStream_t s, const char* name,
-                             const EpiBN& epi) {
-  if (!g_use_t4 || !g_use_t4_s3 || (Ci % 4) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+                             const EpiBN& epi, const XBN& xbn) {
+  if (!g_use_t4 || !g_use_t4_s3 || (Ci % 4) != 0 || (x && (reinterpret_cast<uintptr_t>(x) & 15) != 0)) return 0;
   const int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
   if (!NT) return 0;
   const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
   auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
-  const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW;
+  const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   const int WVs = 8;
   const size_t lds_cap = 160 * 1024;
   // pixel tiles per wave: 2 (bands of <= 16 tiles), or 3 / 4 (<= 24 / 32) where the frame is large enough to use them
@@ -490,8 +498,9 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   if (g_t4_bt > 0 && g_t4_bt <= BT) BT = g_t4_bt;
   if (BT > FT) BT = FT;
   if (BT <= 16) MTs = 2;
+  if (!x) return 1;      // eligibility query (fami_conv_t4_eligible_s3)
   ConvT4Args a;
-  a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn_none();
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
   a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
@@ -598,9 +607,10 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
-  if (half_kind == 2 && !xbn.on) {
-    const int rc = try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi);
+  if (half_kind == 2) {
+    const int rc = try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi, xbn);
     if (rc != 0) return rc;
+    if (xbn.on) return 0;
   }
   if (half_kind == 2)
     return try_conv3x3_t4<float>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
@@ -627,6 +637,12 @@ int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
   if (BT > 16 || positions(BT) > pos_cap) return 0;
   const size_t lds = (size_t)positions(BT) * 80 + (size_t)9 * NT * 1024 + (size_t)2 * Ci * sizeof(float);
   return lds <= 100 * 1024 ? 1 : 0;
+}
+// ... and the same question for f32 storage (the split-product instance)
+int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
+  XBN xb = xbn_none();
+  xb.on = 1;
+  return try_conv3x3_t4_s3(nullptr, nullptr, nullptr, nullptr, N, H, W, Ci, Co, 0, 0, 1, 0, 0, nullptr, "", epi_none(), xb);
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {

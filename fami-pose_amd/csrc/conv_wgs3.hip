@@ -43,6 +43,7 @@ __device__ __forceinline__ void ws3_split_store(char* dst, int plane, u32x4 raw)
 #define WS3_NXS 8     // patch positions per thread and run
 
 struct Wgs3Args {
+  XBN xb;           // BatchNorm + ReLU applied to X while it is staged (the convolution's input was never materialised; xb.on)
   const float* x;   // [N,H,W,Ci]
   const float* dy;  // [N,H,W,Co]
   float* part;      // [G][9][Ci][Co]
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
   }
   const int ygo = (yp0 * p.Co) * 4 + ypc * 16;
   u32x4 prx[WS3_NXS], pry[NYS];
+  unsigned xvalid = 0;   // bit u: sweep u's piece was loaded (a zero-border / outside piece stays zero under XBN)
   auto run_geo = [&](int b, int& img, int& q0, int& q1, int& y0, int& nrow) {
     img = b / p.bpf;
     q0 = (b - img * p.bpf) * p.BT * 16;
@@ -132,7 +134,9 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
 #pragma unroll
     for (int u = 0; u < WS3_NXS; ++u) {
       prx[u] = u32x4{0u, 0u, 0u, 0u};
-      if (xrow[u] < nrow && (unsigned)(r0 + xrow[u]) < (unsigned)p.H) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+      const bool ld = xrow[u] < nrow && (unsigned)(r0 + xrow[u]) < (unsigned)p.H;
+      if (ld) prx[u] = *reinterpret_cast<const u32x4*>(xr + xgo[u]);
+      xvalid = (xvalid & ~(1u << u)) | ((ld ? 1u : 0u) << u);
     }
     const char* yr = yg + ((long)img * HW + q0) * p.Co * 4;
     const int M = q1 - q0;
@@ -142,13 +146,34 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
       if (ythr && yp0 + u * YS < M) pry[u] = *reinterpret_cast<const u32x4*>(yr + ygo + (long)u * YS * p.Co * 4);
     }
   };
+  // XBN: scale / shift of this workgroup's CIT*16 input channels in LDS behind the planes
+  float* xsc = reinterpret_cast<float*>(smem + 3 * (p.xpl + p.ypl));
+  float* xsf = xsc + CIT * 16;
+  if (p.xb.on) {
+    if (tid < CIT * 16) {
+      float a, b;
+      xbn_channel(p.xb, cib * (CIT * 16) + tid, false, a, b);
+      xsc[tid] = a;
+      xsf[tid] = b;
+    }
+    __syncthreads();
+  }
   auto stash = [&](int b) {                            // registers of run b -> the three planes
     int img, q0, q1, y0, nrow;
     run_geo(b, img, q0, q1, y0, nrow);
     const int npos = nrow * p.PW;
 #pragma unroll
     for (int u = 0; u < WS3_NXS; ++u)
-      if (xthr && xp0 + u * XS < npos) ws3_split_store(xbuf + (xp0 + u * XS) * XPS + xpc * 8, p.xpl, prx[u]);
+      if (xthr && xp0 + u * XS < npos) {
+        u32x4 v = prx[u];
+        if (p.xb.on && ((xvalid >> u) & 1u)) {
+          f32x4 t = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = fmaxf(__builtin_fmaf(t[j], xsc[xpc * 4 + j], xsf[xpc * 4 + j]), 0.f);
+          v = __builtin_bit_cast(u32x4, t);
+        }
+        ws3_split_store(xbuf + (xp0 + u * XS) * XPS + xpc * 8, p.xpl, v);
+      }
 #pragma unroll
     for (int u = 0; u < NYS; ++u)
       if (ythr && yp0 + u * YS < p.yrows) ws3_split_store(ybuf + (yp0 + u * YS) * YPS + ypc * 8, p.ypl, pry[u]);
@@ -278,7 +303,7 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
     const long npos = (orows + 2) * (long)PW;
     const int yrows = (bt * 16 + 31) / 32 * 32;
     const int xps = q.CIT == 2 ? 96 : 32 * q.CIT, yps = q.COT == 2 ? 96 : 32 * q.COT;
-    const size_t lds = 3 * ((size_t)npos * xps + (size_t)yrows * yps);
+    const size_t lds = 3 * ((size_t)npos * xps + (size_t)yrows * yps) + 2 * 48 * sizeof(float);   // + the XBN table
     const int nys = (yrows + YS - 1) / YS;      // the zero tail rows are stored too
     if (npos <= (long)WS3_NXS * XS && nys <= 7 && bt <= 16 && lds <= 158 * 1024) {
       q.BT = bt > FT ? FT : bt;
@@ -311,7 +336,7 @@ long fami_wgrad_s3_slabs(int N, int H, int W, int Ci, int Co) {
 
 // -> number of partial slabs written to `part` ([G][9][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
 int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_bytes, int N, int H, int W, int Ci, int Co,
-                      hipStream_t s, const char* name) {
+                      hipStream_t s, const char* name, const XBN& xbn) {
   const Wgs3Plan q = wgs3_plan(N, H, W, Ci, Co);
   if (!q.ok || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return 0;
   if (ws_bytes < (long)q.G * Co * Ci * 9 * (long)sizeof(float)) {
@@ -319,6 +344,7 @@ int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_byte
     return FAMI_EARG;
   }
   Wgs3Args a;
+  a.xb = xbn;
   a.x = x; a.dy = dy; a.part = part;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
   a.BT = q.BT; a.bpf = q.bpf; a.nsub = q.nsub; a.NB = N * q.bpf;

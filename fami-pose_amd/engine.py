@@ -117,10 +117,12 @@ class Engine:
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
-        # XBN; 16-bit modes): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN=1 opts in.  Measured on
-        # MI355X (gpurun_out r03g, interleaved A/B of the bf16 step): 27.91 ms with, 27.70 ms without -- the transform moves
-        # into the staging path of kernels that are bound by exactly that path, so the step does not get shorter.
-        self.use_xbn = os.environ.get('FAMI_XBN', '0') != '0'
+        # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
+        # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
+        # 50.86 and 50.96 -> 50.78 ms (the split-product kernels already spend a dozen VALU instructions per staged element
+        # on the split; two more are free); bf16 27.70 -> 27.91 ms (the transform moves into the staging path of kernels
+        # that are bound by exactly that path).
+        self.use_xbn = os.environ.get('FAMI_XBN', '0' if self.half else '1') != '0'
         self.nfused = {'fwd': 0, 'bwd': 0, 'xbn': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
@@ -632,20 +634,21 @@ class Engine:
 
     def conv_bn_relu_into(self, x, conv, bn, nxt):
         """conv -> BatchNorm -> ReLU whose ONLY consumer is the 3x3 stride-1 convolution `nxt` (conv1 -> bn1 -> relu ->
-        conv2 of a BasicBlock, basic_model.py:34-63).  16-bit modes, train-mode statistics: the normalised tensor is never
+        conv2 of a BasicBlock, basic_model.py:34-63).  Train-mode statistics, 16-bit storage or f32 on the split-product kernels: the normalised tensor is never
         written -- conv's epilogue takes the statistics, nxt's forward and weight-gradient kernels apply scale / shift /
         ReLU while they stage z (conv_epi.h XBN), and the BatchNorm backward recomputes the ReLU mask from z.  Anything
-        else falls back to conv_bn(relu=True).  Opt-in (FAMI_XBN=1, see __init__)."""
+        else falls back to conv_bn(relu=True).  FAMI_XBN (see __init__)."""
         N, H, W, _ = x.shape
         Co, _, kh, kw = conv.weight.shape
         st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
         P = N * Ho * Wo
-        ok = (self.use_xbn and self.half and self.bn2 and self.defer_reduce and bn.training and self.fuse_bn_fwd
+        okq = self.L.cdll.fami_conv2d_xbn_ok if self.half else self.L.cdll.fami_conv2d_xbn_ok_f32
+        ok = (self.use_xbn and self.bn2 and self.defer_reduce and bn.training and self.fuse_bn_fwd
               and self.defer_bn is None and bn.running_mean is not None and self.bn_fusable(P, Co)
               and tuple(nxt.weight.shape[1:]) == (Co, 3, 3) and nxt.stride[0] == 1 and nxt.padding[0] == 1
-              and nxt.dilation[0] == 1 and self.L.cdll.fami_conv2d_xbn_ok(N, Ho, Wo, Co, nxt.weight.shape[0]))
+              and nxt.dilation[0] == 1 and okq(N, Ho, Wo, Co, nxt.weight.shape[0]))
         if not ok:
             return self.conv_bn(x, conv, bn, relu=True)
         slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))

@@ -144,6 +144,15 @@ int fami_bn_is_small(long P, int C);
  * and apply scale / shift / ReLU while they stage it into LDS.  fami_conv2d_xbn_ok: can a 3x3 stride-1 pad-1 convolution of
  * this shape do that (both kernels eligible)? */
 int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co);
+/* the same in f32 storage (the split-product kernels; FAMI_XBN=1) */
+int fami_conv2d_xbn_ok_f32(int N, int H, int W, int Ci, int Co);
+int fami_conv2d_fwd_xbn_f32(const float* z, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci,
+                            int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
+                            const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
+                            float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
+int fami_conv2d_wgrad_defer_xbn_f32(const float* z, const float* dy, float* dw, float* workspace, long ws_bytes, int N,
+                                    int H, int W, int Ci, int Co, int accumulate, long* desc_out, const float* xmean,
+                                    const float* xinvstd, const float* xgamma, const float* xbeta, fami_stream_t stream);
 /* benchmarks: element count up to which a tensor takes the one-launch small-tensor kernels (< 0: default 32768) */
 int fami_bn_tune_small(long elems);
 int fami_bn_apply_slots_f32(const float* x, const float* residual, float* y, const float* gamma, const float* beta,

@@ -137,13 +137,14 @@ def test_fused_bn_statistics(dev, shape, dt, lds_mode):
 
 @pytest.mark.parametrize('shape', [(2, 48, 24, 18, 96), (3, 96, 13, 11, 192), (2, 192, 12, 10, 384), (2, 64, 23, 20, 64),
                                    (4, 48, 96, 72, 96)], ids=lambda s: 'x'.join(map(str, s)))
-@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
 def test_bn_relu_applied_while_the_next_conv_stages_its_input(dev, shape, dt):
     """Engine.conv_bn_relu_into (conv_epi.h XBN): conv1 -> bn1 -> relu -> conv2 of a BasicBlock with the normalised tensor
     never written.  The consumer kernels round the staged values to the storage type exactly as the stand-alone apply pass
     stores them, so the graph computes what the materialising graph computes; the statistics' fp64 atomics are the one
     order-dependent sum (a last-bit difference of mean / invstd can flip a storage rounding), hence a 4-ulp bound on
-    every result plus "at least half of the results are bitwise equal" rather than equality everywhere."""
+    every result plus "at least half of the results are bitwise equal" rather than equality everywhere.  f32 storage (the
+    split-product kernels): nothing rounds such a difference away, so every result is held to 4e-6 of its maximum."""
     from fami_pose_amd._lib import lib
     N, C, H, W, C2 = shape
     torch.manual_seed(sum(shape) + 1)
@@ -156,12 +157,12 @@ def test_bn_relu_applied_while_the_next_conv_stages_its_input(dev, shape, dt):
                 m.running_mean.normal_(0, 0.2)
     x = torch.randn(N, C, H, W) + 0.5
     gy = torch.randn(N, 8, (H + 1) // 2, (W + 1) // 2)
-    assert lib().cdll.fami_conv2d_xbn_ok(N, H, W, C, C) == 1
+    assert (lib().cdll.fami_conv2d_xbn_ok_f32 if dt == 'f32' else lib().cdll.fami_conv2d_xbn_ok)(N, H, W, C, C) == 1
     lazy, nl = _run(dev, ref, x, gy, DT[dt], True, xbn=True, fuse_bwd=False)
     mat, nm = _run(dev, ref, x, gy, DT[dt], True, xbn=False, fuse_bwd=False)
     assert nl['xbn'] == 2 and nm['xbn'] == 0 and nl['fwd'] == nm['fwd']
-    ulp = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dt]
+    ulp = {'f32': 1e-6, 'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dt]
     for k in lazy:
         assert relerr(lazy[k], mat[k]) < 4 * ulp, (k, relerr(lazy[k], mat[k]))
     same = sum(torch.equal(lazy[k], mat[k]) for k in lazy)
-    assert same >= len(lazy) // 2, (same, len(lazy))
+    assert dt == 'f32' or same >= len(lazy) // 2, (same, len(lazy))
