@@ -106,9 +106,18 @@ __device__ __forceinline__ void t4_split_store(char* dst, int plane_bytes, const
 
 // WV: waves per workgroup (8; a 4-wave S3 form with two workgroups per CU measured the same and is not instantiated).
 // MTT: pixel tiles per wave (2; the split-product instance also 3 / 4: bands of 24 / 32 tiles, fewer LDS fragment reads per MFMA)
-template <typename H, int NT, int PM, bool S3 = false, int WV = 8, int MTT = 2>
+// PC (split-product instance only): producer / consumer waves.  Waves 0 .. WV/2-1 multiply (2 pixel tiles each: bands of
+// <= 8 tiles), waves WV/2 .. WV-1 stage: they fetch, split and store chunk c + 1 into a SECOND LDS buffer while chunk c is
+// multiplied out of the first; one barrier per chunk, no store phase on the multiplying waves' timeline.  Measured
+// (tools/bench_t4.py "s3pc"): two buffers leave room for 8-tile bands only -- 1080 workgroups at 48 channels @96x72, each
+// paying its prologue and the 41 KB weight staging for 128 pixels -- 65 us against 44-52; 59-62 against 68 us on the 12x9
+// maps (one band, 24 chunks); f32 step equal with it on the one-band maps.  Off (fami_conv_tune_lds(61 / 62) to try).
+template <typename H, int NT, int PM, bool S3 = false, int WV = 8, int MTT = 2, bool PC = false>
 __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t4_kernel(ConvT4Args p) {
   constexpr int THREADS = WV * 64;
+  static_assert(!PC || (S3 && MTT == 2), "producer / consumer waves: split-product instance, 2 tiles per wave");
+  constexpr int CW = PC ? WV / 2 : WV;                 // waves that multiply
+  constexpr int STH = PC ? (WV - CW) * 64 : THREADS;   // threads that stage
   typedef typename T4Traits<H>::frag frag;
   static_assert(!S3 || sizeof(H) == 4, "the split instance takes f32 storage");
   constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // bytes per element, channels per chunk / per piece
@@ -116,9 +125,11 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   constexpr int WPL = 9 * NT * WBLK;                                 // S3: bytes of one weight plane
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int WPC = 9 * NT * 64;               // 16-byte weight pieces per chunk
-  constexpr int WR = (WPC + THREADS - 1) / THREADS;
+  constexpr int WR = (WPC + STH - 1) / STH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = PC && wave >= CW;              // wave-uniform
+  const int stid = PC ? tid - CW * 64 : tid;           // staging thread index (negative on the multiplying waves of PC)
   const int col = lane & 15, kq = lane >> 4;
   int bxl, byl;
   xcd_tile(1, bxl, byl);   // neighbouring bands (shared halo rows) on one XCD's L2
@@ -131,12 +142,12 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   const int ntg0 = byl * NT;
   char* patch = smem;
   char* wbuf = smem + p.patch_bytes;
-  const int mtw = (ntile - wave + WV - 1) / WV;   // pixel tiles of this wave: wave, wave + 8, ... (wave-uniform)
+  const int mtw = producer ? 0 : (ntile - wave + CW - 1) / CW;   // pixel tiles of this wave: wave, wave + CW, ... (wave-uniform)
 
   int base[MTT];
 #pragma unroll
   for (int mt = 0; mt < MTT; ++mt) {
-    const int pp = min(p0 + (wave + WV * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
+    const int pp = min(p0 + ((producer ? 0 : wave) + CW * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
     const int ry = pp / p.W, rx = pp - ry * p.W;
     base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + (S3 ? 0 : kq * 16);
   }
@@ -165,9 +176,9 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   int goff[PM];
 #pragma unroll
   for (int u = 0; u < PM; ++u) {
-    const int i = tid + u * THREADS;
+    const int i = stid + u * STH;
     goff[u] = -1;
-    if (i < npiece) {
+    if (stid >= 0 && i < npiece) {
       const int pos = i >> 2, pc = i & 3;
       const int r = pos / p.PW, c = pos - r * p.PW;
       const int gy = y0 - 1 + r, gx = c - 1;
@@ -176,32 +187,36 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     }
   }
   const int nchunk = (p.Ci + CHN - 1) / CHN;
-  u32x4 pr[PM], wr[WR];
-  auto fetch = [&](int c) {
+  // (PC: two register sets, so that chunk c + 2 is requested BEFORE chunk c + 1 is split and stored)
+  u32x4 pr[PC ? 2 : 1][PM], wr[PC ? 2 : 1][WR];
+  typedef std::integral_constant<int, 0> Set0;
+  typedef std::integral_constant<int, (PC ? 1 : 0)> Set1;
+  auto fetch = [&](int c, auto setc) {
+    constexpr int SET = decltype(setc)::value;
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
-      pr[u] = u32x4{0u, 0u, 0u, 0u};
-      const int pc = (tid + u * THREADS) & 3;
-      if (goff[u] >= 0 && c * CHN + pc * PCN < p.Ci) pr[u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
+      pr[SET][u] = u32x4{0u, 0u, 0u, 0u};
+      const int pc = (stid + u * STH) & 3;
+      if (goff[u] >= 0 && c * CHN + pc * PCN < p.Ci) pr[SET][u] = *reinterpret_cast<const u32x4*>(xg + goff[u] + c * 64);
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
-      const int i = tid + u * THREADS;
-      wr[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < WPC) {
+      const int i = stid + u * STH;
+      wr[SET][u] = u32x4{0u, 0u, 0u, 0u};
+      if (stid >= 0 && i < WPC) {
         const int blk = i >> 6;                    // blk = tap*NT + nt
         // S3: thread j of a block takes the image's lane (k quarter j & 3, row j >> 2): consecutive threads then store
         // consecutive 8-byte runs of a plane row
         const int l = S3 ? (((i & 3) << 4) | ((i >> 2) & 15)) : (i & 63);
         const int tap = blk / NT, nt = blk - tap * NT;
-        wr[u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
+        wr[SET][u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
       }
     }
   };
-  fetch(0);
+  if (!PC || producer) fetch(0, Set0());
   // XBN: per-channel scale / shift of the input's BatchNorm in LDS (behind the weight slab), computed while the first
   // chunk's loads are in flight; workgroup (0, 0) publishes mean / invstd / running statistics
-  float* xsc = reinterpret_cast<float*>(wbuf + (S3 ? 3 : 1) * 9 * NT * WBLK);      // (16-bit and split-product instances)
+  float* xsc = reinterpret_cast<float*>(wbuf + (S3 ? 3 : 1) * 9 * NT * WBLK + (PC ? p.patch_bytes + 3 * WPL : 0));      // (16-bit and split-product instances; PC: behind the second buffer)
   float* xsf = xsc + p.Ci;
   const bool xon = (SZ == 2 || S3) && p.xb.on;
   if (xon) {
@@ -219,15 +234,14 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
 #else
 #define T4_STAMP(k)
 #endif
-  for (int c = 0; c < nchunk; ++c) {
-    T4_STAMP(0);
-    if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
-    T4_STAMP(1);
+  // registers of chunk c -> LDS (patch at `patch`, weights at `wbuf`)
+  auto store = [&](int c, char* patch, char* wbuf, auto setc) {
+    constexpr int SET = decltype(setc)::value;
 #pragma unroll
     for (int u = 0; u < PM; ++u) {
-      const int i = tid + u * THREADS;
+      const int i = stid + u * STH;
       if (i < npiece) {
-        u32x4 v = pr[u];
+        u32x4 v = pr[SET][u];
         if constexpr (SZ == 2) {
           const int ch0 = c * CHN + (i & 3) * PCN;      // border / outside pieces stay zero: the conv pads the NORMALISED tensor
           if (xon && goff[u] >= 0 && ch0 < p.Ci) v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
@@ -246,17 +260,51 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     }
 #pragma unroll
     for (int u = 0; u < WR; ++u) {
-      const int i = tid + u * THREADS;
+      const int i = stid + u * STH;
       if (i < WPC) {
         // S3: row (i >> 2) & 15 of block i >> 6, channels (i & 3) * 4 .. + 3 of each plane (see fetch)
-        if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, t4_split(wr[u]));
-        else *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[u];
+        if constexpr (S3) t4_split_store(wbuf + (i >> 2) * T4_S3_ROW + (i & 3) * 8, WPL, t4_split(wr[SET][u]));
+        else *reinterpret_cast<u32x4*>(wbuf + i * 16) = wr[SET][u];
       }
     }
-    T4_STAMP(2);
+  };
+  constexpr int BUFSZ_W = 3 * WPL;                 // PC: a buffer = patch planes + weight planes
+  if constexpr (PC) {
+    if (producer) {
+      store(0, smem, smem + p.patch_bytes, Set0());
+      if (nchunk > 1) fetch(1, Set1());
+    }
     __syncthreads();
-    T4_STAMP(3);
-    if (c + 1 < nchunk) fetch(c + 1);   // in flight while this chunk is multiplied
+    if (producer) {
+      // chunk c + 1 -> buffer (c + 1) & 1 while the multiplying waves are on chunk c; sets alternate: chunk k lives in set k & 1
+      const int bsz = p.patch_bytes + BUFSZ_W;
+      for (int c = 0; c < nchunk; c += 2) {
+        if (c + 2 < nchunk) fetch(c + 2, Set0());
+        if (c + 1 < nchunk) store(c + 1, smem + bsz, smem + bsz + p.patch_bytes, Set1());
+        __syncthreads();
+        if (c + 1 >= nchunk) break;
+        if (c + 3 < nchunk) fetch(c + 3, Set1());
+        if (c + 2 < nchunk) store(c + 2, smem, smem + p.patch_bytes, Set0());
+        __syncthreads();
+      }
+    }
+  }
+  for (int c = 0; c < nchunk; ++c) {
+    if constexpr (PC) {
+      if (producer) break;      // (its loop is above; same number of barriers)
+    } else {
+      T4_STAMP(0);
+      if (c > 0) __syncthreads();   // the previous chunk has been multiplied by every wave
+      T4_STAMP(1);
+      store(c, patch, wbuf, Set0());
+      T4_STAMP(2);
+      __syncthreads();
+      T4_STAMP(3);
+      if (c + 1 < nchunk) fetch(c + 1, Set0());   // in flight while this chunk is multiplied
+    }
+    char* const cbuf = PC ? smem + (c & 1) * (p.patch_bytes + BUFSZ_W) : smem;
+    const char* const patch = cbuf;
+    const char* const wbuf = cbuf + p.patch_bytes;
     // the nine taps of this chunk for a wave with MW live pixel tiles (compile-time: a per-tile "is it live" branch cut the
     // loop into 3-MFMA blocks, each behind its own LDS wait -- now a tap's fragments are requested while the previous
     // tap's MFMAs issue)
@@ -335,6 +383,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     else if (MTT >= 3 && mtw == 2) taps(std::integral_constant<int, (MTT >= 3 ? 2 : 1)>());
     else if (mtw == 1) taps(std::integral_constant<int, 1>());
     T4_STAMP(4);
+    if constexpr (PC) __syncthreads();   // chunk c is multiplied, chunk c + 1 is in the other buffer
   }
 
   if constexpr (S3 && T4_S3_ACC2) {
@@ -377,7 +426,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
       }
 #pragma unroll
       for (int mt = 0; mt < MTT; ++mt) {
-        const int j = (wave + WV * mt) * 16 + col;
+        const int j = (wave + CW * mt) * 16 + col;
         if (mt >= mtw || p0 + j >= p1) continue;
         f32x4 v = acc[mt][nt] + bias4;
         const long idx = (pix0 + j) * p.Co + co0;
@@ -433,7 +482,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   }
 #pragma unroll
   for (int mt = 0; mt < MTT; ++mt) {
-    const int j = (wave + WV * mt) * 16 + col;
+    const int j = (wave + CW * mt) * 16 + col;
     if (mt >= mtw || p0 + j >= p1) continue;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -465,6 +514,7 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_t4_s3_pc = 0;          // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
 static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
 static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
                                // fragment reads per 27 MFMAs instead of 12 per 18; 256 VGPRs, 12-64 bytes of scratch): per launch 48 ch @96x72
@@ -485,6 +535,41 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   const int WVs = 8;
   const size_t lds_cap = 160 * 1024;
+  // producer / consumer form (see the kernel): 4 multiplying + 4 staging waves, bands of <= 8 tiles, two LDS buffers
+  if (g_t4_s3_pc && NT == 3 && g_t4_bt == 0 && (g_t4_s3_pc == 2 || FT <= 8)) {   // 1: only frames of one band (12x9 maps), 2: always
+    int BTp = 0;
+    for (int bt = 8; bt >= 1 && !BTp; --bt)
+      if (positions(bt) * 4 <= 6 * 256 && 2 * ((size_t)positions(bt) * 3 * T4_S3_ROW + (wbytes - (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0))) + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0) <= lds_cap) BTp = bt;
+    if (BTp) {
+      if (BTp > FT) BTp = FT;
+      if (!x) return 1;
+      ConvT4Args a;
+      a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
+      a.x = x; a.wp = wp; a.y = y; a.bias = bias;
+      a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BTp; a.bands = (FT + BTp - 1) / BTp;
+      a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
+      const long npos = positions(BTp);
+      a.patch_bytes = (int)(npos * 3 * a.PS);
+      a.dbg = g_t4_dbg;
+      const size_t lds = 2 * ((size_t)a.patch_bytes + (size_t)3 * 9 * NT * 16 * T4_S3_ROW) + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
+      const dim3 grid(N * a.bands, cblocks);
+      const int PMp = (int)((npos * 4 + 255) / 256);
+      static bool attr4 = false, attr6 = false;
+      if (PMp <= 4) {
+        if (!attr4) { (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, 3, 4, true, 8, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); attr4 = true; }
+        hipLaunchKernelGGL((conv3x3_t4_kernel<float, 3, 4, true, 8, 2, true>), grid, dim3(512), lds, s, a);
+      } else {
+        if (!attr6) { (void)hipFuncSetAttribute((const void*)conv3x3_t4_kernel<float, 3, 6, true, 8, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap); attr6 = true; }
+        hipLaunchKernelGGL((conv3x3_t4_kernel<float, 3, 6, true, 8, 2, true>), grid, dim3(512), lds, s, a);
+      }
+      hipError_t err = hipGetLastError();
+      if (err != hipSuccess) {
+        fami_set_error(name, hipGetErrorString(err));
+        return FAMI_EHIP;
+      }
+      return 1;
+    }
+  }
   // pixel tiles per wave: 2 (bands of <= 16 tiles), or 3 / 4 (<= 24 / 32) where the frame is large enough to use them
   int MTs = NT == 3 ? g_t4_s3_mt : 2;       // (3 tiles x 4 channel tiles spill; 4 x 3 too)
   if (MTs > 3) MTs = 3;
@@ -646,10 +731,11 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;
   else if (on >= 52 && on <= 53) g_t4_s3_mt = on - 50;
+  else if (on >= 60 && on <= 62) g_t4_s3_pc = on - 60;
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
   else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;

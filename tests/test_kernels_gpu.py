@@ -768,9 +768,10 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
     cd.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
     res = {}
     try:
-        for name, knob in (('exact', 30), ('split', 31)):
-            lib().cdll.fami_conv_tune_lds(knob)
-            lib().cdll.fami_conv_tune_wgrad_lds(30000 + knob - 30)
+        for name, knob in (('exact', 30), ('split', 31), ('split_pc', 62)):       # 62: producer / consumer form of the split kernel
+            lib().cdll.fami_conv_tune_lds(31 if knob == 62 else knob)
+            lib().cdll.fami_conv_tune_lds(62 if knob == 62 else 60)
+            lib().cdll.fami_conv_tune_wgrad_lds(30000 + (0 if knob == 30 else 1))
             eng = _eng(dev)
             xt = T(nhwc(x.detach().float()).to(dev), True)
             yt = eng.conv(xt, cd.weight, cd.bias, 1, 1, 1)
@@ -784,8 +785,9 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
         lib().cdll.fami_conv_tune_wgrad_lds(-1)
     for i, ref in enumerate((y.detach(), x.grad, conv.weight.grad)):
         m = ref.abs().max().item()
-        ee, es = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split')]
+        ee, es, ep = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split', 'split_pc')]
         assert es < 3 * ee + 1e-7 and es < 3e-6, (i, ee, es)
+        assert ep < 3 * ee + 1e-7 and ep < 3e-6, (i, ee, ep)
     assert not torch.equal(res['exact'][0], res['split'][0])      # the two paths really are different kernels
     if Ci % 16 == 0 and Co % 16 == 0:
         assert not torch.equal(res['exact'][2], res['split'][2])

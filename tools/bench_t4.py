@@ -42,14 +42,21 @@ for (H, W, Ci, Co) in shapes:
         L.cdll.fami_conv_tune_lds(30); L.cdll.fami_conv_tune_lds(21); L.cdll.fami_conv_tune_lds(112)
         res.append(('t4-exact/bt12', timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(31)
-        for bt in (0, 16, 14, 12, 10, 8):
+        L.cdll.fami_conv_tune_lds(52)
+        for bt in (0, 12):
             L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3/bt%d' % bt, timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(100); L.cdll.fami_conv_tune_lds(61)       # producer / consumer waves, two LDS buffers, bands of <= 8 tiles
+        res.append(('s3pc', timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(60)
         L.cdll.fami_conv_tune_lds(53)       # three pixel tiles per wave: bands of <= 24 tiles
-        for bt in (0, 24, 22, 20, 18):
+        for bt in (0, 18):
             L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3m3/bt%d' % bt, timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(52)
+        L.cdll.fami_conv_tune_lds(100); L.cdll.fami_conv_tune_lds(61)       # producer / consumer waves, two LDS buffers, bands of <= 8 tiles
+        res.append(('s3pc', timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(60)
         L.cdll.fami_conv_tune_lds(53)       # three pixel tiles per wave: bands of <= 24 tiles
-        for bt in (0, 24, 22, 20, 18):
+        for bt in (0, 18):
             L.cdll.fami_conv_tune_lds(100 + bt); res.append(('s3m3/bt%d' % bt, timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(52)
     else:

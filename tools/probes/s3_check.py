@@ -19,7 +19,9 @@ for bt in (0,) if not os.environ.get('S3_MT') else (0, 20):
         for knob in (30, 31):
             L.cdll.fami_conv_tune_lds(-1); L.cdll.fami_conv_tune_lds(knob); L.cdll.fami_conv_tune_lds(100 + bt)
             if os.environ.get('S3_MT'): L.cdll.fami_conv_tune_lds(50 + int(os.environ['S3_MT']))
+            if os.environ.get('S3_PC') and knob == 31: L.cdll.fami_conv_tune_lds(61)
             if os.environ.get('S3_MT'): L.cdll.fami_conv_tune_lds(50 + int(os.environ['S3_MT']))
+            if os.environ.get('S3_PC') and knob == 31: L.cdll.fami_conv_tune_lds(61)
             y = torch.zeros(N, H, W, Co, device=dev); dx = torch.zeros(N, H, W, Ci, device=dev)
             L.call('fami_conv2d_fwd_f32', p(x), p(wp0), None, None, p(y), *geo, 0, 0, st)
             L.call('fami_conv2d_dgrad_f32', p(dy), p(wp1), None, p(dx), *geo, 0, st)
