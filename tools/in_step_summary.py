@@ -6,8 +6,8 @@ usage: python tools/in_step_summary.py <source tag> f32=trace_f32.pkl.gz bf16=tr
 import gzip, json, pickle, sys
 
 # (kernel-name substring, grid_x in threads) of the 3x3 convolutions on the 96x72 map with a 48-channel output block (f32: the
-# split-product instance, 27 bands of 16 tiles x 20 frames x 512 threads; bf16: 36 bands of 12 tiles)
-DOMINANT = {'f32': ('conv3x3_t4_kernel<float, 3, 5, true', 276480), 'bf16': ('conv3x3_t4_kernel', 368640)}
+# split-product instance with three tiles per wave, 18 bands of 24 tiles x 20 frames x 512 threads; bf16: 36 bands of 12 tiles)
+DOMINANT = {'f32': ('conv3x3_t4_kernel<float, 3, 7, true, 8, 3', 184320), 'bf16': ('conv3x3_t4_kernel', 368640)}
 out = {}
 tag = sys.argv[1]
 for arg in sys.argv[2:]:
