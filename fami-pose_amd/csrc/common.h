@@ -78,17 +78,11 @@ __device__ __forceinline__ float ld1(const f16_t* p) { return (float)*p; }
 __device__ __forceinline__ void st1(f16_t* p, float v) { *p = (f16_t)v; }
 
 // the two 16-bit storage types on the 16x16x32 matrix-core instruction (8 K-elements per lane, fp32 accumulation)
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <typename H> struct H16;
 template <> struct H16<bf16_t> {
   typedef bf16x8 x8;
   __device__ static __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-  // K = 16 form (a lane holds 4 K-values): the 16-channel tail of a 48-channel layer
-  __device__ static __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
-    typedef short s16x4k __attribute__((ext_vector_type(4)));
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4k, a), __builtin_bit_cast(s16x4k, b), c, 0, 0, 0);
   }
   // one 16-bit pattern -> f32
   __device__ static __forceinline__ float from_bits(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
@@ -97,10 +91,6 @@ template <> struct H16<f16_t> {
   typedef f16x8 x8;
   __device__ static __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-  __device__ static __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
-    typedef _Float16 f16x4k __attribute__((ext_vector_type(4)));
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4k, a), __builtin_bit_cast(f16x4k, b), c, 0, 0, 0);
   }
   __device__ static __forceinline__ float from_bits(unsigned short u) { return (float)__builtin_bit_cast(f16_t, u); }
 };

@@ -2651,7 +2651,7 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
 // -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
-  if (on == 10 || on == 11 || on == 20 || on == 21 || on == 30 || on == 31 || (on >= 52 && on <= 54) || (on >= 60 && on <= 62) || on == 70 || on == 71 || on >= 100) {   // (30 / 31: split-product f32 instance) register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
+  if (on == 10 || on == 11 || on == 20 || on == 21 || on == 30 || on == 31 || (on >= 52 && on <= 54) || (on >= 60 && on <= 62) || on >= 100) {   // (30 / 31: split-product f32 instance) register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
     fami_conv_t4_tune(on);                   // 100 + tiles per band (100 = heuristic)
     return FAMI_OK;
   }

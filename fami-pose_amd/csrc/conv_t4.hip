@@ -35,7 +35,6 @@ struct ConvT4Args {
   int sgn, relu, accumulate, out_f32;
   int patch_bytes;
   long long* dbg;     // FAMI_T4_TRACE builds: phase timestamps of one workgroup (null otherwise)
-  int no_k16;         // benchmarks: multiply the 16-channel tail chunk of a 16-bit layer as a zero-padded 32-channel one (the round-2 form)
 };
 
 // storage-type traits: a fragment is 16 bytes per lane in every case -- 8 K-values of a 32-channel chunk for the 16-bit
@@ -45,16 +44,6 @@ struct ConvT4Args {
 template <typename T> struct T4Traits {
   typedef typename H16<T>::x8 frag;
   __device__ static __forceinline__ f32x4 mma(const frag& w, const frag& a, f32x4 acc) { return H16<T>::mfma(w, a, acc); }
-};
-// K = 16 MFMA of the 16-bit types (never called for float: the primary template only has to exist)
-template <typename T> struct T4K16 {
-  __device__ static __forceinline__ f32x4 mma(u32x2, u32x2, f32x4 c) { return c; }
-};
-template <> struct T4K16<bf16_t> {
-  __device__ static __forceinline__ f32x4 mma(u32x2 w, u32x2 a, f32x4 c) { return H16<bf16_t>::mfma16(w, a, c); }
-};
-template <> struct T4K16<f16_t> {
-  __device__ static __forceinline__ f32x4 mma(u32x2 w, u32x2 a, f32x4 c) { return H16<f16_t>::mfma16(w, a, c); }
 };
 template <> struct T4Traits<float> {
   typedef f32x4 frag;
@@ -319,9 +308,8 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     // the nine taps of this chunk for a wave with MW live pixel tiles (compile-time: a per-tile "is it live" branch cut the
     // loop into 3-MFMA blocks, each behind its own LDS wait -- now a tap's fragments are requested while the previous
     // tap's MFMAs issue)
-    auto taps = [&](auto mwc, auto k16c) {
+    auto taps = [&](auto mwc) {
       constexpr int MW = decltype(mwc)::value;
-      constexpr bool K16 = decltype(k16c)::value;      // 16-bit types: the last chunk holds 16 channels (Ci % 32 == 16)
       constexpr bool DB = MTT <= 2;                    // two fragment sets (a tap ahead) only where the registers allow
       bf16x8 a3[S3 && DB ? 2 : 1][MW][3], w3[S3 && DB ? 2 : 1][NT][2];
       auto s3_load_w = [&](int tap, bf16x8 (&w)[NT][2]) {
@@ -379,21 +367,6 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
           }
           continue;
         }
-        if constexpr (K16 && SZ == 2 && !S3) {
-          // K = 16 MFMA: a lane holds K-values kq*4 .. kq*4+3 = the first half of what lane (kq >> 1) holds in the K = 32
-          // layout (weights), bytes kq*8 .. of the position's 32 channel bytes (patch): no zero half multiplied or read
-          u32x2 a16[MW], w16[NT];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            w16[nt] = *reinterpret_cast<const u32x2*>(wbuf + (tap * NT + nt) * 1024 + ((kq >> 1) * 16 + col) * 16 + (kq & 1) * 8);
-#pragma unroll
-          for (int mt = 0; mt < MW; ++mt) a16[mt] = *reinterpret_cast<const u32x2*>(patch + base[mt] - kq * 8 + toff);
-#pragma unroll
-          for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = T4K16<H>::mma(w16[nt], a16[mt], acc[mt][nt]);
-          continue;
-        }
         frag a[MW], w[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wbuf + (tap * NT + nt) * 1024 + lane * 16);
@@ -405,17 +378,10 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = T4Traits<H>::mma(w[nt], a[mt], acc[mt][nt]);
       }
     };
-    bool tail16 = false;
-    if constexpr (SZ == 2 && !S3) tail16 = (p.Ci & 31) == 16 && c == nchunk - 1 && !p.no_k16;
-    if (tail16) {
-      if constexpr (SZ == 2 && !S3) {
-        if (mtw >= MTT) taps(std::integral_constant<int, MTT>(), std::true_type());
-        else if (mtw == 1) taps(std::integral_constant<int, 1>(), std::true_type());
-      }
-    } else if (mtw >= MTT) taps(std::integral_constant<int, MTT>(), std::false_type());
-    else if (MTT >= 4 && mtw == 3) taps(std::integral_constant<int, (MTT >= 4 ? 3 : 1)>(), std::false_type());
-    else if (MTT >= 3 && mtw == 2) taps(std::integral_constant<int, (MTT >= 3 ? 2 : 1)>(), std::false_type());
-    else if (mtw == 1) taps(std::integral_constant<int, 1>(), std::false_type());
+    if (mtw >= MTT) taps(std::integral_constant<int, MTT>());
+    else if (MTT >= 4 && mtw == 3) taps(std::integral_constant<int, (MTT >= 4 ? 3 : 1)>());
+    else if (MTT >= 3 && mtw == 2) taps(std::integral_constant<int, (MTT >= 3 ? 2 : 1)>());
+    else if (mtw == 1) taps(std::integral_constant<int, 1>());
     T4_STAMP(4);
     if constexpr (PC) __syncthreads();   // chunk c is multiplied, chunk c + 1 is in the other buffer
   }
@@ -548,7 +514,6 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
-static int g_t4_no_k16 = 0;         // fami_conv_tune_lds(70 / 71): K = 16 MFMA for the 16-channel tail chunk on / off
 static int g_t4_s3_pc = 0;          // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
 static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
 static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
@@ -585,7 +550,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
       a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
       const long npos = positions(BTp);
       a.patch_bytes = (int)(npos * 3 * a.PS);
-      a.dbg = g_t4_dbg; a.no_k16 = g_t4_no_k16;
+      a.dbg = g_t4_dbg;
       const size_t lds = 2 * ((size_t)a.patch_bytes + (size_t)3 * 9 * NT * 16 * T4_S3_ROW) + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
       const dim3 grid(N * a.bands, cblocks);
       const int PMp = (int)((npos * 4 + 255) / 256);
@@ -626,7 +591,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * 3 * a.PS);     // three planes
-  a.dbg = g_t4_dbg; a.no_k16 = g_t4_no_k16;
+  a.dbg = g_t4_dbg;
   size_t lds = (size_t)a.patch_bytes + wbytes;
   const dim3 grid(N * a.bands, cblocks);
   if ((long)N * a.bands * cblocks < g_t4_s3_minwg) return 0;
@@ -694,7 +659,7 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   a.PW = W + 2; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * a.PS);
-  a.dbg = g_t4_dbg; a.no_k16 = g_t4_no_k16;
+  a.dbg = g_t4_dbg;
   const size_t wbytes = (size_t)9 * NT * 1024;
   size_t lds = (size_t)a.patch_bytes + wbytes + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   if (lds < (size_t)T4_WAVES * NT * 32 * 4) lds = (size_t)T4_WAVES * NT * 32 * 4;
@@ -766,12 +731,11 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_no_k16 = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;
   else if (on >= 52 && on <= 53) g_t4_s3_mt = on - 50;
   else if (on >= 60 && on <= 62) g_t4_s3_pc = on - 60;
-  else if (on == 70 || on == 71) g_t4_no_k16 = on - 70;
   else if (on == 10 || on == 11) g_use_t4 = on - 10;
   else if (on == 20 || on == 21) g_use_t4_f32 = on - 20;
   else if (on >= 100) g_t4_bt = on - 100;
