@@ -514,6 +514,9 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_t4_s3_fill = 0;        // fami_conv_tune_lds(102000 / 102001): more, smaller bands on launches that leave CUs empty off / on.
+                                    // Per launch it wins (24x18 @192 ch 55 -> 45 us, 48x36 @96 ch 40.6 -> 35.6); inside the step other lanes
+                                    // already fill those CUs and the smaller bands only add staging: 50.8 -> 51.4 and 49.5 -> 50.4 ms.  Off.
 static int g_t4_s3_pc = 0;          // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
 static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
 static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
@@ -579,7 +582,18 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   for (int bt = 8 * MTs; bt >= 1 && !BT; --bt)
     if (positions(bt) <= pos_cap && (size_t)positions(bt) * 3 * T4_S3_ROW + wbytes <= lds_cap) BT = bt;
   if (!BT) return 0;
-  if (MTs > 2 && g_t4_bt == 0) BT = (FT + (FT + BT - 1) / BT - 1) / ((FT + BT - 1) / BT);   // same number of bands, equal sizes
+  if (g_t4_bt == 0) {
+    // bands of equal size; optionally (g_t4_s3_fill) more and smaller bands where the launch would leave CUs without a
+    // workgroup (the low-resolution maps), up to one workgroup per CU
+    long nb = (FT + BT - 1) / BT;
+    const long per = (long)N * cblocks;
+    if (g_t4_s3_fill && nb * per < 256) {
+      long nb2 = 256 / per;
+      if (nb2 > FT) nb2 = FT;
+      if (nb2 > nb) nb = nb2;
+    }
+    BT = (int)((FT + nb - 1) / nb);
+  }
   if (g_t4_bt > 0 && g_t4_bt <= BT) BT = g_t4_bt;
   if (BT > FT) BT = FT;
   if (BT <= 16) MTs = 2;
@@ -731,8 +745,9 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
+  else if (on >= 102000) g_t4_s3_fill = on - 102000;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;
   else if (on >= 52 && on <= 53) g_t4_s3_mt = on - 50;
   else if (on >= 60 && on <= 62) g_t4_s3_pc = on - 60;
