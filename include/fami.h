@@ -41,14 +41,23 @@ int fami_device_info(int device, int* info, char* name, int name_len);
  * Weights are consumed in a fragment-packed image (mode 0 = forward, 1 = dgrad). */
 /* benchmarks only: force the implicit-GEMM tile (MT x NT 16x16 tiles per wave, KS-way split-K); 0 = heuristic */
 int fami_conv_tune(int mt, int nt, int ks);
-int fami_conv_tune_lds(int on);          /* 1 / 0 = route eligible 3x3 stride-1 convs through the LDS-staged / direct kernel,
-                                          * -1 = default (bf16 staged, f32 direct: measured per dtype inside the step) */
+int fami_conv_tune_lds(int on);          /* 1 / 0 = route eligible 3x3 stride-1 convs through the LDS-staged / direct kernels,
+                                          * -1 = defaults: every storage type on the register-blocked LDS kernel (conv_t4.hip), f32 through
+                                          * its split-product instance (operands split exactly into three bf16 terms, six products on the
+                                          * bf16 matrix pipe, fp32 accumulation).  Benchmarks / tests: 10 / 11 register-blocked kernel off /
+                                          * on; 20 / 21 its exact-f32-MFMA instance; 30 / 31 the split-product instance off / on (30 = exact
+                                          * f32 MFMA kernels); 52 / 53 two / three pixel tiles per wave of it; 60 / 61 / 62 its producer-
+                                          * consumer form off / one-band frames / always; 100 + bt tiles per band; 2000 + n only launches of
+                                          * >= n workgroups; 102000 / 102001 CU-filling band rule off / on */
 int fami_conv_tune_wgrad_lds(int on);    /* 0 = weight gradients on the scalar-operand kernels, 1 = LDS-staged kernels wherever eligible,
                                           * 1 + n = the same with n sub-chunks per workgroup of the 16-bit kernel (default 2),
                                           * -1 = defaults (16-bit storage: LDS-staged; f32: linear-address per-tap kernel on stride-1
                                           * same-size convs, general per-tap kernel elsewhere, LDS-staged kernel opt-in);
                                           * 50 / 51 = f32 per-tap kernel in its general / linear-address form (52 / 53 / 54: the latter in
-                                          * 9- / 8- / 16-wave workgroups); 100 + mt, 1000 + n = benchmarks (tile cap, workgroup target) */
+                                          * 9- / 8- / 16-wave workgroups); 100 + mt, 1000 + n = benchmarks (tile cap, workgroup target);
+                                          * 20000 + x: the pipelined 16-bit kernel (conv_wg16.hip): 0 / 1 off / on, 2 / 3 3x3-stride-1 only /
+                                          * every centred geometry, 100 + bt, 1000 + target; 30000 + x: the f32 split-product kernel
+                                          * (conv_wgs3.hip): 0 / 1 off / on (0 = exact-f32 MFMA kernels), 100 + bt, 1000 + target */
 int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous workgroup->tile order in the implicit-GEMM kernels,
                                         * bit 1 = in the weight-gradient kernels; -1 = default (both on) */
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default;
