@@ -318,7 +318,10 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
   if (!q.BT) return q;
   q.bpf = (FT + q.BT - 1) / q.BT;
   const long NB = (long)N * q.bpf;
-  const long target = g_wgs3_target > 0 ? g_wgs3_target : 256;   // one workgroup per CU at a time (see conv_wg16.hip)
+  // one workgroup per CU at a time (see conv_wg16.hip), so never more than 256; 192 measured better inside the step (fewer
+  // partial slabs to write and reduce, the idle CUs go to other lanes: f32 step 51.0 -> 50.65 ms in both A/B orders) although
+  // 256 wins per launch
+  const long target = g_wgs3_target > 0 ? g_wgs3_target : 192;
   long G = target / blocks;
   if (G > NB) G = NB;
   if (G < 1) G = 1;
