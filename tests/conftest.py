@@ -13,6 +13,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    # The CPU oracle is most of the GPU suite's wall time, and torch's CPU convolutions of this model peak at 16 threads on
+    # the 256-thread GPU host (profiles/r02_cpu_threads.txt: 16 threads 0.81 clips/s, 128 threads 0.05): cap the pool.
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope='session')
