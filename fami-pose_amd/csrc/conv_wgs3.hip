@@ -297,16 +297,17 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
   const int cand[10] = {16, 14, 12, 10, 9, 8, 6, 4, 3, 2};
   q.BT = 0;
   for (int i = 0; i < 10 && !q.BT; ++i) {
-    const int bt = g_wgs3_bt > 0 ? g_wgs3_bt : cand[i];
-    // output rows a run can touch: runs of whole rows are aligned, any other length may straddle one row more
-    const long orows = (bt * 16) % W == 0 ? (bt * 16) / W : (bt * 16 + W - 2) / W + 1;
+    int bt = g_wgs3_bt > 0 ? g_wgs3_bt : cand[i];
+    if (bt > FT) bt = FT;                 // a frame smaller than the candidate is one run: size the LDS and the sweeps for it
+    // output rows a run can touch: a whole frame, or runs of whole rows (aligned); any other length may straddle one row more
+    const long orows = bt == FT ? H : ((bt * 16) % W == 0 ? (bt * 16) / W : (bt * 16 + W - 2) / W + 1);
     const long npos = (orows + 2) * (long)PW;
     const int yrows = (bt * 16 + 31) / 32 * 32;
     const int xps = q.CIT == 2 ? 96 : 32 * q.CIT, yps = q.COT == 2 ? 96 : 32 * q.COT;
     const size_t lds = 3 * ((size_t)npos * xps + (size_t)yrows * yps) + 2 * 48 * sizeof(float);   // + the XBN table
     const int nys = (yrows + YS - 1) / YS;      // the zero tail rows are stored too
     if (npos <= (long)WS3_NXS * XS && nys <= 7 && bt <= 16 && lds <= 158 * 1024) {
-      q.BT = bt > FT ? FT : bt;
+      q.BT = bt;
       q.xpl = (int)(npos * xps);
       q.yrows = yrows;
       q.ypl = yrows * yps;
