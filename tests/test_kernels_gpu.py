@@ -791,3 +791,47 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
     assert not torch.equal(res['exact'][0], res['split'][0])      # the two paths really are different kernels
     if Ci % 16 == 0 and Co % 16 == 0:
         assert not torch.equal(res['exact'][2], res['split'][2])
+
+
+def test_split_product_kernels_on_random_shapes(dev):
+    """The split-product f32 3x3 kernels (forward, input gradient, weight gradient; every tiling variant and the producer /
+    consumer form) against the exact-f32 MFMA kernels through the C ABI on 80 random shapes: odd maps, channel tails,
+    accumulate, bias.  Catches planning mistakes (band edges, LDS sizing, staging sweeps) the fixed shapes do not reach."""
+    import random
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    rnd = random.Random(7)
+    try:
+        for it in range(80):
+            N, H, W = rnd.randint(1, 5), rnd.randint(3, 40), rnd.randint(3, 40)
+            Ci, Co = rnd.choice([4, 8, 16, 20, 32, 48, 64, 80, 96, 144]), rnd.choice([48, 64, 96, 128, 144, 192])
+            acc, pc, mt = rnd.randint(0, 1), rnd.choice([60, 60, 62]), rnd.choice([52, 53])
+            torch.manual_seed(it)
+            x, dy = torch.randn(N, H, W, Ci, device=dev), torch.randn(N, H, W, Co, device=dev)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.1
+            bias = torch.randn(Co, device=dev) if rnd.randint(0, 1) else None
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            wp = [torch.empty(L.cdll.fami_packed_weight_elems(Co, Ci, 3, 3, m), device=dev) for m in (0, 1)]
+            for m in (0, 1):
+                L.call('fami_pack_conv_weight_f32', p(w), p(wp[m]), Co, Ci, 3, 3, m, st)
+            y0, dx0, dw0 = torch.randn(N, H, W, Co, device=dev), torch.randn(N, H, W, Ci, device=dev), torch.randn(Co, Ci, 3, 3, device=dev)
+            out = {}
+            for knob in (30, 31):
+                for code in (-1, knob, pc, mt):
+                    L.cdll.fami_conv_tune_lds(code)
+                L.cdll.fami_conv_tune_wgrad_lds(-1)
+                L.cdll.fami_conv_tune_wgrad_lds(30000 + knob - 30)
+                y, dx, dw = y0.clone(), dx0.clone(), dw0.clone()
+                L.call('fami_conv2d_fwd_f32', p(x), p(wp[0]), p(bias), None, p(y), *geo, 0, acc, st)
+                L.call('fami_conv2d_dgrad_f32', p(dy), p(wp[1]), None, p(dx), *geo, acc, st)
+                ws = torch.empty(L.cdll.fami_conv2d_wgrad_workspace(*geo) // 4 + 4, device=dev)
+                L.call('fami_conv2d_wgrad_f32', p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, acc, st)
+                torch.cuda.synchronize(dev)
+                out[knob] = (y, dx, dw)
+            for k in range(3):
+                assert relerr(out[31][k], out[30][k]) < 1e-5, (it, (N, H, W, Ci, Co), acc, pc, mt, k)
+    finally:
+        L.cdll.fami_conv_tune_lds(-1)
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
