@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   // A thread owns piece xpc of patch positions xp0, xp0 + XS, ... and piece ypc of dY pixels yp0, yp0 + YS, ...: its patch
   // (row, column) per sweep does not depend on the run, so a run's fetch is one add and two compares per piece.
   constexpr int XS = WG16_THREADS / XPC, YS = WG16_THREADS / YPC;     // positions / pixels per sweep
-  constexpr int NXS = WG16_XSWEEPS, NYS = (256 + YS - 1) / YS;
+  constexpr int NXS = WG16_XSWEEPS, NYS = (288 + YS - 1) / YS;   // runs of up to 18 tiles
   const int xpc = tid % XPC, xp0 = tid / XPC, ypc = tid % YPC, yp0 = tid / YPC;
   const bool xthr = xp0 < XS, ythr = yp0 < YS;                        // the last threads of the block own no piece
   int xrow[NXS], xgo[NXS];   // patch row of the sweep's position; global byte offset relative to the run's first patch row
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
 struct Wg16Plan { int ok, CIT, COT, taps, BT, bpf, nsub, G, Ho, Wo, ciBlocks, coBlocks; size_t lds; int xps, yps, xbytes; };
-static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0, g_wg16_general = 1;
+static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0, g_wg16_general = 1, g_wg16_bt18 = 0;   // 18-tile aligned runs: per launch 27.6 -> 25.0 us (48 ch @96x72), inside the bf16 step 26.10 -> 26.24 / 25.99 -> 26.09 ms: off
 static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg16Plan q;
   q.ok = 0;
@@ -315,14 +315,20 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
   q.xps = q.CIT == 2 ? 96 : 32 * q.CIT;
   q.yps = q.COT == 2 ? 96 : 32 * q.COT;
   const int PW = W + 2 * pad;
-  const int cand[8] = {16, 14, 12, 10, 8, 6, 4, 2};
+  // 18 tiles = 288 pixels = whole rows of every map of the path (widths 72, 36, 18): an aligned run carries one halo row
+  // less (6 patch rows for 4 output rows of the 96x72 map against 7 for 3.6)
+  const int cand[9] = {18, 16, 14, 12, 10, 8, 6, 4, 2};
   q.BT = 0;
-  for (int i = 0; i < 8 && !q.BT; ++i) {
+  for (int i = 0; i < 9 && !q.BT; ++i) {
     const int bt = g_wg16_bt > 0 ? g_wg16_bt : cand[i];
-    const long orows = (bt * 16 + q.Wo - 2) / q.Wo + 1;                 // output rows a run can touch
+    if (bt > 16 && ((bt * 16) % q.Wo != 0 || !g_wg16_bt18)) {
+      if (g_wg16_bt > 0) break;
+      continue;
+    }
+    const long orows = (bt * 16) % q.Wo == 0 ? (bt * 16) / q.Wo : (bt * 16 + q.Wo - 2) / q.Wo + 1;   // output rows a run can touch (aligned runs: exactly)
     const long npos = (st * (orows - 1) + 2 * pad + 1) * (long)PW;       // patch positions
     const size_t lds = 2 * ((size_t)npos * q.xps + (size_t)((bt * 16 + 31) / 32 * 32) * q.yps) + 2 * 48 * sizeof(float);   // two buffers + the XBN table
-    if (npos <= (long)WG16_XSWEEPS * (WG16_THREADS / (2 * q.CIT)) && bt * 16 <= 256 && lds <= 150 * 1024) {
+    if (npos <= (long)WG16_XSWEEPS * (WG16_THREADS / (2 * q.CIT)) && bt * 16 <= 288 && lds <= 150 * 1024) {
       q.BT = bt > FT ? FT : bt;
       q.xbytes = (int)(npos * q.xps);
       q.lds = lds;
@@ -402,9 +408,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; }
+  if (on < 0) { g_wg16 = 1; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; }
   else if (on <= 1) g_wg16 = on;
   else if (on <= 3) g_wg16_general = on - 2;
+  else if (on == 4 || on == 5) g_wg16_bt18 = on - 4;      // 18-tile aligned runs off / on
   else if (on >= 1000) g_wg16_target = on - 1000;
   else if (on >= 100) g_wg16_bt = on - 100;
 }
