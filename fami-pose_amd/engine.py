@@ -96,6 +96,11 @@ class Engine:
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
         self._wdirty = False
+        # ... but for the HEAD it pays (FAMI_HEAD_WGRAD_LANE, default 1): between the first DCN forward and the last DCN backward
+        # the step is one serial chain of kernels (rocprof trace: 3.5 ms with exactly one kernel in flight), and the weight
+        # gradients in it are leaves.  A model body brackets that part with wlane_scope = True.
+        self.head_wlane = self.use_lanes and os.environ.get('FAMI_HEAD_WGRAD_LANE', '1') != '0'
+        self.wlane_scope = False
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
@@ -572,6 +577,7 @@ class Engine:
                       _p(y), N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0)
         need_w = self.rq(weight) or self.rq(bias)
         out = T(y, x.requires_grad or need_w)
+        wl = self.wlane_scope and self.head_wlane
         if out.requires_grad:
             assert not relu, "fused relu epilogue is forward-only"
             geo = (N, H, W, Ci, Co, kh, kw, stride, pad, dil)
@@ -580,7 +586,7 @@ class Engine:
                 if out.grad is None:
                     return
                 dy = out.grad
-                saved = self._enter_wlane() if (self.use_wlane and need_w) else None
+                saved = self._enter_wlane() if ((self.use_wlane or wl) and need_w) else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     self.wgrad(x.data, dy, g, geo, acc,
@@ -1002,6 +1008,7 @@ class Engine:
                    C, Co, G, kh, kw, 1, pad, dil)
         rg = x.requires_grad or off.requires_grad or msk.requires_grad or self.rq(weight)
         out = T(y, rg)
+        wl = self.wlane_scope and self.head_wlane
         if rg:
             def bwd():
                 if out.grad is None:
@@ -1039,12 +1046,15 @@ class Engine:
                     if gx is not None and gx32 is not gx:
                         self.acall('fami_cast_add', _p(gx32), _p(gx), gx.numel(), accx)
                 if self.rq(weight):
+                    saved = self._enter_wlane() if wl else None      # leaves of the backward graph (see __init__)
                     g, acc = self.pgrad(weight)
                     geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)
                     self.wgrad(col, dy, g, geo, acc)
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
+                    if saved is not None:
+                        self.stream = saved
             self.record_bwd(bwd, [weight, bias], (x, off, msk))
         return out
 

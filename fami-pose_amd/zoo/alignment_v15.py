@@ -168,6 +168,7 @@ class Alignment_V15(EngineModule):
         if forked:
             eng.join(min(S, 4))
             eng.apply_deferred_bn()
+        eng.wlane_scope = True      # the aggregation / DCN stack is one serial chain: its weight gradients go to their own lane
         agg_sup = self.sup_agg_block.run(eng, eng.concat(aligned))
         comb = self.combined_feat_layers.run(eng, eng.concat([agg_sup, kf]))
         comb = self._dcn(eng, 1, comb, comb)
@@ -176,6 +177,7 @@ class Alignment_V15(EngineModule):
         al = self._dcn(eng, 4, al, al)
         all_agg = self.init_feature_agg_block.run(eng, eng.concat([kf, al]))
         final = run_conv(eng, self.agg_final_layer, all_agg, out_f32=True)
+        eng.wlane_scope = False
 
         outs = [eng.to_nchw(final), eng.to_nchw(kf_hm)]
         seeds = [lambda g: eng.seed_nchw(final, g), lambda g: eng.seed_nchw(kf_hm, g)]
