@@ -101,6 +101,9 @@ class Engine:
         # gradients in it are leaves.  A model body brackets that part with wlane_scope = True.
         self.head_wlane = self.use_lanes and os.environ.get('FAMI_HEAD_WGRAD_LANE', '1') != '0'
         self.wlane_scope = False
+        # the same for the backbone's serial head and tail: stem, layer1 and the transitions run before the branches fork
+        # (their backward after the branches have joined), FAMI_STEM_WGRAD_LANE
+        self.stem_wlane = os.environ.get('FAMI_STEM_WGRAD_LANE', '0') != '0'     # measured neutral (f32 49.1 -> 49.3, bf16 26.6 -> 26.5 ms): off
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:

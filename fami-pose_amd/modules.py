@@ -228,15 +228,19 @@ class HRNetBody(nn.Module):
 
     def run(self, eng, x):
         """x: engine tensor [N,H,W,3] -> (heatmap T [N,H/4,W/4,J], stage-4 outputs, pre-stage-4 inputs)."""
+        outer = eng.wlane_scope
+        eng.wlane_scope = outer or eng.stem_wlane     # serial chain: weight gradients on their own lane (Engine.__init__)
         x = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
         x = eng.conv_bn(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:
             x = blk.run(eng, x)
+        eng.wlane_scope = outer
         ys = [x]
         stage4_in = None
         for s in (2, 3, 4):
             tr = getattr(self, 'transition%d' % (s - 1))
             xs = []
+            eng.wlane_scope = outer or eng.stem_wlane
             for i in range(self.stage_branches[s]):
                 if tr[i] is None:
                     xs.append(ys[i])
@@ -248,6 +252,7 @@ class HRNetBody(nn.Module):
                     else:
                         z = run_cbr(eng, tr[i], z)
                     xs.append(z)
+            eng.wlane_scope = outer
             ys = xs
             for mi, mod in enumerate(getattr(self, 'stage%d' % s)):
                 ys = mod.run_branches(eng, ys)
