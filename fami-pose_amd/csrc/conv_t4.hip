@@ -514,6 +514,8 @@ static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance 
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
 static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
+static int g_t4_s3_narrow = 0;      // fami_conv_tune_lds(102030 / 102031): two channel tiles per workgroup on launches of < 200 workgroups off / on.
+                                    // Per launch 55 -> 43 us (24x18 @192 ch) and 70 -> 57 (12x9 @384 ch); f32 step 49.0 -> 49.7 and 48.9 -> 49.6 ms: off.
 static int g_t4_s3_fill = 0;        // fami_conv_tune_lds(102000 / 102001): more, smaller bands on launches that leave CUs empty off / on.
                                     // Per launch it wins (24x18 @192 ch 55 -> 45 us, 48x36 @96 ch 40.6 -> 35.6); inside the step other lanes
                                     // already fill those CUs and the smaller bands only add staging: 50.8 -> 51.4 and 49.5 -> 50.4 ms.  Off.
@@ -531,9 +533,18 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
                              int KC, int NTt, int sgn, int relu, int accumulate, hipStream_t s, const char* name,
                              const EpiBN& epi, const XBN& xbn) {
   if (!g_use_t4 || !g_use_t4_s3 || (Ci % 4) != 0 || (x && (reinterpret_cast<uintptr_t>(x) & 15) != 0)) return 0;
-  const int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
   if (!NT) return 0;
-  const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
+  const int HW = H * W, FT = (HW + 15) / 16;
+  // The low-resolution branches: 2 bands x 20 frames x 4 channel blocks (24x18 @192 ch) or 1 x 20 x 8 (12x9 @384 ch) = 160
+  // workgroups of 12 / 24 chunks each, and in the step's trace these launches run ALONE (the other lanes are waiting at the
+  // module's fuse for exactly them) for 3.8 ms per f32 step on 160 of 256 CUs.  Two channel tiles per workgroup instead
+  // of three: 240 workgroups, a third less MFMA and weight staging each -- more work in total, less on the critical path:
+  // that was the idea; per launch it delivers, the step gets slower (see g_t4_s3_narrow), so it is off.
+  if (g_t4_s3_narrow && NT == 3 && Co % 32 == 0 && (long)N * ((FT + 15) / 16) * (Co / 48) < 200 &&
+      (long)N * ((FT + 15) / 16) * (Co / 32) <= 256)
+    NT = 2;
+  const int cblocks = Co / (16 * NT);
   auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
   const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   const int WVs = 8;
@@ -621,7 +632,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
     hipLaunchKernelGGL((conv3x3_t4_kernel<float, nt, pm, true, 8, mt>), grid, dim3(WVs * 64), lds, s, a);                 \
     ok = true;                                                                                                            \
   }
-  FAMI_T4S3_CASE(3, 3, 2) FAMI_T4S3_CASE(3, 5, 2) FAMI_T4S3_CASE(4, 3, 2) FAMI_T4S3_CASE(4, 5, 2)
+  FAMI_T4S3_CASE(3, 3, 2) FAMI_T4S3_CASE(3, 5, 2) FAMI_T4S3_CASE(4, 3, 2) FAMI_T4S3_CASE(4, 5, 2) FAMI_T4S3_CASE(2, 3, 2) FAMI_T4S3_CASE(2, 5, 2)
   FAMI_T4S3_CASE(3, 5, 3) FAMI_T4S3_CASE(3, 7, 3)
 #undef FAMI_T4S3_CASE
   if (!ok) return 0;
@@ -745,8 +756,9 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 0; g_t4_s3_narrow = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
+  else if (on == 102030 || on == 102031) g_t4_s3_narrow = on - 102030;
   else if (on >= 102000) g_t4_s3_fill = on - 102000;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;
   else if (on >= 52 && on <= 53) g_t4_s3_mt = on - 50;
