@@ -1019,9 +1019,11 @@ class Engine:
                 dy = out.grad
                 P = B * H * W
                 CK = C * K
-                nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
-                wpb = self.empty(nwp)
-                self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
+                wpb = (getattr(self, 'prepacked_dcn_bwd', None) or {}).get(id(weight))     # packed at the start of the step (Trainer)
+                if wpb is None:
+                    nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
+                    wpb = self.empty(nwp)
+                    self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
                 col = self.act(P, CK) if self.rq(weight) else None
                 gx = gx32 = goff = gmsk = None
                 acco = accx = 0

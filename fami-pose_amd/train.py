@@ -351,6 +351,21 @@ class Trainer:
             self.grad.mul_(1.0 / self.world)
         return best
 
+    def _dcn_bwd_images(self):
+        """[(weight, persistent image buffer, (Co, C, kh, kw, G))] of the model's DCN layers (built once)."""
+        if getattr(self, '_dcn_imgs', None) is None:
+            from .zoo.alignment_v15 import DeformConv2d
+            G = getattr(self.model, 'G', None)
+            imgs = []
+            if G is not None:
+                for m in self.model.modules():
+                    if isinstance(m, DeformConv2d):
+                        Co, C, kh, kw = m.weight.shape
+                        n = lib().cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
+                        imgs.append((m.weight, torch.empty(n, device=self.dev), (Co, C, kh, kw, G)))
+            self._dcn_imgs = imgs
+        return self._dcn_imgs
+
     # ------------------------------------------------------------------ the step (eager launch sequence)
     def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
         model = self.model
@@ -358,13 +373,24 @@ class Trainer:
                      deterministic=getattr(model, 'deterministic', None))
         # conv weight images of this step: the forward orientation in one launch now, the input-gradient orientation in a
         # second launch on a side lane beside the forward pass (first read by the backward pass, which waits for it)
+        # ... and the DCN layers' backward weight images + their fixed-point scale bound (a one-workgroup reduction): they
+        # depend on the weights only, and packed inside the backward closures they sat on the head's serial chain
+        dcn = self._dcn_bwd_images()
+
+        def pack_bwd(st):
+            self.packer.run(st, 1)
+            for w, buf, geo in dcn:
+                lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
         if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
             self.packer.run(eng.stream, 0)
-            packed_bwd = eng.side_launch(lambda st: self.packer.run(st, 1))
+            packed_bwd = eng.side_launch(pack_bwd)
         else:
             self.packer.run(eng.stream)
+            for w, buf, geo in dcn:
+                lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, eng.stream)
             packed_bwd = None
         eng.prepacked = self.packer.views
+        eng.prepacked_dcn_bwd = {id(w): buf for w, buf, _ in dcn}
         if self.targets_from_joints:
             # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
             joints, vis = target, weight
