@@ -516,9 +516,10 @@ static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per 
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
 static int g_t4_s3_narrow = 0;      // fami_conv_tune_lds(102030 / 102031): two channel tiles per workgroup on launches of < 200 workgroups off / on.
                                     // Per launch 55 -> 43 us (24x18 @192 ch) and 70 -> 57 (12x9 @384 ch); f32 step 49.0 -> 49.7 and 48.9 -> 49.6 ms: off.
-static int g_t4_s3_fill = 0;        // fami_conv_tune_lds(102000 / 102001): more, smaller bands on launches that leave CUs empty off / on.
+static int g_t4_s3_fill = 2;        // fami_conv_tune_lds(102000 / 102001 / 102002): more, smaller bands on launches that leave CUs empty: off / all / tiny ones.
                                     // Per launch it wins (24x18 @192 ch 55 -> 45 us, 48x36 @96 ch 40.6 -> 35.6); inside the step other lanes
-                                    // already fill those CUs and the smaller bands only add staging: 50.8 -> 51.4 and 49.5 -> 50.4 ms.  Off.
+                                    // already fill those CUs and the smaller bands only add staging: 50.8 -> 51.4 and 49.5 -> 50.4 ms.  2 = only launches of
+                                    // < 128 workgroups: the head's 4-frame convolutions (72 workgroups), which the trace shows running alone.
 static int g_t4_s3_pc = 0;          // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
 static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
 static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
@@ -598,7 +599,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
     // workgroup (the low-resolution maps), up to one workgroup per CU
     long nb = (FT + BT - 1) / BT;
     const long per = (long)N * cblocks;
-    if (g_t4_s3_fill && nb * per < 256) {
+    if ((g_t4_s3_fill == 1 && nb * per < 256) || (g_t4_s3_fill == 2 && nb * per < 128)) {
       long nb2 = 256 / per;
       if (nb2 > FT) nb2 = FT;
       if (nb2 > nb) nb = nb2;
@@ -756,7 +757,7 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 0; g_t4_s3_narrow = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on == 102030 || on == 102031) g_t4_s3_narrow = on - 102030;
   else if (on >= 102000) g_t4_s3_fill = on - 102000;
