@@ -400,8 +400,15 @@ def main():
                          "ddp_plan": plan_name, "ddp_plan_fallbacks": plan_notes, "bucket_mb": args.bucket_mb,
                          "buckets": len(trainer.reducer.ranges()),
                          "gradient_bytes": int(trainer.grad.numel() * 4),
-                         "gradient_payload": os.environ.get('FAMI_DDP_PAYLOAD', 'f32'), **trainer.plan_summary(),
+                         "gradient_payload": trainer.payload_name, **trainer.plan_summary(),
                          "allreduce_ms_standalone": round(trainer.measure_allreduce_ms(), 3)})
+            # what the exchange should cost over xGMI (point-to-point, 7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md):
+            # a ring is bound by one link, 2 (N-1)/N B / link; a direct reduce-scatter + all-gather over the full mesh
+            # moves B/N per link and phase
+            wire = trainer.grad.numel() * (4 if trainer.payload_name == 'f32' else 2)
+            info.update({"allreduce_ms_expected_ring": round(2 * (world - 1) / world * wire / 153e9 * 1e3, 3),
+                         "allreduce_ms_expected_mesh": round(2 * wire / world / 153e9 * 1e3, 3),
+                         "allreduce_wire_bytes": int(wire)})
         del trainer, model
         torch.cuda.empty_cache()
         return dt, loss, info

@@ -59,9 +59,8 @@ class _Lib:
         # FAMI_F32_SPLIT=0: f32 3x3 convolutions (forward, input and weight gradient) on the exact-f32 MFMA
         # (v_mfma_f32_16x16x4_f32) instead of the split-product kernels on the bf16 matrix pipe (conv_t4.hip S3,
         # conv_wgs3.hip; same accuracy class)
-        if os.environ.get('FAMI_F32_SPLIT', '1') == '0':
-            self.cdll.fami_conv_tune_lds(30)
-            self.cdll.fami_conv_tune_wgrad_lds(30000)
+        # stored as the library's default state: fami_tune_reset / fami_conv_tune_lds(-1) restore it
+        self.cdll.fami_tune_defaults(0 if os.environ.get('FAMI_F32_SPLIT', '1') == '0' else 1)
 
     def call(self, name, *args):
         self.ncalls += 1

@@ -1678,6 +1678,10 @@ int fami_dcn_pack_weight_f16(const float* w_oihw, float* wp, int Co, int C, int 
 // benchmarks / tests: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel (register-fed MFMA), -1 = default;
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
+  if (gather < 0) {   // every DCN knob back to its default
+    g_dcn_bwd_abl = 0; g_dcn_bwd_scatter = -1; g_dcn_ksplit = 1; g_dcn_abl = 0; g_dcn_win_r = 0; g_dcn_pf = 0; g_dcn_gather = -1;
+    return FAMI_OK;
+  }
   if (gather >= 1024) g_dcn_bwd_abl = gather - 1024;
   else if (gather >= 512) g_dcn_bwd_scatter = gather - 512;
   else if (gather >= 256) g_dcn_ksplit = gather - 256;

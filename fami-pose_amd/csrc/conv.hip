@@ -2640,6 +2640,8 @@ static inline int out_dim(int i, int k, int stride, int pad, int dil) {
 }
 
 extern "C" {
+int fami_dcn_tune(int mode);          // align.hip
+int fami_bn_tune_small(long elems);   // norm.hip
 
 // tuning hook (benchmarks only): force the implicit-GEMM tile (0 = heuristic)
 int fami_conv_tune(int mt, int nt, int ks) {

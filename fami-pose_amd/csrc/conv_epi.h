@@ -128,6 +128,7 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn = xbn_none());
 void fami_conv_t4_tune(int on);
+void fami_conv_t4_default_split(int on);
 int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co);
 int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co);
 
@@ -144,3 +145,4 @@ long fami_wgrad_s3_slabs(int N, int H, int W, int Ci, int Co);
 int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_bytes, int N, int H, int W, int Ci, int Co,
                       hipStream_t s, const char* name, const XBN& xbn = xbn_none());
 void fami_wgrad_s3_tune(int on);
+void fami_wgrad_s3_default(int on);

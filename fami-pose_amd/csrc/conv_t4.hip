@@ -527,6 +527,7 @@ static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per w
                                // 54 -> 51.5 us, 96 ch @48x36 56 -> 40.6, but 192 ch @24x18 55 -> 71 (hence the frame-size rule); f32 step
                                // 53.5 -> 52.3 ms.  4 tiles per wave (and 3 with 64-wide channel blocks) spill hundreds of bytes: not built.
 static int g_t4_s3_minwg = 0;  // fami_conv_tune_lds(2000 + n): the split-product instance only for launches of >= n workgroups (benchmarks)
+static int g_s3_default = 1;   // fami_tune_defaults: what fami_conv_tune_lds(-1) restores (FAMI_F32_SPLIT=0 -> 0)
 static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
 
 // ---- the split-product f32 instance: plan + launch
@@ -756,8 +757,9 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
   return try_conv3x3_t4_s3(nullptr, nullptr, nullptr, nullptr, N, H, W, Ci, Co, 0, 0, 1, 0, 0, nullptr, "", epi_none(), xb);
 }
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
+void fami_conv_t4_default_split(int on) { g_s3_default = on ? 1 : 0; }
 void fami_conv_t4_tune(int on) {
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = 1; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = g_s3_default; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on == 102030 || on == 102031) g_t4_s3_narrow = on - 102030;
   else if (on >= 102000) g_t4_s3_fill = on - 102000;

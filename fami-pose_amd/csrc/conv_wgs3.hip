@@ -381,8 +381,10 @@ int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_byte
   return q.G;
 }
 // benchmarks / tests: 0 / 1 off / on, 100 + bt forces the tiles per run, 1000 + n the workgroup target, < 0 defaults
+static int g_wgs3_default = 1;   // fami_tune_defaults (FAMI_F32_SPLIT)
+void fami_wgrad_s3_default(int on) { g_wgs3_default = on ? 1 : 0; }
 void fami_wgrad_s3_tune(int on) {
-  if (on < 0) { g_wgs3 = 1; g_wgs3_bt = 0; g_wgs3_target = 0; }
+  if (on < 0) { g_wgs3 = g_wgs3_default; g_wgs3_bt = 0; g_wgs3_target = 0; }
   else if (on <= 1) g_wgs3 = on;
   else if (on >= 1000) g_wgs3_target = on - 1000;
   else if (on >= 100) g_wgs3_bt = on - 100;

@@ -245,6 +245,7 @@ __global__ void adam_prep_kernel(float* state, float beta1, float beta2, unsigne
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     if (flag && *flag) {
       *flag = 0u;
+      flag[1] += 1u;       // skipped-step counter (Trainer.skipped_steps): a persistent overflow must be visible, not silent
       state[2] = 0.f;
       return;
     }

@@ -63,6 +63,13 @@ int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous wor
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default;
                                         * 100 / 101 = linear-address form of the f32 implicit GEMM off / on (default on);
                                         * 110 / 111 = stride-2 input gradient: all taps / the pixel's parity class only (default) */
+/* Every fami_*_tune knob back to its default (tests: autouse fixture).  The knobs are process-wide and only select
+ * between kernels that compute the same function. */
+int fami_tune_reset(void);
+/* The library's default f32 arithmetic for 3x3 stride-1 convolutions (1 = split products on the bf16 matrix pipe,
+ * 0 = exact-f32 MFMA, < 0 = keep) -- stored as the default that fami_tune_reset / fami_conv_tune_lds(-1) restore --
+ * then fami_tune_reset.  _lib.py calls it once at load with FAMI_F32_SPLIT. */
+int fami_tune_defaults(int f32_split);
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);
@@ -213,7 +220,8 @@ int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const fl
                   float beta2, float eps, float weight_decay, fami_stream_t stream);
 /* fp16 static loss scaling with an overflow guard (the reference trains in fp32 and has no counterpart; BASELINE config 5):
  * fami_unscale_check_f32 multiplies the gradient arena by f and raises *flag (device u32) on any inf / NaN;
- * fami_adam_prep_checked_f32 then skips the whole Adam step (no step count, no moment update) and clears the flag. */
+ * fami_adam_prep_checked_f32 then skips the whole Adam step (no step count, no moment update), clears the flag and
+ * counts the skip: flag is a device u32[2] = {raised, skipped steps so far}. */
 int fami_unscale_check_f32(float* g, long n, float f, unsigned* flag, fami_stream_t stream);
 int fami_adam_prep_checked_f32(float* state4, float beta1, float beta2, unsigned* flag, fami_stream_t stream);
 

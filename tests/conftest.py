@@ -28,6 +28,17 @@ def dev():
 
 
 @pytest.fixture(autouse=True)
+def _reset_tune_knobs(request):
+    """The fami_*_tune knobs are process-wide: after every GPU test put them back to the library defaults
+    (fami_tune_reset), so a test that forgets its `finally` cannot change the route of the tests behind it."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from fami_pose_amd._lib import loaded, lib
+        if loaded():
+            lib().cdll.fami_tune_reset()
+
+
+@pytest.fixture(autouse=True)
 def _release_device_objects(request):
     """After every GPU test: collect the garbage NOW (Trainers hold hipGraph executables, and each executable owns the
     HIP streams its parallel branches run on) and let the device drain.  Without it the graph executables of a dozen

@@ -83,7 +83,7 @@ def _worker(rank, world, port, q):
         assert not torch.equal(rm[0], rm[1])
 
         # (3) graph plans == eager plan (rank 0 also checks the serial plan; the single-rank RCCL test covers both)
-        for plan in (('overlap', 'serial') if os.environ.get('FAMI_TEST_ALL_PLANS') else ('overlap',)):
+        for plan in ('overlap', 'serial'):
             os.environ['FAMI_DDP_PLAN'] = plan
             tr_c = Trainer(model(), use_graph=True, targets_from_joints=True, bucket_mb=8)
             tr_c.step(kf, sup, joints, vis)

@@ -409,7 +409,7 @@ def test_adam_skips_a_step_with_nonfinite_gradients(dev):
     opt = torch.optim.Adam([ref], lr=1e-3)
     flat = p.clone().to(dev)
     ad = FlatAdam(flat, lr=1e-3)
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)      # {raised, skipped steps}
     st = torch.cuda.current_stream(dev).cuda_stream
     scale = 8192.0
     for it in range(6):
@@ -424,13 +424,13 @@ def test_adam_skips_a_step_with_nonfinite_gradients(dev):
         ad.grad.copy_(gd)
         before = (flat.clone(), ad.m.clone(), ad.v.clone(), ad.state[0].item())
         lib().call('fami_unscale_check_f32', ad.grad.data_ptr(), ad.grad.numel(), 1.0 / scale, flag.data_ptr(), st)
-        assert flag.item() == (1 if bad else 0)
+        assert flag[0].item() == (1 if bad else 0)
         ad.step(flag)
-        assert flag.item() == 0
+        assert flag[0].item() == 0
         if bad:
             assert torch.equal(flat, before[0]) and torch.equal(ad.m, before[1]) and torch.equal(ad.v, before[2])
             assert ad.state[0].item() == before[3]
-    assert ad.state[0].item() == 4.0
+    assert ad.state[0].item() == 4.0 and flag[1].item() == 2          # two skipped steps, counted on the device
     assert relerr(flat, ref.data) < 1e-6
 
 

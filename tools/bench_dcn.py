@@ -27,7 +27,7 @@ w = torch.randn(C, C, 3, 3, device=dev) * 0.05
 bias = torch.zeros(C, device=dev)
 y = torch.empty(B, H, W, C, device=dev)
 wp = torch.empty(L.cdll.fami_dcn_packed_weight_elems(C, C, 3, 3, G), device=dev)
-L.call('fami_dcn_pack_weight_f32', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
+L.call('fami_dcn_pack_weight_bf16', w.data_ptr(), wp.data_ptr(), C, C, 3, 3, G, s.cuda_stream)   # the two fp32 images + the 16-bit image fami_dcn_fwd_bf16 contracts with
 P = B * H * W
 fwd_bytes = (C + 27 * G + C) * P * 4.0
 ys = []
