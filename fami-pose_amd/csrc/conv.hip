@@ -2720,6 +2720,30 @@ int fami_conv_tune_stages(int stages) {
   g_stages = (stages >= 2 && stages <= 4) ? stages : 0;
   return FAMI_OK;
 }
+// Every benchmark / test knob of the library back to its default.  The knobs are process-wide (they select between
+// kernels that compute the same function); tests call this from an autouse fixture, so a test that forgets its
+// `finally` cannot poison the rest of the suite.
+int fami_tune_reset(void) {
+  fami_conv_tune(0, 0, 0);
+  fami_conv_tune_lds(-1);
+  fami_conv_tune_wgrad_lds(-1);
+  fami_conv_tune_xcd(-1);
+  g_stages = 0; g_prio = 0; g_lin_conv = 1; g_par = 1;
+  g_wgrad_ps = 0; g_wgrad_mt = 0;
+  fami_dcn_tune(-1);
+  fami_bn_tune_small(-1);
+  return FAMI_OK;
+}
+// The library's DEFAULT f32 arithmetic for 3x3 stride-1 convolutions: 1 = split products on the bf16 matrix pipe,
+// 0 = exact-f32 MFMA (FAMI_F32_SPLIT=0).  Stored as the default state, so fami_tune_reset / fami_conv_tune_lds(-1)
+// restore it instead of silently re-enabling the split kernels.
+int fami_tune_defaults(int f32_split) {
+  if (f32_split >= 0) {
+    fami_conv_t4_default_split(f32_split);
+    fami_wgrad_s3_default(f32_split);
+  }
+  return fami_tune_reset();
+}
 
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
