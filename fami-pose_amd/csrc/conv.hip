@@ -2745,9 +2745,11 @@ int fami_tune_defaults(int f32_split) {
   return fami_tune_reset();
 }
 
+// f32 image = [16x16 fragment image][32x32 fragment image (wide 1x1 only)][split image (3x3, K % 16 == 0: three bf16 planes of
+// every weight, the layout conv_t5.hip copies straight into LDS; fami_split_image_elems)]
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
-  return pack16_elems(kd, nd, kh * kw) + pack32_elems(kd, nd, kh * kw);
+  return pack16_elems(kd, nd, kh * kw) + pack32_elems(kd, nd, kh * kw) + fami_split_image_elems(kd, nd, kh * kw);
 }
 
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
@@ -2757,6 +2759,10 @@ int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, in
   const long total = pack16_elems(kd, nd, kh * kw) + pack32_elems(kd, nd, kh * kw);
   hipLaunchKernelGGL(pack_w_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, wp, Co, Ci, kh * kw, mode);
   FAMI_CHECK_LAUNCH("fami_pack_conv_weight_f32");
+  if (fami_split_image_elems(kd, nd, kh * kw) > 0) {
+    fami_pack_split_single(w_oihw, wp + total, Co, Ci, kh * kw, mode, s);
+    FAMI_CHECK_LAUNCH("fami_pack_conv_weight_f32/split");
+  }
   return FAMI_OK;
 }
 
@@ -3447,6 +3453,8 @@ int fami_pack_conv_weights_batch_f32(const float* params, float* packed, const v
   FAMI_REQUIRE(params && packed && desc && n > 0 && n < 65536, "fami_pack_conv_weights_batch_f32", "bad argument");
   hipLaunchKernelGGL(pack_w_batch_kernel<float>, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const PackDesc*>(desc));
   FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_f32");
+  fami_pack_split_batch(params, packed, desc, n, s);      // the split images behind the 3x3 fragment images (conv_t5.hip)
+  FAMI_CHECK_LAUNCH("fami_pack_conv_weights_batch_f32/split");
   return FAMI_OK;
 }
 

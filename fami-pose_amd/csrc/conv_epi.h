@@ -146,3 +146,16 @@ int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_byte
                       hipStream_t s, const char* name, const XBN& xbn = xbn_none());
 void fami_wgrad_s3_tune(int on);
 void fami_wgrad_s3_default(int on);
+
+// conv_t5.hip: persistent, unit-pipelined form of the 3x3 stride-1 kernels (round 4) and the pre-split f32 weight image it
+// reads.  The split image follows the f32 fragment images of a 3x3 convolution with K % 16 == 0:
+//   [tap][K/16][N/16][plane 3][n 16][k 16] bf16 -- w = plane0 + plane1 + plane2 exactly (the split of conv_t4.hip's t4_split)
+// fami_split_image_elems -> its size in floats (0: no split image for this geometry).
+long fami_split_image_elems(int kd, int nd, int taps);
+void fami_pack_split_single(const float* w_oihw, float* split, int Co, int Ci, int taps, int mode, hipStream_t s);
+void fami_pack_split_batch(const float* params, float* packed, const void* desc, int n, hipStream_t s);
+int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                        int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi, const XBN& xbn);
+void fami_conv_t5_tune(int on);
+int fami_conv_t5_eligible_s3(int N, int H, int W, int Ci, int Co);

@@ -719,6 +719,11 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
+  if (half_kind == 2 && g_use_t4 && g_use_t4_s3) {
+    // round 4: the persistent, unit-pipelined form (conv_t5.hip) wherever it is eligible; bitwise the same results
+    const int rc5 = fami_try_conv3x3_t5(2, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
+    if (rc5 != 0) return rc5;
+  }
   if (half_kind == 2) {
     const int rc = try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi, xbn);
     if (rc != 0) return rc;
@@ -759,6 +764,10 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_default_split(int on) { g_s3_default = on ? 1 : 0; }
 void fami_conv_t4_tune(int on) {
+  if (on < 0 || (on >= 7000 && on < 8000)) {   // conv_t5.hip: 7000 / 7001 off / on, 7100 + rows per band, 7400 + minimum frame tiles, 7500 + workgroups
+    fami_conv_t5_tune(on);
+    if (on >= 0) return;
+  }
   if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = g_s3_default; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
   else if (on == 102030 || on == 102031) g_t4_s3_narrow = on - 102030;

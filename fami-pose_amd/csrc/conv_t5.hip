@@ -1,0 +1,619 @@
+// Persistent, unit-pipelined 3x3 convolution (stride 1, pad 1), round 4: forward and input gradient of the HRNet branch
+// convolutions (posetimation/backbones/hrnet.py:17-172 via layers/basic_model.py:25-63) -- the f32-storage split-product
+// arithmetic of conv_t4.hip (three bf16 terms per operand, six products on the bf16 matrix pipe, fp32 accumulation) and
+// the 16-bit storage types -- restructured around what the round-3 kernel's trace showed:
+//   * conv_t4's workgroup = one band: prologue (first fetch), 2-24 chunks of [store -> barrier -> taps -> barrier], store
+//     of the results; with 100 KB of LDS one workgroup per CU, so none of these phases overlapped anything, and a launch
+//     was 1.4 "rounds" of workgroups on 256 CUs (360 workgroups: the second round 41 % full);
+//   * every workgroup re-split the same f32 weights into bf16 terms (42 % of the staging arithmetic, a third of the LDS
+//     stores).
+// Here
+//   * the grid is PERSISTENT: <= 256 workgroups walk a job list (frame, band of R whole rows, output-channel block) sized
+//     so that every workgroup gets the same number of jobs (no tail round);
+//   * the weights come PRE-SPLIT from the packed image (three bf16 planes per weight, written once per step by the
+//     weight pack: fami_pack_split_*) and go global -> LDS by DMA (global_load_lds_dwordx4): no registers, no VALU, no
+//     ds_write for 49 % of what a chunk stages;
+//   * the K loop is cut into UNITS of one tap row of one 16-channel chunk (split-product form; a whole chunk for the
+//     16-bit types): while unit u is multiplied out of weight slab u & 1, the DMA of slab u + 1 is in flight into the
+//     other one, and the NEXT chunk's activation patch (fetched into registers one chunk ahead, split while it is
+//     stored) is written into the second patch buffer in the middle of the current chunk -- one barrier per unit, the
+//     pipeline runs across chunk AND job boundaries, so a job's prologue / epilogue hide behind its neighbours' MFMAs.
+// Same summation order per output element as conv_t4's split-product instance: results are bitwise equal to it
+// (tests/test_kernels_gpu.py::test_persistent_conv_is_bitwise_the_band_kernel).
+#include "conv_epi.h"
+#include <type_traits>
+
+typedef __bf16 t5_bf16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ the pre-split weight image
+// [tap][K/16][N/16][plane 3][n 16][k 16] bf16 (a (tap, K group, N tile) block is 1536 bytes = what the kernel copies);
+// mode 0: K = Cin, N = Cout; mode 1 (input gradient): K = Cout, N = Cin -- the orientation of the f32 fragment image
+// it follows.
+long fami_split_image_elems(int kd, int nd, int taps) {
+  return (taps == 9 && kd % 16 == 0) ? (long)taps * (kd / 16) * ((nd + 15) / 16) * 384 : 0;
+}
+__device__ __forceinline__ void t5_split3(float v, __bf16& h0, __bf16& h1, __bf16& h2) {
+  h0 = (__bf16)v;
+  const float r1 = v - (float)h0;     // exact
+  h1 = (__bf16)r1;
+  const float r2 = r1 - (float)h1;    // exact, representable
+  h2 = (__bf16)r2;
+}
+struct T5PackDesc { long src, dst; int Co, Ci, taps, mode; };
+__device__ __forceinline__ void t5_pack_split_image(const float* __restrict__ w, __bf16* __restrict__ sp, int Co, int Ci,
+                                                    int mode, int first, int stride) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  const int KC = kd / 16, NTt = (nd + 15) / 16;
+  const long total = (long)9 * KC * NTt * 256;      // (tap, kc, nt, n, k) elements
+  for (long i = first; i < total; i += stride) {
+    const int k = (int)(i & 15), n = (int)((i >> 4) & 15);
+    long r = i >> 8;
+    const int nt = (int)(r % NTt);
+    r /= NTt;
+    const int kc = (int)(r % KC), tap = (int)(r / KC);
+    const int kidx = kc * 16 + k, nidx = nt * 16 + n;
+    const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
+    const float v = (co < Co && ci < Ci) ? w[((long)co * Ci + ci) * 9 + tap] : 0.f;
+    __bf16 h0, h1, h2;
+    t5_split3(v, h0, h1, h2);
+    __bf16* blk = sp + (i >> 8) * 768 + n * 16 + k;
+    blk[0] = h0;
+    blk[256] = h1;
+    blk[512] = h2;
+  }
+}
+__global__ __launch_bounds__(256) void t5_pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ sp, int Co, int Ci, int mode) {
+  t5_pack_split_image(w, sp, Co, Ci, mode, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+__global__ __launch_bounds__(256) void t5_pack_split_batch_kernel(const float* __restrict__ params, float* __restrict__ packed,
+                                                                   const T5PackDesc* __restrict__ desc) {
+  const T5PackDesc d = desc[blockIdx.y];
+  const int kd = d.mode == 0 ? d.Ci : d.Co, nd = d.mode == 0 ? d.Co : d.Ci;
+  if (d.taps != 9 || (kd % 16) != 0) return;
+  const long n16 = (long)9 * (kd / 16) * ((nd + 15) / 16) * 256;      // the f32 fragment image in front (no 32x32 image for 3x3)
+  t5_pack_split_image(params + d.src, reinterpret_cast<__bf16*>(packed + d.dst + n16), d.Co, d.Ci, d.mode,
+                      blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+void fami_pack_split_single(const float* w_oihw, float* split, int Co, int Ci, int taps, int mode, hipStream_t s) {
+  const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
+  if (fami_split_image_elems(kd, nd, taps) == 0) return;
+  const long total = (long)9 * (kd / 16) * ((nd + 15) / 16) * 256;
+  hipLaunchKernelGGL(t5_pack_split_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, reinterpret_cast<__bf16*>(split), Co, Ci, mode);
+}
+void fami_pack_split_batch(const float* params, float* packed, const void* desc, int n, hipStream_t s) {
+  hipLaunchKernelGGL(t5_pack_split_batch_kernel, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const T5PackDesc*>(desc));
+}
+
+// ------------------------------------------------------------------ the kernel
+struct ConvT5Args {
+  EpiBN e;
+  int emode;
+  XBN xb;
+  const void* x;      // [N,H,W,Ci]
+  const void* wimg;   // S3: the split image; 16-bit: the packed fragment image [tap][KC][NTt][64][8]
+  void* y;            // [N,H,W,Co]
+  const float* bias;
+  int N, H, W, Ci, Co;
+  int R, bands, cblocks, njobs;   // output rows per band, bands per frame, output-channel blocks, N * bands * cblocks
+  int PW, KC, NTt;
+  int sgn, relu, accumulate, out_f32;
+  int ppl;            // S3: bytes of one patch plane
+  int patch_bytes;    // bytes of one patch buffer
+  int nposmax;        // positions of a full band's patch ((R + 2) * PW)
+};
+
+#define T5_THREADS 512
+#define T5_WAVES 8
+#define T5_MTT 3      // pixel tiles per wave at most: bands of <= 18 tiles (waves 0, 1: three; the others two)
+#define T5_PM 4       // 16-byte patch pieces per thread and chunk (<= 512 positions)
+
+template <typename H, bool S3> struct T5Frag { typedef typename H16<H>::x8 type; };
+template <> struct T5Frag<float, true> { typedef bf16x8 type; };
+
+template <typename H, int NT, bool S3>
+__global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p) {
+  static_assert(S3 == (sizeof(H) == 4), "f32 storage runs the split-product form, 16-bit storage the plain one");
+  typedef typename T5Frag<H, S3>::type frag;
+  constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // a chunk is 64 bytes of a pixel: 16 f32 / 32 16-bit channels
+  constexpr int TRG = S3 ? 3 : 1, TPU = 9 / TRG;                     // units per chunk, taps per unit
+  constexpr int BLK = S3 ? 1536 : 1024;                              // bytes of one (tap, N tile) weight block
+  constexpr int SLAB = TPU * NT * BLK;                               // one unit's weights
+  constexpr int NPIECE = (SLAB + 1023) / 1024, WPW = (NPIECE + T5_WAVES - 1) / T5_WAVES;
+  constexpr int PS = S3 ? 32 : 80;                                   // LDS bytes per patch position (S3: per plane)
+  constexpr int PST = S3 ? 1 : 0;                                    // the unit of a chunk in which the next chunk's patch is stored
+  constexpr int MTT = T5_MTT, PM = T5_PM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbase = smem + 2 * p.patch_bytes;
+  float* const ered = reinterpret_cast<float*>(wbase + 2 * SLAB);   // [waves][NT * 32]: the EpiBN epilogue's exchange
+  float* const xsc = ered + T5_WAVES * NT * 32;
+  float* const xsf = xsc + p.Ci;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+
+  // ---- this workgroup's jobs: XCD x (= workgroup id % 8, observed placement; only speed depends on it) owns the x-th
+  // contiguous eighth of the job list, so bands that share halo rows and the channel blocks of one band meet in one L2
+  int job, jstride, jend;
+  {
+    const int G = gridDim.x, wg = blockIdx.x;
+    if ((G & 7) == 0) {
+      const int x = wg & 7, q = p.njobs >> 3, r = p.njobs & 7;
+      const int xs = x * q + min(x, r);
+      job = xs + (wg >> 3);
+      jstride = G >> 3;
+      jend = xs + q + (x < r ? 1 : 0);
+    } else {
+      job = wg;
+      jstride = G;
+      jend = p.njobs;
+    }
+  }
+  if (job >= jend) return;
+  const int HW = p.H * p.W;
+  const int nchunk = (p.Ci + CHN - 1) / CHN;
+  struct Geo { int img, y0, rows, cb; };
+  auto geo = [&](int j) {
+    Geo g;
+    g.cb = j % p.cblocks;
+    const int t = j / p.cblocks;
+    const int bnd = t % p.bands;
+    g.img = t / p.bands;
+    g.y0 = bnd * p.R;
+    g.rows = min(p.R, p.H - g.y0);
+    return g;
+  };
+
+  // ---- staging plan of the activation patch (job-invariant): piece i = tid + u * 512 -> position i >> 2, 16-byte piece i & 3
+  const char* const xg = reinterpret_cast<const char*>(p.x);
+  int prel[PM], prow[PM];
+#pragma unroll
+  for (int u = 0; u < PM; ++u) {
+    const int i = tid + u * T5_THREADS;
+    const int pos = i >> 2, pc = i & 3;
+    const int r = pos / p.PW, c = pos - r * p.PW;
+    const bool ok = pos < p.nposmax && c >= 1 && c <= p.W;          // the border columns are the zero padding
+    prow[u] = ok ? r : 0x40000000;
+    prel[u] = ((r * p.W + c - 1) * p.Ci + pc * PCN) * SZ;
+  }
+  u32x4 pr[PM];
+  unsigned pvalid = 0;
+  auto fetch = [&](const Geo& g, int c) {
+    const char* xb = xg + ((long)(g.img * p.H + g.y0 - 1) * p.W) * p.Ci * SZ + c * 64;
+#pragma unroll
+    for (int u = 0; u < PM; ++u) {
+      pr[u] = u32x4{0u, 0u, 0u, 0u};
+      const int pc = (tid + u * T5_THREADS) & 3;
+      const bool ld = prow[u] < g.rows + 2 && (unsigned)(g.y0 - 1 + prow[u]) < (unsigned)p.H && c * CHN + pc * PCN < p.Ci;
+      if (ld) pr[u] = *reinterpret_cast<const u32x4*>(xb + prel[u]);
+      pvalid = (pvalid & ~(1u << u)) | ((ld ? 1u : 0u) << u);
+    }
+  };
+  const bool xon = p.xb.on;
+  auto store = [&](char* buf, int c) {
+#pragma unroll
+    for (int u = 0; u < PM; ++u) {
+      const int i = tid + u * T5_THREADS;
+      if ((i >> 2) < p.nposmax) {
+        u32x4 v = pr[u];
+        const int ch0 = c * CHN + (i & 3) * PCN;
+        if (xon && ((pvalid >> u) & 1u)) {       // border / outside pieces stay zero: the convolution pads the NORMALISED tensor
+          if constexpr (S3) {
+            f32x4 t = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = fmaxf(__builtin_fmaf(t[j], xsc[ch0 + j], xsf[ch0 + j]), 0.f);
+            v = __builtin_bit_cast(u32x4, t);
+          } else {
+            v = xbn_piece<H>(v, xsc + ch0, xsf + ch0);
+          }
+        }
+        if constexpr (S3) {
+          const f32x4 f = __builtin_bit_cast(f32x4, v);
+          const t5_bf16x4 h0 = __builtin_convertvector(f, t5_bf16x4);
+          const f32x4 r1 = f - __builtin_convertvector(h0, f32x4);
+          const t5_bf16x4 h1 = __builtin_convertvector(r1, t5_bf16x4);
+          const f32x4 r2 = r1 - __builtin_convertvector(h1, f32x4);
+          const t5_bf16x4 h2 = __builtin_convertvector(r2, t5_bf16x4);
+          char* dst = buf + (i >> 2) * PS + (i & 3) * 8;
+          *reinterpret_cast<t5_bf16x4*>(dst) = h0;
+          *reinterpret_cast<t5_bf16x4*>(dst + p.ppl) = h1;
+          *reinterpret_cast<t5_bf16x4*>(dst + 2 * p.ppl) = h2;
+        } else {
+          *reinterpret_cast<u32x4*>(buf + (i >> 2) * PS + (i & 3) * 16) = v;
+        }
+      }
+    }
+  };
+
+  // ---- weight slab DMA plan: this wave copies 1 KiB pieces wave, wave + 8, ... of a slab; lane -> 16 bytes of a
+  // (tap, N tile) block of the image (the LDS slab is the blocks of the unit's taps and this job's N tiles back to back)
+  const char* const wg = reinterpret_cast<const char*>(p.wimg);
+  int wsrc[WPW];
+#pragma unroll
+  for (int k = 0; k < WPW; ++k) {
+    const int b = (wave + T5_WAVES * k) * 1024 + lane * 16;
+    const int blk = b / BLK, within = b - blk * BLK;
+    const int t3 = blk / NT, nt = blk - t3 * NT;
+    wsrc[k] = b < SLAB ? (t3 * p.KC * p.NTt + nt) * BLK + within : -1;
+  }
+  auto dma_w = [&](int cb, int c, int r, char* slab) {
+    const char* src = wg + ((long)((r * TPU) * p.KC + c) * p.NTt + cb * NT) * BLK;
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) {
+      if ((wave + T5_WAVES * k) * 1024 < SLAB) {         // wave-uniform
+        if (wsrc[k] >= 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wsrc[k]),
+                                           (__attribute__((address_space(3))) void*)(slab + (wave + T5_WAVES * k) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- XBN: per-channel scale / shift of the input's BatchNorm (one table per workgroup; workgroup 0 publishes the statistics)
+  if (xon) {
+    for (int ch = tid; ch < p.Ci; ch += T5_THREADS) {
+      float a, b;
+      xbn_channel(p.xb, ch, blockIdx.x == 0, a, b);
+      xsc[ch] = a;
+      xsf[ch] = b;
+    }
+    __syncthreads();
+  }
+
+  // ---- per-lane fragment offsets
+  const int s3h = kq >> 1, s3l = (kq & 1) * 16;
+  const int xo0 = s3l, xo1 = p.ppl + s3l, xo2 = (s3h ? 2 : 0) * p.ppl + s3l;                       // X(0|0), X(1|1), X(0|2)
+  const int wo0 = (s3h ? 1 : 0) * 512 + col * 32 + s3l, wo1 = (s3h ? 0 : 2) * 512 + col * 32 + s3l;   // W(0|1), W(2|0)
+
+  // ---- prologue of the pipeline
+  Geo gj = geo(job);
+  fetch(gj, 0);
+  store(smem, 0);
+  int fjob = job, fc = 0;                     // the patch sequence's look-ahead: (fjob, fc) is in the registers
+  auto advance = [&](int& j, int& c) {
+    if (++c == nchunk) {
+      c = 0;
+      j += jstride;
+    }
+  };
+  advance(fjob, fc);
+  bool fvalid = fjob < jend;
+  if (fvalid) fetch(geo(fjob), fc);
+  dma_w(gj.cb, 0, 0, wbase);
+  int u = 0, sq = 0;                          // unit counter (weight slab u & 1), patch counter (patch buffer sq & 1)
+
+  for (; job < jend; job += jstride) {
+    gj = geo(job);
+    const int npx = gj.rows * p.W;
+    const int ntile = (npx + 15) >> 4;
+    int mtw = (ntile - wave + T5_WAVES - 1) / T5_WAVES;     // tiles wave, wave + 8, wave + 16 (wave-uniform)
+    mtw = mtw < 0 ? 0 : (mtw > MTT ? MTT : mtw);
+    int base[MTT];
+#pragma unroll
+    for (int mt = 0; mt < MTT; ++mt) {
+      const int pp = min((wave + T5_WAVES * mt) * 16 + col, npx - 1);   // lanes past the band re-read its last pixel (never stored)
+      const int ry = pp / p.W, rx = pp - ry * p.W;
+      base[mt] = ((ry + 1) * p.PW + rx + 1) * PS + (S3 ? 0 : kq * 16);
+    }
+    f32x4 acc[MTT][NT], acc2[S3 ? MTT : 1][S3 ? NT : 1];
+#pragma unroll
+    for (int mt = 0; mt < MTT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (S3) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+
+    for (int c = 0; c < nchunk; ++c, ++sq) {
+#pragma unroll
+      for (int r = 0; r < TRG; ++r, ++u) {
+        __syncthreads();   // slab u has landed (DMA), patch sq is stored, every wave has left unit u - 1
+        {                  // the next unit's weights -> the slab unit u - 1 read
+          int nr = r + 1, nc = c, nj = job;
+          if (nr == TRG) {
+            nr = 0;
+            advance(nj, nc);
+          }
+          if (nj < jend) dma_w(geo(nj).cb, nc, nr, wbase + ((u + 1) & 1) * SLAB);
+        }
+        if (r == PST && fvalid) {
+          // the next chunk's patch (in registers since the previous chunk) -> the buffer chunk sq - 1 was read from;
+          // then request the one after it
+          store(smem + ((sq + 1) & 1) * p.patch_bytes, fc);
+          advance(fjob, fc);
+          fvalid = fjob < jend;
+          if (fvalid) fetch(geo(fjob), fc);
+        }
+        const char* const patch = smem + (sq & 1) * p.patch_bytes;
+        const char* const wslab = wbase + (u & 1) * SLAB;
+        auto taps = [&](auto mwc) {
+          constexpr int MW = decltype(mwc)::value;
+#pragma unroll
+          for (int t = 0; t < TPU; ++t) {
+            const int tap = r * TPU + t;
+            const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * PS;
+            if constexpr (S3) {
+              frag a3[MW][3], w3[NT][2];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const char* wb = wslab + (t * NT + nt) * BLK;
+                w3[nt][0] = *reinterpret_cast<const frag*>(wb + wo0);
+                w3[nt][1] = *reinterpret_cast<const frag*>(wb + wo1);
+              }
+#pragma unroll
+              for (int mt = 0; mt < MW; ++mt) {
+                const char* pb = patch + base[mt] + toff;
+                a3[mt][0] = *reinterpret_cast<const frag*>(pb + xo0);
+                a3[mt][1] = *reinterpret_cast<const frag*>(pb + xo1);
+                a3[mt][2] = *reinterpret_cast<const frag*>(pb + xo2);
+              }
+#pragma unroll
+              for (int m = 2; m >= 0; --m)          // low-order products first (as conv_t4: bitwise the same sums)
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                  for (int nt = 0; nt < NT; ++nt) {
+                    f32x4& dst = m > 0 ? acc2[S3 ? mt : 0][S3 ? nt : 0] : acc[mt][nt];
+                    dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], dst, 0, 0, 0);
+                  }
+            } else {
+              frag a[MW], w[NT];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wslab + (t * NT + nt) * BLK + lane * 16);
+#pragma unroll
+              for (int mt = 0; mt < MW; ++mt) a[mt] = *reinterpret_cast<const frag*>(patch + base[mt] + toff);
+#pragma unroll
+              for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<typename std::conditional<S3, bf16_t, H>::type>::mfma(w[nt], a[mt], acc[mt][nt]);
+            }
+          }
+        };
+        if (mtw == 3) taps(std::integral_constant<int, 3>());
+        else if (mtw == 2) taps(std::integral_constant<int, 2>());
+        else if (mtw == 1) taps(std::integral_constant<int, 1>());
+      }
+    }
+
+    if constexpr (S3) {
+#pragma unroll
+      for (int mt = 0; mt < MTT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] += acc2[mt][nt];
+    }
+    // ---- epilogue of the job: D row = kq*4 + r (output channel), col = lane & 15 (pixel)
+    const long pix0 = (long)gj.img * HW + gj.y0 * p.W;
+    const int ntg0 = gj.cb * NT;
+    const int emode = p.emode;
+    if (emode) {
+      // EpiBN (conv_epi.h): the wave's tiles in registers, the 16 pixel lanes by DPP, the eight waves through LDS
+      EpiPtr e = epi_late(__builtin_offsetof(ConvT5Args, e));
+      const H* ez = reinterpret_cast<const H*>(e->z);
+      const H* eyr = reinterpret_cast<const H*>(e->yr);
+      const int erelu = e->relu, eC = e->C;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co0 = (ntg0 + nt) * 16 + kq * 4;
+        f32x4 es = z4, eq = z4, ek = z4, emu = z4, eis = z4, esc = z4, esf = z4, bias4 = z4;
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co0);
+        if (emode == 1) {
+          if (e->pivot_src) ek = *reinterpret_cast<const f32x4*>(e->pivot_src + co0);
+        } else {
+          emu = *reinterpret_cast<const f32x4*>(e->mean + co0);
+          eis = *reinterpret_cast<const f32x4*>(e->invstd + co0);
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + co0), be = *reinterpret_cast<const f32x4*>(e->beta + co0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float a, b;
+            epi_scale_shift(emu[r], eis[r], ga[r], be[r], a, b);
+            esc[r] = a;
+            esf[r] = b;
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+          const int j = (wave + T5_WAVES * mt) * 16 + col;
+          if (mt >= mtw || j >= npx) continue;
+          f32x4 v = acc[mt][nt] + bias4;
+          const long idx = (pix0 + j) * p.Co + co0;
+          H* yp = reinterpret_cast<H*>(p.y) + idx;
+          if (p.accumulate) v += ld4(yp);
+          if (emode == 2) {
+            const f32x4 zz = ld4(ez + idx);
+            f32x4 yy = z4;
+            if (erelu == 1) yy = ld4(eyr + idx);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bool keep = true;
+              if (erelu == 1) keep = yy[r] > 0.f;
+              else if (erelu == 2) keep = __builtin_fmaf(zz[r], esc[r], esf[r]) > 0.f;
+              v[r] = keep ? v[r] : 0.f;
+            }
+            st4(yp, v);
+            const f32x4 g = ld4_round<H>(v);
+            es += g;
+            eq += g * ((zz - emu) * eis);
+          } else {
+            st4(yp, v);
+            const f32x4 d = ld4_round<H>(v) - ek;
+            es += d;
+            eq += d * d;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          es[r] = row16_sum(es[r]);
+          eq[r] = row16_sum(eq[r]);
+        }
+        if (col == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ered[wave * (NT * 32) + nt * 32 + kq * 4 + r] = es[r];
+            ered[wave * (NT * 32) + nt * 32 + 16 + kq * 4 + r] = eq[r];
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < NT * 32) {
+        const int nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
+        const int co = (ntg0 + nt) * 16 + c16;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < T5_WAVES; ++wv) v += ered[wv * (NT * 32) + tid];
+        const int slot = (gj.img * p.bands + gj.y0 / p.R) % e->ns;
+        double* srow = e->slots + (long)slot * 2 * eC;
+        unsafeAtomicAdd(srow + st * eC + co, (double)v);
+        if (emode == 1 && st == 0 && gj.img == 0 && gj.y0 == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+      }
+      // (the next epilogue writes `ered` at least nine barriers from here)
+      continue;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTT; ++mt) {
+      const int j = (wave + T5_WAVES * mt) * 16 + col;
+      if (mt >= mtw || j >= npx) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co0 = (ntg0 + nt) * 16 + kq * 4;
+        f32x4 v = acc[mt][nt];
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+        if (p.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const long idx = (pix0 + j) * p.Co + co0;
+        if (p.out_f32 || SZ == 4) {
+          float* yp = reinterpret_cast<float*>(p.y) + idx;
+          if (p.accumulate) v += ld4(yp);
+          st4(yp, v);
+        } else {
+          H* yp = reinterpret_cast<H*>(p.y) + idx;
+          if (p.accumulate) v += ld4(yp);
+          st4(yp, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ plan + launch
+static int g_use_t5 = 1;        // fami_conv_tune_lds(7000 / 7001): off / on
+static int g_t5_rows = 0;       // fami_conv_tune_lds(7100 + R): force the rows per band (benchmarks)
+static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): workgroups of the persistent grid at most (benchmarks)
+static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
+
+struct T5Plan { int ok, NT, R, bands, cblocks, njobs, G, npos; size_t lds; };
+template <bool S3>
+static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
+  T5Plan q;
+  q.ok = 0;
+  q.NT = Co % 48 == 0 ? 3 : 0;      // (64-wide channel blocks: three pixel tiles x four channel tiles spill; conv_t4 keeps those)
+  if (!q.NT || !g_use_t5) return q;
+  if (S3 ? (Ci % 16) != 0 : (Ci % 8) != 0) return q;
+  if ((long)((H * W + 15) / 16) < g_t5_min_tiles) return q;
+  q.cblocks = Co / (16 * q.NT);
+  const int PW = W + 2;
+  const int blk = S3 ? 1536 : 1024, tpu = S3 ? 3 : 9, ps = S3 ? 96 : 80;
+  const size_t fixed = (size_t)2 * tpu * q.NT * blk + (size_t)T5_WAVES * q.NT * 32 * 4 + (xbn ? (size_t)2 * Ci * 4 : 0);
+  // rows per band: the one with the least (rounds of the persistent grid) x (MFMA work of the busiest SIMD per band);
+  // waves w and w + 4 share a SIMD, wave w owns tiles w, w + 8, w + 16
+  double best = 1e30;
+  q.R = 0;
+  for (int R = 1; R <= H; ++R) {
+    if (g_t5_rows > 0 && R != g_t5_rows) continue;
+    const int tiles = (R * W + 15) / 16;
+    const long npos = (long)(R + 2) * PW;
+    if (tiles > T5_WAVES * T5_MTT - 6 || npos * 4 > (long)T5_PM * T5_THREADS) break;      // 18 tiles: waves 0, 1 carry three
+    if (2 * (size_t)npos * ps + fixed > 160 * 1024) break;
+    const int bands = (H + R - 1) / R;
+    const long njobs = (long)N * bands * q.cblocks;
+    const long rounds = (njobs + g_t5_maxwg - 1) / g_t5_maxwg;
+    int simd = 0;
+    for (int w = 0; w < 4; ++w) {
+      int t = 0;
+      for (int k = 0; k < T5_MTT; ++k) t += (w + 8 * k < tiles) + (w + 4 + 8 * k < tiles);
+      simd = t > simd ? t : simd;
+    }
+    const double cost = (double)rounds * (simd + 0.35);      // + a band's fixed cost (pipeline bubbles, halo rows, epilogue)
+    if (cost < best - 1e-9 || (cost < best + 1e-9 && R > q.R)) {
+      best = cost;
+      q.R = R;
+    }
+  }
+  if (!q.R) return q;
+  q.bands = (H + q.R - 1) / q.R;
+  const long njobs = (long)N * q.bands * q.cblocks;
+  if (njobs >= (1L << 30)) return q;
+  q.njobs = (int)njobs;
+  const long rounds = (njobs + g_t5_maxwg - 1) / g_t5_maxwg;
+  long G = (njobs + rounds - 1) / rounds;          // every workgroup the same number of jobs (+- 1)
+  if (G >= 8) G = (G + 7) / 8 * 8;
+  if (G > g_t5_maxwg) G = g_t5_maxwg >= 8 ? g_t5_maxwg / 8 * 8 : g_t5_maxwg;
+  if (G > njobs) G = njobs;
+  q.G = (int)G;
+  q.npos = (q.R + 2) * PW;
+  q.lds = 2 * (size_t)q.npos * ps + fixed;
+  q.ok = 1;
+  return q;
+}
+
+template <typename HT, bool S3>
+static int t5_launch(const T5Plan& q, const void* x, const void* wimg, const float* bias, void* y, int N, int H, int W, int Ci,
+                     int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const EpiBN& epi,
+                     const XBN& xbn) {
+  ConvT5Args a;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
+  a.x = x; a.wimg = wimg; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+  a.R = q.R; a.bands = q.bands; a.cblocks = q.cblocks; a.njobs = q.njobs;
+  a.PW = W + 2; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  a.nposmax = q.npos;
+  a.ppl = q.npos * 32;
+  a.patch_bytes = q.npos * (S3 ? 96 : 80);
+  bool ok = false;
+#define FAMI_T5_CASE(nt)                                                                                                  \
+  if (q.NT == nt) {                                                                                                       \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t5_kernel<HT, nt, S3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_t5_kernel<HT, nt, S3>), dim3(q.G), dim3(T5_THREADS), q.lds, s, a);                        \
+    ok = true;                                                                                                            \
+  }
+  FAMI_T5_CASE(3)
+#undef FAMI_T5_CASE
+  return ok ? 1 : 0;
+}
+
+// Returns 1 if launched, 0 if the shape is not eligible, < 0 on error.  half_kind: 0 bf16, 1 fp16, 2 f32 (split products).
+int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                        int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi, const XBN& xbn) {
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  int rc = 0;
+  if (half_kind == 2) {
+    const T5Plan q = t5_plan<true>(N, H, W, Ci, Co, xbn.on != 0);
+    if (!q.ok || KC * 16 != Ci) return 0;
+    // the split image follows the f32 fragment image [9][KC][NTt][64][4] (fami_packed_weight_elems)
+    const char* wimg = reinterpret_cast<const char*>(wp) + (size_t)9 * KC * NTt * 1024;
+    rc = t5_launch<float, true>(q, x, wimg, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, 1, s, epi, xbn);
+  } else {
+    return 0;   // (16-bit instances: see fami_conv_t5_tune)
+  }
+  if (!rc) return 0;
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    fami_set_error(name, hipGetErrorString(err));
+    return FAMI_EHIP;
+  }
+  return 1;
+}
+int fami_conv_t5_eligible_s3(int N, int H, int W, int Ci, int Co) { return t5_plan<true>(N, H, W, Ci, Co, true).ok; }
+extern "C" int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co) { return fami_conv_t5_eligible_s3(N, H, W, Ci, Co); }
+void fami_conv_t5_tune(int on) {
+  if (on < 0) { g_use_t5 = 1; g_t5_rows = 0; g_t5_maxwg = 256; g_t5_min_tiles = 0; }
+  else if (on == 7000 || on == 7001) g_use_t5 = on - 7000;
+  else if (on >= 7500) g_t5_maxwg = on - 7500;
+  else if (on >= 7400) g_t5_min_tiles = on - 7400;
+  else if (on >= 7100) g_t5_rows = on - 7100;
+}

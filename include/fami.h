@@ -70,6 +70,8 @@ int fami_tune_reset(void);
  * 0 = exact-f32 MFMA, < 0 = keep) -- stored as the default that fami_tune_reset / fami_conv_tune_lds(-1) restore --
  * then fami_tune_reset.  _lib.py calls it once at load with FAMI_F32_SPLIT. */
 int fami_tune_defaults(int f32_split);
+/* would a 3x3 stride-1 pad-1 f32 convolution [N,H,W,Ci] -> Co take the persistent split-product kernel (conv_t5.hip)? (tests) */
+int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co);
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);

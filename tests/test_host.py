@@ -36,7 +36,9 @@ def test_host_only_entry_points():
     """Entry points that do no device work are callable without a GPU: size queries and argument checks."""
     from fami_pose_amd._lib import lib, FamiError
     L = lib()
-    assert L.cdll.fami_packed_weight_elems(48, 48, 3, 3, 0) == 9 * 3 * 3 * 256
+    # f32 fragment image [9][3][3][64][4] + (round 4) the pre-split image behind it: three bf16 planes = 1.5x the floats
+    assert L.cdll.fami_packed_weight_elems(48, 48, 3, 3, 0) == 9 * 3 * 3 * 256 + 9 * 3 * 3 * 384
+    assert L.cdll.fami_packed_weight_elems(48, 20, 3, 3, 0) == 9 * 2 * 3 * 256            # K % 16 != 0: no split image
     assert L.cdll.fami_packed_weight_elems(256, 64, 1, 1, 0) == 4 * 16 * 256 + 8 * 8 * 256      # 16- and 32-tile images
     assert L.cdll.fami_packed_weight_elems(17, 48, 1, 1, 0) == 3 * 2 * 256
     assert L.cdll.fami_conv2d_wgrad_workspace(20, 96, 72, 48, 48, 3, 3, 1, 1, 1) > 0

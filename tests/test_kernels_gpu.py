@@ -768,9 +768,12 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
     cd.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
     res = {}
     try:
-        for name, knob in (('exact', 30), ('split', 31), ('split_pc', 62)):       # 62: producer / consumer form of the split kernel
+        # 'split': the default route (round 4: the persistent kernel of conv_t5.hip where eligible); 'split_band': conv_t4's
+        # band kernel; 'split_pc' (62): its producer / consumer form
+        for name, knob in (('exact', 30), ('split', 31), ('split_band', 31), ('split_pc', 62)):
             lib().cdll.fami_conv_tune_lds(31 if knob == 62 else knob)
             lib().cdll.fami_conv_tune_lds(62 if knob == 62 else 60)
+            lib().cdll.fami_conv_tune_lds(7001 if name == 'split' else 7000)
             lib().cdll.fami_conv_tune_wgrad_lds(30000 + (0 if knob == 30 else 1))
             eng = _eng(dev)
             xt = T(nhwc(x.detach().float()).to(dev), True)
@@ -785,8 +788,9 @@ def test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma(dev, shape):
         lib().cdll.fami_conv_tune_wgrad_lds(-1)
     for i, ref in enumerate((y.detach(), x.grad, conv.weight.grad)):
         m = ref.abs().max().item()
-        ee, es, ep = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split', 'split_pc')]
+        ee, es, eb, ep = [(res[k][i] - ref).abs().max().item() / m for k in ('exact', 'split', 'split_band', 'split_pc')]
         assert es < 3 * ee + 1e-7 and es < 3e-6, (i, ee, es)
+        assert eb < 3 * ee + 1e-7 and eb < 3e-6, (i, ee, eb)
         assert ep < 3 * ee + 1e-7 and ep < 3e-6, (i, ee, ep)
     assert not torch.equal(res['exact'][0], res['split'][0])      # the two paths really are different kernels
     if Ci % 16 == 0 and Co % 16 == 0:
@@ -807,7 +811,7 @@ def test_split_product_kernels_on_random_shapes(dev):
         for it in range(80):
             N, H, W = rnd.randint(1, 5), rnd.randint(3, 40), rnd.randint(3, 40)
             Ci, Co = rnd.choice([4, 8, 16, 20, 32, 48, 64, 80, 96, 144]), rnd.choice([48, 64, 96, 128, 144, 192])
-            acc, pc, mt = rnd.randint(0, 1), rnd.choice([60, 60, 62]), rnd.choice([52, 53])
+            acc, pc, mt, t5 = rnd.randint(0, 1), rnd.choice([60, 60, 62]), rnd.choice([52, 53]), rnd.choice([7000, 7001])
             torch.manual_seed(it)
             x, dy = torch.randn(N, H, W, Ci, device=dev), torch.randn(N, H, W, Co, device=dev)
             w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.1
@@ -819,7 +823,7 @@ def test_split_product_kernels_on_random_shapes(dev):
             y0, dx0, dw0 = torch.randn(N, H, W, Co, device=dev), torch.randn(N, H, W, Ci, device=dev), torch.randn(Co, Ci, 3, 3, device=dev)
             out = {}
             for knob in (30, 31):
-                for code in (-1, knob, pc, mt):
+                for code in (-1, knob, pc, mt, t5):
                     L.cdll.fami_conv_tune_lds(code)
                 L.cdll.fami_conv_tune_wgrad_lds(-1)
                 L.cdll.fami_conv_tune_wgrad_lds(30000 + knob - 30)
@@ -831,7 +835,62 @@ def test_split_product_kernels_on_random_shapes(dev):
                 torch.cuda.synchronize(dev)
                 out[knob] = (y, dx, dw)
             for k in range(3):
-                assert relerr(out[31][k], out[30][k]) < 1e-5, (it, (N, H, W, Ci, Co), acc, pc, mt, k)
+                assert relerr(out[31][k], out[30][k]) < 1e-5, (it, (N, H, W, Ci, Co), acc, pc, mt, t5, k)
     finally:
         L.cdll.fami_conv_tune_lds(-1)
         L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
+def test_persistent_conv_is_bitwise_the_band_kernel(dev):
+    """conv_t5.hip (round 4: persistent workgroups, pre-split weight image copied to LDS by DMA, one tap row of a 16-channel
+    chunk per barrier, patch and weight slabs double-buffered across chunk and job boundaries) keeps the summation order
+    of conv_t4.hip's split-product band kernel, so forward and input gradient must be BITWISE equal to it -- the four
+    HRNet branch shapes of the bench workload, the head's 4-frame shape, and 60 random shapes (odd maps, ragged last
+    bands, bias, ReLU, accumulate, forced rows per band and grid sizes).  The band kernel itself is held to fp64 by
+    test_split_product_f32_conv_is_as_accurate_as_the_f32_mfma."""
+    import random
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    rnd = random.Random(11)
+    cases = [(20, 96, 72, 48, 48, 0, 0, 0), (20, 48, 36, 96, 96, 0, 0, 0), (20, 24, 18, 192, 192, 0, 0, 0),
+             (20, 12, 9, 384, 384, 0, 0, 0), (4, 96, 72, 48, 48, 0, 0, 0), (2, 96, 72, 192, 48, 0, 0, 0)]
+    for _ in range(60):
+        cases.append((rnd.randint(1, 5), rnd.randint(1, 40), rnd.randint(1, 40), rnd.choice([16, 32, 48, 96, 144]),
+                      rnd.choice([48, 96, 144]), rnd.choice([0, 0, 1, 2, 3, 5]), rnd.choice([0, 0, 8, 24, 100]), 1))
+    taken = 0
+    try:
+        for it, (N, H, W, Ci, Co, rows, maxwg, extras) in enumerate(cases):
+            torch.manual_seed(it)
+            x, dy = torch.randn(N, H, W, Ci, device=dev), torch.randn(N, H, W, Co, device=dev)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.1
+            bias = torch.randn(Co, device=dev) if (extras and rnd.randint(0, 1)) else None
+            relu, acc = (rnd.randint(0, 1), rnd.randint(0, 1)) if extras else (0, 0)
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            wp = [torch.empty(L.cdll.fami_packed_weight_elems(Co, Ci, 3, 3, m), device=dev) for m in (0, 1)]
+            for m in (0, 1):
+                L.call('fami_pack_conv_weight_f32', p(w), p(wp[m]), Co, Ci, 3, 3, m, st)
+            y0, dx0 = torch.randn(N, H, W, Co, device=dev), torch.randn(N, H, W, Ci, device=dev)
+            out = {}
+            for code in (7000, 7001):
+                L.cdll.fami_conv_tune_lds(-1)
+                L.cdll.fami_conv_tune_lds(code)
+                if code == 7001:
+                    if rows:
+                        L.cdll.fami_conv_tune_lds(7100 + rows)
+                    if maxwg:
+                        L.cdll.fami_conv_tune_lds(7500 + maxwg)
+                y, dx = y0.clone(), dx0.clone()
+                L.call('fami_conv2d_fwd_f32', p(x), p(wp[0]), p(bias), None, p(y), *geo, relu, acc, st)
+                L.call('fami_conv2d_dgrad_f32', p(dy), p(wp[1]), None, p(dx), *geo, acc, st)
+                torch.cuda.synchronize(dev)
+                out[code] = (y, dx)
+            L.cdll.fami_conv_tune_lds(-1)
+            taken += int(L.cdll.fami_conv_t5_eligible(N, H, W, Ci, Co))
+            for k in range(2):
+                assert torch.equal(out[7000][k], out[7001][k]), (it, (N, H, W, Ci, Co), rows, maxwg, relu, acc, k,
+                                                                 (out[7000][k] - out[7001][k]).abs().max().item())
+    finally:
+        L.cdll.fami_conv_tune_lds(-1)
+    assert taken >= 40          # the persistent kernel really ran on most of them
