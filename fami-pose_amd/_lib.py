@@ -61,6 +61,10 @@ class _Lib:
         # conv_wgs3.hip; same accuracy class)
         # stored as the library's default state: fami_tune_reset / fami_conv_tune_lds(-1) restore it
         self.cdll.fami_tune_defaults(0 if os.environ.get('FAMI_F32_SPLIT', '1') == '0' else 1)
+        if os.environ.get('FAMI_T5', '1') == '0':      # A/B: the round-3 band kernel instead of the persistent one (conv_t5.hip)
+            self.cdll.fami_conv_tune_lds(7000)
+        if os.environ.get('FAMI_T5_WG'):               # A/B: workgroups of the persistent grid / 8 (99: one job per workgroup)
+            self.cdll.fami_conv_tune_lds(7500 + int(os.environ['FAMI_T5_WG']))
 
     def call(self, name, *args):
         self.ncalls += 1

@@ -100,11 +100,29 @@ struct ConvT5Args {
   int ppl;            // S3: bytes of one patch plane
   int patch_bytes;    // bytes of one patch buffer
   int nposmax;        // positions of a full band's patch ((R + 2) * PW)
+  long long* dbg;     // FAMI_T5_TRACE builds: s_memtime stamps of workgroup 9 (null otherwise)
 };
 
 #define T5_THREADS 512
 #define T5_WAVES 8
 #define T5_MTT 3      // pixel tiles per wave at most: bands of <= 18 tiles (waves 0, 1: three; the others two)
+#ifndef T5_STAGGER
+#define T5_STAGGER 1
+#endif
+#ifndef T5_FRAGPIPE
+#define T5_FRAGPIPE 0   // 1: explicit fragment pipeline over (tap, tile) steps (measured: no gain, spills)
+#endif
+#ifndef T5_SBON
+#define T5_SBON 1
+#endif
+#if T5_SBON
+#define T5_SB __builtin_amdgcn_sched_barrier(0)
+#else
+#define T5_SB
+#endif
+#ifndef T5_WDB
+#define T5_WDB 0     // weight fragments of the next tap in their own registers (1) or reloaded at the tap's first step (0)
+#endif
 #define T5_PM 4       // 16-byte patch pieces per thread and chunk (<= 512 positions)
 
 template <typename H, bool S3> struct T5Frag { typedef typename H16<H>::x8 type; };
@@ -115,16 +133,22 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
   static_assert(S3 == (sizeof(H) == 4), "f32 storage runs the split-product form, 16-bit storage the plain one");
   typedef typename T5Frag<H, S3>::type frag;
   constexpr int SZ = (int)sizeof(H), CHN = 64 / SZ, PCN = 16 / SZ;   // a chunk is 64 bytes of a pixel: 16 f32 / 32 16-bit channels
-  constexpr int TRG = S3 ? 3 : 1, TPU = 9 / TRG;                     // units per chunk, taps per unit
+  // Units: the split-product form cuts a chunk's nine taps into two units (taps 0-4, 5-8) with a weight region each
+  // (41.5 KB together: region r is refilled by DMA while region 1 - r is multiplied); the 16-bit types take a whole
+  // chunk per unit with two 27 KB regions.  (Three units of a tap row each, the first build, spent a third of every
+  // unit at the barrier and in the DMA issue: s_memtime trace, tools/trace_t5.py.)
+  constexpr int TRG = S3 ? 2 : 1;                                    // units per chunk
+  constexpr int TP0 = S3 ? 5 : 9;                                    // taps of unit 0 (unit 1: the rest)
   constexpr int BLK = S3 ? 1536 : 1024;                              // bytes of one (tap, N tile) weight block
-  constexpr int SLAB = TPU * NT * BLK;                               // one unit's weights
+  constexpr int SLAB = TP0 * NT * BLK;                               // the larger unit's weights = offset of the second region
+  constexpr int WBYTES = S3 ? 9 * NT * BLK : 2 * SLAB;               // both regions
   constexpr int NPIECE = (SLAB + 1023) / 1024, WPW = (NPIECE + T5_WAVES - 1) / T5_WAVES;
   constexpr int PS = S3 ? 32 : 80;                                   // LDS bytes per patch position (S3: per plane)
   constexpr int PST = S3 ? 1 : 0;                                    // the unit of a chunk in which the next chunk's patch is stored
   constexpr int MTT = T5_MTT, PM = T5_PM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbase = smem + 2 * p.patch_bytes;
-  float* const ered = reinterpret_cast<float*>(wbase + 2 * SLAB);   // [waves][NT * 32]: the EpiBN epilogue's exchange
+  float* const ered = reinterpret_cast<float*>(wbase + WBYTES);   // [waves][NT * 32]: the EpiBN epilogue's exchange
   float* const xsc = ered + T5_WAVES * NT * 32;
   float* const xsf = xsc + p.Ci;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -149,6 +173,15 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
     }
   }
   if (job >= jend) return;
+#ifdef FAMI_T5_TRACE
+  const bool trace = p.dbg && blockIdx.x == 9 && lane == 0;
+  int tru = 0;
+#define T5_STAMP(k) if (trace && tru < 40) p.dbg[(wave * 40 + tru) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime()
+#define T5_NEXT() ++tru
+#else
+#define T5_STAMP(k)
+#define T5_NEXT()
+#endif
   const int HW = p.H * p.W;
   const int nchunk = (p.Ci + CHN - 1) / CHN;
   struct Geo { int img, y0, rows, cb; };
@@ -236,11 +269,12 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
     wsrc[k] = b < SLAB ? (t3 * p.KC * p.NTt + nt) * BLK + within : -1;
   }
   auto dma_w = [&](int cb, int c, int r, char* slab) {
-    const char* src = wg + ((long)((r * TPU) * p.KC + c) * p.NTt + cb * NT) * BLK;
+    const int t0 = r ? TP0 : 0, bytes = (r ? 9 - TP0 : TP0) * NT * BLK;
+    const char* src = wg + ((long)(t0 * p.KC + c) * p.NTt + cb * NT) * BLK;
 #pragma unroll
     for (int k = 0; k < WPW; ++k) {
-      if ((wave + T5_WAVES * k) * 1024 < SLAB) {         // wave-uniform
-        if (wsrc[k] >= 0)
+      if ((wave + T5_WAVES * k) * 1024 < bytes) {         // wave-uniform
+        if (wsrc[k] >= 0 && (wave + T5_WAVES * k) * 1024 + lane * 16 < bytes)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wsrc[k]),
                                            (__attribute__((address_space(3))) void*)(slab + (wave + T5_WAVES * k) * 1024), 16, 0, 0);
       }
@@ -267,18 +301,35 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
   Geo gj = geo(job);
   fetch(gj, 0);
   store(smem, 0);
-  int fjob = job, fc = 0;                     // the patch sequence's look-ahead: (fjob, fc) is in the registers
-  auto advance = [&](int& j, int& c) {
-    if (++c == nchunk) {
-      c = 0;
-      j += jstride;
+  // look-ahead state, advanced incrementally (a division per job, not per unit):
+  //   the patch sequence -- (fjob, fc) is the chunk in the staging registers, gf its job's geometry
+  //   the unit sequence -- (nj, nc, nr) is the next unit whose weights have to be requested, ncb its channel block
+  int fjob = job, fc = 0;
+  Geo gf = gj;
+  auto advance_patch = [&]() {
+    if (++fc == nchunk) {
+      fc = 0;
+      fjob += jstride;
+      if (fjob < jend) gf = geo(fjob);
     }
   };
-  advance(fjob, fc);
-  bool fvalid = fjob < jend;
-  if (fvalid) fetch(geo(fjob), fc);
+  advance_patch();
+  bool pfull = fjob < jend;                   // the staging registers hold chunk (fjob, fc)
+  if (pfull) fetch(gf, fc);
   dma_w(gj.cb, 0, 0, wbase);
-  int u = 0, sq = 0;                          // unit counter (weight slab u & 1), patch counter (patch buffer sq & 1)
+  int nj = job, nc = 0, nr = 0, ncb = gj.cb;
+  auto advance_unit = [&]() {
+    if (++nr == TRG) {
+      nr = 0;
+      if (++nc == nchunk) {
+        nc = 0;
+        nj += jstride;
+        if (nj < jend) ncb = nj % p.cblocks;
+      }
+    }
+  };
+  advance_unit();
+  int u = 0, sq = 0;                          // unit counter, patch counter (patch buffer sq & 1)
 
   for (; job < jend; job += jstride) {
     gj = geo(job);
@@ -303,34 +354,46 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
       }
 
     for (int c = 0; c < nchunk; ++c, ++sq) {
-#pragma unroll
-      for (int r = 0; r < TRG; ++r, ++u) {
-        __syncthreads();   // slab u has landed (DMA), patch sq is stored, every wave has left unit u - 1
-        {                  // the next unit's weights -> the slab unit u - 1 read
-          int nr = r + 1, nc = c, nj = job;
-          if (nr == TRG) {
-            nr = 0;
-            advance(nj, nc);
-          }
-          if (nj < jend) dma_w(geo(nj).cb, nc, nr, wbase + ((u + 1) & 1) * SLAB);
-        }
-        if (r == PST && fvalid) {
-          // the next chunk's patch (in registers since the previous chunk) -> the buffer chunk sq - 1 was read from;
-          // then request the one after it
+      auto unit = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int TPU = r == 0 ? TP0 : 9 - TP0;        // taps of this unit
+        constexpr int T0 = r == 0 ? 0 : TP0;
+        // weight region of this unit / of the next one: the two regions alternate (16-bit: by unit parity)
+        const int reg = TRG == 1 ? (u & 1) : r, nreg = TRG == 1 ? ((u + 1) & 1) : (r + 1) % TRG;
+        T5_STAMP(0);
+        __syncthreads();   // this unit's weights have landed (DMA), patch sq is stored, every wave has left unit u - 1
+        T5_STAMP(1);
+        // The next chunk's patch (in the staging registers since the previous chunk) -> the buffer chunk sq - 1 was read from.
+        // Waves w and w + 4 share a SIMD: the lower half stores at the START of the unit, the upper half at its END, so
+        // on every SIMD one wave splits and stores (VALU + LDS writes, ~1500 cycles) while the other multiplies.
+        // Early form: store BEFORE the weight DMA below is issued -- the registers' loads are older than everything else in
+        // flight; behind the DMA the compiler's vmcnt(0) made the store wait for the next unit's weights (3000-3800 cycles).
+        const bool late = T5_STAGGER && wave >= T5_WAVES / 2;     // wave-uniform
+        if (r == PST && !late && pfull) {
           store(smem + ((sq + 1) & 1) * p.patch_bytes, fc);
-          advance(fjob, fc);
-          fvalid = fjob < jend;
-          if (fvalid) fetch(geo(fjob), fc);
+          advance_patch();
+          pfull = false;
         }
+        T5_STAMP(2);
+        if (nj < jend) dma_w(ncb, nc, nr, wbase + nreg * SLAB);     // the next unit's weights -> the region unit u - 1 read
+        advance_unit();
+        if (!pfull && fjob < jend && (late ? r == 0 : r == PST)) {  // ... and request the patch after the one just stored
+          fetch(gf, fc);
+          pfull = true;
+        }
+        T5_STAMP(3);
         const char* const patch = smem + (sq & 1) * p.patch_bytes;
-        const char* const wslab = wbase + (u & 1) * SLAB;
+        const char* const wslab = wbase + reg * SLAB;
         auto taps = [&](auto mwc) {
           constexpr int MW = decltype(mwc)::value;
+          if constexpr (S3 && !T5_FRAGPIPE) {
+            // plain form: a tap's fifteen fragments, then its 27 MFMAs.  The s_memtime trace (tools/trace_t5.py) shows the tap
+            // loop at ~800 cycles per tap on the SIMD that carries five tiles (720 cycles of MFMA): the two waves of a SIMD
+            // cover each other's LDS waits; the explicit fragment pipeline below costs 20+ registers (spills) and gains nothing
 #pragma unroll
-          for (int t = 0; t < TPU; ++t) {
-            const int tap = r * TPU + t;
-            const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * PS;
-            if constexpr (S3) {
+            for (int t = 0; t < TPU; ++t) {
+              const int tap = T0 + t;
+              const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * PS;
               frag a3[MW][3], w3[NT][2];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) {
@@ -354,7 +417,54 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
                     f32x4& dst = m > 0 ? acc2[S3 ? mt : 0][S3 ? nt : 0] : acc[mt][nt];
                     dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[nt][m == 2 ? 1 : 0], a3[mt][m], dst, 0, 0, 0);
                   }
-            } else {
+            }
+          } else if constexpr (S3) {
+            // Software pipeline over STEPS (tap t, pixel tile mt): the fragments of step s + 1 -- three activation
+            // fragments of its tile, and at a tap's first step the six weight fragments of the NEXT tap -- are requested
+            // before the nine MFMAs of step s issue, in their own registers.  Left to itself the scheduler requested a
+            // fragment one to three MFMAs ahead of its use and the wave sat in s_waitcnt lgkmcnt(0) fifteen times per tap
+            // (the ISA of the first build).  The per-accumulator order (m = 2, 1 into the low-order accumulator, m = 0
+            // into the high-order one; taps ascending) is conv_t4's: bitwise the same sums.
+            constexpr int NS = TPU * MW;
+            frag a3[2][3], w3[T5_WDB ? 2 : 1][NT][2];
+            auto load_w = [&](int t, frag (&w)[NT][2]) {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const char* wb = wslab + (t * NT + nt) * BLK;
+                w[nt][0] = *reinterpret_cast<const frag*>(wb + wo0);
+                w[nt][1] = *reinterpret_cast<const frag*>(wb + wo1);
+              }
+            };
+            auto load_a = [&](int t, int mt, frag (&a)[3]) {
+              const int tap = T0 + t;
+              const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * PS;
+              const char* pb = patch + base[mt] + toff;
+              a[0] = *reinterpret_cast<const frag*>(pb + xo0);
+              a[1] = *reinterpret_cast<const frag*>(pb + xo1);
+              a[2] = *reinterpret_cast<const frag*>(pb + xo2);
+            };
+            load_w(0, w3[0]);
+            load_a(0, 0, a3[0]);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+              const int t = st / MW, mt = st % MW;
+              if (T5_WDB ? (mt == 0 && t + 1 < TPU) : (mt == 0 && st > 0)) load_w(T5_WDB ? t + 1 : t, w3[T5_WDB ? (t + 1) & 1 : 0]);
+              if (st + 1 < NS) load_a((st + 1) / MW, (st + 1) % MW, a3[(st + 1) & 1]);
+              T5_SB;
+#pragma unroll
+              for (int m = 2; m >= 0; --m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                  f32x4& dst = m > 0 ? acc2[S3 ? mt : 0][S3 ? nt : 0] : acc[mt][nt];
+                  dst = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[T5_WDB ? t & 1 : 0][nt][m == 2 ? 1 : 0], a3[st & 1][m], dst, 0, 0, 0);
+                }
+              T5_SB;
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < TPU; ++t) {
+              const int tap = T0 + t;
+              const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * PS;
               frag a[MW], w[NT];
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) w[nt] = *reinterpret_cast<const frag*>(wslab + (t * NT + nt) * BLK + lane * 16);
@@ -370,7 +480,17 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
         if (mtw == 3) taps(std::integral_constant<int, 3>());
         else if (mtw == 2) taps(std::integral_constant<int, 2>());
         else if (mtw == 1) taps(std::integral_constant<int, 1>());
-      }
+        if (r == PST && late && pfull) {
+          store(smem + ((sq + 1) & 1) * p.patch_bytes, fc);
+          advance_patch();
+          pfull = false;
+        }
+        T5_STAMP(4);
+        T5_NEXT();
+        ++u;
+      };
+      unit(std::integral_constant<int, 0>());
+      if constexpr (TRG > 1) unit(std::integral_constant<int, 1>());
     }
 
     if constexpr (S3) {
@@ -496,9 +616,12 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
 }
 
 // ------------------------------------------------------------------ plan + launch
+static long long* g_t5_dbg = nullptr;   // fami_conv_t5_debug (FAMI_T5_TRACE builds)
+extern "C" void fami_conv_t5_debug(void* buf) { g_t5_dbg = reinterpret_cast<long long*>(buf); }
 static int g_use_t5 = 1;        // fami_conv_tune_lds(7000 / 7001): off / on
 static int g_t5_rows = 0;       // fami_conv_tune_lds(7100 + R): force the rows per band (benchmarks)
-static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): workgroups of the persistent grid at most (benchmarks)
+static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): at most 8 n workgroups in the persistent grid (benchmarks; 7599: one job per workgroup)
+static int g_t5_min_jobs = 200; // fami_conv_tune_lds(7600 + n): only launches of >= n jobs
 static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
 
 struct T5Plan { int ok, NT, R, bands, cblocks, njobs, G, npos; size_t lds; };
@@ -509,13 +632,23 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
   q.NT = Co % 48 == 0 ? 3 : 0;      // (64-wide channel blocks: three pixel tiles x four channel tiles spill; conv_t4 keeps those)
   if (!q.NT || !g_use_t5) return q;
   if (S3 ? (Ci % 16) != 0 : (Ci % 8) != 0) return q;
-  if ((long)((H * W + 15) / 16) < g_t5_min_tiles) return q;
   q.cblocks = Co / (16 * q.NT);
   const int PW = W + 2;
-  const int blk = S3 ? 1536 : 1024, tpu = S3 ? 3 : 9, ps = S3 ? 96 : 80;
-  const size_t fixed = (size_t)2 * tpu * q.NT * blk + (size_t)T5_WAVES * q.NT * 32 * 4 + (xbn ? (size_t)2 * Ci * 4 : 0);
-  // rows per band: the one with the least (rounds of the persistent grid) x (MFMA work of the busiest SIMD per band);
-  // waves w and w + 4 share a SIMD, wave w owns tiles w, w + 8, w + 16
+  const int blk = S3 ? 1536 : 1024, ps = S3 ? 96 : 80;
+  const size_t fixed = (size_t)(S3 ? 9 : 18) * q.NT * blk + (size_t)T5_WAVES * q.NT * 32 * 4 + (xbn ? (size_t)2 * Ci * 4 : 0);   // the two weight regions, the EpiBN exchange, the XBN tables
+  // rows per band: the least MFMA work of the busiest SIMD per frame (waves w and w + 4 share a SIMD, wave w owns tiles w,
+  // w + 8, w + 16) plus a fixed cost per band (pipeline bubbles at the job boundary, halo rows, epilogue).  The grid size
+  // does not enter: inside the training step other stream lanes fill the CUs a launch leaves idle, so what counts is the
+  // CU time of a launch, not its length alone (the round-3 finding; tools/ab_step.py)
+  auto simd_cost = [](int tiles) {
+    int simd = 0;
+    for (int w = 0; w < 4; ++w) {
+      int t = 0;
+      for (int k = 0; k < T5_MTT; ++k) t += (w + 8 * k < tiles) + (w + 4 + 8 * k < tiles);
+      simd = t > simd ? t : simd;
+    }
+    return simd;
+  };
   double best = 1e30;
   q.R = 0;
   for (int R = 1; R <= H; ++R) {
@@ -524,16 +657,8 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
     const long npos = (long)(R + 2) * PW;
     if (tiles > T5_WAVES * T5_MTT - 6 || npos * 4 > (long)T5_PM * T5_THREADS) break;      // 18 tiles: waves 0, 1 carry three
     if (2 * (size_t)npos * ps + fixed > 160 * 1024) break;
-    const int bands = (H + R - 1) / R;
-    const long njobs = (long)N * bands * q.cblocks;
-    const long rounds = (njobs + g_t5_maxwg - 1) / g_t5_maxwg;
-    int simd = 0;
-    for (int w = 0; w < 4; ++w) {
-      int t = 0;
-      for (int k = 0; k < T5_MTT; ++k) t += (w + 8 * k < tiles) + (w + 4 + 8 * k < tiles);
-      simd = t > simd ? t : simd;
-    }
-    const double cost = (double)rounds * (simd + 0.35);      // + a band's fixed cost (pipeline bubbles, halo rows, epilogue)
+    const int full = H / R, rest = H - full * R;
+    const double cost = full * (simd_cost(tiles) + 0.35) + (rest ? simd_cost((rest * W + 15) / 16) + 0.35 : 0.0);
     if (cost < best - 1e-9 || (cost < best + 1e-9 && R > q.R)) {
       best = cost;
       q.R = R;
@@ -544,6 +669,10 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
   const long njobs = (long)N * q.bands * q.cblocks;
   if (njobs >= (1L << 30)) return q;
   q.njobs = (int)njobs;
+  // Launches that cannot give every CU a job (the head's 4-frame convolutions: 96 jobs) and the 12x9 maps (one 7-tile band per
+  // frame: 24 chunks of a single-tile-per-wave tap loop) stay on the band kernel: per launch 13.2 vs 16.0 us and 69 vs 79 us
+  // (tools/bench_t5.py)
+  if (g_t5_rows == 0 && (njobs < g_t5_min_jobs || (long)((H * W + 15) / 16) < (g_t5_min_tiles ? g_t5_min_tiles : 16))) return q;
   const long rounds = (njobs + g_t5_maxwg - 1) / g_t5_maxwg;
   long G = (njobs + rounds - 1) / rounds;          // every workgroup the same number of jobs (+- 1)
   if (G >= 8) G = (G + 7) / 8 * 8;
@@ -567,6 +696,7 @@ static int t5_launch(const T5Plan& q, const void* x, const void* wimg, const flo
   a.R = q.R; a.bands = q.bands; a.cblocks = q.cblocks; a.njobs = q.njobs;
   a.PW = W + 2; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   a.nposmax = q.npos;
+  a.dbg = g_t5_dbg;
   a.ppl = q.npos * 32;
   a.patch_bytes = q.npos * (S3 ? 96 : 80);
   bool ok = false;
@@ -611,9 +741,10 @@ int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const floa
 int fami_conv_t5_eligible_s3(int N, int H, int W, int Ci, int Co) { return t5_plan<true>(N, H, W, Ci, Co, true).ok; }
 extern "C" int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co) { return fami_conv_t5_eligible_s3(N, H, W, Ci, Co); }
 void fami_conv_t5_tune(int on) {
-  if (on < 0) { g_use_t5 = 1; g_t5_rows = 0; g_t5_maxwg = 256; g_t5_min_tiles = 0; }
+  if (on < 0) { g_use_t5 = 1; g_t5_rows = 0; g_t5_maxwg = 256; g_t5_min_tiles = 0; g_t5_min_jobs = 200; }
+  else if (on >= 7600) g_t5_min_jobs = on - 7600;
   else if (on == 7000 || on == 7001) g_use_t5 = on - 7000;
-  else if (on >= 7500) g_t5_maxwg = on - 7500;
+  else if (on >= 7500 && on < 7600) g_t5_maxwg = (on - 7500) * 8;
   else if (on >= 7400) g_t5_min_tiles = on - 7400;
   else if (on >= 7100) g_t5_rows = on - 7100;
 }

@@ -858,7 +858,7 @@ def test_persistent_conv_is_bitwise_the_band_kernel(dev):
              (20, 12, 9, 384, 384, 0, 0, 0), (4, 96, 72, 48, 48, 0, 0, 0), (2, 96, 72, 192, 48, 0, 0, 0)]
     for _ in range(60):
         cases.append((rnd.randint(1, 5), rnd.randint(1, 40), rnd.randint(1, 40), rnd.choice([16, 32, 48, 96, 144]),
-                      rnd.choice([48, 96, 144]), rnd.choice([0, 0, 1, 2, 3, 5]), rnd.choice([0, 0, 8, 24, 100]), 1))
+                      rnd.choice([48, 96, 144]), rnd.choice([0, 0, 1, 2, 3, 5]), rnd.choice([0, 0, 1, 3, 12, 99]), 1))
     taken = 0
     try:
         for it, (N, H, W, Ci, Co, rows, maxwg, extras) in enumerate(cases):
@@ -877,6 +877,9 @@ def test_persistent_conv_is_bitwise_the_band_kernel(dev):
                 L.cdll.fami_conv_tune_lds(-1)
                 L.cdll.fami_conv_tune_lds(code)
                 if code == 7001:
+                    L.cdll.fami_conv_tune_lds(7600)          # no minimum job count / frame size: every eligible geometry
+                    L.cdll.fami_conv_tune_lds(7401)
+                    taken += int(L.cdll.fami_conv_t5_eligible(N, H, W, Ci, Co))
                     if rows:
                         L.cdll.fami_conv_tune_lds(7100 + rows)
                     if maxwg:
@@ -887,7 +890,6 @@ def test_persistent_conv_is_bitwise_the_band_kernel(dev):
                 torch.cuda.synchronize(dev)
                 out[code] = (y, dx)
             L.cdll.fami_conv_tune_lds(-1)
-            taken += int(L.cdll.fami_conv_t5_eligible(N, H, W, Ci, Co))
             for k in range(2):
                 assert torch.equal(out[7000][k], out[7001][k]), (it, (N, H, W, Ci, Co), rows, maxwg, relu, acc, k,
                                                                  (out[7000][k] - out[7001][k]).abs().max().item())

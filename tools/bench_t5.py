@@ -35,8 +35,8 @@ for (N, H, W, Ci, Co) in shapes:
             if R > H or (R * W + 15) // 16 > 18: continue
             L.cdll.fami_conv_tune_lds(7100 + R); res.append(('t5/R%d' % R, timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(7100)
-        for G in (128, 192, 240):
-            L.cdll.fami_conv_tune_lds(7500 + G); res.append(('t5/G%d' % G, timeit(fwd), timeit(bwd)))
+        for G in (128, 192, 240, 512, 792):
+            L.cdll.fami_conv_tune_lds(7500 + G // 8); res.append(('t5/G%d' % G, timeit(fwd), timeit(bwd)))
     L.cdll.fami_conv_tune_lds(-1)
     gf = 2.0 * N * H * W * Ci * Co * 9 / 1e9
     print('f32 N%-2d %3dx%-3d %3d->%-3d %.2f GFLOP bitwise=%s | ' % (N, H, W, Ci, Co, gf, same) + ' | '.join('%s %.1f/%.1f' % r for r in res), flush=True)
