@@ -63,6 +63,13 @@ class _Lib:
         self.cdll.fami_tune_defaults(0 if os.environ.get('FAMI_F32_SPLIT', '1') == '0' else 1)
         if os.environ.get('FAMI_T5', '1') == '0':      # A/B: the round-3 band kernel instead of the persistent one (conv_t5.hip)
             self.cdll.fami_conv_tune_lds(7000)
+        for env, base in (('FAMI_WG16_TARGET', 21000), ('FAMI_WGS3_TARGET', 31000)):     # A/B: workgroup target of the weight-gradient kernels
+            if os.environ.get(env):
+                self.cdll.fami_conv_tune_wgrad_lds(base + int(os.environ[env]))
+        if os.environ.get('FAMI_T5_ABL'):              # upper-bound experiment (WRONG results): only n chunks per convolution
+            self.cdll.fami_conv_tune_lds(7600)
+            self.cdll.fami_conv_tune_lds(7401)
+            self.cdll.fami_conv_tune_lds(7700 + int(os.environ['FAMI_T5_ABL']))
         if os.environ.get('FAMI_T5_WG'):               # A/B: workgroups of the persistent grid / 8 (99: one job per workgroup)
             self.cdll.fami_conv_tune_lds(7500 + int(os.environ['FAMI_T5_WG']))
 

@@ -724,6 +724,10 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
     const int rc5 = fami_try_conv3x3_t5(2, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
     if (rc5 != 0) return rc5;
   }
+  if (half_kind != 2 && g_use_t4) {
+    const int rc5 = fami_try_conv3x3_t5(half_kind, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
+    if (rc5 != 0) return rc5;
+  }
   if (half_kind == 2) {
     const int rc = try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi, xbn);
     if (rc != 0) return rc;

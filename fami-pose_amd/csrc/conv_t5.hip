@@ -100,6 +100,7 @@ struct ConvT5Args {
   int ppl;            // S3: bytes of one patch plane
   int patch_bytes;    // bytes of one patch buffer
   int nposmax;        // positions of a full band's patch ((R + 2) * PW)
+  int abl_chunks;     // benchmarks (fami_conv_tune_lds(7700 + n)): walk only the first n channel chunks (WRONG results: an upper-bound experiment)
   long long* dbg;     // FAMI_T5_TRACE builds: s_memtime stamps of workgroup 9 (null otherwise)
 };
 
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
 #define T5_NEXT()
 #endif
   const int HW = p.H * p.W;
-  const int nchunk = (p.Ci + CHN - 1) / CHN;
+  const int nchunk = p.abl_chunks > 0 ? min(p.abl_chunks, (p.Ci + CHN - 1) / CHN) : (p.Ci + CHN - 1) / CHN;
   struct Geo { int img, y0, rows, cb; };
   auto geo = [&](int j) {
     Geo g;
@@ -621,6 +622,8 @@ extern "C" void fami_conv_t5_debug(void* buf) { g_t5_dbg = reinterpret_cast<long
 static int g_use_t5 = 1;        // fami_conv_tune_lds(7000 / 7001): off / on
 static int g_t5_rows = 0;       // fami_conv_tune_lds(7100 + R): force the rows per band (benchmarks)
 static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): at most 8 n workgroups in the persistent grid (benchmarks; 7599: one job per workgroup)
+static int g_t5_h16 = 0;        // fami_conv_tune_lds(7010 / 7011): the 16-bit instances off / on
+static int g_t5_abl = 0;        // fami_conv_tune_lds(7700 + n): ablation, see ConvT5Args.abl_chunks
 static int g_t5_min_jobs = 200; // fami_conv_tune_lds(7600 + n): only launches of >= n jobs
 static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
 
@@ -697,6 +700,7 @@ static int t5_launch(const T5Plan& q, const void* x, const void* wimg, const flo
   a.PW = W + 2; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
   a.nposmax = q.npos;
   a.dbg = g_t5_dbg;
+  a.abl_chunks = g_t5_abl;
   a.ppl = q.npos * 32;
   a.patch_bytes = q.npos * (S3 ? 96 : 80);
   bool ok = false;
@@ -728,7 +732,11 @@ int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const floa
     const char* wimg = reinterpret_cast<const char*>(wp) + (size_t)9 * KC * NTt * 1024;
     rc = t5_launch<float, true>(q, x, wimg, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, 1, s, epi, xbn);
   } else {
-    return 0;   // (16-bit instances: see fami_conv_t5_tune)
+    if (!g_t5_h16) return 0;
+    const T5Plan q = t5_plan<false>(N, H, W, Ci, Co, xbn.on != 0);
+    if (!q.ok || KC * 32 < Ci) return 0;
+    rc = half_kind == 1 ? t5_launch<f16_t, false>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi, xbn)
+                        : t5_launch<bf16_t, false>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi, xbn);
   }
   if (!rc) return 0;
   hipError_t err = hipGetLastError();
@@ -741,9 +749,11 @@ int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const floa
 int fami_conv_t5_eligible_s3(int N, int H, int W, int Ci, int Co) { return t5_plan<true>(N, H, W, Ci, Co, true).ok; }
 extern "C" int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co) { return fami_conv_t5_eligible_s3(N, H, W, Ci, Co); }
 void fami_conv_t5_tune(int on) {
-  if (on < 0) { g_use_t5 = 1; g_t5_rows = 0; g_t5_maxwg = 256; g_t5_min_tiles = 0; g_t5_min_jobs = 200; }
+  if (on < 0) { g_use_t5 = 1; g_t5_rows = 0; g_t5_maxwg = 256; g_t5_min_tiles = 0; g_t5_min_jobs = 200; g_t5_abl = 0; g_t5_h16 = 0; }
+  else if (on >= 7700) g_t5_abl = on - 7700;
   else if (on >= 7600) g_t5_min_jobs = on - 7600;
   else if (on == 7000 || on == 7001) g_use_t5 = on - 7000;
+  else if (on == 7010 || on == 7011) g_t5_h16 = on - 7010;
   else if (on >= 7500 && on < 7600) g_t5_maxwg = (on - 7500) * 8;
   else if (on >= 7400) g_t5_min_tiles = on - 7400;
   else if (on >= 7100) g_t5_rows = on - 7100;

@@ -155,6 +155,28 @@ __global__ void bn_running_update_kernel(float* running_mean, float* running_var
   running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
 }
 
+
+// Batched form: the deferred updates of a forked region (32 per step for the translation regressors) in ONE launch, in
+// call order -- thread c walks the entries sequentially for its channel, so several updates of one module's buffers
+// apply in the order the reference applies them (frame by frame).
+#define FAMI_BNRU_BATCH 32
+struct BnRunBatch { float* rm[FAMI_BNRU_BATCH]; float* rv[FAMI_BNRU_BATCH]; const float* mean[FAMI_BNRU_BATCH]; const float* invstd[FAMI_BNRU_BATCH];
+                    int C[FAMI_BNRU_BATCH]; float P[FAMI_BNRU_BATCH], mom[FAMI_BNRU_BATCH], eps[FAMI_BNRU_BATCH]; int n; };
+__global__ __launch_bounds__(256) void bn_running_update_batch_kernel(BnRunBatch b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = 0; k < b.n; ++k) {
+    if (c >= b.C[k]) continue;
+    const double mu = (double)b.mean[k][c], is = (double)b.invstd[k][c];
+    double var = 1.0 / (is * is) - (double)b.eps[k];
+    if (var < 0.0) var = 0.0;
+    const double P = (double)b.P[k];
+    const double unb = P > 1.0 ? var * P / (P - 1.0) : var;
+    const float momentum = b.mom[k];
+    b.rm[k][c] = (float)((1.0 - momentum) * b.rm[k][c] + momentum * mu);
+    b.rv[k][c] = (float)((1.0 - momentum) * b.rv[k][c] + momentum * unb);
+  }
+}
+
 __global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* mean, float* invstd,
                                      int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -966,6 +988,33 @@ int fami_bn_running_update_f32(float* running_mean, float* running_var, const fl
   hipLaunchKernelGGL(bn_running_update_kernel, dim3(fami_cdiv(C, 64)), dim3(64), 0, s, running_mean, running_var, mean,
                      invstd, C, P, momentum, eps);
   FAMI_CHECK_LAUNCH("fami_bn_running_update_f32");
+  return FAMI_OK;
+}
+
+
+// n deferred running-statistics updates in call order: ptrs = host array of 4 n longs (running_mean, running_var, mean,
+// invstd per entry), meta = host array of 4 n floats (C, P, momentum, eps per entry; C and P are exact in fp32 here).
+int fami_bn_running_update_batch_f32(const long* ptrs, const float* meta, int n, hipStream_t s) {
+  FAMI_REQUIRE(ptrs && meta && n > 0, "fami_bn_running_update_batch_f32", "bad argument");
+  for (int i0 = 0; i0 < n; i0 += FAMI_BNRU_BATCH) {
+    BnRunBatch b;
+    b.n = n - i0 < FAMI_BNRU_BATCH ? n - i0 : FAMI_BNRU_BATCH;
+    int maxc = 1;
+    for (int i = 0; i < FAMI_BNRU_BATCH; ++i) {
+      const int j = i < b.n ? i0 + i : i0;
+      b.rm[i] = reinterpret_cast<float*>(ptrs[4 * j]);
+      b.rv[i] = reinterpret_cast<float*>(ptrs[4 * j + 1]);
+      b.mean[i] = reinterpret_cast<const float*>(ptrs[4 * j + 2]);
+      b.invstd[i] = reinterpret_cast<const float*>(ptrs[4 * j + 3]);
+      b.C[i] = (int)meta[4 * j];
+      b.P[i] = meta[4 * j + 1];
+      b.mom[i] = meta[4 * j + 2];
+      b.eps[i] = meta[4 * j + 3];
+      if (i < b.n && b.C[i] > maxc) maxc = b.C[i];
+    }
+    hipLaunchKernelGGL(bn_running_update_batch_kernel, dim3(fami_cdiv(maxc, 256)), dim3(256), 0, s, b);
+    FAMI_CHECK_LAUNCH("fami_bn_running_update_batch_f32");
+  }
   return FAMI_OK;
 }
 

@@ -255,9 +255,15 @@ class Engine:
         self.set_lane(0)
         self._forked = 0
         # parameters used on several lanes of the region: fold the lane-private gradients into the owner's buffer
-        for key, buf in self._merge:
-            g = self.param_grads[key]
-            self.call('fami_axpby_f32', _p(buf), _p(g), _p(g), g.numel(), 1.0, 1.0)
+        # ... in ONE launch per 32 buffers (fami_add_batch_f32): the translation regressors alone are 37 parameters x 3 lanes,
+        # 111 launches of 2-3 us back to back on the critical path of the head's backward pass (0.8 ms in the kernel trace)
+        if self._merge:
+            n = len(self._merge)
+            ptrs, counts = (ctypes.c_long * (2 * n))(), (ctypes.c_int * n)()
+            for i, (key, buf) in enumerate(self._merge):
+                g = self.param_grads[key]
+                ptrs[2 * i], ptrs[2 * i + 1], counts[i] = buf.data_ptr(), g.data_ptr(), g.numel()
+            self.call('fami_add_batch_f32', ptrs, counts, n)
         self._merge = []
         self._lane_priv = {}
 
@@ -456,9 +462,14 @@ class Engine:
     def apply_deferred_bn(self):
         """Running-statistics updates of the BatchNorm calls made while `defer_bn` was a list, in call order (lane 0)."""
         items, self.defer_bn = self.defer_bn, None
-        for bn, mean, invstd, P, mom in items or ():
-            self.call('fami_bn_running_update_f32', _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(invstd),
-                      mean.numel(), P, mom, float(bn.eps))
+        items = list(items or ())
+        if items:      # one launch per 32 updates, applied in call order inside the kernel (was: one launch each)
+            n = len(items)
+            ptrs, meta = (ctypes.c_long * (4 * n))(), (ctypes.c_float * (4 * n))()
+            for i, (bn, mean, invstd, P, mom) in enumerate(items):
+                ptrs[4 * i:4 * i + 4] = [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean.data_ptr(), invstd.data_ptr()]
+                meta[4 * i:4 * i + 4] = [float(mean.numel()), float(P), float(mom), float(bn.eps)]
+            self.call('fami_bn_running_update_batch_f32', ptrs, meta, n)
 
     def _lane_guard(self, key):
         """Shared mutable state (a parameter's gradient accumulator, a BatchNorm's running statistics) may be touched by
@@ -1003,9 +1014,16 @@ class Engine:
         B, H, W, C = x.shape
         Co, _, kh, kw = weight.shape
         K = kh * kw
-        n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
-        wp = self.empty(n)
-        self.acall('fami_dcn_pack_weight', _p(weight.data), _p(wp), Co, C, kh, kw, G)   # 16-bit modes: + the 16-bit image
+        wp = (getattr(self, 'prepacked_dcn_fwd', None) or {}).get(id(weight))      # packed at the start of the step (Trainer)
+        if wp is not None:
+            ev = getattr(self, 'dcn_fwd_ready', None)
+            if ev is not None:
+                self.wait_main(ev)
+                self.dcn_fwd_ready = None
+        else:
+            n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
+            wp = self.empty(n)
+            self.acall('fami_dcn_pack_weight', _p(weight.data), _p(wp), Co, C, kh, kw, G)   # 16-bit modes: + the 16-bit image
         y = self.act(B, H, W, Co)
         self.acall('fami_dcn_fwd', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
                    C, Co, G, kh, kw, 1, pad, dil)

@@ -369,7 +369,9 @@ class Trainer:
                     if isinstance(m, DeformConv2d):
                         Co, C, kh, kw = m.weight.shape
                         n = lib().cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
-                        imgs.append((m.weight, torch.empty(n, device=self.dev), (Co, C, kh, kw, G)))
+                        nf = lib().cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
+                        imgs.append((m.weight, torch.empty(n, device=self.dev), (Co, C, kh, kw, G),
+                                     torch.empty(nf, device=self.dev)))
             self._dcn_imgs = imgs
         return self._dcn_imgs
 
@@ -384,20 +386,33 @@ class Trainer:
         # depend on the weights only, and packed inside the backward closures they sat on the head's serial chain
         dcn = self._dcn_bwd_images()
 
+        from .engine import _SFX
+        pack_fwd_fn = 'fami_dcn_pack_weight' + _SFX[self.act_dtype]
+
+        def pack_dcn_fwd(st):
+            # the DCN layers' FORWARD weight images (three small launches per layer) sat on the head's serial chain too:
+            # packed on a side lane at the start of the step, joined before the head
+            for w, _, geo, fbuf in dcn:
+                lib().call(pack_fwd_fn, _p(w.data), _p(fbuf), *geo, st)
+
         def pack_bwd(st):
             self.packer.run(st, 1)
-            for w, buf, geo in dcn:
+            for w, buf, geo, _ in dcn:
                 lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
         if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
             self.packer.run(eng.stream, 0)
+            packed_fwd = eng.side_launch(pack_dcn_fwd) if dcn else None
             packed_bwd = eng.side_launch(pack_bwd)
         else:
             self.packer.run(eng.stream)
-            for w, buf, geo in dcn:
+            pack_dcn_fwd(eng.stream)
+            for w, buf, geo, _ in dcn:
                 lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, eng.stream)
-            packed_bwd = None
+            packed_fwd = packed_bwd = None
         eng.prepacked = self.packer.views
-        eng.prepacked_dcn_bwd = {id(w): buf for w, buf, _ in dcn}
+        eng.prepacked_dcn_bwd = {id(w): buf for w, buf, _, _ in dcn}
+        eng.prepacked_dcn_fwd = {id(w): fbuf for w, _, _, fbuf in dcn}
+        eng.dcn_fwd_ready = packed_fwd          # event the first DCN forward waits for
         if self.targets_from_joints:
             # on-device Gaussian targets (generate_heatmaps): `target` carries joints [B,J,2], `weight` visibility [B,J]
             joints, vis = target, weight

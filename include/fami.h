@@ -132,6 +132,9 @@ int fami_bn_train_fwd_f32(const float* x, const float* residual, float* y, const
  * order (var = 1/invstd^2 - eps, unbiased for running_var as nn.BatchNorm2d) */
 int fami_bn_running_update_f32(float* running_mean, float* running_var, const float* mean, const float* invstd, int C,
                                long P, float momentum, float eps, fami_stream_t stream);
+/* n deferred updates in call order, one launch per 32: ptrs = host array of 4 n longs (running_mean, running_var, mean,
+ * invstd), meta = host array of 4 n floats (C, P, momentum, eps) */
+int fami_bn_running_update_batch_f32(const long* ptrs, const float* meta, int n, fami_stream_t stream);
 int fami_bn_eval_stats_f32(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                            float eps, fami_stream_t stream);
 int fami_bn_apply_f32(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -217,6 +220,9 @@ int fami_fuse_sum_f32(int nterms, const float* const* x, const float* const* mea
 int fami_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, int accumulate, fami_stream_t stream);
 int fami_pool_relu_bwd_f32(const float* dy, const float* y, float* out, int N, int Hl, int Wl, int C, int shift,
                            int relu, fami_stream_t stream);
+/* out_k += a_k for n pairs of fp32 tensors in one launch per 32 pairs (the engine's lane join: lane-private gradients of a
+ * module that ran on several stream lanes).  ptrs: host array of 2 n longs (a_0, out_0, a_1, out_1, ...), counts: n ints. */
+int fami_add_batch_f32(const long* ptrs, const int* counts, int n, fami_stream_t stream);
 int fami_adam_prep_f32(float* state4, float beta1, float beta2, fami_stream_t stream);
 int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* state4, float beta1,
                   float beta2, float eps, float weight_decay, fami_stream_t stream);
