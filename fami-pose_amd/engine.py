@@ -92,6 +92,7 @@ class Engine:
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
         self.regressor_lanes = os.environ.get('FAMI_REGRESSOR_LANES', '1') != '0'   # shared-weight regressors on lanes
+        self.mi_lanes = self.use_lanes and os.environ.get('FAMI_MI_LANES', '1') != '0'   # the six MI terms of the loss on three lanes
         self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
@@ -535,6 +536,20 @@ class Engine:
         out = self.empty(N, C, H, W)
         self.call('fami_nhwc_to_nchw' + _sfx(x.data), _p(x.data), _p(out), N, C, H, W, 0)
         return out
+
+    def seed_nchw_split(self, x, g_nchw):
+        """seed_nchw in two halves: the NCHW -> NHWC transpose now (on the current lane), the accumulation into x's gradient
+        buffer by the returned closure (call it on lane 0 after the join: several lanes may seed the same tensor)."""
+        if g_nchw is None or not x.requires_grad:
+            return lambda: None
+        N, H, W, C = x.shape
+        tmp = self.like(x.data)
+        self.call('fami_nchw_to_nhwc' + _sfx(tmp), _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
+
+        def finish():
+            g, acc = self.gbuf(x)
+            self.call('fami_axpby' + _sfx(g), _p(tmp), _p(g) if acc else None, _p(g), g.numel(), 1.0, 1.0 if acc else 0.0)
+        return finish
 
     def seed_nchw(self, x, g_nchw):
         """Add an NCHW gradient to NHWC tensor x."""
@@ -1093,12 +1108,16 @@ class Engine:
         ws = self.ws(R * 4)
         self.call('fami_softmax_kl_fwd_f32', _p(a_nchw), _p(bt), _p(val), _p(stats), R, Ln, float(temperature), _p(ws))
 
-        def seed(gscale, gdev=None):
+        def seed(gscale, gdev=None, split=False):
+            """split: -> closure that adds the gradient to b on the caller's lane (the six MI terms of the training step run
+            their backward kernels on parallel lanes and accumulate after the join)."""
             if not b.requires_grad:
-                return
+                return (lambda: None) if split else None
             d = self.empty(N, C, H, W)
             self.call('fami_softmax_kl_bwd_f32', _p(a_nchw), _p(bt), _p(stats), _p(d), R, Ln, float(temperature),
                       float(gscale), _p(gdev), 0)
+            if split:
+                return self.seed_nchw_split(b, d)
             self.seed_nchw(b, d)
         return val, seed
 

@@ -450,9 +450,19 @@ class Trainer:
         if self.use_mi and aux['mis']:
             a, b = self.alpha, self.beta
             coef = [-b * a, b * a, a, -a, a, -a]        # core fn :119-148
+            lanes = eng.use_lanes and eng.mi_lanes
+            if lanes:
+                eng._do_fork(3)        # (not taped: the seeds are enqueued here, ahead of the tape walk)
+            pending = []
             for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
+                if lanes:
+                    eng.set_lane(k % 3)
                 eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
-                seed(c * ls)
+                pending.append(seed(c * ls, None, True))
+            if lanes:
+                eng._do_join(3)
+            for fin in pending:        # the accumulations into the (shared) gradient buffers, in term order, on lane 0
+                fin()
         hook = None
         if on_bucket is not None:
             def bucket_ready(lo, hi):

@@ -194,8 +194,19 @@ class Alignment_V15(EngineModule):
             def feat_mi(f1, f2):  # feat_feat_mi_estimation: A = F1.detach(), Bt = F2
                 return eng.softmax_kl(eng.to_nchw(f1), f2, MI_TEMPERATURE)
 
-            mis = [label_mi(all_agg), feat_mi(kf, all_agg), label_mi(agg_sup), feat_mi(agg_sup, all_agg),
-                   label_mi(kf), feat_mi(kf, all_agg)]
+            # the six MI terms only READ the head's tensors: three stream lanes (each ~50-90 us of small dependent kernels
+            # -- transposes, a 17-channel conv, the row softmax / KL pass; they were ~0.35 ms back to back on the head's
+            # serial chain)
+            terms = [lambda: label_mi(all_agg), lambda: feat_mi(kf, all_agg), lambda: label_mi(agg_sup),
+                     lambda: feat_mi(agg_sup, all_agg), lambda: label_mi(kf), lambda: feat_mi(kf, all_agg)]
+            forked = eng.fork(3) if eng.mi_lanes else False
+            mis = []
+            for i, fn in enumerate(terms):
+                if forked:
+                    eng.set_lane(i % 3)
+                mis.append(fn())
+            if forked:
+                eng.join(3)
             eng.aux['mis'] = mis
             for val, seed in mis:
                 outs.append(val.reshape(()))
