@@ -391,6 +391,10 @@ def main():
             dt = max(per)
             rank_ms = [round(v / steps * 1e3, 3) for v in per]
         loss = trainer.loss_value()
+        if not (loss == loss and abs(loss) < 1e30):
+            # a throughput measured on NaN weights is not a measurement (round 4: a wrong-dtype gradient seed went unnoticed
+            # in the bf16 line because NaN arithmetic runs at full speed)
+            raise RuntimeError('bench: the training loss is not finite after %d steps (%r)' % (steps, loss))
         info = {"pck_final": round(trainer.accuracy()[0][1], 4), "pck_kf_backbone": round(trainer.accuracy()[1][1], 4),
                 "conv_flops_per_step": int(trainer.conv_flops)}
         if rank_ms is not None:

