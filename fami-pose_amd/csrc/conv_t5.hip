@@ -40,45 +40,62 @@ __device__ __forceinline__ void t5_split3(float v, __bf16& h0, __bf16& h1, __bf1
   h2 = (__bf16)r2;
 }
 struct T5PackDesc { long src, dst; int Co, Ci, taps, mode; };
+// One (K group, N tile) block at a time through LDS: its source is 16 output-channel rows of 16 * 9 contiguous floats (OIHW
+// keeps a (co, ci) pair's taps adjacent) -- read coalesced, written as 8-byte runs of a plane row (the element-by-element
+// form with its stride-9 reads and 2-byte stores took 477 us per launch for the step's 3x3 images, on the critical path at
+// the top of the step).
 __device__ __forceinline__ void t5_pack_split_image(const float* __restrict__ w, __bf16* __restrict__ sp, int Co, int Ci,
-                                                    int mode, int first, int stride) {
+                                                    int mode, int first_block, int block_stride, float* tile) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
   const int KC = kd / 16, NTt = (nd + 15) / 16;
-  const long total = (long)9 * KC * NTt * 256;      // (tap, kc, nt, n, k) elements
-  for (long i = first; i < total; i += stride) {
-    const int k = (int)(i & 15), n = (int)((i >> 4) & 15);
-    long r = i >> 8;
-    const int nt = (int)(r % NTt);
-    r /= NTt;
-    const int kc = (int)(r % KC), tap = (int)(r / KC);
-    const int kidx = kc * 16 + k, nidx = nt * 16 + n;
-    const int co = mode == 0 ? nidx : kidx, ci = mode == 0 ? kidx : nidx;
-    const float v = (co < Co && ci < Ci) ? w[((long)co * Ci + ci) * 9 + tap] : 0.f;
-    __bf16 h0, h1, h2;
-    t5_split3(v, h0, h1, h2);
-    __bf16* blk = sp + (i >> 8) * 768 + n * 16 + k;
-    blk[0] = h0;
-    blk[256] = h1;
-    blk[512] = h2;
+  constexpr int PITCH = 16 * 9 + 1;
+  for (int b = first_block; b < KC * NTt; b += block_stride) {
+    const int kc = b / NTt, nt = b - kc * NTt;
+    const int co0 = mode == 0 ? nt * 16 : kc * 16, ci0 = mode == 0 ? kc * 16 : nt * 16;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 144; i += 256) {
+      const int r = i / 144, c = i - r * 144;
+      const int co = co0 + r, ci = ci0 + c / 9;
+      tile[r * PITCH + c] = (co < Co && ci < Ci) ? w[((long)co * Ci + ci0) * 9 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 9 * 64; o += 256) {          // (tap, n, k quad) -> four values of a plane row
+      const int tap = o >> 6, n = (o >> 2) & 15, k4 = (o & 3) * 4;
+      t5_bf16x4 h0, h1, h2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k4 + j;
+        const float v = mode == 0 ? tile[n * PITCH + k * 9 + tap] : tile[k * PITCH + n * 9 + tap];
+        __bf16 a0, a1, a2;
+        t5_split3(v, a0, a1, a2);
+        h0[j] = a0; h1[j] = a1; h2[j] = a2;
+      }
+      __bf16* blk = sp + ((long)(tap * KC + kc) * NTt + nt) * 768 + n * 16 + k4;
+      *reinterpret_cast<t5_bf16x4*>(blk) = h0;
+      *reinterpret_cast<t5_bf16x4*>(blk + 256) = h1;
+      *reinterpret_cast<t5_bf16x4*>(blk + 512) = h2;
+    }
   }
 }
 __global__ __launch_bounds__(256) void t5_pack_split_kernel(const float* __restrict__ w, __bf16* __restrict__ sp, int Co, int Ci, int mode) {
-  t5_pack_split_image(w, sp, Co, Ci, mode, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+  __shared__ float tile[16 * (16 * 9 + 1)];
+  t5_pack_split_image(w, sp, Co, Ci, mode, blockIdx.x, gridDim.x, tile);
 }
 __global__ __launch_bounds__(256) void t5_pack_split_batch_kernel(const float* __restrict__ params, float* __restrict__ packed,
                                                                    const T5PackDesc* __restrict__ desc) {
+  __shared__ float tile[16 * (16 * 9 + 1)];
   const T5PackDesc d = desc[blockIdx.y];
   const int kd = d.mode == 0 ? d.Ci : d.Co, nd = d.mode == 0 ? d.Co : d.Ci;
   if (d.taps != 9 || (kd % 16) != 0) return;
   const long n16 = (long)9 * (kd / 16) * ((nd + 15) / 16) * 256;      // the f32 fragment image in front (no 32x32 image for 3x3)
-  t5_pack_split_image(params + d.src, reinterpret_cast<__bf16*>(packed + d.dst + n16), d.Co, d.Ci, d.mode,
-                      blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+  t5_pack_split_image(params + d.src, reinterpret_cast<__bf16*>(packed + d.dst + n16), d.Co, d.Ci, d.mode, blockIdx.x, gridDim.x, tile);
 }
 void fami_pack_split_single(const float* w_oihw, float* split, int Co, int Ci, int taps, int mode, hipStream_t s) {
   const int kd = mode == 0 ? Ci : Co, nd = mode == 0 ? Co : Ci;
   if (fami_split_image_elems(kd, nd, taps) == 0) return;
-  const long total = (long)9 * (kd / 16) * ((nd + 15) / 16) * 256;
-  hipLaunchKernelGGL(t5_pack_split_kernel, dim3(fami_ew_grid(total)), dim3(256), 0, s, w_oihw, reinterpret_cast<__bf16*>(split), Co, Ci, mode);
+  int blocks = (kd / 16) * ((nd + 15) / 16);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(t5_pack_split_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, reinterpret_cast<__bf16*>(split), Co, Ci, mode);
 }
 void fami_pack_split_batch(const float* params, float* packed, const void* desc, int n, hipStream_t s) {
   hipLaunchKernelGGL(t5_pack_split_batch_kernel, dim3(48, n), dim3(256), 0, s, params, packed, reinterpret_cast<const T5PackDesc*>(desc));

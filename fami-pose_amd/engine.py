@@ -234,6 +234,14 @@ class Engine:
         done.record(side)
         return done
 
+    late_weights_ready = None
+
+    def join_late_weights(self):
+        """Lane 0 waits for the side-lane pack of the later stages' weight images (train.Trainer sets the event)."""
+        if self.late_weights_ready is not None:
+            self._main.wait_event(self.late_weights_ready)
+            self.late_weights_ready = None
+
     def join_side(self):
         """Lane 0 waits for the side-lane work launched so far whose events nobody has waited for."""
         for ev in self._side_events:

@@ -238,6 +238,8 @@ class HRNetBody(nn.Module):
         ys = [x]
         stage4_in = None
         for s in (2, 3, 4):
+            if s == 3:
+                eng.join_late_weights()      # the Trainer packs the weight images of stage 3 .. the head beside the stem
             tr = getattr(self, 'transition%d' % (s - 1))
             xs = []
             eng.wlane_scope = outer or eng.stem_wlane

@@ -161,6 +161,19 @@ class WeightPacker:
         recs.sort(key=lambda r: r[5])
         self.n = len(recs)
         self.n_fwd = sum(1 for r in recs if r[5] == 0)
+        # ... and the forward images in two: what the stem, layer1 and stage 2 read (packed on the main lane before the first
+        # convolution) and the rest (stage 3 / 4 and the head: ~95 % of the bytes), packed on a side lane beside the stem --
+        # the whole forward pack sat alone at the top of every step (0.36-0.42 ms + the f32 split images)
+        names = {id(p): n for n, p in model.named_parameters()}
+        early = ('hrnet.conv1.', 'hrnet.conv2.', 'hrnet.layer1.', 'hrnet.transition1.', 'hrnet.stage2.', 'conv1.', 'conv2.',
+                 'layer1.', 'transition1.', 'stage2.')
+        order = [prm for prm, _, _ in table if id(prm) in convs]
+        self.n_early = 0
+        for prm in order:
+            if names.get(id(prm), '').startswith(early):
+                self.n_early += 1
+            else:
+                break
         self.flat = flat
         self.arena = torch.empty(max(off, 1), dtype=dtype, device=flat.device)
         desc = np.array(recs, dtype=[('src', '<i8'), ('dst', '<i8'), ('Co', '<i4'), ('Ci', '<i4'), ('taps', '<i4'),
@@ -171,8 +184,10 @@ class WeightPacker:
         self.fn = 'fami_pack_conv_weights_batch' + _SFX[dtype]
 
     def run(self, stream, part=None):
-        """part None: every image; 0: the forward images; 1: the input-gradient images."""
-        lo, hi = (0, self.n) if part is None else ((0, self.n_fwd) if part == 0 else (self.n_fwd, self.n))
+        """part None: every image; 0: the forward images; 1: the input-gradient images; 'early' / 'late': the forward images of
+        the stem .. stage 2 / of everything behind them."""
+        lo, hi = {None: (0, self.n), 0: (0, self.n_fwd), 1: (self.n_fwd, self.n), 'early': (0, self.n_early),
+                  'late': (self.n_early, self.n_fwd)}[part]
         if hi > lo:
             lib().call(self.fn, _p(self.flat), _p(self.arena), self.desc.data_ptr() + 32 * lo, hi - lo, stream)
 
@@ -400,7 +415,11 @@ class Trainer:
             for w, buf, geo, _ in dcn:
                 lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
         if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
-            self.packer.run(eng.stream, 0)
+            if self.packer.n_early > 0 and os.environ.get('FAMI_PACK_EARLY', '1') != '0':
+                self.packer.run(eng.stream, 'early')
+                eng.late_weights_ready = eng.side_launch(lambda st: self.packer.run(st, 'late'))   # HRNetBody.run waits before stage 3
+            else:
+                self.packer.run(eng.stream, 0)
             packed_fwd = eng.side_launch(pack_dcn_fwd) if dcn else None
             packed_bwd = eng.side_launch(pack_bwd)
         else:
