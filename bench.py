@@ -56,6 +56,15 @@ def build(args, dev):
     return model.to(dev)
 
 
+def pmc_record(key):
+    """The committed rocprofv3 --pmc record of the launch the roofline times (profiles/pmc_traffic.json, written by
+    tools/pmc_sets.sh + tools/pmc_json.py on the MI355X): MFMA instruction count and matrix-pipe busy share."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(key)
+    except Exception:
+        return None
+
+
 def pmc_traffic(key):
     """HBM bytes per launch measured with rocprofv3 --pmc (profiles/pmc_traffic.json; separate FETCH_SIZE / WRITE_SIZE
     passes, gfx950 wide-read correction applied) for the SAME launch the roofline times; None if not on record."""
@@ -124,13 +133,23 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
     # f32 product on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- so the peak that bounds it is a sixth of the dense
     # bf16 MFMA peak; the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, peak 157.3) route is timed beside it.
     split = (not half) and os.environ.get('FAMI_F32_SPLIT', '1') != '0'
+    t5 = split and os.environ.get('FAMI_T5', '1') != '0' and bool(L.cdll.fami_conv_t5_eligible(N, H, W, C, C))
     peak = PEAK_BF16_MFMA_TFLOPS if half else (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS)
-    kname = ('conv3x3_t4_kernel<%s>' % dtype) if half else ('conv3x3_t4_kernel<float, split-product>' if split else 'conv_igemm_f32')
-    key = {'f32': 'conv3x3_t4_s3_f32' if split else 'conv_igemm_f32', 'bf16': 'conv3x3_t4_bf16'}.get(dtype)
+    kname = ('conv3x3_t4_kernel<%s>' % dtype) if half else (
+        ('conv3x3_t5_kernel<float, persistent split-product>' if t5 else 'conv3x3_t4_kernel<float, split-product>') if split else 'conv_igemm_f32')
+    key = {'f32': ('conv3x3_t5_s3_f32' if t5 else 'conv3x3_t4_s3_f32') if split else 'conv_igemm_f32', 'bf16': 'conv3x3_t4_bf16'}.get(dtype)
     out = {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
            "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
+    rec_p = pmc_record(key) if (N == 20 and C == 48 and H == 96 and key) else None
+    if rec_p and rec_p.get('mfma_busy') is not None:
+        # north_star: "MFMA-busy reported against gfx950 peaks" -- SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of
+        # the same launch, and the MFMA instruction count against 2 N H W C 9 C / 16384 (x 6 products in the split form)
+        out["mfma_busy"] = rec_p['mfma_busy']
+        out["mfma_insts"] = rec_p.get('sq_insts_mfma')
+        out["mfma_insts_expected"] = int(flops / 16384 * (6 if split else 1)) if (half or split) else int(flops / 2048)
+        out["pmc_source"] = rec_p.get('source')
     if split:
         out["peak_note"] = ("dense bf16 MFMA peak %.0f / 6 products per f32 product; achieved counts each f32 "
                             "multiply-add once" % PEAK_BF16_MFMA_TFLOPS)
