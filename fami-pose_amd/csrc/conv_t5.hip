@@ -656,10 +656,8 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
   const int PW = W + 2;
   const int blk = S3 ? 1536 : 1024, ps = S3 ? 96 : 80;
   const size_t fixed = (size_t)(S3 ? 9 : 18) * q.NT * blk + (size_t)T5_WAVES * q.NT * 32 * 4 + (xbn ? (size_t)2 * Ci * 4 : 0);   // the two weight regions, the EpiBN exchange, the XBN tables
-  // rows per band: the least MFMA work of the busiest SIMD per frame (waves w and w + 4 share a SIMD, wave w owns tiles w,
-  // w + 8, w + 16) plus a fixed cost per band (pipeline bubbles at the job boundary, halo rows, epilogue).  The grid size
-  // does not enter: inside the training step other stream lanes fill the CUs a launch leaves idle, so what counts is the
-  // CU time of a launch, not its length alone (the round-3 finding; tools/ab_step.py)
+  // rows per band: the least (rounds of the persistent grid) x (MFMA work of the busiest SIMD per band); waves w and w + 4 share
+  // a SIMD, wave w owns tiles w, w + 8, w + 16; + a fixed cost per band (pipeline bubbles at the job boundary, halo rows, epilogue)
   auto simd_cost = [](int tiles) {
     int simd = 0;
     for (int w = 0; w < 4; ++w) {
@@ -677,8 +675,12 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
     const long npos = (long)(R + 2) * PW;
     if (tiles > T5_WAVES * T5_MTT - 6 || npos * 4 > (long)T5_PM * T5_THREADS) break;      // 18 tiles: waves 0, 1 carry three
     if (2 * (size_t)npos * ps + fixed > 160 * 1024) break;
-    const int full = H / R, rest = H - full * R;
-    const double cost = full * (simd_cost(tiles) + 0.35) + (rest ? simd_cost((rest * W + 15) / 16) + 0.35 : 0.0);
+    // (rounds of the persistent grid) x (a band's cost): a launch that is in flight alone -- 57 % of the f32 step's wall time has
+    // exactly one kernel in flight -- is as long as its busiest workgroup.  (Ranking by CU time alone, i.e. without the rounds,
+    // picked 7-row bands on the 48x36 maps: 280 jobs on 140 workgroups, 56 us per launch against 36 us; inside the step the two
+    // rankings measured the same, 49.3 vs 49.6 ms.)
+    const long njobs_r = (long)N * ((H + R - 1) / R) * q.cblocks;
+    const double cost = (double)((njobs_r + g_t5_maxwg - 1) / g_t5_maxwg) * (simd_cost(tiles) + 0.35);
     if (cost < best - 1e-9 || (cost < best + 1e-9 && R > q.R)) {
       best = cost;
       q.R = R;

@@ -133,6 +133,12 @@ class Engine:
         # on the split; two more are free); bf16 27.70 -> 27.91 ms (the transform moves into the staging path of kernels
         # that are bound by exactly that path).
         self.use_xbn = os.environ.get('FAMI_XBN', '0' if self.half else '1') != '0'
+        # Tried in round 4: backward fusion only on the SERIAL stretches of the step (stem, layer1: one lane, nothing beside it --
+        # 3.6 ms of the f32 backward pass), `serial_scope` set by HRNetBody.run.  Interleaved bench runs on one box: f32 48.16
+        # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  FAMI_SERIAL_FUSE=1
+        # keeps it available.
+        self.serial_scope = False
+        self.serial_fuse = os.environ.get('FAMI_SERIAL_FUSE', '0') != '0'
         self.nfused = {'fwd': 0, 'bwd': 0, 'xbn': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
@@ -630,6 +636,7 @@ class Engine:
         need_w = self.rq(weight) or self.rq(bias)
         out = T(y, x.requires_grad or need_w)
         wl = self.wlane_scope and self.head_wlane
+        fuse_here = self.bn2 and self.serial_scope and self.serial_fuse     # see serial_scope in __init__
         if out.requires_grad:
             assert not relu, "fused relu epilogue is forward-only"
             geo = (N, H, W, Ci, Co, kh, kw, stride, pad, dil)
@@ -655,7 +662,7 @@ class Engine:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
                     rec = x.bnrec
-                    if (rec is not None and self.fuse_bn_bwd and x.uses == 0 and not x.nofuse and x.lanes is not None
+                    if (rec is not None and (self.fuse_bn_bwd or fuse_here) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
                         # the epilogue applies the ReLU mask and takes the two sums of the BatchNorm backward

@@ -230,11 +230,13 @@ class HRNetBody(nn.Module):
         """x: engine tensor [N,H,W,3] -> (heatmap T [N,H/4,W/4,J], stage-4 outputs, pre-stage-4 inputs)."""
         outer = eng.wlane_scope
         eng.wlane_scope = outer or eng.stem_wlane     # serial chain: weight gradients on their own lane (Engine.__init__)
+        eng.serial_scope = True                       # ... and BatchNorm backward statistics in the dgrad epilogues
         x = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
         x = eng.conv_bn(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:
             x = blk.run(eng, x)
         eng.wlane_scope = outer
+        eng.serial_scope = False
         ys = [x]
         stage4_in = None
         for s in (2, 3, 4):
