@@ -2653,7 +2653,7 @@ int fami_conv_tune(int mt, int nt, int ks) {
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
 // -1 = default (bf16: staged, f32: direct)
 int fami_conv_tune_lds(int on) {
-  if (on == 10 || on == 11 || on == 20 || on == 21 || on == 30 || on == 31 || (on >= 52 && on <= 54) || (on >= 60 && on <= 62) || on >= 100) {   // (30 / 31: split-product f32 instance) register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
+  if (on == 10 || on == 11 || on == 20 || on == 21 || on == 30 || on == 31 || (on >= 40 && on <= 42) || (on >= 52 && on <= 54) || (on >= 60 && on <= 62) || on >= 100) {   // (30 / 31: split-product f32 instance) register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
     fami_conv_t4_tune(on);                   // 100 + tiles per band (100 = heuristic)
     return FAMI_OK;
   }
@@ -2829,6 +2829,10 @@ static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, co
     const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == dil && dil > 1 && !addend && !e.slots && !xbn.on && g_use_lds != 0) {
+    const int rc = fami_try_conv3x3_t4_dil(2, x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, dil, s, nm);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   if (xbn.on) {
     fami_set_error(nm, "input BatchNorm needs the split-product 3x3 kernel (ask fami_conv2d_xbn_ok_f32 first)");
     return FAMI_ESHAPE;
@@ -2885,6 +2889,10 @@ static int conv_dgrad_f32_impl(const char* nm, const float* dy, const float* wp,
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
     // dgrad of a stride-1 "same" conv is the same conv on dy with the taps mirrored: GEMM K = Co, N = Ci
     const int rc = try_conv3x3_lds<float>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 1, s, nm, e);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == dil && dil > 1 && !addend && !e.slots && g_use_lds != 0) {
+    const int rc = fami_try_conv3x3_t4_dil(2, dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 1, dil, s, nm);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
   return run_igemm(a, 1, s, nm);
@@ -3406,6 +3414,11 @@ static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const floa
     const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == dil && dil > 1 && !e.slots && !xbn.on && g_use_lds != 0) {
+    const int rc = fami_try_conv3x3_t4_dil(std::is_same<HT, f16_t>::value ? 1 : 0, x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu,
+                                           accumulate, out_f32, dil, s, nm);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   if (xbn.on) {
     fami_set_error(nm, "input BatchNorm needs the register-blocked 3x3 kernel (ask fami_conv2d_xbn_ok first)");
     return FAMI_ESHAPE;
@@ -3440,6 +3453,11 @@ static int conv_dgrad_h_impl(const char* nm, const HT* dy, const HT* wp, HT* dx,
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
     const int rc = try_conv3x3_lds<HT>(dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0, accumulate, 0, s, nm, e);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
+  if (kh == 3 && kw == 3 && stride == 1 && pad == dil && dil > 1 && !e.slots && g_use_lds != 0) {
+    const int rc = fami_try_conv3x3_t4_dil(std::is_same<HT, f16_t>::value ? 1 : 0, dy, wp, nullptr, dx, N, H, W, Co, Ci, a.KC, a.NTt, -1, 0,
+                                           accumulate, 0, dil, s, nm);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;
   }
   return run_igemm_h<HT>(a, 1, s, nm);

@@ -127,6 +127,9 @@ __device__ __forceinline__ u32x4 xbn_piece(u32x4 raw, const float* sc, const flo
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn = xbn_none());
+int fami_try_conv3x3_t4_dil(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                            int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, int dil, hipStream_t s,
+                            const char* name);
 void fami_conv_t4_tune(int on);
 void fami_conv_t4_default_split(int on);
 int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co);

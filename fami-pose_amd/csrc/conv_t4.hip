@@ -33,6 +33,7 @@ struct ConvT4Args {
   int PW, PS;         // patch row length in positions (W + 2), bytes per position (80)
   int KC, NTt;
   int sgn, relu, accumulate, out_f32;
+  int dil;            // dilation (= padding: the centred 3x3 kernels of the path; 1 for the HRNet blocks, 3 for the DCN predictors)
   int patch_bytes;
   long long* dbg;     // FAMI_T4_TRACE builds: phase timestamps of one workgroup (null otherwise)
 };
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   const int p0 = bnd * p.BT * 16, p1 = min(p0 + p.BT * 16, HW);
   const int ntile = (p1 - p0 + 15) >> 4;
   const int y0 = p0 / p.W, y1 = (p1 - 1) / p.W;
-  const int npos = (y1 - y0 + 3) * p.PW;          // patch rows y0-1 .. y1+1, columns -1 .. W
+  const int dil = p.dil;
+  const int npos = (y1 - y0 + 1 + 2 * dil) * p.PW;   // patch rows y0-dil .. y1+dil, columns -dil .. W-1+dil (PW = W + 2 dil)
   const int ntg0 = byl * NT;
   char* patch = smem;
   char* wbuf = smem + p.patch_bytes;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
   for (int mt = 0; mt < MTT; ++mt) {
     const int pp = min(p0 + ((producer ? 0 : wave) + CW * mt) * 16 + col, p1 - 1);   // lanes past the band re-read its last pixel (never stored)
     const int ry = pp / p.W, rx = pp - ry * p.W;
-    base[mt] = ((ry - y0 + 1) * p.PW + rx + 1) * p.PS + (S3 ? 0 : kq * 16);
+    base[mt] = ((ry - y0 + dil) * p.PW + rx + dil) * p.PS + (S3 ? 0 : kq * 16);
   }
   // S3: per-lane byte offset of fragment m inside a row: K 0..15 (kq 0, 1) from one plane, K 16..31 (kq 2, 3) from another
   const int s3h = kq >> 1, s3l = (kq & 1) * 16;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
     if (stid >= 0 && i < npiece) {
       const int pos = i >> 2, pc = i & 3;
       const int r = pos / p.PW, c = pos - r * p.PW;
-      const int gy = y0 - 1 + r, gx = c - 1;
+      const int gy = y0 - dil + r, gx = c - dil;
       if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
         goff[u] = (((img * p.H + gy) * p.W + gx) * p.Ci + pc * PCN) * SZ;
     }
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
         // consecutive 8-byte runs of a plane row
         const int l = S3 ? (((i & 3) << 4) | ((i >> 2) & 15)) : (i & 63);
         const int tap = blk / NT, nt = blk - tap * NT;
-        wr[SET][u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
+        if (ntg0 + nt < p.NTt)      // (output-channel tail of the last block: Co = 216 / 108 of the DCN predictors)
+          wr[SET][u] = *reinterpret_cast<const u32x4*>(wg + ((long)((tap * p.KC + c) * p.NTt + ntg0 + nt)) * 1024 + l * 16);
       }
     }
   };
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
         }
       };
       auto s3_load_a = [&](int tap, bf16x8 (&a)[MW][3]) {
-        const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+        const int toff = p.sgn * dil * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
           const char* pb = patch + base[mt] + toff;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
       };
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int toff = p.sgn * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
+        const int toff = p.sgn * dil * ((tap / 3 - 1) * p.PW + (tap % 3 - 1)) * p.PS;
         if constexpr (S3) {
           // fragments of tap t + 1 are requested before tap t is multiplied (two register sets): left to itself the
           // scheduler issued a tap's twelve LDS reads one to three MFMAs ahead of their use and the wave sat in
@@ -487,6 +490,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co0 = (ntg0 + nt) * 16 + kq * 4;
+      if (co0 >= p.Co) continue;        // channel tail (Co % 4 == 0)
       f32x4 v = acc[mt][nt];
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
       if (p.relu) {
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
 
 // ---- register-blocked LDS kernel (16-bit): plan + launch.  Returns 1 if launched, 0 if not eligible, <0 on error.
 static int g_use_t4 = 1;
+static int g_t4_dil = 1;      // fami_conv_tune_lds(40 / 41): dilated 3x3 convolutions on the band kernels off / on
 static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance off / on.  Off by default: per launch it wins where
                                // the launch fills the chip (below), inside the f32 step it does not (61.2 vs 61.7 ms, and 61.4 vs 60.9
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
@@ -533,9 +538,19 @@ static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on th
 // ---- the split-product f32 instance: plan + launch
 static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                              int KC, int NTt, int sgn, int relu, int accumulate, hipStream_t s, const char* name,
-                             const EpiBN& epi, const XBN& xbn) {
+                             const EpiBN& epi, const XBN& xbn, int dil = 1) {
   if (!g_use_t4 || !g_use_t4_s3 || (Ci % 4) != 0 || (x && (reinterpret_cast<uintptr_t>(x) & 15) != 0)) return 0;
   int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  // dilated form (round 4: the DCN offset / mask predictors, 48 -> 216 / 108 and their input gradients): the last 48-wide
+  // channel block may be partial (Co % 4 == 0); no BatchNorm hooks on that route
+  // Measured (tools/bench_dil.py, B = 4 frames of 96x72): 48 -> 216 forward 54 vs 69 us for the exact-f32 implicit GEMM; 48 -> 108
+  // 47 vs 40 and the input gradients 96 vs 61 / 48 vs 35 (one channel block = 96 workgroups, each restaging eleven patch rows
+  // for four output rows): only wide forward launches take it (g_t4_dil = 2 forces every eligible one: tests)
+  if (dil > 1) {
+    if (!g_t4_dil || (Co % 4) != 0 || epi.slots || xbn.on) return 0;
+    if (g_t4_dil == 1 && (sgn < 0 || Co < 160)) return 0;
+    NT = 3;
+  }
   if (!NT) return 0;
   const int HW = H * W, FT = (HW + 15) / 16;
   // The low-resolution branches: 2 bands x 20 frames x 4 channel blocks (24x18 @192 ch) or 1 x 20 x 8 (12x9 @384 ch) = 160
@@ -546,13 +561,13 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   if (g_t4_s3_narrow && NT == 3 && Co % 32 == 0 && (long)N * ((FT + 15) / 16) * (Co / 48) < 200 &&
       (long)N * ((FT + 15) / 16) * (Co / 32) <= 256)
     NT = 2;
-  const int cblocks = Co / (16 * NT);
-  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
+  const int cblocks = (Co + 16 * NT - 1) / (16 * NT);
+  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 1 + 2 * dil) * (W + 2 * dil); };
   const size_t wbytes = (size_t)3 * 9 * NT * 16 * T4_S3_ROW + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0);
   const int WVs = 8;
   const size_t lds_cap = 160 * 1024;
   // producer / consumer form (see the kernel): 4 multiplying + 4 staging waves, bands of <= 8 tiles, two LDS buffers
-  if (g_t4_s3_pc && NT == 3 && g_t4_bt == 0 && (g_t4_s3_pc == 2 || FT <= 8)) {   // 1: only frames of one band (12x9 maps), 2: always
+  if (g_t4_s3_pc && NT == 3 && dil == 1 && g_t4_bt == 0 && (g_t4_s3_pc == 2 || FT <= 8)) {   // 1: only frames of one band (12x9 maps), 2: always
     int BTp = 0;
     for (int bt = 8; bt >= 1 && !BTp; --bt)
       if (positions(bt) * 4 <= 6 * 256 && 2 * ((size_t)positions(bt) * 3 * T4_S3_ROW + (wbytes - (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0))) + (xbn.on ? (size_t)2 * Ci * sizeof(float) : 0) <= lds_cap) BTp = bt;
@@ -564,6 +579,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
       a.x = x; a.wp = wp; a.y = y; a.bias = bias;
       a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BTp; a.bands = (FT + BTp - 1) / BTp;
       a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
+      a.dil = 1;
       const long npos = positions(BTp);
       a.patch_bytes = (int)(npos * 3 * a.PS);
       a.dbg = g_t4_dbg;
@@ -600,7 +616,7 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
     // workgroup (the low-resolution maps), up to one workgroup per CU
     long nb = (FT + BT - 1) / BT;
     const long per = (long)N * cblocks;
-    if ((g_t4_s3_fill == 1 && nb * per < 256) || (g_t4_s3_fill == 2 && nb * per < 128)) {
+    if (dil == 1 && ((g_t4_s3_fill == 1 && nb * per < 256) || (g_t4_s3_fill == 2 && nb * per < 128))) {   // (dilated: the halo rows make small bands pure staging)
       long nb2 = 256 / per;
       if (nb2 > FT) nb2 = FT;
       if (nb2 > nb) nb = nb2;
@@ -615,7 +631,8 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
   a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
-  a.PW = W + 2; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
+  a.PW = W + 2 * dil; a.PS = T4_S3_ROW; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = 1;
+  a.dil = dil;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * 3 * a.PS);     // three planes
   a.dbg = g_t4_dbg;
@@ -649,22 +666,26 @@ static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, v
 template <typename HT>
 static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                           int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const char* name,
-                          const EpiBN& epi, const XBN& xbn) {
+                          const EpiBN& epi, const XBN& xbn, int dil = 1) {
   if (xbn.on && (sizeof(HT) != 2 || (Ci % 8) != 0)) return 0;
   if (!g_use_t4 || ((Ci * (int)sizeof(HT)) % 16) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
   if (sizeof(HT) == 4 && !g_use_t4_f32) return 0;
   int NT = 0;
   if (Co % 48 == 0) NT = 3;
   else if (Co % 64 == 0) NT = 4;
+  if (dil > 1) {                       // dilated form: see try_conv3x3_t4_s3
+    if (!g_t4_dil || (Co % 4) != 0 || epi.slots || xbn.on || sizeof(HT) == 4) return 0;
+    NT = 3;
+  }
   if (!NT) return 0;
-  const int HW = H * W, FT = (HW + 15) / 16, cblocks = Co / (16 * NT);
+  const int HW = H * W, FT = (HW + 15) / 16, cblocks = (Co + 16 * NT - 1) / (16 * NT);
   // tiles per band.  Measured (tools/bench_t4.py, profiles/r03_bench_t4.txt): 12 tiles (192 pixels) is the best or equal
   // on every branch shape -- 16.1 / 13.0 / 13.7 us at 48 / 96 / 192 channels against 19-21 us with 6-8 tiles (the weight
   // slab is re-staged per band) and 23 us with 16 at 48 channels (staging registers spill); a frame smaller than that
   // (12x9 maps: 7 tiles) is one band: 19.3 us against 25-28 with 4-6 tiles (waves without a tile idle).  More workgroups
   // than that do not help even where the grid is below one workgroup per CU: other stream lanes fill the rest.
   const int cand[8] = {12, 10, 8, 6, 5, 4, 3, 2};
-  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 3) * (W + 2); };
+  auto positions = [&](int bt) { return (long)((bt * 16 + W - 2) / W + 1 + 2 * dil) * (W + 2 * dil); };
   const long pos_cap = (long)(NT == 3 ? 4 : T4_PMAX) * T4_THREADS / 4;   // staging registers (NT = 3: the 128-VGPR build)
   int BT = 0;
   for (int i = 0; i < 8 && !BT; ++i)
@@ -683,7 +704,8 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
   a.e = epi; a.emode = epi.slots ? epi.mode : 0; a.xb = xbn;
   a.x = x; a.wp = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.BT = BT; a.bands = (FT + BT - 1) / BT;
-  a.PW = W + 2; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  a.PW = W + 2 * dil; a.PS = 80; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.relu = relu; a.accumulate = accumulate; a.out_f32 = out_f32;
+  a.dil = dil;
   const long npos = positions(BT);
   a.patch_bytes = (int)(npos * a.PS);
   a.dbg = g_t4_dbg;
@@ -716,6 +738,18 @@ static int try_conv3x3_t4(const void* x, const void* wp, const float* bias, void
 }
 
 
+// the dilated 3x3 stride-1 convolutions (padding = dilation): plain band kernels, no BatchNorm hooks
+int fami_try_conv3x3_t4_dil(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                            int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, int dil, hipStream_t s,
+                            const char* name) {
+  const EpiBN epi = epi_none();
+  const XBN xbn = xbn_none();
+  if (half_kind == 2)
+    return try_conv3x3_t4_s3(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, s, name, epi, xbn, dil);
+  if (half_kind == 1)
+    return try_conv3x3_t4<f16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn, dil);
+  return try_conv3x3_t4<bf16_t>(x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn, dil);
+}
 int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
@@ -772,8 +806,9 @@ void fami_conv_t4_tune(int on) {
     fami_conv_t5_tune(on);
     if (on >= 0) return;
   }
-  if (on < 0) { g_use_t4 = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = g_s3_default; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
+  if (on < 0) { g_use_t4 = 1; g_t4_dil = 1; g_t4_bt = 0; g_use_t4_f32 = 0; g_use_t4_s3 = g_s3_default; g_t4_s3_minwg = 0; g_t4_s3_mt = 3; g_t4_s3_pc = 0; g_t4_s3_fill = 2; g_t4_s3_narrow = 0; }
   else if (on == 30 || on == 31) g_use_t4_s3 = on - 30;
+  else if (on >= 40 && on <= 42) g_t4_dil = on - 40;
   else if (on == 102030 || on == 102031) g_t4_s3_narrow = on - 102030;
   else if (on >= 102000) g_t4_s3_fill = on - 102000;
   else if (on >= 2000) g_t4_s3_minwg = on - 2000;

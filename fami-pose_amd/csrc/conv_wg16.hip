@@ -143,15 +143,27 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     }
     const char* yr = yg + ((long)img * HW + q0) * p.Co * 2;
     const int M = q1 - q0;
+    // ONE load kind per loop: with the 16-byte / 8-byte choice inside the loop hipcc branched around each load and put an
+    // s_waitcnt vmcnt(0) behind it -- the four dY loads of a run were four DEPENDENT HBM round trips in every fetch (found in
+    // the ISA in round 4; the 8 patch loads above always were in flight together).  The 8-byte form only exists for output-
+    // channel tails (Co % 8 != 0: the DCN predictors), a kernel-uniform condition.
+    if ((p.Co & 7) == 0) {
 #pragma unroll
-    for (int u = 0; u < NYS; ++u) {
-      pry[u] = u32x4{0u, 0u, 0u, 0u};
-      if (ythr && yp0 + u * YS < M) {
-        const char* src = yr + ygo + (long)u * YS * p.Co * 2;
-        if (ykind == 2) pry[u] = *reinterpret_cast<const u32x4*>(src);
-        else if (ykind == 1) {
-          const u32x2 h2 = *reinterpret_cast<const u32x2*>(src);
-          pry[u] = u32x4{h2.x, h2.y, 0u, 0u};
+      for (int u = 0; u < NYS; ++u) {
+        pry[u] = u32x4{0u, 0u, 0u, 0u};
+        if (ythr && ykind == 2 && yp0 + u * YS < M) pry[u] = *reinterpret_cast<const u32x4*>(yr + ygo + (long)u * YS * p.Co * 2);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NYS; ++u) {
+        pry[u] = u32x4{0u, 0u, 0u, 0u};
+        if (ythr && yp0 + u * YS < M) {
+          const char* src = yr + ygo + (long)u * YS * p.Co * 2;
+          if (ykind == 2) pry[u] = *reinterpret_cast<const u32x4*>(src);
+          else if (ykind == 1) {
+            const u32x2 h2 = *reinterpret_cast<const u32x2*>(src);
+            pry[u] = u32x4{h2.x, h2.y, 0u, 0u};
+          }
         }
       }
     }

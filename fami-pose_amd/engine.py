@@ -27,6 +27,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_ABL_WGRAD = os.environ.get('FAMI_ABL_WGRAD', '0') != '0'
 _SFX = {torch.float32: '_f32', torch.bfloat16: '_bf16', torch.float16: '_f16'}
 
 
@@ -324,6 +325,8 @@ class Engine:
     def wgrad(self, x_data, dy, g, geo, acc, xbn=None):
         """dW (=|+=) of one convolution: the partial-slab kernel now, its reduce batched with the stream's others.
         xbn: x_data is the input of a not materialised BatchNorm+ReLU (mean, invstd, gamma, beta)."""
+        if _ABL_WGRAD:          # upper-bound experiment (FAMI_ABL_WGRAD=1, WRONG gradients): no weight-gradient kernels at all
+            return
         nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
         ws = self.ws(nb)
         assert xbn is None or self.defer_reduce

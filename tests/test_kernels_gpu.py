@@ -19,6 +19,7 @@ def lds_mode(request):
         lib().cdll.fami_tune_reset()
         lib().cdll.fami_conv_tune_lds(7600)      # the persistent kernel without its launch-size rule (these are small cases)
         lib().cdll.fami_conv_tune_lds(7401)
+        lib().cdll.fami_conv_tune_lds(42)        # ... and the dilated band kernels on every eligible launch (default: wide forward ones)
         yield request.param
         lib().cdll.fami_tune_reset()
         return
