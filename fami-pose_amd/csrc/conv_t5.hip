@@ -642,7 +642,7 @@ static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): at most 8 n wor
 static int g_t5_h16 = 0;        // fami_conv_tune_lds(7010 / 7011): the 16-bit instances off / on
 static int g_t5_abl = 0;        // fami_conv_tune_lds(7700 + n): ablation, see ConvT5Args.abl_chunks
 static int g_t5_min_jobs = 200; // fami_conv_tune_lds(7600 + n): only launches of >= n jobs
-static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
+static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= 8 n tiles (7401: >= 1)  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
 
 struct T5Plan { int ok, NT, R, bands, cblocks, njobs, G, npos; size_t lds; };
 template <bool S3>
@@ -691,10 +691,11 @@ static T5Plan t5_plan(int N, int H, int W, int Ci, int Co, bool xbn) {
   const long njobs = (long)N * q.bands * q.cblocks;
   if (njobs >= (1L << 30)) return q;
   q.njobs = (int)njobs;
-  // Launches that cannot give every CU a job (the head's 4-frame convolutions: 96 jobs) and the 12x9 maps (one 7-tile band per
-  // frame: 24 chunks of a single-tile-per-wave tap loop) stay on the band kernel: per launch 13.2 vs 16.0 us and 69 vs 79 us
-  // (tools/bench_t5.py)
-  if (g_t5_rows == 0 && (njobs < g_t5_min_jobs || (long)((H * W + 15) / 16) < (g_t5_min_tiles ? g_t5_min_tiles : 16))) return q;
+  // Launches that cannot give every CU a job (the head's 4-frame convolutions: 96 jobs) and the low-resolution maps stay on
+  // the band kernel.  Per launch the 12x9 maps lose (one 7-tile band per frame: 69 vs 79 us) and the 24x18 maps win (52 -> 47 us),
+  // but inside the step (tools/ab_env.py: graphs captured per routing and replayed alternately on one box, +-0.1 ms) the 24x18
+  // maps lose: no persistent kernel 47.90 ms, frames >= 16 tiles 48.24, >= 32 tiles (96x72 and 48x36) **47.09**, 96x72 only 47.18.
+  if (g_t5_rows == 0 && (njobs < g_t5_min_jobs || (long)((H * W + 15) / 16) < (g_t5_min_tiles ? g_t5_min_tiles : 32))) return q;
   const long rounds = (njobs + g_t5_maxwg - 1) / g_t5_maxwg;
   long G = (njobs + rounds - 1) / rounds;          // every workgroup the same number of jobs (+- 1)
   if (G >= 8) G = (G + 7) / 8 * 8;
@@ -774,6 +775,6 @@ void fami_conv_t5_tune(int on) {
   else if (on == 7000 || on == 7001) g_use_t5 = on - 7000;
   else if (on == 7010 || on == 7011) g_t5_h16 = on - 7010;
   else if (on >= 7500 && on < 7600) g_t5_maxwg = (on - 7500) * 8;
-  else if (on >= 7400) g_t5_min_tiles = on - 7400;
+  else if (on >= 7400) g_t5_min_tiles = on == 7401 ? 1 : (on - 7400) * 8;      // 7401: every frame; else 8 n tiles
   else if (on >= 7100) g_t5_rows = on - 7100;
 }

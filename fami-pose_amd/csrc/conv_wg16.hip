@@ -50,6 +50,7 @@ struct Wg16Args {
   int PW;           // W + 2 * pad: patch row length in positions
   int xps, yps;     // LDS bytes per patch position / per dY pixel
   int xbytes;       // LDS bytes reserved for the patch
+  int abl;          // benchmarks (fami_conv_tune_wgrad_lds(22000 + bits), WRONG results): 1 no K loop, 2 no slab store, 4 no staging after the first run
 };
 
 template <typename H, int CIT, int COT, int TAPS>
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
     run_geo(b, img, q0, q1, y0, nrow);
     const int M = q1 - q0;
     char* xt = smem + (sub & 1) * bufsz;
-    const bool more = sub + 1 < p.nsub && b + 1 < p.NB;
+    const bool more = sub + 1 < p.nsub && b + 1 < p.NB && !(p.abl & 4);
     if (more) fetch(b + 1);   // in flight while the first half of this run is multiplied
 
     // this lane's two pixels of the current K step (local index pl = ks*32 + kq*8 + h*4 + rsel): image coordinates kept
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
       pxx[h] = q - py[h] * p.Wo;
       ya[h] = p.xbytes + pl[h] * p.yps + piece * 8;
     }
-    const int ksteps = (M + 31) >> 5;
+    const int ksteps = (p.abl & 1) ? 0 : (M + 31) >> 5;
     // one K step with NP live pairs (compile-time: the per-pair "is this slot used" branch kept every pair's LDS reads
     // behind the previous pair's MFMAs -- ds_read x2, s_waitcnt, 3 MFMAs, four times over).  All fragments of the step
     // are requested first, then multiplied.
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 
   // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [g][tap][ci][co]
   float* slab = p.part + (long)g * TAPS * p.Ci * p.Co;
+  if (p.abl & 2) return;
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     if (ptap[i] < 0) continue;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
 struct Wg16Plan { int ok, CIT, COT, taps, BT, bpf, nsub, G, Ho, Wo, ciBlocks, coBlocks; size_t lds; int xps, yps, xbytes; };
+static int g_wg16_abl = 0;
 static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0, g_wg16_general = 1, g_wg16_bt18 = 0;   // 18-tile aligned runs: per launch 27.6 -> 25.0 us (48 ch @96x72), inside the bf16 step 26.10 -> 26.24 / 25.99 -> 26.09 ms: off
 static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg16Plan q;
@@ -352,7 +355,11 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
   const long NB = (long)N * q.bpf;
   // runs per workgroup: the kernel holds 140-230 VGPRs x 8 waves, i.e. ONE workgroup per CU at a time -- one workgroup
   // more than 256 costs a whole second round (A: 270 workgroups 41.7 us, 180 workgroups 30.5 us; tools/bench_wg16.py)
-  const long target = g_wg16_target > 0 ? g_wg16_target : 256;
+  // Round 4 (tools/ab_env.py: one graph per setting, replayed alternately on one box, +-0.1 ms): a target of 128 workgroups beats
+  // 256 inside the bf16 step (24.81 vs 24.96, 25.19 vs 25.30 ms; 64: 25.79) although a launch alone is slower -- half the partial
+  // slabs (the slab store + reduce are 41 % of a launch: tools/abl_wg16.py) and half the per-workgroup prologues, and the other
+  // stream lanes use the CUs it leaves
+  const long target = g_wg16_target > 0 ? g_wg16_target : 128;
   long G = target / blocks;
   if (G > NB) G = NB;
   if (G < 1) G = 1;
@@ -377,6 +384,7 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
   a.BT = q.BT; a.bpf = q.bpf; a.nsub = q.nsub; a.NB = N * q.bpf;
   a.ciBlocks = q.ciBlocks; a.coBlocks = q.coBlocks;
   a.PW = W + 2 * pad; a.xps = q.xps; a.yps = q.yps; a.xbytes = q.xbytes;
+  a.abl = g_wg16_abl;
   const dim3 grid(q.G, a.ciBlocks * a.coBlocks);
   bool ok = false;
 #define FAMI_WG16_CASE(cit, cot, TP)                                                                                    \
@@ -420,10 +428,11 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; }
   else if (on <= 1) g_wg16 = on;
   else if (on <= 3) g_wg16_general = on - 2;
   else if (on == 4 || on == 5) g_wg16_bt18 = on - 4;      // 18-tile aligned runs off / on
+  else if (on >= 2000) g_wg16_abl = on - 2000;
   else if (on >= 1000) g_wg16_target = on - 1000;
   else if (on >= 100) g_wg16_bt = on - 100;
 }

@@ -106,7 +106,10 @@ class Engine:
         self.wlane_scope = False
         # the same for the backbone's serial head and tail: stem, layer1 and the transitions run before the branches fork
         # (their backward after the branches have joined), FAMI_STEM_WGRAD_LANE
-        self.stem_wlane = os.environ.get('FAMI_STEM_WGRAD_LANE', '0') != '0'     # measured neutral (f32 49.1 -> 49.3, bf16 26.6 -> 26.5 ms): off
+        # round 3: measured neutral (f32 49.1 -> 49.3, bf16 26.6 -> 26.5 ms).  Round 4, interleaved graph replays on one box
+        # (tools/ab_env.py): f32 equal on two boxes (46.39 / 46.15, 47.96 / 48.04); bf16 with the 128-workgroup weight gradients
+        # 25.50 -> 25.10 ms: on in the 16-bit modes
+        self.stem_wlane = os.environ.get('FAMI_STEM_WGRAD_LANE', '1' if self.half else '0') != '0'
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
@@ -133,7 +136,7 @@ class Engine:
         # 50.86 and 50.96 -> 50.78 ms (the split-product kernels already spend a dozen VALU instructions per staged element
         # on the split; two more are free); bf16 27.70 -> 27.91 ms (the transform moves into the staging path of kernels
         # that are bound by exactly that path).
-        self.use_xbn = os.environ.get('FAMI_XBN', '0' if self.half else '1') != '0'
+        self.use_xbn = os.environ.get('FAMI_XBN', '1') != '0'        # round 4: on in every mode (bf16 25.30 vs 25.30 ms: neutral, 104 launches and a tensor round trip per block fewer)
         # Tried in round 4: backward fusion only on the SERIAL stretches of the step (stem, layer1: one lane, nothing beside it --
         # 3.6 ms of the f32 backward pass), `serial_scope` set by HRNetBody.run.  Interleaved bench runs on one box: f32 48.16
         # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  FAMI_SERIAL_FUSE=1
