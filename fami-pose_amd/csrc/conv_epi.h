@@ -162,3 +162,11 @@ int fami_try_conv3x3_t5(int half_kind, const void* x, const void* wp, const floa
                         const char* name, const EpiBN& epi, const XBN& xbn);
 void fami_conv_t5_tune(int on);
 int fami_conv_t5_eligible_s3(int N, int H, int W, int Ci, int Co);
+
+// conv_t6.hip: weight-resident, DMA-staged 3x3 stride-1 kernel for the 16-bit types (round 4; 48 input channels, rows of 64 / 72 pixels).
+// Same contract as fami_try_conv3x3_t4; no input BatchNorm (XBN) and no backward-statistics epilogue (EpiBN mode 2): returns 0 for those.
+int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                        int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi, const XBN& xbn);
+extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co);
+void fami_conv_t6_tune(int on);

@@ -759,6 +759,9 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
     if (rc5 != 0) return rc5;
   }
   if (half_kind != 2 && g_use_t4) {
+    // round 4: the weight-resident DMA-staged form (conv_t6.hip) where the whole weight image fits the LDS (48 input channels)
+    const int rc6 = fami_try_conv3x3_t6(half_kind, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
+    if (rc6 != 0) return rc6;
     const int rc5 = fami_try_conv3x3_t5(half_kind, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, name, epi, xbn);
     if (rc5 != 0) return rc5;
   }
@@ -777,6 +780,7 @@ int fami_try_conv3x3_t4(int half_kind, const void* x, const void* wp, const floa
 // to materialise the normalised input)?
 int fami_conv_t4_eligible16(int N, int H, int W, int Ci, int Co) {
   if (!g_use_t4 || (Ci % 8) != 0) return 0;
+  if (fami_conv_t6_eligible(N, H, W, Ci, Co)) return 0;      // conv_t6.hip copies its patch by DMA: no transform on the way (its launch + the apply pass beat this kernel with the transform)
   const int NT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
   if (!NT) return 0;
   const int FT = (H * W + 15) / 16;
@@ -802,6 +806,10 @@ int fami_conv_t4_eligible_s3(int N, int H, int W, int Ci, int Co) {
 extern "C" void fami_conv_t4_debug(void* buf) { g_t4_dbg = reinterpret_cast<long long*>(buf); }
 void fami_conv_t4_default_split(int on) { g_s3_default = on ? 1 : 0; }
 void fami_conv_t4_tune(int on) {
+  if (on < 0 || (on >= 8000 && on < 9000)) {   // conv_t6.hip: 8000 / 8001 off / on, 8100 + rows per band, 8400 + minimum jobs
+    fami_conv_t6_tune(on);
+    if (on >= 0) return;
+  }
   if (on < 0 || (on >= 7000 && on < 8000)) {   // conv_t5.hip: 7000 / 7001 off / on, 7100 + rows per band, 7400 + minimum frame tiles, 7500 + workgroups
     fami_conv_t5_tune(on);
     if (on >= 0) return;

@@ -72,6 +72,9 @@ int fami_tune_reset(void);
 int fami_tune_defaults(int f32_split);
 /* would a 3x3 stride-1 pad-1 f32 convolution [N,H,W,Ci] -> Co take the persistent split-product kernel (conv_t5.hip)? (tests) */
 int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co);
+/* ... and conv_t6.hip (round 4: 16-bit storage, 48 input channels, whole weight image LDS-resident, patch and weights copied by
+ * LDS DMA; fami_conv_tune_lds(8000 / 8001) off / on, 8100 + rows per band, 8201 / 8202 units of two / four rows, 8400 + minimum jobs) */
+int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co);
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
                               fami_stream_t stream);

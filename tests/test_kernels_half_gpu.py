@@ -190,3 +190,69 @@ def test_shift_dcn_half(dev):
     # 20 bits per contribution at the bound: the two regions differ far below the storage type's resolution, i.e. the
     # stored 16-bit gradients differ by roundings that fall the other way (at most an ulp of the largest value or two)
     assert relerr(gxs[0], gxs[1]) < 8e-3
+
+
+def test_weight_resident_dma_conv(dev, half):
+    """conv_t6.hip (round 4): the 48-channel 3x3 stride-1 convolution with the whole weight image LDS-resident, patch and
+    weights copied by LDS DMA (buffer loads: borders / out-of-image rows are out-of-range offsets = zeros), a dense K order
+    over (tap, 8-channel granule).  Forward (+ bias), input gradient (plain and accumulating) and the forward BatchNorm
+    statistics epilogue against fp64 on the same 16-bit operands, and against the band kernel (conv_t4.hip) it replaces:
+    the bench shape, the head's 4-frame shape, 64-pixel rows (no ninth tile), two output-channel blocks, bands of 2 / 4 / 6 / 8
+    / 12 rows, units of two and four rows."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    cases = [(20, 96, 72, 48, 48, 0, 0), (4, 96, 72, 48, 48, 0, 0), (3, 12, 72, 48, 48, 6, 0), (2, 16, 64, 48, 96, 0, 0),
+             (5, 24, 72, 48, 96, 12, 0), (2, 8, 72, 48, 48, 2, 0), (2, 8, 72, 48, 48, 4, 1), (3, 16, 64, 48, 48, 8, 2), (1, 10, 72, 48, 48, 0, 0)]
+    try:
+        for it, (N, H, W, Ci, Co, rows, mt) in enumerate(cases):
+            torch.manual_seed(it)
+            x, dy = torch.randn(N, H, W, Ci, device=dev).to(BF), torch.randn(N, H, W, Co, device=dev).to(BF)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.1
+            bias = torch.randn(Co, device=dev) if it % 2 else None
+            pivot = torch.randn(Co, device=dev) * 0.1
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            wp = [torch.empty(getattr(L.cdll, 'fami_packed_weight_elems' + sfx)(Co, Ci, 3, 3, m), device=dev, dtype=BF) for m in (0, 1)]
+            for m in (0, 1):
+                L.call('fami_pack_conv_weight' + sfx, p(w), p(wp[m]), Co, Ci, 3, 3, m, st)
+            wq = w.to(BF).double()
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), wq, None if bias is None else bias.double(), padding=1).permute(0, 2, 3, 1)
+            refd = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
+            dx0 = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            out = {}
+            for code in (8000, 8001):
+                L.cdll.fami_conv_tune_lds(-1)
+                L.cdll.fami_conv_tune_lds(code)
+                if code == 8001:
+                    L.cdll.fami_conv_tune_lds(8400)          # no minimum job count
+                    if rows:
+                        L.cdll.fami_conv_tune_lds(8100 + rows)
+                    if mt:
+                        L.cdll.fami_conv_tune_lds(8200 + mt)
+                    assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == 1, (N, H, W, Ci, Co, rows)
+                y, ys, dx, dxa = (torch.empty(N, H, W, Co, device=dev, dtype=BF), torch.empty(N, H, W, Co, device=dev, dtype=BF),
+                                  torch.empty(N, H, W, Ci, device=dev, dtype=BF), dx0.clone())
+                slots = torch.zeros(L.cdll.fami_bn_slots_bytes(Co) // 8, device=dev, dtype=torch.float64)
+                L.call('fami_conv2d_fwd' + sfx, p(x), p(wp[0]), p(bias), p(y), *geo, 0, 0, 0, st)
+                L.call('fami_conv2d_fwd_stats' + sfx, p(x), p(wp[0]), p(bias), p(ys), *geo, p(slots), p(pivot), st)
+                L.call('fami_conv2d_dgrad' + sfx, p(dy), p(wp[1]), p(dx), *geo, 0, st)
+                L.call('fami_conv2d_dgrad' + sfx, p(dy), p(wp[1]), p(dxa), *geo, 1, st)
+                torch.cuda.synchronize(dev)
+                assert torch.equal(y, ys)
+                assert relerr(y, ref) < ACT_TOL and relerr(dx, refd) < ACT_TOL and relerr(dxa, refd + dx0.double()) < ACT_TOL, (it, code)
+                # statistics of the values AS STORED, shifted by the pivot: the slot rows hold [ns][2][Co] sums
+                ns = 8 if Co <= 96 else 4
+                rows_ = slots[:8 * 2 * Co].view(8, 2, Co).sum(0).cpu()
+                d = ys.double().reshape(-1, Co) - pivot.double()
+                assert relerr(rows_[0], d.sum(0)) < 1e-5 and relerr(rows_[1], (d * d).sum(0)) < 1e-5, (it, code)
+                piv = slots[8 * 2 * Co:].view(torch.float32)[:Co]
+                assert torch.equal(piv.cpu(), pivot.cpu())
+                out[code] = (y, dx, dxa)
+            L.cdll.fami_conv_tune_lds(-1)
+            # two kernels, two summation orders: they agree to the storage type's rounding of a few elements
+            for k in range(3):
+                assert relerr(out[8001][k], out[8000][k].double()) < ACT_TOL, (it, k)
+    finally:
+        L.cdll.fami_conv_tune_lds(-1)
