@@ -300,6 +300,264 @@ __global__ __launch_bounds__(WG16_THREADS) void conv_wgrad16_kernel(Wg16Args p) 
   }
 }
 
+// ------------------------------------------------------------------ DMA-staged form for the 48-channel branch ("wg6", round 4)
+// The 48 -> 48 3x3 weight gradient @96x72 is the most numerous weight-gradient launch of the 16-bit step, and tools/abl_wg16.py
+// says where its 28 us go: launch + prologue + first staging 6.6, K loop 7.7, restaging 3.8, partial-slab store 4.7, slab reduce
+// 7.0 -- the MFMA work is 8 % of it, and 128-256 workgroups each pay prologue, staging through registers and an 83 KB slab.
+// Here a workgroup owns a band of RB whole rows of ONE frame (default 16: 120 workgroups, half as many slabs per pixel as
+// before at twice the pixels each) and walks it in units of four rows (288 pixels = nine K steps of 32):
+//   * the unit's X patch (six rows, zero border columns, 96-byte positions) and its dY rows (contiguous in HBM and in LDS) are
+//     copied by LDS DMA (buffer loads: border / out-of-image granules carry an out-of-range offset = zeros) -- no registers,
+//     no stash phase, no zeroing; two buffers: unit u + 1 is requested right after the barrier that opens unit u;
+//   * one barrier per unit (288 pixels x 81 MFMA tiles), every pixel of a unit is a whole K step (no ragged tail);
+//   * fragments, the pixel <-> K-slot map and the (input tile, tap) pairs are conv_wgrad16_kernel's.
+// LDS DMA issued from inline assembly: hipcc's wait-count pass puts an s_waitcnt vmcnt(0) in front of the K loop's transposing
+// LDS reads while an LDS-DMA builtin is outstanding (it cannot tell the two buffers apart) -- unit u + 1's copy then never
+// overlaps unit u's MFMAs (found in the ISA; the kernel ran 7.5 k cycles per unit against 3 k of MFMA).  The asm form is
+// invisible to that pass; the kernel waits with its own s_waitcnt vmcnt(0) at the top of every unit.
+typedef int wg6_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg6_i32x4 wg6_rsrc(const void* base, int bytes) {
+  const unsigned long a = (unsigned long)base;
+  const wg6_i32x4 r = {(int)(unsigned)a, (int)((a >> 32) & 0xffff), bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void wg6_dma16(wg6_i32x4 r, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(r) : "memory");
+}
+struct Wg6Args {
+  const void* x;    // [N,H,W,48]
+  const void* dy;   // [N,H,W,48]
+  float* part;      // [G = N * bands][9][48][48]
+  int N, H, W;
+  int RB, bands;    // rows per band (multiple of 4), bands per frame
+  int PW, RG;       // W + 2, 16-byte granules per patch row
+  int q512, r512;   // 512 / RG, 512 % RG
+  int XI, YI;       // DMA instructions (1 KiB) of a unit's patch / dY rows
+  long long* dbg;   // FAMI_WG6_TRACE builds: s_memtime stamps of one workgroup
+};
+#define WG6_UR 4
+#define WG6_XJ 6      // most patch DMA instructions per wave and unit (XI <= 48)
+#define WG6_YJ 4      // ... dY (YI <= 32)
+
+template <typename H, int KS>      // KS: K steps of 32 pixels per unit (4 W / 32)
+__global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p) {
+  typedef typename H16<H>::x8 hx8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CIT = 3, COT = 3, TAPS = 9, NPW = 4, PS = 96;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int rsel = l16 >> 2, piece = l16 & 3;
+  int job;
+  {   // XCD x owns the x-th contiguous eighth of the job list
+    const int n = gridDim.x, lin = blockIdx.x;
+    const int q = n >> 3, r = n & 7, xc = lin & 7, l = lin >> 3;
+    job = xc * q + (xc < r ? xc : r) + l;
+  }
+  const int img = job / p.bands, bnd = job - img * p.bands;
+  const int y0 = bnd * p.RB;
+  const int nunits = p.RB / WG6_UR;
+  const int W = p.W, PW = p.PW;
+  const int XB = p.XI * 1024, BUFSZ = XB + p.YI * 1024;
+#ifdef FAMI_WG6_TRACE
+  const bool trace = p.dbg && job == 50 && lane == 0;
+  int tslot = 0;
+#define WG6_STAMP() if (trace) p.dbg[wave * 64 + tslot++] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define WG6_STAMP()
+#endif
+  WG6_STAMP();
+
+  // ---- DMA plan of this lane (unit-invariant): patch granule -> (row of the six, byte offset from the unit's first patch row)
+  const long fbytes = (long)p.H * W * PS;
+  const wg6_i32x4 rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * fbytes, (int)fbytes);
+  const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * fbytes, (int)fbytes);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  int xrow[WG6_XJ], xoff[WG6_XJ];
+  {
+    const int q0 = wave * 64 + lane;
+    int r = q0 / p.RG, wi = q0 - r * p.RG;
+#pragma unroll
+    for (int j = 0; j < WG6_XJ; ++j) {
+      const int pos = wi / 6, c = wi - pos * 6;
+      const bool ok = r < WG6_UR + 2 && pos >= 1 && pos <= W;
+      xrow[j] = ok ? r : 0x40000000;                  // never a valid image row
+      xoff[j] = ((r * W + pos - 1) * 6 + c) * 16;
+      r += p.q512;
+      wi += p.r512;
+      if (wi >= p.RG) {
+        wi -= p.RG;
+        ++r;
+      }
+    }
+  }
+  // piece k of unit u's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
+  auto dma_piece = [&](int u, unsigned buf, int k) {
+    const int yt = y0 + u * WG6_UR - 1;                // image row of the unit's first patch row
+    if (k < WG6_XJ) {
+      const int i = wave + WG16_WAVES * k;             // (wave-uniform)
+      if (i < p.XI) {
+        unsigned off = (unsigned)(yt * W * PS + xoff[k]);
+        if ((unsigned)(yt + xrow[k]) >= (unsigned)p.H) off = 0x80000000u;
+        wg6_dma16(rx, off, buf + i * 1024);
+      }
+    } else {
+      const int i = wave + WG16_WAVES * (k - WG6_XJ);
+      if (i < p.YI) wg6_dma16(ry, (unsigned)((yt + 1) * W * PS + lane * 16) + i * 1024, buf + XB + i * 1024);
+    }
+  };
+  auto dma_unit = [&](int u, unsigned buf) {
+#pragma unroll
+    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u, buf, k);
+  };
+  dma_unit(0, lds0);
+  WG6_STAMP();
+
+  // ---- pairs of this wave: q = wave + 8 i -> (ci tile, tap)
+  int poff[NPW], ptap[NPW], pci[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = wave + WG16_WAVES * i;
+    const bool ok = q < CIT * TAPS;
+    pci[i] = ok ? q / TAPS : 0;
+    ptap[i] = ok ? q - pci[i] * TAPS : -1;
+    const int t = ok ? ptap[i] : 0;
+    poff[i] = ((t / 3) * PW + (t % 3)) * PS + pci[i] * 32 + piece * 8;
+  }
+  f32x4 acc[NPW][COT];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool full = ptap[NPW - 1] >= 0;   // wave-uniform: does this wave use its last pair slot?
+
+  for (int u = 0; u < nunits; ++u) {
+    WG6_STAMP();
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of unit u has landed
+    __builtin_amdgcn_s_barrier();         // ... everybody's, and every wave has left unit u - 1 (the other buffer is free)
+    asm volatile("" ::: "memory");
+    WG6_STAMP();
+    const bool more = u + 1 < nunits;
+    const unsigned nbuf = lds0 + ((u + 1) & 1) * BUFSZ;
+    const char* xt = smem + (u & 1) * BUFSZ;
+    // this lane's two pixels of the current K step (local index pl = ks*32 + kq*4 + h*16 + rsel, conv_wgrad16_kernel's map)
+    int py[2], pxx[2], ya[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pl = kq * 4 + h * 16 + rsel;          // < 32 <= W
+      py[h] = 0;
+      pxx[h] = pl;
+      ya[h] = XB + pl * PS + piece * 8;
+    }
+    // Two fragment sets: step ks + 1 is requested (and one piece of unit u + 1's copy issued) before step ks is multiplied;
+    // the loop is unrolled (KS is 8 or 9) and the scheduler fenced, so the order below is the order in the ISA.
+    auto body = [&](auto npc) {
+      constexpr int NP = decltype(npc)::value;
+      hx8 bfr[2][COT], afr[2][NP];
+      auto load = [&](int set) {
+        int xb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          xb[h] = (py[h] * PW + pxx[h]) * PS;
+          pxx[h] += 32;
+          if (pxx[h] >= W) {
+            pxx[h] -= W;
+            py[h] += 1;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[0] + c * 32));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + ya[1] + c * 32));
+          bfr[set][c] = frag_of<hx8>(lo, hi);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[0] + poff[i]));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[1] + poff[i]));
+          afr[set][i] = frag_of<hx8>(lo, hi);
+        }
+        ya[0] += 32 * PS;
+        ya[1] += 32 * PS;
+      };
+      load(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load((ks + 1) & 1);
+        if (more) {
+          dma_piece(u + 1, nbuf, ks);
+          if (ks == KS - 1) {
+#pragma unroll
+            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u + 1, nbuf, k);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+          for (int c = 0; c < COT; ++c) acc[i][c] = H16<H>::mfma(afr[ks & 1][i], bfr[ks & 1][c], acc[i][c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (full) body(std::integral_constant<int, NPW>());
+    else body(std::integral_constant<int, NPW - 1>());
+  }
+  WG6_STAMP();
+
+  // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [job][tap][ci][co]
+  float* slab = p.part + (long)job * TAPS * 48 * 48;
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    if (ptap[i] < 0) continue;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      const int co = c * 16 + l16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = pci[i] * 16 + kq * 4 + r;
+        slab[((long)ptap[i] * 48 + ci) * 48 + co] = acc[i][c][r];
+      }
+    }
+  }
+  WG6_STAMP();
+}
+
+static long long* g_wg6_dbg = nullptr;
+extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
+struct Wg6Plan { int ok, RB, bands, G, XI, YI; size_t lds; };
+static int g_wg6 = 1, g_wg6_rb = 0;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + RB: rows per band
+static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
+  Wg6Plan q;
+  q.ok = 0;
+  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1 || Ci != 48 || Co != 48) return q;
+  if (!(W == 72 || W == 64) || (H % WG6_UR) != 0) return q;      // (nine / eight K steps of 32 pixels per four rows)
+  const int RG = (W + 2) * 6;
+  q.XI = ((WG6_UR + 2) * RG + 63) / 64;
+  q.YI = WG6_UR * W * 6 / 64;
+  if (q.XI > 8 * WG6_XJ || q.YI > 8 * WG6_YJ) return q;
+  q.lds = 2 * (size_t)(q.XI + q.YI) * 1024;
+  if (q.lds > 160 * 1024) return q;
+  // rows per band: about 120 workgroups (half the slabs of the 256-workgroup form at twice the pixels each; the other stream
+  // lanes use the CUs a launch leaves)
+  q.RB = 0;
+  long bestd = 1L << 40;
+  for (int rb = WG6_UR; rb <= H; rb += WG6_UR) {
+    if (H % rb != 0) continue;
+    if (g_wg6_rb > 0 && rb != g_wg6_rb) continue;
+    const long g = (long)N * (H / rb);
+    const long d = g > 120 ? g - 120 : 120 - g;
+    if (d < bestd || (d == bestd && rb > q.RB)) {
+      bestd = d;
+      q.RB = rb;
+    }
+  }
+  if (!q.RB) return q;
+  q.bands = H / q.RB;
+  q.G = N * q.bands;
+  q.ok = (long)H * W * 96 < (1L << 31) && q.G < 65536;
+  return q;
+}
+
 // ------------------------------------------------------------------ host side
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
@@ -371,7 +629,9 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
 
 long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
-  return q.ok ? q.G : 0;
+  const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);      // (workspace sizing: whichever kernel takes the launch)
+  const long g = q.ok ? q.G : 0, g6 = q6.ok ? q6.G : 0;
+  return g > g6 ? g : g6;
 }
 
 template <typename HT>
@@ -409,6 +669,36 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
 // -> number of partial slabs written to `part` ([G][k*k][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
                      int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn) {
+  if (!xbn.on && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);
+    if (q6.ok && ws_bytes >= (long)q6.G * 9 * 48 * 48 * (long)sizeof(float)) {
+      Wg6Args a;
+      a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.RB = q6.RB; a.bands = q6.bands;
+      a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+      }
+      const bool k9 = WG6_UR * W / 32 == 9;
+      if (half_kind == 1) {
+        if (k9) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, 9>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, 8>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
+      } else {
+        if (k9) hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, 9>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, 8>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
+      }
+      hipError_t err6 = hipGetLastError();
+      if (err6 != hipSuccess) {
+        fami_set_error(name, hipGetErrorString(err6));
+        return FAMI_EHIP;
+      }
+      return q6.G;
+    }
+  }
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   if (!q.ok || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return 0;
   if (ws_bytes < (long)q.G * Co * Ci * k * k * (long)sizeof(float)) {
@@ -428,7 +718,9 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_rb = 0; }
+  else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
+  else if (on >= 3100 && on < 3400) g_wg6_rb = on - 3100;        // (23100 + rows per band)
   else if (on <= 1) g_wg16 = on;
   else if (on <= 3) g_wg16_general = on - 2;
   else if (on == 4 || on == 5) g_wg16_bt18 = on - 4;      // 18-tile aligned runs off / on
