@@ -325,21 +325,25 @@ __device__ __forceinline__ void wg6_dma16(wg6_i32x4 r, unsigned voff, unsigned l
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(r) : "memory");
 }
 struct Wg6Args {
-  const void* x;    // [N,H,W,48]
-  const void* dy;   // [N,H,W,48]
-  float* part;      // [G = N * bands][9][48][48]
-  int N, H, W;
-  int RB, bands;    // rows per band (multiple of 4), bands per frame
-  int PW, RG;       // W + 2, 16-byte granules per patch row
+  const void* x;    // [N,H,W,Ci]
+  const void* dy;   // [N,H,W,Co]
+  float* part;      // [G][9][Ci][Co]
+  int N, H, W, Ci, Co;
+  int UR, upf;      // rows per unit, units per frame (H / UR)
+  int M;            // pixels of a unit (UR * W)
+  int nunits;       // units per workgroup (consecutive, frame-major)
+  int NU;           // units in total (N * upf)
+  int coBlocks;
+  int PW, RG;       // W + 2, 16-byte granules per patch row (6 PW: a 48-channel slice)
   int q512, r512;   // 512 / RG, 512 % RG
+  int dyq, dxr;     // 32 / W, 32 % W
   int XI, YI;       // DMA instructions (1 KiB) of a unit's patch / dY rows
   long long* dbg;   // FAMI_WG6_TRACE builds: s_memtime stamps of one workgroup
 };
-#define WG6_UR 4
 #define WG6_XJ 6      // most patch DMA instructions per wave and unit (XI <= 48)
 #define WG6_YJ 4      // ... dY (YI <= 32)
 
-template <typename H, int KS>      // KS: K steps of 32 pixels per unit (4 W / 32)
+template <typename H, int KS>      // KS: K steps of 32 pixels per unit (ceil(M / 32): the dY rows past M are zeros)
 __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p) {
   typedef typename H16<H>::x8 hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -354,13 +358,13 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     const int q = n >> 3, r = n & 7, xc = lin & 7, l = lin >> 3;
     job = xc * q + (xc < r ? xc : r) + l;
   }
-  const int img = job / p.bands, bnd = job - img * p.bands;
-  const int y0 = bnd * p.RB;
-  const int nunits = p.RB / WG6_UR;
+  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  const int u0g = job * p.nunits;                    // first unit (global index) of this workgroup
+  const int nunits = min(p.nunits, p.NU - u0g);
   const int W = p.W, PW = p.PW;
   const int XB = p.XI * 1024, BUFSZ = XB + p.YI * 1024;
 #ifdef FAMI_WG6_TRACE
-  const bool trace = p.dbg && job == 50 && lane == 0;
+  const bool trace = p.dbg && job == 5 && blockIdx.y == 0 && lane == 0;
   int tslot = 0;
 #define WG6_STAMP() if (trace) p.dbg[wave * 64 + tslot++] = (long long)__builtin_amdgcn_s_memtime()
 #else
@@ -368,21 +372,20 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #endif
   WG6_STAMP();
 
-  // ---- DMA plan of this lane (unit-invariant): patch granule -> (row of the six, byte offset from the unit's first patch row)
-  const long fbytes = (long)p.H * W * PS;
-  const wg6_i32x4 rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * fbytes, (int)fbytes);
-  const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * fbytes, (int)fbytes);
+  // ---- DMA plan of this lane (unit-invariant): patch granule -> (patch row, byte offset from the first patch row's pixel 0,
+  // channel slice included); dY granule -> byte offset from the unit's first pixel
+  const long xfb = (long)p.H * W * p.Ci * 2, yfb = (long)p.H * W * p.Co * 2;     // one frame
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-  int xrow[WG6_XJ], xoff[WG6_XJ];
+  int xrow[WG6_XJ], xoff[WG6_XJ], yoff[WG6_YJ];
   {
     const int q0 = wave * 64 + lane;
     int r = q0 / p.RG, wi = q0 - r * p.RG;
 #pragma unroll
     for (int j = 0; j < WG6_XJ; ++j) {
       const int pos = wi / 6, c = wi - pos * 6;
-      const bool ok = r < WG6_UR + 2 && pos >= 1 && pos <= W;
+      const bool ok = r < p.UR + 2 && pos >= 1 && pos <= W;
       xrow[j] = ok ? r : 0x40000000;                  // never a valid image row
-      xoff[j] = ((r * W + pos - 1) * 6 + c) * 16;
+      xoff[j] = ((r * W + pos - 1) * p.Ci + cib * 48 + c * 8) * 2;
       r += p.q512;
       wi += p.r512;
       if (wi >= p.RG) {
@@ -390,27 +393,38 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
         ++r;
       }
     }
+#pragma unroll
+    for (int j = 0; j < WG6_YJ; ++j) {
+      const int q = (wave + WG16_WAVES * j) * 64 + lane;
+      const int pix = q / 6, c = q - pix * 6;
+      yoff[j] = pix < p.M ? (pix * p.Co + cob * 48 + c * 8) * 2 : (int)0x80000000;
+    }
   }
-  // piece k of unit u's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
-  auto dma_piece = [&](int u, unsigned buf, int k) {
-    const int yt = y0 + u * WG6_UR - 1;                // image row of the unit's first patch row
+  // piece k of a unit's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
+  auto dma_piece = [&](int ug, unsigned buf, int k) {
+    const int img = ug / p.upf, ui = ug - img * p.upf;
+    const int yt = ui * p.UR - 1;                      // image row of the unit's first patch row
     if (k < WG6_XJ) {
       const int i = wave + WG16_WAVES * k;             // (wave-uniform)
       if (i < p.XI) {
-        unsigned off = (unsigned)(yt * W * PS + xoff[k]);
+        const wg6_i32x4 rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * xfb, (int)xfb);
+        unsigned off = (unsigned)(yt * W * p.Ci * 2 + xoff[k]);
         if ((unsigned)(yt + xrow[k]) >= (unsigned)p.H) off = 0x80000000u;
         wg6_dma16(rx, off, buf + i * 1024);
       }
     } else {
       const int i = wave + WG16_WAVES * (k - WG6_XJ);
-      if (i < p.YI) wg6_dma16(ry, (unsigned)((yt + 1) * W * PS + lane * 16) + i * 1024, buf + XB + i * 1024);
+      if (i < p.YI) {
+        const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
+        const int yo = yoff[k - WG6_XJ];
+        wg6_dma16(ry, yo < 0 ? 0x80000000u : (unsigned)((yt + 1) * W * p.Co * 2 + yo), buf + XB + i * 1024);
+      }
     }
   };
-  auto dma_unit = [&](int u, unsigned buf) {
+  if (nunits > 0) {
 #pragma unroll
-    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u, buf, k);
-  };
-  dma_unit(0, lds0);
+    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u0g, lds0, k);
+  }
   WG6_STAMP();
 
   // ---- pairs of this wave: q = wave + 8 i -> (ci tile, tap)
@@ -430,6 +444,14 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
     for (int c = 0; c < COT; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool full = ptap[NPW - 1] >= 0;   // wave-uniform: does this wave use its last pair slot?
+  // this lane's two pixels of K step 0 (local index pl = ks*32 + kq*4 + h*16 + rsel, conv_wgrad16_kernel's map)
+  int py0[2], px0[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int pl = kq * 4 + h * 16 + rsel;
+    py0[h] = pl / W;
+    px0[h] = pl - py0[h] * W;
+  }
 
   for (int u = 0; u < nunits; ++u) {
     WG6_STAMP();
@@ -440,17 +462,16 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     const bool more = u + 1 < nunits;
     const unsigned nbuf = lds0 + ((u + 1) & 1) * BUFSZ;
     const char* xt = smem + (u & 1) * BUFSZ;
-    // this lane's two pixels of the current K step (local index pl = ks*32 + kq*4 + h*16 + rsel, conv_wgrad16_kernel's map)
-    int py[2], pxx[2], ya[2];
+    int py[2], pxx[2], pl[2], ya[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int pl = kq * 4 + h * 16 + rsel;          // < 32 <= W
-      py[h] = 0;
-      pxx[h] = pl;
-      ya[h] = XB + pl * PS + piece * 8;
+      pl[h] = kq * 4 + h * 16 + rsel;
+      py[h] = py0[h];
+      pxx[h] = px0[h];
+      ya[h] = XB + pl[h] * PS + piece * 8;
     }
     // Two fragment sets: step ks + 1 is requested (and one piece of unit u + 1's copy issued) before step ks is multiplied;
-    // the loop is unrolled (KS is 8 or 9) and the scheduler fenced, so the order below is the order in the ISA.
+    // the loop is unrolled and the scheduler fenced, so the order below is the order in the ISA.
     auto body = [&](auto npc) {
       constexpr int NP = decltype(npc)::value;
       hx8 bfr[2][COT], afr[2][NP];
@@ -458,8 +479,11 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
         int xb[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          xb[h] = (py[h] * PW + pxx[h]) * PS;
-          pxx[h] += 32;
+          // pixels past the unit meet a zero dY row; their X address only has to stay inside the buffer
+          xb[h] = pl[h] < p.M ? (py[h] * PW + pxx[h]) * PS : 0;
+          pl[h] += 32;
+          pxx[h] += p.dxr;
+          py[h] += p.dyq;
           if (pxx[h] >= W) {
             pxx[h] -= W;
             py[h] += 1;
@@ -485,10 +509,10 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) load((ks + 1) & 1);
         if (more) {
-          dma_piece(u + 1, nbuf, ks);
+          if (ks < WG6_XJ + WG6_YJ) dma_piece(u0g + u + 1, nbuf, ks);
           if (ks == KS - 1) {
 #pragma unroll
-            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u + 1, nbuf, k);
+            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u0g + u + 1, nbuf, k);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -505,17 +529,17 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
   WG6_STAMP();
 
   // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [job][tap][ci][co]
-  float* slab = p.part + (long)job * TAPS * 48 * 48;
+  float* slab = p.part + (long)job * TAPS * p.Ci * p.Co;
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     if (ptap[i] < 0) continue;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
-      const int co = c * 16 + l16;
+      const int co = cob * 48 + c * 16 + l16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ci = pci[i] * 16 + kq * 4 + r;
-        slab[((long)ptap[i] * 48 + ci) * 48 + co] = acc[i][c][r];
+        const int ci = cib * 48 + pci[i] * 16 + kq * 4 + r;
+        slab[((long)ptap[i] * p.Ci + ci) * p.Co + co] = acc[i][c][r];
       }
     }
   }
@@ -524,37 +548,43 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 
 static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
-struct Wg6Plan { int ok, RB, bands, G, XI, YI; size_t lds; };
-static int g_wg6 = 1, g_wg6_rb = 0;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + RB: rows per band
+struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks; size_t lds; };
+static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
   q.ok = 0;
-  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1 || Ci != 48 || Co != 48) return q;
-  if (!(W == 72 || W == 64) || (H % WG6_UR) != 0) return q;      // (nine / eight K steps of 32 pixels per four rows)
+  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1 || (Ci % 48) != 0 || (Co % 48) != 0) return q;
+  // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple
+  q.UR = 0;
+  for (int ur = H; ur >= 1; --ur) {
+    if (H % ur != 0 || ur * W > 288) continue;
+    q.UR = ur;
+    break;
+  }
+  if (!q.UR) return q;
+  q.M = q.UR * W;
+  q.KS = (q.M + 31) / 32;
+  if (!(q.KS == 9 || q.KS == 8 || q.KS == 7 || q.KS == 5 || q.KS == 4)) return q;
+  if (q.KS * 32 - q.M > 24) return q;                // (a quarter of the last step may be padding, not more)
   const int RG = (W + 2) * 6;
-  q.XI = ((WG6_UR + 2) * RG + 63) / 64;
-  q.YI = WG6_UR * W * 6 / 64;
+  q.XI = ((q.UR + 2) * RG + 63) / 64;
+  q.YI = q.KS * 3;
   if (q.XI > 8 * WG6_XJ || q.YI > 8 * WG6_YJ) return q;
   q.lds = 2 * (size_t)(q.XI + q.YI) * 1024;
   if (q.lds > 160 * 1024) return q;
-  // rows per band: about 120 workgroups (half the slabs of the 256-workgroup form at twice the pixels each; the other stream
-  // lanes use the CUs a launch leaves)
-  q.RB = 0;
-  long bestd = 1L << 40;
-  for (int rb = WG6_UR; rb <= H; rb += WG6_UR) {
-    if (H % rb != 0) continue;
-    if (g_wg6_rb > 0 && rb != g_wg6_rb) continue;
-    const long g = (long)N * (H / rb);
-    const long d = g > 120 ? g - 120 : 120 - g;
-    if (d < bestd || (d == bestd && rb > q.RB)) {
-      bestd = d;
-      q.RB = rb;
-    }
-  }
-  if (!q.RB) return q;
-  q.bands = H / q.RB;
-  q.G = N * q.bands;
-  q.ok = (long)H * W * 96 < (1L << 31) && q.G < 65536;
+  q.upf = H / q.UR;
+  q.blocks = (Ci / 48) * (Co / 48);
+  const long NU = (long)N * q.upf;
+  // units per workgroup: about g_wg6_target workgroups in the launch (the other stream lanes use the CUs a launch leaves, and a
+  // workgroup's 83 KB partial slab -- written, then read by the reduce -- is the kernel's largest HBM item).  Alone 240 is the
+  // fastest (19.9 us with the reduce at 48 channels against 21.1 / 25.0 / 31.1 at 160 / 96 / 64); inside the bf16 step
+  // (tools/ab_env.py) 80: 22.44 ms against 22.58 (120) and 23.08 (240); 48 and 64 equal to 80
+  long nu = g_wg6_nu > 0 ? g_wg6_nu : (NU * q.blocks + g_wg6_target - 1) / g_wg6_target;
+  if (nu < 1) nu = 1;
+  if (nu > NU) nu = NU;
+  q.nunits = (int)nu;
+  q.G = (int)((NU + nu - 1) / nu);
+  q.ok = (long)H * W * Ci * 2 < (1L << 31) && (long)H * W * Co * 2 < (1L << 31) && q.G < 65536 && q.blocks < 65536;
   return q;
 }
 
@@ -671,32 +701,36 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
                      int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn) {
   if (!xbn.on && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
     const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);
-    if (q6.ok && ws_bytes >= (long)q6.G * 9 * 48 * 48 * (long)sizeof(float)) {
+    if (q6.ok && ws_bytes >= (long)q6.G * 9 * Ci * Co * (long)sizeof(float)) {
       Wg6Args a;
-      a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.RB = q6.RB; a.bands = q6.bands;
-      a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+      a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+      a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = Co / 48;
+      a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / W; a.dxr = 32 % W;
+      a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
+      const dim3 grid(q6.G, q6.blocks);
+      bool ok6 = false;
+#define FAMI_WG6_CASE(ks)                                                                                                 \
+  if (q6.KS == ks) {                                                                                                      \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, ks>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, ks>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, ks>), grid, dim3(WG16_THREADS), q6.lds, s, a);      \
+    else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, ks>), grid, dim3(WG16_THREADS), q6.lds, s, a);                    \
+    ok6 = true;                                                                                                           \
+  }
+      FAMI_WG6_CASE(9) FAMI_WG6_CASE(8) FAMI_WG6_CASE(7) FAMI_WG6_CASE(5) FAMI_WG6_CASE(4)
+#undef FAMI_WG6_CASE
+      if (ok6) {
+        hipError_t err6 = hipGetLastError();
+        if (err6 != hipSuccess) {
+          fami_set_error(name, hipGetErrorString(err6));
+          return FAMI_EHIP;
+        }
+        return q6.G;
       }
-      const bool k9 = WG6_UR * W / 32 == 9;
-      if (half_kind == 1) {
-        if (k9) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, 9>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
-        else hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, 8>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
-      } else {
-        if (k9) hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, 9>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
-        else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, 8>), dim3(q6.G), dim3(WG16_THREADS), q6.lds, s, a);
-      }
-      hipError_t err6 = hipGetLastError();
-      if (err6 != hipSuccess) {
-        fami_set_error(name, hipGetErrorString(err6));
-        return FAMI_EHIP;
-      }
-      return q6.G;
     }
   }
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
@@ -718,9 +752,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_rb = 0; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_nu = 0; g_wg6_target = 80; }
   else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
-  else if (on >= 3100 && on < 3400) g_wg6_rb = on - 3100;        // (23100 + rows per band)
+  else if (on >= 3100 && on < 3400) g_wg6_nu = on - 3100;        // (23100 + units per workgroup)
+  else if (on >= 3400 && on < 4000) g_wg6_target = on - 3400;    // (23400 + workgroup target)
   else if (on <= 1) g_wg16 = on;
   else if (on <= 3) g_wg16_general = on - 2;
   else if (on == 4 || on == 5) g_wg16_bt18 = on - 4;      // 18-tile aligned runs off / on

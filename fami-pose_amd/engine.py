@@ -136,7 +136,10 @@ class Engine:
         # 50.86 and 50.96 -> 50.78 ms (the split-product kernels already spend a dozen VALU instructions per staged element
         # on the split; two more are free); bf16 27.70 -> 27.91 ms (the transform moves into the staging path of kernels
         # that are bound by exactly that path).
-        self.use_xbn = os.environ.get('FAMI_XBN', '1') != '0'        # round 4: on in every mode (bf16 25.30 vs 25.30 ms: neutral, 104 launches and a tensor round trip per block fewer)
+        # Late round 4: off again in the 16-bit modes -- the DMA-staged kernels (conv_t6.hip, conv_wgrad6_kernel) copy their operands
+        # global -> LDS without passing registers, so they take a materialised input; with every weight gradient on them the
+        # bf16 step is 23.23 -> 22.64 ms (tools/ab_env.py, one box) against the consumer-side transform on the band kernels.
+        self.use_xbn = os.environ.get('FAMI_XBN', '0' if self.half else '1') != '0'
         # Tried in round 4: backward fusion only on the SERIAL stretches of the step (stem, layer1: one lane, nothing beside it --
         # 3.6 ms of the f32 backward pass), `serial_scope` set by HRNetBody.run.  Interleaved bench runs on one box: f32 48.16
         # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  FAMI_SERIAL_FUSE=1

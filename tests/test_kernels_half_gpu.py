@@ -259,36 +259,37 @@ def test_weight_resident_dma_conv(dev, half):
 
 
 def test_dma_staged_weight_gradient(dev, half):
-    """conv_wgrad6_kernel (conv_wg16.hip, round 4): the 48-channel 3x3 stride-1 weight gradient with the X patch and the dY rows of
-    a four-row unit copied by LDS DMA (out-of-range buffer offsets = the zero border), two buffers, one barrier per unit, a band
-    of whole rows per workgroup.  Against fp64 on the same 16-bit operands and against conv_wgrad16_kernel: the bench shape, the
-    head's 4-frame shape, 64-pixel rows (eight K steps per unit), every band height, accumulate."""
+    """conv_wgrad6_kernel (conv_wg16.hip, round 4): the 3x3 stride-1 weight gradient in 48 x 48 channel blocks with the X patch and
+    the dY rows of a unit (whole rows, about 288 pixels) copied by LDS DMA (out-of-range buffer offsets = the zero border and the
+    zero dY rows that pad the last K step), two buffers, one barrier per unit, consecutive units per workgroup (across frames).
+    Against fp64 on the same 16-bit operands and against conv_wgrad16_kernel: the four branch shapes of the bench workload, the
+    head's 4-frame shape, 64-pixel rows, Ci != Co, forced units per workgroup, accumulate."""
     from fami_pose_amd._lib import lib
     L = lib()
     st = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: None if t is None else t.data_ptr()
     sfx = '_' + half
-    C = 48
     try:
-        for it, (N, H, W, rb) in enumerate([(20, 96, 72, 0), (4, 96, 72, 0), (3, 8, 64, 0), (2, 12, 72, 4), (2, 24, 72, 8), (1, 24, 64, 12),
-                                            (2, 96, 72, 96), (5, 16, 72, 16)]):
+        for it, (N, H, W, Ci, Co, nu) in enumerate([(20, 96, 72, 48, 48, 0), (4, 96, 72, 48, 48, 0), (20, 48, 36, 96, 96, 0), (20, 24, 18, 192, 192, 0),
+                                                    (20, 12, 9, 384, 384, 0), (3, 8, 64, 48, 48, 0), (2, 12, 72, 48, 96, 1), (2, 24, 72, 96, 48, 2),
+                                                    (3, 24, 18, 48, 144, 5), (2, 96, 72, 48, 48, 48), (5, 16, 72, 48, 48, 3), (3, 12, 9, 96, 48, 2)]):
             torch.manual_seed(it)
-            x = torch.randn(N, H, W, C, device=dev).to(BF)
-            dy = (torch.randn(N, H, W, C, device=dev) * 0.1).to(BF)
-            geo = (N, H, W, C, C, 3, 3, 1, 1, 1)
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
             nb = L.cdll.fami_conv2d_wgrad_workspace(*geo)
             ws = torch.empty(nb // 4 + 4, device=dev)
-            wref = torch.zeros(C, C, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
             F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=1).backward(dy.double().permute(0, 3, 1, 2))
             ref = wref.grad
-            dw0 = torch.randn(C, C, 3, 3, device=dev)
+            dw0 = torch.randn(Co, Ci, 3, 3, device=dev)
             out = {}
             for code in (23000, 23001):
                 L.cdll.fami_conv_tune_wgrad_lds(-1)
                 L.cdll.fami_conv_tune_wgrad_lds(code)
-                if code == 23001 and rb:
-                    L.cdll.fami_conv_tune_wgrad_lds(23100 + rb)
-                dw, dwa = torch.empty(C, C, 3, 3, device=dev), dw0.clone()
+                if code == 23001 and nu:
+                    L.cdll.fami_conv_tune_wgrad_lds(23100 + nu)
+                dw, dwa = torch.empty(Co, Ci, 3, 3, device=dev), dw0.clone()
                 L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, 0, st)
                 L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dwa), p(ws), ws.numel() * 4, *geo, 1, st)
                 torch.cuda.synchronize(dev)

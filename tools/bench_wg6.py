@@ -16,8 +16,7 @@ def timeit(fn, reps=40):
     return e0.elapsed_time(e1) / reps * 1e3
 for DT in ('bf16', 'f16'):
     tdt = {'bf16': torch.bfloat16, 'f16': torch.float16}[DT]
-    for (N, H, W) in ((20, 96, 72), (4, 96, 72), (3, 8, 64), (2, 12, 72)):
-        C = 48
+    for (N, H, W, C) in ((20, 96, 72, 48), (20, 48, 36, 96), (20, 24, 18, 192), (20, 12, 9, 384), (4, 96, 72, 48)):
         torch.manual_seed(2)
         x = torch.randn(N, H, W, C, device=dev).to(tdt); dy = (torch.randn(N, H, W, C, device=dev) * 0.1).to(tdt)
         dw = torch.empty(C, C, 3, 3, device=dev)
@@ -35,8 +34,7 @@ for DT in ('bf16', 'f16'):
             dw.zero_(); run(); torch.cuda.synchronize()
             err = ((dw.double() - ref).abs().max() / ref.abs().max()).item()
             res.append('%s err %.1e %.1f us' % (name, err, timeit(run)))
-        for rb in (4, 8, 16, 24, 32, 48, 96):
-            if H % rb == 0:
-                L.cdll.fami_conv_tune_wgrad_lds(23100 + rb); res.append('RB%d %.1f' % (rb, timeit(run)))
+        for tg in (64, 96, 160, 240, 480):
+            L.cdll.fami_conv_tune_wgrad_lds(23400 + tg); res.append('tg%d %.1f' % (tg, timeit(run)))
         L.cdll.fami_conv_tune_wgrad_lds(-1)
-        print('%s N%d %dx%d | ' % (DT, N, H, W) + ' | '.join(res), flush=True)
+        print('%s N%d %dx%d C%d | ' % (DT, N, H, W, C) + ' | '.join(res), flush=True)
