@@ -326,6 +326,318 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   }
 }
 
+// ------------------------------------------------------------------ the same kernel for 96 / 192 / 384 input channels ("t7")
+// The weight image of a 48-channel SLICE of the input (42 KiB for 48 output channels) is what fits the LDS, so the wider layers
+// walk their input channels in PHASES of 48: a workgroup owns a band of whole rows of one frame (all of its pixels' accumulators
+// stay in registers: 18 tiles = 2 per wave + two shared ones on the 48x36 maps, 9 = 1 + a shared one on the 24x18 maps, the whole
+// 7-tile frame on the 12x9 maps) and, per phase, the dense-K weight slab of the slice and the slice of the patch (96 of a
+// position's 2 Ci bytes) are copied by LDS DMA into one of two buffers while the previous phase is multiplied out of the other --
+// conv_wgrad6_kernel's pipeline (one wait + barrier per phase, the copy issued from inline assembly so that hipcc's wait-count pass
+// does not serialise it against the LDS reads).  Replaces conv3x3_t4_kernel on these shapes: its 32-channel chunks meet twice per
+// chunk, stage through registers, and re-stage the 27 KB weight slab of a chunk for every 192 pixels.
+typedef int t7_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ t7_i32x4 t7_rsrc(const void* base, int bytes) {
+  const unsigned long a = (unsigned long)base;
+  const t7_i32x4 r = {(int)(unsigned)a, (int)((a >> 32) & 0xffff), bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void t7_dma16(t7_i32x4 r, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(r) : "memory");
+}
+struct ConvT7Args {
+  EpiBN e;
+  int emode;
+  const void* x;      // [N,H,W,Ci]
+  const void* wimg;   // packed fragment image [tap][KC][NTt][64][8]
+  void* y;            // [N,H,W,Co]
+  const float* bias;
+  int N, H, W, Ci, Co;
+  int KC, NTt;
+  int sgn, accumulate;
+  int RB, bands;      // output rows per band (H % RB == 0), bands per frame
+  int PW, RG;         // W + 2, 16-byte granules per patch row of a slice (6 PW)
+  int q512, r512;     // 512 / RG, 512 % RG
+  int nph;            // phases (Ci / 48)
+  int TU, npix;       // 16-pixel tiles of a band (the last may be ragged), pixels of a band (RB * W)
+  int REMP;           // (tile, channel tile) pairs of the tiles past the 8 MT-th
+  int PI;             // patch DMA instructions (1 KiB) of a phase
+  int jpw;            // jobs (bands) per workgroup, consecutive
+};
+#define T7_PJ 6       // most patch DMA instructions per wave and phase (PI <= 48)
+
+template <typename H, int NT, int MT, int EX, bool ACC, int EM>
+__global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p) {
+  typedef typename H16<H>::x8 frag;
+  constexpr int G = 6, NK = (9 * G + 3) / 4, PSB = G * 16, PF = 2;
+  constexpr int WI = NK * NT;                      // weight DMA instructions of a phase (42)
+  constexpr int WJ = (WI + T6_WAVES - 1) / T6_WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kq = lane >> 4;
+  int wg;
+  {   // XCD x owns the x-th contiguous eighth of the workgroup list (consecutive jobs = neighbouring bands)
+    const int n = gridDim.x, lin = blockIdx.x;
+    const int q = n >> 3, r = n & 7, xc = lin & 7, l = lin >> 3;
+    wg = xc * q + (xc < r ? xc : r) + l;
+  }
+  const int job0 = wg * p.jpw, job1 = min(job0 + p.jpw, p.N * p.bands);     // this workgroup's jobs (bands), consecutive
+  const int ntg0 = blockIdx.y * NT;
+  const int W = p.W, PW = p.PW;
+  const int BUFSZ = (WI + p.PI) * 1024;
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA plan of this lane (job- and phase-invariant parts): patch granule -> (patch row, byte offset from the pixel 0 of
+  // the band's first row at phase 0, or < 0: a border-column granule)
+  const long fbytes = (long)p.H * W * p.Ci * 2;
+  const t7_i32x4 rw = t7_rsrc(p.wimg, 9 * p.KC * p.NTt * 1024);
+  int xrow[T7_PJ], xoff[T7_PJ];
+  {
+    const int q0 = wave * 64 + lane;
+    int r = q0 / p.RG, wi = q0 - r * p.RG;
+#pragma unroll
+    for (int j = 0; j < T7_PJ; ++j) {
+      const int pos = wi / G, c = wi - pos * G;
+      const bool ok = r < p.RB + 2 && pos >= 1 && pos <= W;
+      xrow[j] = ok ? r - 1 : 0x40000000;            // image row relative to the band's first row; never valid for a border column
+      xoff[j] = (((r - 1) * W + pos - 1) * p.Ci + c * 8) * 2;
+      r += p.q512;
+      wi += p.r512;
+      if (wi >= p.RG) {
+        wi -= p.RG;
+        ++r;
+      }
+    }
+  }
+  // piece k of the copy of (job, phase) (k < WJ: weight slab, else patch slice); wave-uniform guards
+  auto dma_piece = [&](int jb, int ph, unsigned buf, int k) {
+    if (k < WJ) {
+      const int i = wave + T6_WAVES * k;
+      if (i < WI) {
+        const int kc = i / NT, nt = i - kc * NT;
+        const int kg = 4 * kc + kq;
+        const int tap = kg / G, c8 = ph * G + (kg - tap * G);      // 8-channel granule of the whole input
+        unsigned off = (unsigned)(((tap * p.KC + (c8 >> 2)) * p.NTt + ntg0 + nt) * 1024 + ((c8 & 3) << 8) + col * 16);
+        if (kg >= 9 * G || ntg0 + nt >= p.NTt) off = 0x80000000u;
+        t7_dma16(rw, off, buf + i * 1024);
+      }
+    } else {
+      const int j = k - WJ;
+      const int i = wave + T6_WAVES * j;
+      if (i < p.PI) {
+        const int img = jb / p.bands, y0 = (jb - img * p.bands) * p.RB;
+        const t7_i32x4 rx = t7_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * fbytes, (int)fbytes);
+        unsigned off = (unsigned)(y0 * W * p.Ci * 2 + xoff[j] + ph * 96);
+        if ((unsigned)(y0 + xrow[j]) >= (unsigned)p.H) off = 0x80000000u;
+        t7_dma16(rx, off, buf + (WI + i) * 1024);
+      }
+    }
+  };
+  if (job0 < job1) {
+#pragma unroll
+    for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(job0, 0, lds0, k);
+  }
+
+  // ---- per-lane constants
+  int koff[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    int kg = 4 * k + kq;
+    if (kg >= 9 * G) kg = 4 * G;
+    const int tap = kg / G, c8 = kg - tap * G;
+    koff[k] = (p.sgn * ((tap / 3 - 1) * PW + (tap % 3 - 1)) * G + c8) * 16;
+  }
+  const int nte = wave % NT;
+  const bool has_e = EX && wave < p.REMP;
+  bool own[MT], pvalid[MT], pvalide = false;       // own: the wave has this tile (wave-uniform); pvalid: the lane's pixel is inside the band
+  int base[MT], oown[MT], basee = 0, oex = 0;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int t = wave + T6_WAVES * m;
+    own[m] = t < p.TU;
+    int j = t * 16 + col;
+    pvalid[m] = own[m] && j < p.npix;
+    if (j >= p.npix) j = p.npix - 1;                // ragged last tile: re-read the band's last pixel (never stored)
+    const int rr = j / W, xx = j - rr * W;
+    base[m] = WI * 1024 + ((rr + 1) * PW + xx + 1) * PSB;
+    oown[m] = j * p.Co + ntg0 * 16 + kq * 4;
+  }
+  if (EX) {
+    int je = (T6_WAVES * MT + wave / NT) * 16 + col;
+    pvalide = has_e && je < p.npix;
+    if (je >= p.npix) je = p.npix - 1;
+    const int rre = je / W, xxe = je - rre * W;
+    basee = WI * 1024 + ((rre + 1) * PW + xxe + 1) * PSB;
+    oex = je * p.Co + (ntg0 + nte) * 16 + kq * 4;
+  }
+  const int wl = lane * 16, wle = lane * 16 + nte * 1024;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // a finished job's results wait one step for their stores: bias added, rounded to the storage type and packed (8 bytes per tile
+  // and lane) unless the launch accumulates into y (then fp32, the old value is added when they are written)
+  typedef H hx4 __attribute__((ext_vector_type(4)));
+  typedef typename std::conditional<ACC, f32x4, hx4>::type SV;
+  f32x4 acc[MT][NT], acce = z4;
+  SV sv[MT][NT], sve;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = z4;
+  f32x4 es[NT], eq[NT], ese = z4, eqe = z4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) es[nt] = eq[nt] = z4;
+  auto save1 = [&](f32x4 v, SV& out, int co0, bool valid, f32x4& s, f32x4& q) {
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
+    if constexpr (ACC) out = v;
+    else {
+      out = __builtin_convertvector(v, hx4);
+      if (EM == 1 && valid) {
+        f32x4 k4 = z4;
+        if (p.e.pivot_src) k4 = *reinterpret_cast<const f32x4*>(p.e.pivot_src + co0);
+        const f32x4 d = __builtin_convertvector(out, f32x4) - k4;
+        s += d;
+        q += d * d;
+      }
+    }
+  };
+  auto emit1 = [&](const SV& v, H* yp) {
+    if constexpr (ACC) st4(yp, v + ld4(yp));
+    else *reinterpret_cast<hx4*>(yp) = v;
+  };
+  auto emit = [&](int jb) {                          // the saved results of job jb
+    const int img = jb / p.bands, y0 = (jb - img * p.bands) * p.RB;
+    H* yb = reinterpret_cast<H*>(p.y) + (long)(img * p.H + y0) * W * p.Co;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (pvalid[m]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16);
+      }
+    if (EX && pvalide) emit1(sve, yb + oex);
+  };
+
+  // ---- (job, phase) steps: one wait + barrier each; the next step's copy is issued while this one is multiplied, across job
+  // boundaries; a job's results are written after the NEXT step's barrier (no store in front of a wait)
+  int jb = job0, ph = 0, step = 0, pending = -1;
+  while (jb < job1) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the step has landed
+    __builtin_amdgcn_s_barrier();         // ... everybody's, and every wave has left the previous step (the other buffer is free)
+    asm volatile("" ::: "memory");
+    int nj = jb, nph = ph + 1;
+    if (nph == p.nph) {
+      nph = 0;
+      ++nj;
+    }
+    const bool more = nj < job1;
+    const unsigned nbuf = lds0 + ((step + 1) & 1) * BUFSZ;
+    const char* cb = smem + (step & 1) * BUFSZ;
+    if (pending >= 0) {
+      emit(pending);
+      pending = -1;
+    }
+    auto body = [&](auto ec, auto oc) {
+      constexpr bool E = decltype(ec)::value;
+      constexpr bool O = decltype(oc)::value;          // the wave has own tiles (only the 12x9 maps leave a wave without)
+      frag a[PF][NT], b[PF][MT], ae[PF], be[PF];
+      auto ld = [&](int k, int s) {
+        if constexpr (O) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const frag*>(cb + base[m] + koff[k]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) a[s][nt] = *reinterpret_cast<const frag*>(cb + (k * NT + nt) * 1024 + wl);
+        }
+        if constexpr (E) {
+          be[s] = *reinterpret_cast<const frag*>(cb + basee + koff[k]);
+          ae[s] = *reinterpret_cast<const frag*>(cb + k * NT * 1024 + wle);
+        }
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int s = k % PF;
+        if (k + 1 < NK) ld(k + 1, (k + 1) % PF);
+        if (more && k < WJ + T7_PJ) dma_piece(nj, nph, nbuf, k);      // (NK = 14 >= WJ + T7_PJ = 12)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (O) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = H16<H>::mfma(a[s][nt], b[s][m], acc[m][nt]);
+        }
+        if constexpr (E) acce = H16<H>::mfma(ae[s], be[s], acce);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    if (own[MT - 1]) {
+      if (has_e) body(std::integral_constant<bool, EX != 0>(), Yes());
+      else body(No(), Yes());
+    } else if (more) {                               // a wave without tiles still issues its share of the next step's copy
+#pragma unroll
+      for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(nj, nph, nbuf, k);
+    }
+    if (nph == 0) {                                  // the job is complete: keep its results for the next step, clear the accumulators
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          save1(acc[m][nt], sv[m][nt], (ntg0 + nt) * 16 + kq * 4, pvalid[m], es[nt], eq[nt]);
+          acc[m][nt] = z4;
+        }
+      if (EX) save1(acce, sve, (ntg0 + nte) * 16 + kq * 4, pvalide, ese, eqe);
+      acce = z4;
+      pending = jb;
+    }
+    jb = nj;
+    ph = nph;
+    ++step;
+  }
+  if (pending >= 0) emit(pending);
+
+  if (EM == 1) {
+    EpiPtr e = epi_late(__builtin_offsetof(ConvT7Args, e));
+    __syncthreads();                                   // every wave is done with the buffers
+    float* ered = reinterpret_cast<float*>(smem);      // [waves][NT*32] own tiles, then [waves][32] extra pairs
+    float* erex = ered + T6_WAVES * NT * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = row16_sum(es[nt][r]), q = row16_sum(eq[nt][r]);
+        if (col == 0) {
+          ered[wave * (NT * 32) + nt * 32 + kq * 4 + r] = s;
+          ered[wave * (NT * 32) + nt * 32 + 16 + kq * 4 + r] = q;
+        }
+      }
+    }
+    if (EX) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = row16_sum(ese[r]), q = row16_sum(eqe[r]);
+        if (col == 0) {
+          erex[wave * 32 + kq * 4 + r] = s;
+          erex[wave * 32 + 16 + kq * 4 + r] = q;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NT * 32) {
+      const int nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
+      const int co = (ntg0 + nt) * 16 + c16;
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < T6_WAVES; ++wv) v += ered[wv * (NT * 32) + tid];
+      if (EX) {
+        for (int wv = nt; wv < p.REMP; wv += NT) v += erex[wv * 32 + (tid & 31)];
+      }
+      const int eC = e->C;
+      double* srow = e->slots + (long)(wg % e->ns) * 2 * eC;
+      unsafeAtomicAdd(srow + st * eC + co, (double)v);
+      if (st == 0 && wg == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+    }
+  }
+}
+
 // ---- plan + launch
 static int g_use_t6 = 1;        // fami_conv_tune_lds(8000 / 8001): off / on
 static int g_t6_rows = 0;       // fami_conv_tune_lds(8100 + RB): force the rows per band (benchmarks)
@@ -406,6 +718,81 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
   return 1;
 }
 
+struct T7Plan { int ok, RB, bands, TU, MT, EX, PI, jpw, G; size_t lds; };
+static int g_t7_target = 120;   // fami_conv_tune_lds(8700 + n): workgroups per output-channel block (jobs are dealt consecutively)
+static int g_use_t7 = 1;        // fami_conv_tune_lds(8500 / 8501): off / on
+static int g_t7_rows = 0;       // fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks)
+static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
+  T7Plan q;
+  q.ok = 0;
+  if (!g_use_t7 || Ci < 96 || Ci % 48 != 0 || Co % 48 != 0) return q;
+  const int RG = (W + 2) * 6;
+  double best = 1e30;
+  for (int RB = 1; RB <= H; ++RB) {
+    if (H % RB != 0) continue;
+    if (g_t7_rows > 0 && RB != g_t7_rows) continue;
+    const int npix = RB * W, TU = (npix + 15) / 16;
+    int MT, EX;
+    if (TU <= 8) { MT = 1; EX = 0; }
+    else if (TU <= 10) { MT = 1; EX = 1; }
+    else if (TU >= 16 && TU <= 18) { MT = 2; EX = TU > 16 ? 1 : 0; }
+    else continue;
+    const int PI = ((RB + 2) * RG + 63) / 64;
+    if (PI > 8 * T7_PJ) continue;
+    const size_t lds = 2 * (size_t)(42 + PI) * 1024;
+    if (lds > 160 * 1024) continue;
+    const long jobs = (long)N * (H / RB) * (Co / 48);
+    if (jobs > 512 && g_t7_rows == 0) continue;       // (more than one round of workgroups: the band kernel's two workgroups per CU win, e.g. 96 -> 48 @64x64 19.2 vs 14.3 us)
+    // rounds x (MFMA tiles of the busiest SIMD + a fixed cost per phase-set)
+    const int per_simd = TU <= 8 ? (TU > 4 ? 2 : 1) * 3 : (MT * 6 + (EX ? 1 : 0));
+    const double c2 = (double)((jobs + 255) / 256) * (per_simd + 2.0);      // ~ time of the launch
+    if (c2 < best - 1e-9) {
+      best = c2;
+      q.RB = RB; q.TU = TU; q.MT = MT; q.EX = EX; q.PI = PI; q.lds = lds;
+      q.ok = 1;
+    }
+  }
+  if (!q.ok) return q;
+  q.bands = H / q.RB;
+  {
+    const long njobs = (long)N * q.bands;
+    long tgt = g_t7_target / (Co / 48);
+    if (tgt < 1) tgt = 1;
+    q.jpw = (int)((njobs + tgt - 1) / tgt);
+    q.G = (int)((njobs + q.jpw - 1) / q.jpw);
+  }
+  return q;
+}
+template <typename HT>
+static int t7_launch(const T7Plan& q, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
+                     int Co, int KC, int NTt, int sgn, int accumulate, hipStream_t s, const EpiBN& epi) {
+  ConvT7Args a;
+  a.e = epi; a.emode = epi.slots ? epi.mode : 0;
+  a.x = x; a.wimg = wp; a.y = y; a.bias = bias;
+  a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.accumulate = accumulate;
+  a.RB = q.RB; a.bands = q.bands; a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG;
+  a.nph = Ci / 48; a.TU = q.TU; a.npix = q.RB * W; a.REMP = q.TU > 8 * q.MT ? (q.TU - 8 * q.MT) * 3 : 0; a.PI = q.PI; a.jpw = q.jpw;
+  const dim3 grid(q.G, Co / 48);
+  bool ok = false;
+  const bool acc_ = accumulate != 0, em1 = a.emode == 1;
+#define FAMI_T7_CASE(mt, ex, ac, em)                                                                                      \
+  if (!ok && q.MT == mt && q.EX == ex && acc_ == ac && em1 == (em == 1)) {                                                \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>), grid, dim3(T6_THREADS), q.lds, s, a);                  \
+    ok = true;                                                                                                            \
+  }
+  FAMI_T7_CASE(1, 1, false, 0) FAMI_T7_CASE(1, 1, false, 1) FAMI_T7_CASE(1, 1, true, 0)
+  FAMI_T7_CASE(1, 0, false, 0) FAMI_T7_CASE(1, 0, false, 1) FAMI_T7_CASE(1, 0, true, 0)
+  FAMI_T7_CASE(2, 1, false, 0) FAMI_T7_CASE(2, 1, false, 1) FAMI_T7_CASE(2, 1, true, 0)
+  FAMI_T7_CASE(2, 0, false, 0) FAMI_T7_CASE(2, 0, false, 1) FAMI_T7_CASE(2, 0, true, 0)
+#undef FAMI_T7_CASE
+  return ok ? 1 : 0;
+}
+
 // Returns 1 if launched, 0 if the shape is not eligible, < 0 on error.  half_kind: 0 bf16, 1 fp16.
 int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
@@ -414,8 +801,21 @@ int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const floa
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(wp) & 15) != 0) return 0;
   if (out_f32 || relu || (accumulate && epi.slots)) return 0;                      // (forward-only fused ReLU / fp32 heatmap outputs stay on conv_t4)
   if ((long)H * W * Ci * 2 >= (1L << 31) || (long)9 * KC * NTt * 1024 >= (1L << 31)) return 0;
+  if (KC * 32 < Ci || NTt * 16 < Co) return 0;
+  const T7Plan q7 = t7_plan(N, H, W, Ci, Co);
+  if (q7.ok) {
+    const int rc7 = half_kind == 1 ? t7_launch<f16_t>(q7, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, accumulate, s, epi)
+                                   : t7_launch<bf16_t>(q7, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, accumulate, s, epi);
+    if (!rc7) return 0;
+    hipError_t err7 = hipGetLastError();
+    if (err7 != hipSuccess) {
+      fami_set_error(name, hipGetErrorString(err7));
+      return FAMI_EHIP;
+    }
+    return 1;
+  }
   const T6Plan q = t6_plan(N, H, W, Ci, Co);
-  if (!q.ok || KC * 32 < Ci || NTt * 16 < Co) return 0;
+  if (!q.ok) return 0;
   int rc;
   if (half_kind == 1) rc = t6_launch<f16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi);
   else rc = t6_launch<bf16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi);
@@ -427,11 +827,14 @@ int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const floa
   }
   return 1;
 }
-extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) { return t6_plan(N, H, W, Ci, Co).ok; }
+extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) { return (t6_plan(N, H, W, Ci, Co).ok || t7_plan(N, H, W, Ci, Co).ok) ? 1 : 0; }
 void fami_conv_t6_tune(int on) {
-  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; }
+  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 120; }
+  else if (on >= 8700 && on < 8999) g_t7_target = on - 8700;
+  else if (on == 8500 || on == 8501) g_use_t7 = on - 8500;
+  else if (on >= 8600 && on < 8700) g_t7_rows = on - 8600;
   else if (on >= 8200 && on <= 8202) g_t6_mt = on - 8200;
   else if (on == 8000 || on == 8001) g_use_t6 = on - 8000;
-  else if (on >= 8400 && on < 8900) g_t6_min_jobs = on - 8400;
+  else if (on >= 8400 && on < 8500) g_t6_min_jobs = on - 8400;
   else if (on >= 8100 && on < 8200) g_t6_rows = on - 8100;
 }

@@ -204,8 +204,12 @@ def test_weight_resident_dma_conv(dev, half):
     st = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: None if t is None else t.data_ptr()
     sfx = '_' + half
+    # (N, H, W, Ci, Co, rows per band, rows per unit of the 48-channel kernel | workgroup target of the phase kernel)
     cases = [(20, 96, 72, 48, 48, 0, 0), (4, 96, 72, 48, 48, 0, 0), (3, 12, 72, 48, 48, 6, 0), (2, 16, 64, 48, 96, 0, 0),
-             (5, 24, 72, 48, 96, 12, 0), (2, 8, 72, 48, 48, 2, 0), (2, 8, 72, 48, 48, 4, 1), (3, 16, 64, 48, 48, 8, 2), (1, 10, 72, 48, 48, 0, 0)]
+             (5, 24, 72, 48, 96, 12, 0), (2, 8, 72, 48, 48, 2, 0), (2, 8, 72, 48, 48, 4, 1), (3, 16, 64, 48, 48, 8, 2), (1, 10, 72, 48, 48, 0, 0),
+             # conv3x3_t7_kernel: input channels in phases of 48, several bands per workgroup
+             (20, 48, 36, 96, 96, 0, 0), (20, 24, 18, 192, 192, 0, 0), (20, 12, 9, 384, 384, 0, 0), (3, 48, 36, 96, 48, 0, 7),
+             (2, 24, 18, 144, 96, 4, 1), (3, 12, 9, 96, 144, 6, 500), (2, 16, 36, 192, 48, 8, 3), (1, 10, 72, 96, 48, 2, 0)]
     try:
         for it, (N, H, W, Ci, Co, rows, mt) in enumerate(cases):
             torch.manual_seed(it)
@@ -225,12 +229,13 @@ def test_weight_resident_dma_conv(dev, half):
             for code in (8000, 8001):
                 L.cdll.fami_conv_tune_lds(-1)
                 L.cdll.fami_conv_tune_lds(code)
+                L.cdll.fami_conv_tune_lds(code + 500)          # (8500 / 8501: the phase kernel)
                 if code == 8001:
                     L.cdll.fami_conv_tune_lds(8400)          # no minimum job count
                     if rows:
-                        L.cdll.fami_conv_tune_lds(8100 + rows)
+                        L.cdll.fami_conv_tune_lds((8100 if Ci == 48 else 8600) + rows)
                     if mt:
-                        L.cdll.fami_conv_tune_lds(8200 + mt)
+                        L.cdll.fami_conv_tune_lds(8200 + mt if Ci == 48 else 8700 + mt)
                     assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == 1, (N, H, W, Ci, Co, rows)
                 y, ys, dx, dxa = (torch.empty(N, H, W, Co, device=dev, dtype=BF), torch.empty(N, H, W, Co, device=dev, dtype=BF),
                                   torch.empty(N, H, W, Ci, device=dev, dtype=BF), dx0.clone())
@@ -244,7 +249,7 @@ def test_weight_resident_dma_conv(dev, half):
                 assert relerr(y, ref) < ACT_TOL and relerr(dx, refd) < ACT_TOL and relerr(dxa, refd + dx0.double()) < ACT_TOL, (it, code)
                 # statistics of the values AS STORED, shifted by the pivot: the slot rows hold [ns][2][Co] sums
                 ns = 8 if Co <= 96 else 4
-                rows_ = slots[:8 * 2 * Co].view(8, 2, Co).sum(0).cpu()
+                rows_ = slots[:8 * 2 * Co].view(8, 2, Co).sum(0).cpu()      # (unused slot rows stay zero)
                 d = ys.double().reshape(-1, Co) - pivot.double()
                 assert relerr(rows_[0], d.sum(0)) < 1e-5 and relerr(rows_[1], (d * d).sum(0)) < 1e-5, (it, code)
                 piv = slots[8 * 2 * Co:].view(torch.float32)[:Co]

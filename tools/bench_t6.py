@@ -16,7 +16,7 @@ def timeit(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 for DT in ('bf16', 'f16'):
     tdt = {'bf16': torch.bfloat16, 'f16': torch.float16}[DT]
-    for (N, H, W, Ci, Co) in ((20, 96, 72, 48, 48), (4, 96, 72, 48, 48), (20, 64, 64, 48, 96), (3, 10, 72, 48, 48)):
+    for (N, H, W, Ci, Co) in ((20, 96, 72, 48, 48), (20, 48, 36, 96, 96), (20, 24, 18, 192, 192), (20, 12, 9, 384, 384), (4, 96, 72, 48, 48), (20, 64, 64, 48, 96), (2, 48, 36, 96, 48)):
         torch.manual_seed(1)
         x = torch.randn(N, H, W, Ci, device=dev).to(tdt); y = torch.empty(N, H, W, Co, device=dev, dtype=tdt)
         dy = torch.randn(N, H, W, Co, device=dev).to(tdt); dx = torch.empty_like(x)
@@ -33,7 +33,7 @@ for DT in ('bf16', 'f16'):
         refd = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1)
         out = {}
         for name, knob in (('t4', 8000), ('t6', 8001)):
-            L.cdll.fami_conv_tune_lds(knob)
+            L.cdll.fami_conv_tune_lds(-1); L.cdll.fami_conv_tune_lds(knob); L.cdll.fami_conv_tune_lds(knob + 500)
             fwd(bias); bwd()
             torch.cuda.synchronize()
             ef = ((y.double() - ref).abs().max() / ref.abs().max()).item()
@@ -43,12 +43,16 @@ for DT in ('bf16', 'f16'):
         print('   t6 vs t4 max |diff| fwd %.3e dgrad %.3e' % ((out['t4'][0].float() - out['t6'][0].float()).abs().max().item(),
                                                            (out['t4'][1].float() - out['t6'][1].float()).abs().max().item()))
         res = []
-        L.cdll.fami_conv_tune_lds(8000); res.append(('t4', timeit(fwd), timeit(bwd)))
-        L.cdll.fami_conv_tune_lds(8001); res.append(('t6', timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(8000); L.cdll.fami_conv_tune_lds(8500); res.append(('t4', timeit(fwd), timeit(bwd)))
+        L.cdll.fami_conv_tune_lds(-1); res.append(('t6/t7', timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(8201); res.append(('t6/MT1', timeit(fwd), timeit(bwd))); L.cdll.fami_conv_tune_lds(8200)
         for rb in (2, 4, 6, 8, 12):
-            if rb <= H:
-                L.cdll.fami_conv_tune_lds(8100 + rb); res.append(('t6/RB%d' % rb, timeit(fwd), timeit(bwd)))
+            if rb <= H and H % rb == 0:
+                L.cdll.fami_conv_tune_lds((8100 if Ci == 48 else 8600) + rb); res.append(('RB%d' % rb, timeit(fwd), timeit(bwd)))
+        if Ci != 48:
+            L.cdll.fami_conv_tune_lds(-1)
+            for tg in (60, 80, 160, 240):
+                L.cdll.fami_conv_tune_lds(8700 + tg); res.append(('tg%d' % tg, timeit(fwd), timeit(bwd)))
         L.cdll.fami_conv_tune_lds(-1)
         gf = 2.0 * N * H * W * Ci * Co * 9 / 1e9
         print('   %.2f GFLOP | ' % gf + ' | '.join('%s %.1f/%.1f' % r for r in res), flush=True)
