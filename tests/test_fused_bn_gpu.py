@@ -157,6 +157,13 @@ def test_bn_relu_applied_while_the_next_conv_stages_its_input(dev, shape, dt):
                 m.running_mean.normal_(0, 0.2)
     x = torch.randn(N, C, H, W) + 0.5
     gy = torch.randn(N, 8, (H + 1) // 2, (W + 1) // 2)
+    if dt != 'f32':
+        # late round 4: the DMA-staged kernels (conv_t6.hip) take a materialised input, and where they are eligible the engine
+        # does not ask for the consumer-side transform; this test holds the transform on the band kernels (conv_t4.hip, conv_wg16.hip),
+        # which stay the route of every shape the DMA kernels do not take.  (The autouse fixture restores the knobs.)
+        lib().cdll.fami_conv_tune_lds(8000)
+        lib().cdll.fami_conv_tune_lds(8500)
+        lib().cdll.fami_conv_tune_wgrad_lds(23000)
     assert (lib().cdll.fami_conv2d_xbn_ok_f32 if dt == 'f32' else lib().cdll.fami_conv2d_xbn_ok)(N, H, W, C, C) == 1
     lazy, nl = _run(dev, ref, x, gy, DT[dt], True, xbn=True, fuse_bwd=False)
     mat, nm = _run(dev, ref, x, gy, DT[dt], True, xbn=False, fuse_bwd=False)
