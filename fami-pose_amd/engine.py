@@ -98,6 +98,10 @@ class Engine:
         self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
+        self._wstream2 = None      # second weight-gradient stream (wlane_pair scopes: the stem / layer1 / transition stretch)
+        self._wflip = False
+        self.wlane_pair = False
+        self.stem_wlanes = int(os.environ.get('FAMI_STEM_WGRAD_LANES', '1'))      # 2: measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38): the stretch is bandwidth-contended, not lane-bound
         self._wdirty = False
         # ... but for the HEAD it pays (FAMI_HEAD_WGRAD_LANE, default 1): between the first DCN forward and the last DCN backward
         # the step is one serial chain of kernels (rocprof trace: 3.5 ms with exactly one kernel in flight), and the weight
@@ -203,36 +207,61 @@ class Engine:
     def _lane_stream(self):
         return self._main if self.lane == 0 else self._side[self.lane - 1]
 
-    def _enter_wlane(self):
-        """Route the following calls to the weight-gradient stream, ordered after the current lane's work so far."""
+    def _new_wstream(self, extra=()):
+        # same aliasing hazard as _lanes(): torch hands streams out of a 32-entry round-robin pool, so a cached stream can BE this
+        # step's main / capture stream or one of its side lanes -- re-pick until distinct
+        taken = {self._main.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])} | set(extra)
+        ws, tries = None, 0
+        while (ws is None or ws.cuda_stream in taken) and tries < 64:
+            ws = torch.cuda.Stream(self.dev)
+            tries += 1
+        if ws.cuda_stream in taken:
+            raise RuntimeError('could not obtain a distinct weight-gradient stream')
+        return ws
+
+    def _enter_wlane(self, pair=False):
+        """Route the following calls to a weight-gradient stream, ordered after the current lane's work so far.  Inside a
+        wlane_pair scope (HRNetBody: stem, layer1, transitions -- a serial chain whose weight gradients read tensors of up to
+        70 MB and run at a fifth of the HBM rate each) two such streams take the launches alternately: in the kernel trace of
+        the bf16 step the single stream was the critical path of the last 0.4 ms of the backward pass."""
         if self._wstream is None:
-            # same aliasing hazard as _lanes(): torch hands streams out of a 32-entry round-robin pool, so the cached
-            # stream can BE this step's main / capture stream or one of its side lanes -- re-pick until distinct
             taken = {self._main.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])}
             ws = Engine._wgrad_pool.get(self.dev)
-            tries = 0
-            while (ws is None or ws.cuda_stream in taken) and tries < 64:
-                ws = torch.cuda.Stream(self.dev)
-                tries += 1
-            if ws.cuda_stream in taken:
-                raise RuntimeError('could not obtain a distinct weight-gradient stream')
+            if ws is None or ws.cuda_stream in taken:
+                ws = self._new_wstream()
             Engine._wgrad_pool[self.dev] = ws
             self._wstream = ws
+        target = self._wstream
+        if pair and self.stem_wlanes >= 2:
+            if self._wstream2 is None:
+                ws2 = Engine._wgrad_pool.get((self.dev, 2))
+                taken = {self._main.cuda_stream, self._wstream.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])}
+                if ws2 is None or ws2.cuda_stream in taken:
+                    ws2 = self._new_wstream((self._wstream.cuda_stream,))
+                Engine._wgrad_pool[(self.dev, 2)] = ws2
+                self._wstream2 = ws2
+            self._wflip = not self._wflip
+            if self._wflip:
+                target = self._wstream2
+                self._wdirty2 = True
         ev = torch.cuda.Event()
         ev.record(self._lane_stream())
-        self._wstream.wait_event(ev)
+        target.wait_event(ev)
         saved = self.stream
-        self.stream = self._wstream.cuda_stream
+        self.stream = target.cuda_stream
         self._wdirty = True
         return saved
 
     def sync_wgrad_lane(self):
         """Lane 0 continues after every weight-gradient kernel enqueued so far (before an all-reduce / the optimizer)."""
         if self._wdirty:
-            self.flush_reduces(self._wstream.cuda_stream)
-            ev = torch.cuda.Event()
-            ev.record(self._wstream)
-            self._main.wait_event(ev)
+            for ws in (self._wstream, self._wstream2):
+                if ws is None:
+                    continue
+                self.flush_reduces(ws.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(ws)
+                self._main.wait_event(ev)
             self._wdirty = False
 
     def side_launch(self, fn):
@@ -645,6 +674,7 @@ class Engine:
         need_w = self.rq(weight) or self.rq(bias)
         out = T(y, x.requires_grad or need_w)
         wl = self.wlane_scope and self.head_wlane
+        wpair = self.wlane_pair            # (captured now: the backward closure runs long after the scope has closed)
         fuse_here = self.bn2 and self.serial_scope and self.serial_fuse     # see serial_scope in __init__
         if out.requires_grad:
             assert not relu, "fused relu epilogue is forward-only"
@@ -654,7 +684,7 @@ class Engine:
                 if out.grad is None:
                     return
                 dy = out.grad
-                saved = self._enter_wlane() if ((self.use_wlane or wl) and need_w) else None
+                saved = self._enter_wlane(wpair) if ((self.use_wlane or wl) and need_w) else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     self.wgrad(x.data, dy, g, geo, acc,

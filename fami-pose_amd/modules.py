@@ -230,12 +230,14 @@ class HRNetBody(nn.Module):
         """x: engine tensor [N,H,W,3] -> (heatmap T [N,H/4,W/4,J], stage-4 outputs, pre-stage-4 inputs)."""
         outer = eng.wlane_scope
         eng.wlane_scope = outer or eng.stem_wlane     # serial chain: weight gradients on their own lane (Engine.__init__)
+        eng.wlane_pair = True                         # ... on two of them, alternately (Engine._enter_wlane)
         eng.serial_scope = True                       # ... and BatchNorm backward statistics in the dgrad epilogues
         x = eng.conv_bn(x, self.conv1, self.bn1, relu=True)
         x = eng.conv_bn(x, self.conv2, self.bn2, relu=True)
         for blk in self.layer1:
             x = blk.run(eng, x)
         eng.wlane_scope = outer
+        eng.wlane_pair = False
         eng.serial_scope = False
         ys = [x]
         stage4_in = None
@@ -245,6 +247,7 @@ class HRNetBody(nn.Module):
             tr = getattr(self, 'transition%d' % (s - 1))
             xs = []
             eng.wlane_scope = outer or eng.stem_wlane
+            eng.wlane_pair = True
             for i in range(self.stage_branches[s]):
                 if tr[i] is None:
                     xs.append(ys[i])
@@ -257,6 +260,7 @@ class HRNetBody(nn.Module):
                         z = run_cbr(eng, tr[i], z)
                     xs.append(z)
             eng.wlane_scope = outer
+            eng.wlane_pair = False
             ys = xs
             for mi, mod in enumerate(getattr(self, 'stage%d' % s)):
                 ys = mod.run_branches(eng, ys)
