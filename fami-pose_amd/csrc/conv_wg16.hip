@@ -588,6 +588,155 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
   return q;
 }
 
+// ------------------------------------------------------------------ 1x1 weight gradient of the wide layers ("wg1", round 4)
+// dW[ci][co] = sum_p X[p][ci] dY[p][co] for the 1x1 convolutions of stage 1 (64 <-> 256 channels @96x72, 20 frames: operands of
+// 17.7 and 70.8 MB in bf16).  conv_wgrad16_kernel excludes them by a measured rule and the scalar-operand kernel they fell back to
+// takes 65-82 us per launch alone (87-123 us in the step's tail, where it is the busiest thing on the weight-gradient stream)
+// against an HBM floor of 7-18 us.  A 1x1 convolution has no spatial structure: the pixels are one flat axis, a unit is 288 of
+// them (nine K steps), a workgroup owns a 64 x 64 channel block and a run of consecutive units, and a unit's X slice and dY
+// slice (128 bytes per pixel each) are copied by LDS DMA into one of two buffers while the previous unit is multiplied --
+// conv_wgrad6_kernel's pipeline without the patch.  Wave w owns input tile w / 2 and output tiles 2 (w % 2), + 1.
+struct Wg1Args {
+  const void* x;    // [P][Ci]
+  const void* dy;   // [P][Co]
+  float* part;      // [G][Ci][Co]
+  long P;
+  int Ci, Co, coBlocks;
+  int nunits, NU;   // units per workgroup, units in total (ceil(P / 288))
+};
+#define WG1_M 288
+#define WG1_I 36      // DMA instructions (1 KiB) per operand and unit: 288 pixels x 128 bytes
+
+template <typename H>
+__global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad1_kernel(Wg1Args p) {
+  typedef typename H16<H>::x8 hx8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PS = 128, KS = WG1_M / 32, XB = WG1_I * 1024, BUFSZ = 2 * WG1_I * 1024, PJ = (WG1_I + WG16_WAVES - 1) / WG16_WAVES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int rsel = l16 >> 2, piece = l16 & 3;
+  int job;
+  {
+    const int n = gridDim.x, lin = blockIdx.x;
+    const int q = n >> 3, r = n & 7, xc = lin & 7, l = lin >> 3;
+    job = xc * q + (xc < r ? xc : r) + l;
+  }
+  const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
+  const int u0 = job * p.nunits;
+  const int nunits = min(p.nunits, p.NU - u0);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  // operands past 2 GiB: the buffer descriptor is rebased per unit (a unit is 288 pixels: its offsets stay small)
+  // DMA plan: granule q of a unit -> (pixel, 16-byte piece of the 128-byte slice)
+  int xo[PJ], yo[PJ], pixj[PJ];
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) {
+    const int q = (wave + WG16_WAVES * j) * 64 + lane;
+    const int pix = q >> 3, c = q & 7;
+    pixj[j] = pix;
+    xo[j] = (pix * p.Ci + cib * 64 + c * 8) * 2;
+    yo[j] = (pix * p.Co + cob * 64 + c * 8) * 2;
+  }
+  auto dma_piece = [&](int ug, unsigned buf, int k) {      // k < PJ: X, else dY
+    const long p0 = (long)ug * WG1_M;
+    const long left = p.P - p0;                              // pixels from the unit's first to the tensor's end
+    const int j = k < PJ ? k : k - PJ;
+    const int i = wave + WG16_WAVES * j;
+    if (i < WG1_I) {
+      if (k < PJ) {
+        const wg6_i32x4 rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + p0 * p.Ci * 2, WG1_M * p.Ci * 2);
+        wg6_dma16(rx, pixj[j] < left ? (unsigned)xo[j] : 0x80000000u, buf + i * 1024);
+      } else {
+        const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + p0 * p.Co * 2, WG1_M * p.Co * 2);
+        wg6_dma16(ry, pixj[j] < left ? (unsigned)yo[j] : 0x80000000u, buf + XB + i * 1024);
+      }
+    }
+  };
+  if (nunits > 0) {
+#pragma unroll
+    for (int k = 0; k < 2 * PJ; ++k) dma_piece(u0, lds0, k);
+  }
+  const int cit = wave >> 1, cot0 = (wave & 1) * 2;
+  f32x4 acc[2];
+  acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's two pixels of K step 0 (local index pl = ks*32 + kq*4 + h*16 + rsel, conv_wgrad16_kernel's map)
+  const int pl0 = kq * 4 + rsel;
+  const int xa0 = pl0 * PS + cit * 32 + piece * 8, ya0 = XB + pl0 * PS + cot0 * 32 + piece * 8;
+
+  for (int u = 0; u < nunits; ++u) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of unit u has landed
+    __builtin_amdgcn_s_barrier();         // ... everybody's, and every wave has left unit u - 1
+    asm volatile("" ::: "memory");
+    const bool more = u + 1 < nunits;
+    const unsigned nbuf = lds0 + ((u + 1) & 1) * BUFSZ;
+    const char* xt = smem + (u & 1) * BUFSZ;
+    hx8 afr[2], bfr[2][2];
+    auto load = [&](int ks, int set) {
+      const char* xp = xt + xa0 + ks * 32 * PS;
+      const char* yp = xt + ya0 + ks * 32 * PS;
+      {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xp));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xp + 16 * PS));
+        afr[set] = frag_of<hx8>(lo, hi);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yp + c * 32));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yp + 16 * PS + c * 32));
+        bfr[set][c] = frag_of<hx8>(lo, hi);
+      }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) load(ks + 1, (ks + 1) & 1);
+      if (more) {
+        dma_piece(u0 + u + 1, nbuf, ks);                   // (KS = 9 <= 2 PJ = 10)
+        if (ks == KS - 1) {
+#pragma unroll
+          for (int k = KS; k < 2 * PJ; ++k) dma_piece(u0 + u + 1, nbuf, k);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[c] = H16<H>::mfma(afr[ks & 1], bfr[ks & 1][c], acc[c]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // D row = kq*4 + r (ci), col = l16 (co)  ->  slab [job][ci][co]
+  float* slab = p.part + (long)job * p.Ci * p.Co;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int co = cob * 64 + (cot0 + c) * 16 + l16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = cib * 64 + cit * 16 + kq * 4 + r;
+      slab[(long)ci * p.Co + co] = acc[c][r];
+    }
+  }
+}
+
+struct Wg1Plan { int ok, nunits, G, blocks; long NU; };
+static int g_wg1 = 1, g_wg1_target = 192;     // inside the bf16 step (tools/ab_env.py): 48 / 96 / 192 workgroups 22.63 / 22.54 / 22.45 ms against 22.96 without the kernel      // fami_conv_tune_wgrad_lds(24000 / 24001): off / on; 24100 + n: workgroup target
+static Wg1Plan wg1_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
+  Wg1Plan q;
+  q.ok = 0;
+  if (!g_wg1 || k != 1 || st != 1 || pad != 0 || (Ci % 64) != 0 || (Co % 64) != 0) return q;
+  const long P = (long)N * H * W;
+  q.blocks = (Ci / 64) * (Co / 64);
+  q.NU = (P + WG1_M - 1) / WG1_M;
+  // the layers this kernel is for: large pixel counts (the fuse-layer 1x1 convolutions of the low-resolution maps stay on
+  // conv_wgrad16_kernel, 14 us per launch)
+  if (P < 65536) return q;
+  long nu = (q.NU * q.blocks + g_wg1_target - 1) / g_wg1_target;
+  if (nu < 1) nu = 1;
+  if (nu > q.NU) nu = q.NU;
+  q.nunits = (int)nu;
+  q.G = (int)((q.NU + nu - 1) / nu);
+  q.ok = q.G < 65536 && q.blocks < 65536 && (long)WG1_M * Ci * 2 < (1L << 31) && (long)WG1_M * Co * 2 < (1L << 31);
+  return q;
+}
+
 // ------------------------------------------------------------------ host side
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
@@ -660,8 +809,11 @@ static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, in
 long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);      // (workspace sizing: whichever kernel takes the launch)
-  const long g = q.ok ? q.G : 0, g6 = q6.ok ? q6.G : 0;
-  return g > g6 ? g : g6;
+  const Wg1Plan q1 = wg1_plan(N, H, W, Ci, Co, k, st, pad, dil);
+  long g = q.ok ? q.G : 0;
+  if (q6.ok && q6.G > g) g = q6.G;
+  if (q1.ok && q1.G > g) g = q1.G;
+  return g;
 }
 
 template <typename HT>
@@ -700,6 +852,28 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
                      int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn) {
   if (!xbn.on && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+    const Wg1Plan q1 = wg1_plan(N, H, W, Ci, Co, k, st, pad, dil);
+    if (q1.ok && ws_bytes >= (long)q1.G * Ci * Co * (long)sizeof(float)) {
+      Wg1Args a;
+      a.x = x; a.dy = dy; a.part = part; a.P = (long)N * H * W; a.Ci = Ci; a.Co = Co; a.coBlocks = Co / 64;
+      a.nunits = q1.nunits; a.NU = (int)q1.NU;
+      static bool attr1 = false;
+      if (!attr1) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad1_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad1_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr1 = true;
+      }
+      const dim3 grid1(q1.G, q1.blocks);
+      const size_t lds1 = (size_t)4 * WG1_I * 1024;
+      if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad1_kernel<f16_t>), grid1, dim3(WG16_THREADS), lds1, s, a);
+      else hipLaunchKernelGGL((conv_wgrad1_kernel<bf16_t>), grid1, dim3(WG16_THREADS), lds1, s, a);
+      hipError_t err1 = hipGetLastError();
+      if (err1 != hipSuccess) {
+        fami_set_error(name, hipGetErrorString(err1));
+        return FAMI_EHIP;
+      }
+      return q1.G;
+    }
     const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);
     if (q6.ok && ws_bytes >= (long)q6.G * 9 * Ci * Co * (long)sizeof(float)) {
       Wg6Args a;
@@ -752,7 +926,9 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_nu = 0; g_wg6_target = 80; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
+  else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
   else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
   else if (on >= 3100 && on < 3400) g_wg6_nu = on - 3100;        // (23100 + units per workgroup)
   else if (on >= 3400 && on < 4000) g_wg6_target = on - 3400;    // (23400 + workgroup target)

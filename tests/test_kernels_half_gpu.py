@@ -303,3 +303,40 @@ def test_dma_staged_weight_gradient(dev, half):
             assert relerr(out[23001], out[23000].double()) < 2e-6
     finally:
         L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
+def test_dma_staged_wide_1x1_weight_gradient(dev, half):
+    """conv_wgrad1_kernel (conv_wg16.hip, round 4): the 1x1 weight gradients of stage 1 (64 <-> 256 channels on the full-resolution
+    map) in 64 x 64 channel blocks over the flat pixel axis, units of 288 pixels copied by LDS DMA (the last unit padded with
+    out-of-range = zero granules).  Against fp64 on the same 16-bit operands and against the kernel it replaces."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W, Ci, Co, tg) in enumerate([(20, 96, 72, 64, 256, 0), (20, 96, 72, 256, 64, 0), (20, 96, 72, 64, 64, 0), (7, 101, 97, 128, 64, 7),
+                                                    (9, 96, 80, 64, 128, 500)]):
+            torch.manual_seed(it)
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)
+            geo = (N, H, W, Ci, Co, 1, 1, 1, 0, 1)
+            nb = L.cdll.fami_conv2d_wgrad_workspace(*geo)
+            ws = torch.empty(nb // 4 + 4, device=dev)
+            ref = (dy.double().reshape(-1, Co).t() @ x.double().reshape(-1, Ci)).reshape(Co, Ci, 1, 1)
+            dw0 = torch.randn(Co, Ci, 1, 1, device=dev)
+            out = {}
+            for code in (24000, 24001):
+                L.cdll.fami_conv_tune_wgrad_lds(-1)
+                L.cdll.fami_conv_tune_wgrad_lds(code)
+                if code == 24001 and tg:
+                    L.cdll.fami_conv_tune_wgrad_lds(24100 + tg)
+                dw, dwa = torch.empty(Co, Ci, 1, 1, device=dev), dw0.clone()
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, 0, st)
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dwa), p(ws), ws.numel() * 4, *geo, 1, st)
+                torch.cuda.synchronize(dev)
+                assert relerr(dw, ref) < 3e-6 and relerr(dwa - dw0, ref) < 3e-5, (it, code, relerr(dw, ref))
+                out[code] = dw
+            assert relerr(out[24001], out[24000].double()) < 3e-6
+    finally:
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
