@@ -334,20 +334,22 @@ struct Wg6Args {
   int nunits;       // units per workgroup (consecutive, frame-major)
   int NU;           // units in total (N * upf)
   int coBlocks;
-  int PW, RG;       // W + 2, 16-byte granules per patch row (6 PW: a 48-channel slice)
+  int PW, RG;       // W + 2, 16-byte granules per patch row (2 CIT PW: the block's channel slice)
   int q512, r512;   // 512 / RG, 512 % RG
   int dyq, dxr;     // 32 / W, 32 % W
   int XI, YI;       // DMA instructions (1 KiB) of a unit's patch / dY rows
   long long* dbg;   // FAMI_WG6_TRACE builds: s_memtime stamps of one workgroup
 };
-#define WG6_XJ 6      // most patch DMA instructions per wave and unit (XI <= 48)
+#define WG6_XJ 7      // most patch DMA instructions per wave and unit (XI <= 56)
 #define WG6_YJ 4      // ... dY (YI <= 32)
 
-template <typename H, int KS>      // KS: K steps of 32 pixels per unit (ceil(M / 32): the dY rows past M are zeros)
+// KS: K steps of 32 pixels per unit (ceil(M / 32): the dY rows past M are zeros); CIT x COT: 16-channel tiles of the workgroup's
+// channel block (3 x 3: the HRNet branches; 4 x 4 / 4 x 3: the 64-channel 3x3 convolutions of stage 1 and the 256 -> 48 transition)
+template <typename H, int KS, int CIT, int COT>
 __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p) {
   typedef typename H16<H>::x8 hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CIT = 3, COT = 3, TAPS = 9, NPW = 4, PS = 96;
+  constexpr int TAPS = 9, NPW = (CIT * TAPS + WG16_WAVES - 1) / WG16_WAVES, PS = 32 * CIT, PSY = 32 * COT, GX = 2 * CIT, GY = 2 * COT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, kq = lane >> 4;
@@ -382,10 +384,10 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     int r = q0 / p.RG, wi = q0 - r * p.RG;
 #pragma unroll
     for (int j = 0; j < WG6_XJ; ++j) {
-      const int pos = wi / 6, c = wi - pos * 6;
+      const int pos = wi / GX, c = wi - pos * GX;
       const bool ok = r < p.UR + 2 && pos >= 1 && pos <= W;
       xrow[j] = ok ? r : 0x40000000;                  // never a valid image row
-      xoff[j] = ((r * W + pos - 1) * p.Ci + cib * 48 + c * 8) * 2;
+      xoff[j] = ((r * W + pos - 1) * p.Ci + cib * (16 * CIT) + c * 8) * 2;
       r += p.q512;
       wi += p.r512;
       if (wi >= p.RG) {
@@ -396,8 +398,8 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
     for (int j = 0; j < WG6_YJ; ++j) {
       const int q = (wave + WG16_WAVES * j) * 64 + lane;
-      const int pix = q / 6, c = q - pix * 6;
-      yoff[j] = pix < p.M ? (pix * p.Co + cob * 48 + c * 8) * 2 : (int)0x80000000;
+      const int pix = q / GY, c = q - pix * GY;
+      yoff[j] = pix < p.M ? (pix * p.Co + cob * (16 * COT) + c * 8) * 2 : (int)0x80000000;
     }
   }
   // piece k of a unit's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       pl[h] = kq * 4 + h * 16 + rsel;
       py[h] = py0[h];
       pxx[h] = px0[h];
-      ya[h] = XB + pl[h] * PS + piece * 8;
+      ya[h] = XB + pl[h] * PSY + piece * 8;
     }
     // Two fragment sets: step ks + 1 is requested (and one piece of unit u + 1's copy issued) before step ks is multiplied;
     // the loop is unrolled and the scheduler fenced, so the order below is the order in the ISA.
@@ -501,8 +503,8 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
           s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xt + xb[1] + poff[i]));
           afr[set][i] = frag_of<hx8>(lo, hi);
         }
-        ya[0] += 32 * PS;
-        ya[1] += 32 * PS;
+        ya[0] += 32 * PSY;
+        ya[1] += 32 * PSY;
       };
       load(0);
 #pragma unroll
@@ -535,10 +537,10 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     if (ptap[i] < 0) continue;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
-      const int co = cob * 48 + c * 16 + l16;
+      const int co = cob * (16 * COT) + c * 16 + l16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ci = cib * 48 + pci[i] * 16 + kq * 4 + r;
+        const int ci = cib * (16 * CIT) + pci[i] * 16 + kq * 4 + r;
         slab[((long)ptap[i] * p.Ci + ci) * p.Co + co] = acc[i][c][r];
       }
     }
@@ -548,32 +550,33 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 
 static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
-struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks; size_t lds; };
+struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT; size_t lds; };
+static int g_wg6_c4 = 1;      // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
 static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
   q.ok = 0;
-  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1 || (Ci % 48) != 0 || (Co % 48) != 0) return q;
-  // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple
+  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1) return q;
+  q.CIT = Ci % 48 == 0 ? 3 : (Ci % 64 == 0 ? 4 : 0);
+  q.COT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  if (!q.CIT || !q.COT || (q.CIT == 3 && q.COT == 4) || (q.CIT == 4 && !g_wg6_c4)) return q;       // (3 x 4 is not instantiated: no layer of the path has it)
+  // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple, two buffers in the LDS
+  const int RG = (W + 2) * 2 * q.CIT;
   q.UR = 0;
   for (int ur = H; ur >= 1; --ur) {
     if (H % ur != 0 || ur * W > 288) continue;
-    q.UR = ur;
+    const int M = ur * W, KS = (M + 31) / 32;
+    if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
+    if (q.CIT == 4 && KS != 5) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
+    const int XI = ((ur + 2) * RG + 63) / 64, YI = KS * q.COT;
+    if (XI > 8 * WG6_XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
+    q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI;
     break;
   }
   if (!q.UR) return q;
-  q.M = q.UR * W;
-  q.KS = (q.M + 31) / 32;
-  if (!(q.KS == 9 || q.KS == 8 || q.KS == 7 || q.KS == 5 || q.KS == 4)) return q;
-  if (q.KS * 32 - q.M > 24) return q;                // (a quarter of the last step may be padding, not more)
-  const int RG = (W + 2) * 6;
-  q.XI = ((q.UR + 2) * RG + 63) / 64;
-  q.YI = q.KS * 3;
-  if (q.XI > 8 * WG6_XJ || q.YI > 8 * WG6_YJ) return q;
   q.lds = 2 * (size_t)(q.XI + q.YI) * 1024;
-  if (q.lds > 160 * 1024) return q;
   q.upf = H / q.UR;
-  q.blocks = (Ci / 48) * (Co / 48);
+  q.blocks = (Ci / (16 * q.CIT)) * (Co / (16 * q.COT));
   const long NU = (long)N * q.upf;
   // units per workgroup: about g_wg6_target workgroups in the launch (the other stream lanes use the CUs a launch leaves, and a
   // workgroup's 83 KB partial slab -- written, then read by the reduce -- is the kernel's largest HBM item).  Alone 240 is the
@@ -878,24 +881,25 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
     if (q6.ok && ws_bytes >= (long)q6.G * 9 * Ci * Co * (long)sizeof(float)) {
       Wg6Args a;
       a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
-      a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = Co / 48;
-      a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / W; a.dxr = 32 % W;
+      a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = Co / (16 * q6.COT);
+      a.PW = W + 2; a.RG = (W + 2) * 2 * q6.CIT; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / W; a.dxr = 32 % W;
       a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
       const dim3 grid(q6.G, q6.blocks);
       bool ok6 = false;
-#define FAMI_WG6_CASE(ks)                                                                                                 \
-  if (q6.KS == ks) {                                                                                                      \
+#define FAMI_WG6_CASE(ks, cit, cot)                                                                                       \
+  if (q6.KS == ks && q6.CIT == cit && q6.COT == cot) {                                                                    \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, ks>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, ks>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, ks, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, ks, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, ks>), grid, dim3(WG16_THREADS), q6.lds, s, a);      \
-    else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, ks>), grid, dim3(WG16_THREADS), q6.lds, s, a);                    \
+    if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, ks, cit, cot>), grid, dim3(WG16_THREADS), q6.lds, s, a);      \
+    else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, ks, cit, cot>), grid, dim3(WG16_THREADS), q6.lds, s, a);                    \
     ok6 = true;                                                                                                           \
   }
-      FAMI_WG6_CASE(9) FAMI_WG6_CASE(8) FAMI_WG6_CASE(7) FAMI_WG6_CASE(5) FAMI_WG6_CASE(4)
+      FAMI_WG6_CASE(9, 3, 3) FAMI_WG6_CASE(8, 3, 3) FAMI_WG6_CASE(7, 3, 3) FAMI_WG6_CASE(5, 3, 3) FAMI_WG6_CASE(4, 3, 3)
+      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3)
 #undef FAMI_WG6_CASE
       if (ok6) {
         hipError_t err6 = hipGetLastError();
@@ -926,9 +930,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
+  else if (on == 3002 || on == 3003) g_wg6_c4 = on - 3002;
   else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
   else if (on >= 3100 && on < 3400) g_wg6_nu = on - 3100;        // (23100 + units per workgroup)
   else if (on >= 3400 && on < 4000) g_wg6_target = on - 3400;    // (23400 + workgroup target)

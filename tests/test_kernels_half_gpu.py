@@ -277,7 +277,9 @@ def test_dma_staged_weight_gradient(dev, half):
     try:
         for it, (N, H, W, Ci, Co, nu) in enumerate([(20, 96, 72, 48, 48, 0), (4, 96, 72, 48, 48, 0), (20, 48, 36, 96, 96, 0), (20, 24, 18, 192, 192, 0),
                                                     (20, 12, 9, 384, 384, 0), (3, 8, 64, 48, 48, 0), (2, 12, 72, 48, 96, 1), (2, 24, 72, 96, 48, 2),
-                                                    (3, 24, 18, 48, 144, 5), (2, 96, 72, 48, 48, 48), (5, 16, 72, 48, 48, 3), (3, 12, 9, 96, 48, 2)]):
+                                                    (3, 24, 18, 48, 144, 5), (2, 96, 72, 48, 48, 48), (5, 16, 72, 48, 48, 3), (3, 12, 9, 96, 48, 2),
+                                                    # 64-channel blocks (stage 1, the 256 -> 48 transition): units of two rows, five K steps
+                                                    (20, 96, 72, 64, 64, 0), (4, 96, 72, 256, 48, 0), (2, 24, 72, 128, 64, 3)]):
             torch.manual_seed(it)
             x = torch.randn(N, H, W, Ci, device=dev).to(BF)
             dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)
