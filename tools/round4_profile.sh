@@ -14,6 +14,9 @@ for w in conv_f32 conv_bf16 dcn_f32 dcn_bf16 dcnbwd_f32 dcnbwd_bf16; do
   rm -rf $out/pmc_$w        # keep the summaries, not the raw csv trees
 done
 python tools/bench_t5.py > $out/bench_t5.txt 2>&1
+python tools/bench_t6.py > $out/bench_t6.txt 2>&1
+python tools/bench_wg6.py > $out/bench_wg6.txt 2>&1
+python tools/bench_layer1.py > $out/bench_layer1.txt 2>&1
 python tools/bench_t4.py > $out/bench_t4_bf16.txt 2>&1
 python tools/phase_times.py bf16 > $out/phase_times.txt 2>&1; python tools/phase_times.py f32 >> $out/phase_times.txt 2>&1
 grep -v amdgpu $out/phase_times.txt | tail -14

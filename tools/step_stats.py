@@ -10,7 +10,7 @@ import gzip, json, pickle, sys, collections
 NSTEPS = 3      # replayed steps aggregated
 # the 3x3 convolution of the 96x72 map with a 48-channel block, N = 20 frames (name substring; grid threads)
 DOMINANT = {'f32': [('conv3x3_t5_kernel<float', 122880), ('conv3x3_t4_kernel<float, 3, 7, true, 8, 3', 184320)],
-            'bf16': [('conv3x3_t4_kernelIDF16b', 368640), ('conv3x3_t4_kernel', 368640)]}
+            'bf16': [('conv3x3_t6_kernel', 122880), ('conv3x3_t4_kernelIDF16b', 368640), ('conv3x3_t4_kernel', 368640)]}
 tag, prefix = sys.argv[1], sys.argv[2]
 out = {}
 for arg in sys.argv[3:]:
