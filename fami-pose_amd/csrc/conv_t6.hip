@@ -10,18 +10,25 @@
 //     per tile and channel tile instead of 18); a lane quarter (kq) of one MFMA may sit on a different tap than its
 //     neighbour -- the per-lane LDS offset koff[k] carries tap shift and channel granule together;
 //   * the whole weight image of the job's 48 output channels (42 KiB) is LDS-RESIDENT, gathered by DMA
-//     (global_load_lds_dwordx4, per-lane source addresses into the packed fragment image) in the dense order;
+//     (buffer_load_dwordx4 ... lds, per-lane source offsets into the packed fragment image) in the dense order;
 //   * a workgroup owns a band of RB whole rows of one frame; its patch (RB + 2 rows, zero border columns, 96-byte
 //     positions, unpadded: conflict-free for ds_read_b128, see below) is ONE contiguous LDS region filled by DMA too --
-//     border and out-of-image granules are copied from a 16-byte zero constant, so there is no store phase, no VGPR
-//     staging and no zeroing; every DMA of the job is issued up front, in the order the units need it;
-//   * the band is multiplied in UNITS of two rows (144 pixels = 9 tiles at W = 72): unit 0 waits for rows 0-3 + the
-//     weights (s_waitcnt vmcnt(n) on the wave's own queue, then a barrier), unit 1 for rows 4-5, unit 2 for the rest;
-//     later units need no barrier at all;
-//   * wave w owns tile w (all three channel tiles); the ninth tile's three channel tiles go to waves 0-2: per SIMD
-//     (waves s, s + 4) 7 / 7 / 7 / 6 (tile, channel tile) pairs;
-//   * a unit's results are written while the NEXT unit is multiplied (after its barrier), so no store sits in front of
-//     a vmcnt wait.
+//     border and out-of-image granules carry an out-of-range buffer offset (the buffer unit writes zeros), so there is no
+//     store phase, no VGPR staging and no zeroing;
+//   * the band is multiplied in UNITS of four rows (288 pixels = 18 tiles at W = 72; two rows where the band is not a multiple of
+//     four): the weight slab and the rows of unit 0 are requested at the top of the kernel, the rows of unit u + 1 behind the
+//     barrier that opens unit u; a unit opens with s_waitcnt vmcnt(0) on the wave's own queue + one barrier;
+//   * wave w owns tiles w and w + 8 (all three channel tiles); the remaining two tiles' six (tile, channel tile) pairs go to
+//     waves 0-5: per SIMD (waves s, s + 4) 14 / 14 / 13 / 13 pairs;
+//   * a unit's results are written behind the NEXT unit's barrier (no store sits in front of a vmcnt wait); the fragments of
+//     K chunk k + 1 are requested before chunk k is multiplied (scheduler fenced with sched_barrier: left alone it requests
+//     a fragment one to two MFMAs ahead of its use).
+// Measured (tools/bench_t6.py, tools/trace_t6.py with -DFAMI_T6_TRACE): 48 -> 48 @96x72, 20 frames 18.0 -> 11.2 us; of a
+// workgroup's 17.5 k cycles 6.4 k pass before the first MFMA (kernel arguments, 96 KB through the CU's 64 B / clk vector-memory
+// path, the second wave of each SIMD 1.1 k cycles behind the first), the two units take 4.1 k each for 3.1 k of MFMA on the
+// busiest SIMD.  Earlier forms: two-row units with every DMA up front and counted vmcnt waits 14.5 us (LDS-read bound: three
+// weight fragments per pixel fragment), global_load_lds with a zero constant for the border instead of buffer loads 13.3 us
+// (5.7 k cycles of address arithmetic and divergent branches in front of the first wait).
 // LDS bank check, 96-byte positions (6 granules of 16 bytes), ds_read_b128 served in lane groups {0-3, 12-15, 20-27}, ...:
 // the eight lanes of one kq in a group read granules (pos0 + col) * 6 + c -> bank quads {0, 6, 12, 2, 8, 14, 4, 10} + const,
 // the eight lanes of the neighbouring kq read granule c + 1 (or granule 0 of the next tap: 6 is even) -> the odd quads:
@@ -49,25 +56,6 @@ struct ConvT6Args {
 
 #define T6_THREADS 512
 #define T6_WAVES 8
-
-__device__ __forceinline__ void t6_wait_vm(int n) {   // wave-uniform n: s_waitcnt vmcnt(n) (lgkmcnt / expcnt untouched)
-  switch (n) {
-    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
-    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
-    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
-    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
-    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
-    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
-    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
-    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
-    case 11: __builtin_amdgcn_s_waitcnt(0x0f7b); break;
-    case 12: __builtin_amdgcn_s_waitcnt(0x0f7c); break;
-    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
-  }
-}
 
 // G: 16-byte granules per pixel (Ci / 8); NT: channel tiles per workgroup; MT: own pixel tiles per wave (a unit is 2 MT rows);
 // EX: 1 if the unit has tiles past the 8 MT-th; ACC: y += result; EM: EpiBN mode (0 | 1)
@@ -641,11 +629,10 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
 // ---- plan + launch
 static int g_use_t6 = 1;        // fami_conv_tune_lds(8000 / 8001): off / on
 static int g_t6_rows = 0;       // fami_conv_tune_lds(8100 + RB): force the rows per band (benchmarks)
-static int g_t6_min_jobs = 96;
+static int g_t6_min_jobs = 96;  // fami_conv_tune_lds(8400 + n): only launches of >= n jobs
 static int g_t6_mt = 0;         // fami_conv_tune_lds(8201 / 8202): units of two / four rows (0: four where the band allows)
 static long long* g_t6_dbg = nullptr;
 extern "C" void fami_conv_t6_debug(void* buf) { g_t6_dbg = reinterpret_cast<long long*>(buf); }
-         // fami_conv_tune_lds(8200 + n): fragment sets in flight (2 .. 4)  // fami_conv_tune_lds(8400 + n): only launches of >= n jobs
 
 struct T6Plan { int ok, RB, bands, pj, TU, MT; size_t lds; };
 static T6Plan t6_plan(int N, int H, int W, int Ci, int Co) {
