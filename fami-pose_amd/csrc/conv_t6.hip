@@ -57,8 +57,34 @@ struct ConvT6Args {
 #define T6_THREADS 512
 #define T6_WAVES 8
 
+// EpiBN mode 2 on one lane's four output channels (conv_epi.h; conv_t4.hip's epilogue): v = dL/d(BN output) complete -> ReLU mask
+// (from the BN output, or recomputed from its input z exactly as the forward apply pass computes it), the masked value rounded to
+// the storage type is what gets stored; sum g and sum g * xhat are taken from the rounded values.
+template <typename H>
+__device__ __forceinline__ f32x4 t6_epi2(EpiPtr e, f32x4 v, long idx, int co0, f32x4& s, f32x4& q) {      // e: epi_late (conv_epi.h): the fields stay out of the main loop's SGPRs
+  const f32x4 zz = ld4(reinterpret_cast<const H*>(e->z) + idx);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(e->mean + co0), is = *reinterpret_cast<const f32x4*>(e->invstd + co0);
+  if (e->relu == 1) {
+    const f32x4 yy = ld4(reinterpret_cast<const H*>(e->yr) + idx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = yy[r] > 0.f ? v[r] : 0.f;
+  } else if (e->relu == 2) {
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + co0), be = *reinterpret_cast<const f32x4*>(e->beta + co0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a, b;
+      epi_scale_shift(mu[r], is[r], ga[r], be[r], a, b);
+      v[r] = __builtin_fmaf(zz[r], a, b) > 0.f ? v[r] : 0.f;
+    }
+  }
+  const f32x4 g = ld4_round<H>(v);
+  s += g;
+  q += g * ((zz - mu) * is);
+  return v;
+}
+
 // G: 16-byte granules per pixel (Ci / 8); NT: channel tiles per workgroup; MT: own pixel tiles per wave (a unit is 2 MT rows);
-// EX: 1 if the unit has tiles past the 8 MT-th; ACC: y += result; EM: EpiBN mode (0 | 1)
+// EX: 1 if the unit has tiles past the 8 MT-th; ACC: y += result; EM: EpiBN mode (0 | 1 | 2)
 template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM>
 __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p) {
   typedef typename H16<H>::x8 frag;
@@ -190,9 +216,10 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   const int wl = lane * 16, wle = lane * 16 + nte * 1024;
 
   f32x4 sv[MT][NT], sve = z4;
-  auto emit1 = [&](f32x4 v, H* yp, const f32x4& b4, const f32x4& k4, f32x4& s, f32x4& q) {
+  auto emit1 = [&](f32x4 v, H* yp, int co0, const f32x4& b4, const f32x4& k4, f32x4& s, f32x4& q) {
     v += b4;
     if (ACC) v += ld4(yp);
+    if (EM == 2) v = t6_epi2<H>(epi_late(__builtin_offsetof(ConvT6Args, e)), v, yp - reinterpret_cast<H*>(p.y), co0, s, q);
     st4(yp, v);
     if (EM == 1) {
       const f32x4 d = ld4_round<H>(v) - k4;
@@ -205,8 +232,9 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16, bias4[nt], ek[nt], es[nt], eq[nt]);
-    if (has_e) emit1(sve, yb + oex, biase, eke, ese, eqe);
+      for (int nt = 0; nt < NT; ++nt)
+        emit1(sv[m][nt], yb + oown[m] + nt * 16, (ntg0 + nt) * 16 + kq * 4, bias4[nt], ek[nt], es[nt], eq[nt]);
+    if (has_e) emit1(sve, yb + oex, (ntg0 + nte) * 16 + kq * 4, biase, eke, ese, eqe);
   };
 
   // ---- units
@@ -269,8 +297,8 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   if (nunits > 0) emit(nunits - 1);
   T6_STAMP();
 
-  // ---- EpiBN mode 1: per-channel sums of the workgroup -> fp64 slot rows
-  if (EM == 1) {
+  // ---- EpiBN: per-channel sums of the workgroup -> fp64 slot rows
+  if (EM != 0) {
     EpiPtr e = epi_late(__builtin_offsetof(ConvT6Args, e));
     __syncthreads();                                   // every wave is done with the patch
     float* ered = reinterpret_cast<float*>(patch);     // [waves][NT*32] own tiles, then [waves][32] extra pairs
@@ -309,7 +337,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
       const int eC = e->C;
       double* srow = e->slots + (long)(job % e->ns) * 2 * eC;
       unsafeAtomicAdd(srow + st * eC + co, (double)v);
-      if (st == 0 && job == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+      if (EM == 1 && st == 0 && job == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
     }
   }
 }
@@ -487,8 +515,13 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       }
     }
   };
-  auto emit1 = [&](const SV& v, H* yp) {
-    if constexpr (ACC) st4(yp, v + ld4(yp));
+  auto emit1 = [&](const SV& v, H* yp, int co0, f32x4& s, f32x4& q) {
+    if constexpr (EM == 2) {
+      f32x4 t;
+      if constexpr (ACC) t = v + ld4(yp);
+      else t = __builtin_convertvector(v, f32x4);          // (rounded once already: masking commutes with the rounding)
+      st4(yp, t6_epi2<H>(epi_late(__builtin_offsetof(ConvT7Args, e)), t, yp - reinterpret_cast<H*>(p.y), co0, s, q));
+    } else if constexpr (ACC) st4(yp, v + ld4(yp));
     else *reinterpret_cast<hx4*>(yp) = v;
   };
   auto emit = [&](int jb) {                          // the saved results of job jb
@@ -498,9 +531,9 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     for (int m = 0; m < MT; ++m)
       if (pvalid[m]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16);
+        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16, (ntg0 + nt) * 16 + kq * 4, es[nt], eq[nt]);
       }
-    if (EX && pvalide) emit1(sve, yb + oex);
+    if (EX && pvalide) emit1(sve, yb + oex, (ntg0 + nte) * 16 + kq * 4, ese, eqe);
   };
 
   // ---- (job, phase) steps: one wait + barrier each; the next step's copy is issued while this one is multiplied, across job
@@ -582,7 +615,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
   }
   if (pending >= 0) emit(pending);
 
-  if (EM == 1) {
+  if (EM != 0) {
     EpiPtr e = epi_late(__builtin_offsetof(ConvT7Args, e));
     __syncthreads();                                   // every wave is done with the buffers
     float* ered = reinterpret_cast<float*>(smem);      // [waves][NT*32] own tiles, then [waves][32] extra pairs
@@ -621,7 +654,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       const int eC = e->C;
       double* srow = e->slots + (long)(wg % e->ns) * 2 * eC;
       unsafeAtomicAdd(srow + st * eC + co, (double)v);
-      if (st == 0 && wg == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
+      if (EM == 1 && st == 0 && wg == 0) bn_slots_pivot(e->slots, eC)[co] = e->pivot_src ? e->pivot_src[co] : 0.f;
     }
   }
 }
@@ -684,10 +717,10 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
   a.q512 = 512 / a.RG; a.r512 = 512 % a.RG;
   const dim3 grid(N * q.bands, Co / 48);
   bool ok = false;
-  const bool acc_ = accumulate != 0, em1 = a.emode == 1;
+  const bool acc_ = accumulate != 0;
   const int ex_ = q.TU > 8 * q.MT ? 1 : 0;
 #define FAMI_T6_CASE(mt, ex, ac, em)                                                                                      \
-  if (!ok && q.MT == mt && ex_ == ex && acc_ == ac && em1 == (em == 1)) {                                                 \
+  if (!ok && q.MT == mt && ex_ == ex && acc_ == ac && a.emode == em) {                                                 \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
       (void)hipFuncSetAttribute((const void*)conv3x3_t6_kernel<HT, 6, 3, mt, ex, ac, em>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -696,10 +729,10 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
     hipLaunchKernelGGL((conv3x3_t6_kernel<HT, 6, 3, mt, ex, ac, em>), grid, dim3(T6_THREADS), q.lds, s, a);               \
     ok = true;                                                                                                            \
   }
-  FAMI_T6_CASE(1, 1, false, 0) FAMI_T6_CASE(1, 1, false, 1) FAMI_T6_CASE(1, 1, true, 0)
-  FAMI_T6_CASE(1, 0, false, 0) FAMI_T6_CASE(1, 0, false, 1) FAMI_T6_CASE(1, 0, true, 0)
-  FAMI_T6_CASE(2, 1, false, 0) FAMI_T6_CASE(2, 1, false, 1) FAMI_T6_CASE(2, 1, true, 0)
-  FAMI_T6_CASE(2, 0, false, 0) FAMI_T6_CASE(2, 0, false, 1) FAMI_T6_CASE(2, 0, true, 0)
+  FAMI_T6_CASE(1, 1, false, 0) FAMI_T6_CASE(1, 1, false, 1) FAMI_T6_CASE(1, 1, true, 0) FAMI_T6_CASE(1, 1, false, 2) FAMI_T6_CASE(1, 1, true, 2)
+  FAMI_T6_CASE(1, 0, false, 0) FAMI_T6_CASE(1, 0, false, 1) FAMI_T6_CASE(1, 0, true, 0) FAMI_T6_CASE(1, 0, false, 2) FAMI_T6_CASE(1, 0, true, 2)
+  FAMI_T6_CASE(2, 1, false, 0) FAMI_T6_CASE(2, 1, false, 1) FAMI_T6_CASE(2, 1, true, 0) FAMI_T6_CASE(2, 1, false, 2) FAMI_T6_CASE(2, 1, true, 2)
+  FAMI_T6_CASE(2, 0, false, 0) FAMI_T6_CASE(2, 0, false, 1) FAMI_T6_CASE(2, 0, true, 0) FAMI_T6_CASE(2, 0, false, 2) FAMI_T6_CASE(2, 0, true, 2)
 #undef FAMI_T6_CASE
   if (!ok) return 0;
   return 1;
@@ -761,9 +794,9 @@ static int t7_launch(const T7Plan& q, const void* x, const void* wp, const float
   a.nph = Ci / 48; a.TU = q.TU; a.npix = q.RB * W; a.REMP = q.TU > 8 * q.MT ? (q.TU - 8 * q.MT) * 3 : 0; a.PI = q.PI; a.jpw = q.jpw;
   const dim3 grid(q.G, Co / 48);
   bool ok = false;
-  const bool acc_ = accumulate != 0, em1 = a.emode == 1;
+  const bool acc_ = accumulate != 0;
 #define FAMI_T7_CASE(mt, ex, ac, em)                                                                                      \
-  if (!ok && q.MT == mt && q.EX == ex && acc_ == ac && em1 == (em == 1)) {                                                \
+  if (!ok && q.MT == mt && q.EX == ex && acc_ == ac && a.emode == em) {                                                \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
       (void)hipFuncSetAttribute((const void*)conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -772,10 +805,10 @@ static int t7_launch(const T7Plan& q, const void* x, const void* wp, const float
     hipLaunchKernelGGL((conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>), grid, dim3(T6_THREADS), q.lds, s, a);                  \
     ok = true;                                                                                                            \
   }
-  FAMI_T7_CASE(1, 1, false, 0) FAMI_T7_CASE(1, 1, false, 1) FAMI_T7_CASE(1, 1, true, 0)
-  FAMI_T7_CASE(1, 0, false, 0) FAMI_T7_CASE(1, 0, false, 1) FAMI_T7_CASE(1, 0, true, 0)
-  FAMI_T7_CASE(2, 1, false, 0) FAMI_T7_CASE(2, 1, false, 1) FAMI_T7_CASE(2, 1, true, 0)
-  FAMI_T7_CASE(2, 0, false, 0) FAMI_T7_CASE(2, 0, false, 1) FAMI_T7_CASE(2, 0, true, 0)
+  FAMI_T7_CASE(1, 1, false, 0) FAMI_T7_CASE(1, 1, false, 1) FAMI_T7_CASE(1, 1, true, 0) FAMI_T7_CASE(1, 1, false, 2) FAMI_T7_CASE(1, 1, true, 2)
+  FAMI_T7_CASE(1, 0, false, 0) FAMI_T7_CASE(1, 0, false, 1) FAMI_T7_CASE(1, 0, true, 0) FAMI_T7_CASE(1, 0, false, 2) FAMI_T7_CASE(1, 0, true, 2)
+  FAMI_T7_CASE(2, 1, false, 0) FAMI_T7_CASE(2, 1, false, 1) FAMI_T7_CASE(2, 1, true, 0) FAMI_T7_CASE(2, 1, false, 2) FAMI_T7_CASE(2, 1, true, 2)
+  FAMI_T7_CASE(2, 0, false, 0) FAMI_T7_CASE(2, 0, false, 1) FAMI_T7_CASE(2, 0, true, 0) FAMI_T7_CASE(2, 0, false, 2) FAMI_T7_CASE(2, 0, true, 2)
 #undef FAMI_T7_CASE
   return ok ? 1 : 0;
 }
@@ -784,9 +817,9 @@ static int t7_launch(const T7Plan& q, const void* x, const void* wp, const float
 int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
-  if (half_kind > 1 || xbn.on || (epi.slots && epi.mode != 1)) return 0;
+  if (half_kind > 1 || xbn.on || (epi.slots && epi.mode != 1 && epi.mode != 2)) return 0;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(wp) & 15) != 0) return 0;
-  if (out_f32 || relu || (accumulate && epi.slots)) return 0;                      // (forward-only fused ReLU / fp32 heatmap outputs stay on conv_t4)
+  if (out_f32 || relu || (accumulate && epi.slots && epi.mode == 1)) return 0;                      // (forward-only fused ReLU / fp32 heatmap outputs stay on conv_t4)
   if ((long)H * W * Ci * 2 >= (1L << 31) || (long)9 * KC * NTt * 1024 >= (1L << 31)) return 0;
   if (KC * 32 < Ci || NTt * 16 < Co) return 0;
   const T7Plan q7 = t7_plan(N, H, W, Ci, Co);

@@ -254,6 +254,28 @@ def test_weight_resident_dma_conv(dev, half):
                 assert relerr(rows_[0], d.sum(0)) < 1e-5 and relerr(rows_[1], (d * d).sum(0)) < 1e-5, (it, code)
                 piv = slots[8 * 2 * Co:].view(torch.float32)[:Co]
                 assert torch.equal(piv.cpu(), pivot.cpu())
+                # EpiBN mode 2 (the input gradient also takes the ReLU mask and the two sums of the BatchNorm that produced the
+                # convolution's input): mask from the BN output / recomputed from its input, plain and accumulating
+                z = torch.randn(N, H, W, Ci, device=dev).to(BF)
+                mean, invstd = torch.randn(Ci, device=dev) * 0.2, torch.rand(Ci, device=dev) + 0.5
+                gamma, beta = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+                sc = invstd * gamma
+                ybn = torch.relu(torch.addcmul(torch.addcmul(beta, -mean, sc), z.float(), sc)).to(BF)     # fma(z, sc, fma(-mean, sc, beta))
+                for rmode in (1, 2):
+                    for acc in (0, 1):
+                        dxm = dx0.clone() if acc else torch.empty(N, H, W, Ci, device=dev, dtype=BF)
+                        slots2 = torch.zeros(L.cdll.fami_bn_slots_bytes(Ci) // 8, device=dev, dtype=torch.float64)
+                        L.call('fami_conv2d_dgrad_bnstats' + sfx, p(dy), p(wp[1]), p(dxm), *geo, acc, p(z), p(ybn if rmode == 1 else None),
+                               p(mean), p(invstd), p(gamma), p(beta), rmode, p(slots2), st)
+                        torch.cuda.synchronize(dev)
+                        full = (refd + dx0.double()) if acc else refd
+                        keep = (ybn.float() > 0) if rmode == 1 else (torch.addcmul(torch.addcmul(beta, -mean, sc), z.float(), sc) > 0)
+                        want = torch.where(keep, full, torch.zeros_like(full))
+                        assert relerr(dxm, want) < ACT_TOL, (it, code, rmode, acc, relerr(dxm, want))
+                        g = dxm.double().reshape(-1, Ci)
+                        xh = (z.double().reshape(-1, Ci) - mean.double()) * invstd.double()
+                        r2 = slots2[:8 * 2 * Ci].view(8, 2, Ci).sum(0).cpu()
+                        assert relerr(r2[0], g.sum(0)) < 1e-5 and relerr(r2[1], (g * xh).sum(0)) < 1e-5, (it, code, rmode, acc)
                 out[code] = (y, dx, dxa)
             L.cdll.fami_conv_tune_lds(-1)
             # two kernels, two summation orders: they agree to the storage type's rounding of a few elements
