@@ -326,17 +326,19 @@ __device__ __forceinline__ void wg6_dma16(wg6_i32x4 r, unsigned voff, unsigned l
 }
 struct Wg6Args {
   const void* x;    // [N,H,W,Ci]
-  const void* dy;   // [N,H,W,Co]
+  const void* dy;   // [N,Ho,Wo,Co]
   float* part;      // [G][9][Ci][Co]
   int N, H, W, Ci, Co;
-  int UR, upf;      // rows per unit, units per frame (H / UR)
-  int M;            // pixels of a unit (UR * W)
+  int st, Ho, Wo;   // stride (1 | 2), output map
+  int UR, upf;      // OUTPUT rows per unit, units per frame (Ho / UR)
+  int PR;           // patch rows of a unit (st (UR - 1) + 3)
+  int M;            // output pixels of a unit (UR * Wo)
   int nunits;       // units per workgroup (consecutive, frame-major)
   int NU;           // units in total (N * upf)
   int coBlocks;
   int PW, RG;       // W + 2, 16-byte granules per patch row (2 CIT PW: the block's channel slice)
   int q512, r512;   // 512 / RG, 512 % RG
-  int dyq, dxr;     // 32 / W, 32 % W
+  int dyq, dxr;     // 32 / Wo, 32 % Wo
   int XI, YI;       // DMA instructions (1 KiB) of a unit's patch / dY rows
   long long* dbg;   // FAMI_WG6_TRACE builds: s_memtime stamps of one workgroup
 };
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
   const int cob = blockIdx.y % p.coBlocks, cib = blockIdx.y / p.coBlocks;
   const int u0g = job * p.nunits;                    // first unit (global index) of this workgroup
   const int nunits = min(p.nunits, p.NU - u0g);
-  const int W = p.W, PW = p.PW;
+  const int W = p.W, PW = p.PW, Wo = p.Wo;
   const int XB = p.XI * 1024, BUFSZ = XB + p.YI * 1024;
 #ifdef FAMI_WG6_TRACE
   const bool trace = p.dbg && job == 5 && blockIdx.y == 0 && lane == 0;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 
   // ---- DMA plan of this lane (unit-invariant): patch granule -> (patch row, byte offset from the first patch row's pixel 0,
   // channel slice included); dY granule -> byte offset from the unit's first pixel
-  const long xfb = (long)p.H * W * p.Ci * 2, yfb = (long)p.H * W * p.Co * 2;     // one frame
+  const long xfb = (long)p.H * W * p.Ci * 2, yfb = (long)p.Ho * Wo * p.Co * 2;     // one frame
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
   int xrow[WG6_XJ], xoff[WG6_XJ], yoff[WG6_YJ];
   {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
     for (int j = 0; j < WG6_XJ; ++j) {
       const int pos = wi / GX, c = wi - pos * GX;
-      const bool ok = r < p.UR + 2 && pos >= 1 && pos <= W;
+      const bool ok = r < p.PR && pos >= 1 && pos <= W;
       xrow[j] = ok ? r : 0x40000000;                  // never a valid image row
       xoff[j] = ((r * W + pos - 1) * p.Ci + cib * (16 * CIT) + c * 8) * 2;
       r += p.q512;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
   // piece k of a unit's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
   auto dma_piece = [&](int ug, unsigned buf, int k) {
     const int img = ug / p.upf, ui = ug - img * p.upf;
-    const int yt = ui * p.UR - 1;                      // image row of the unit's first patch row
+    const int yt = p.st * ui * p.UR - 1;               // image row of the unit's first patch row
     if (k < WG6_XJ) {
       const int i = wave + WG16_WAVES * k;             // (wave-uniform)
       if (i < p.XI) {
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       if (i < p.YI) {
         const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
         const int yo = yoff[k - WG6_XJ];
-        wg6_dma16(ry, yo < 0 ? 0x80000000u : (unsigned)((yt + 1) * W * p.Co * 2 + yo), buf + XB + i * 1024);
+        wg6_dma16(ry, yo < 0 ? 0x80000000u : (unsigned)(ui * p.UR * Wo * p.Co * 2 + yo), buf + XB + i * 1024);
       }
     }
   };
@@ -451,8 +453,8 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int pl = kq * 4 + h * 16 + rsel;
-    py0[h] = pl / W;
-    px0[h] = pl - py0[h] * W;
+    py0[h] = pl / Wo;
+    px0[h] = pl - py0[h] * Wo;
   }
 
   for (int u = 0; u < nunits; ++u) {
@@ -482,12 +484,12 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           // pixels past the unit meet a zero dY row; their X address only has to stay inside the buffer
-          xb[h] = pl[h] < p.M ? (py[h] * PW + pxx[h]) * PS : 0;
+          xb[h] = pl[h] < p.M ? p.st * (py[h] * PW + pxx[h]) * PS : 0;
           pl[h] += 32;
           pxx[h] += p.dxr;
           py[h] += p.dyq;
-          if (pxx[h] >= W) {
-            pxx[h] -= W;
+          if (pxx[h] >= Wo) {
+            pxx[h] -= Wo;
             py[h] += 1;
           }
         }
@@ -550,32 +552,35 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 
 static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
-struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT; size_t lds; };
+struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho, Wo, PR; size_t lds; };
+static int g_wg6_s2 = 1;      // fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on
 static int g_wg6_c4 = 1;      // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
 static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
   q.ok = 0;
-  if (!g_wg6 || k != 3 || st != 1 || pad != 1 || dil != 1) return q;
+  if (!g_wg6 || k != 3 || !(st == 1 || (st == 2 && g_wg6_s2)) || pad != 1 || dil != 1) return q;
+  q.Ho = (H + 2 - 3) / st + 1;
+  q.Wo = (W + 2 - 3) / st + 1;
   q.CIT = Ci % 48 == 0 ? 3 : (Ci % 64 == 0 ? 4 : 0);
   q.COT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
   if (!q.CIT || !q.COT || (q.CIT == 3 && q.COT == 4) || (q.CIT == 4 && !g_wg6_c4)) return q;       // (3 x 4 is not instantiated: no layer of the path has it)
   // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple, two buffers in the LDS
   const int RG = (W + 2) * 2 * q.CIT;
   q.UR = 0;
-  for (int ur = H; ur >= 1; --ur) {
-    if (H % ur != 0 || ur * W > 288) continue;
-    const int M = ur * W, KS = (M + 31) / 32;
+  for (int ur = q.Ho; ur >= 1; --ur) {
+    if (q.Ho % ur != 0 || ur * q.Wo > 288) continue;
+    const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 3;
     if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
     if (q.CIT == 4 && KS != 5) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
-    const int XI = ((ur + 2) * RG + 63) / 64, YI = KS * q.COT;
+    const int XI = (PR * RG + 63) / 64, YI = KS * q.COT;
     if (XI > 8 * WG6_XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
-    q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI;
+    q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI; q.PR = PR;
     break;
   }
   if (!q.UR) return q;
   q.lds = 2 * (size_t)(q.XI + q.YI) * 1024;
-  q.upf = H / q.UR;
+  q.upf = q.Ho / q.UR;
   q.blocks = (Ci / (16 * q.CIT)) * (Co / (16 * q.COT));
   const long NU = (long)N * q.upf;
   // units per workgroup: about g_wg6_target workgroups in the launch (the other stream lanes use the CUs a launch leaves, and a
@@ -881,8 +886,9 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
     if (q6.ok && ws_bytes >= (long)q6.G * 9 * Ci * Co * (long)sizeof(float)) {
       Wg6Args a;
       a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+      a.st = st; a.Ho = q6.Ho; a.Wo = q6.Wo; a.PR = q6.PR;
       a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = Co / (16 * q6.COT);
-      a.PW = W + 2; a.RG = (W + 2) * 2 * q6.CIT; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / W; a.dxr = 32 % W;
+      a.PW = W + 2; a.RG = (W + 2) * 2 * q6.CIT; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / q6.Wo; a.dxr = 32 % q6.Wo;
       a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
       const dim3 grid(q6.G, q6.blocks);
       bool ok6 = false;
@@ -930,9 +936,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_s2 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
+  else if (on == 3004 || on == 3005) g_wg6_s2 = on - 3004;
   else if (on == 3002 || on == 3003) g_wg6_c4 = on - 3002;
   else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
   else if (on >= 3100 && on < 3400) g_wg6_nu = on - 3100;        // (23100 + units per workgroup)

@@ -364,3 +364,38 @@ def test_dma_staged_wide_1x1_weight_gradient(dev, half):
             assert relerr(out[24001], out[24000].double()) < 3e-6
     finally:
         L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
+def test_dma_staged_weight_gradient_stride2(dev, half):
+    """conv_wgrad6_kernel on the stride-2 3x3 convolutions of the fuse / transition chains (hrnet.py:117-150): the unit's patch is
+    st (UR - 1) + 3 input rows, a pixel's tap sits at twice its output coordinates.  Against fp64 and conv_wgrad16_kernel."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W, Ci, Co) in enumerate([(20, 96, 72, 48, 96), (20, 48, 36, 96, 192), (20, 24, 18, 192, 384), (3, 16, 24, 48, 48),
+                                                (2, 96, 72, 48, 48)]):
+            torch.manual_seed(it)
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dy = (torch.randn(N, Ho, Wo, Co, device=dev) * 0.1).to(BF)
+            geo = (N, H, W, Ci, Co, 3, 3, 2, 1, 1)
+            nb = L.cdll.fami_conv2d_wgrad_workspace(*geo)
+            ws = torch.empty(nb // 4 + 4, device=dev)
+            wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=1, stride=2).backward(dy.double().permute(0, 3, 1, 2))
+            ref = wref.grad
+            out = {}
+            for code in (23004, 23005):
+                L.cdll.fami_conv_tune_wgrad_lds(-1)
+                L.cdll.fami_conv_tune_wgrad_lds(code)
+                dw = torch.empty(Co, Ci, 3, 3, device=dev)
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, 0, st)
+                torch.cuda.synchronize(dev)
+                assert relerr(dw, ref) < 3e-6, (it, code, relerr(dw, ref))
+                out[code] = dw
+            assert relerr(out[23005], out[23004].double()) < 3e-6
+    finally:
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
