@@ -10,6 +10,8 @@ Reference: posetimation/layers/basic_model.py:25-63 (BasicBlock), :66-113
 (conv_bn_relu); posetimation/backbones/hrnet.py:17-172 (HighResolutionModule),
 :186-332 (HRNet), :521-690 (HRNetPlus).
 """
+import os
+
 import torch.nn as nn
 
 BN_MOMENTUM = 0.1
@@ -175,8 +177,42 @@ class HighResolutionModule(nn.Module):
             eng.join(nb)
         return [eng.fuse(hs) for hs in handles]
 
+    def run_both(self, eng, xs):
+        """run_branches + run_fuse inside ONE forked region: lane j runs branch j and then the fuse terms that read it -- no
+        join / fork pair between the two halves (a lane join costs the chip an idle gap on every lane but the slowest).
+        -> (branch outputs, fused outputs)"""
+        nb = self.num_branches
+        if nb == 1 or not eng.fuse_lanes or os.environ.get('FAMI_MERGE_FORK', '1') == '0':
+            ys = self.run_branches(eng, xs)
+            return ys, self.run_fuse(eng, ys)
+        forked = eng.fork(nb)
+        if not forked:
+            ys = self.run_branches(eng, xs)
+            return ys, self.run_fuse(eng, ys)
+        ys = []
+        handles = [[None] * nb for _ in self.fuse_layers]
+        for j in range(nb):
+            eng.set_lane(j)
+            y = xs[j]
+            for blk in self.branches[j]:
+                y = blk.run(eng, y)
+            ys.append(y)
+            for i, row in enumerate(self.fuse_layers):
+                if j == i:
+                    handles[i][j] = eng.fuse_term(y, None, 0)
+                elif j > i:
+                    handles[i][j] = eng.conv_fuse_term(y, row[j][0], row[j][1], j - i)
+                else:
+                    z = y
+                    chain = row[j]
+                    for k in range(len(chain) - 1):
+                        z = run_cbr(eng, chain[k], z)
+                    handles[i][j] = eng.conv_fuse_term(z, chain[-1][0], chain[-1][1], 0)
+        eng.join(nb)
+        return ys, [eng.fuse(hs) for hs in handles]
+
     def run(self, eng, xs):
-        return self.run_fuse(eng, self.run_branches(eng, xs))
+        return self.run_both(eng, xs)[1]
 
 
 class HRNetBody(nn.Module):
@@ -263,11 +299,10 @@ class HRNetBody(nn.Module):
             eng.wlane_pair = False
             ys = xs
             for mi, mod in enumerate(getattr(self, 'stage%d' % s)):
-                ys = mod.run_branches(eng, ys)
+                yb, ys = mod.run_both(eng, ys)
                 if s == 4 and mi == 0:
                     # the reference's `feature = x3_list` is overwritten in place by stage4[0]'s
                     # branches (hrnet.py:156-157,323): HRNet.forward returns these branch outputs
-                    stage4_in = list(ys)
-                ys = mod.run_fuse(eng, ys)
+                    stage4_in = list(yb)
         hm = run_conv(eng, self.final_layer, ys[0], out_f32=True)     # heatmaps are fp32 in every mode
         return hm, ys, stage4_in
