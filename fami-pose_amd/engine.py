@@ -96,6 +96,10 @@ class Engine:
         self.regressor_lanes = os.environ.get('FAMI_REGRESSOR_LANES', '1') != '0'   # shared-weight regressors on lanes
         self.mi_lanes = self.use_lanes and os.environ.get('FAMI_MI_LANES', '1') != '0'   # the six MI terms of the loss on three lanes
         self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
+        # lanes stay forked across the modules of an HRNet stage (modules.HRNetBody.run): a module's fuse sum i runs on lane i behind
+        # events of the other lanes instead of on lane 0 behind a join.  The Trainer switches it off when gradient buckets are
+        # all-reduced during backward (their hooks fire between forked regions).
+        self.persist_lanes = os.environ.get('FAMI_PERSIST_LANES', '1') != '0'
         self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
         self._wstream = None
         self._wstream2 = None      # second weight-gradient stream (wlane_pair scopes: the stem / layer1 / transition stretch)
@@ -324,6 +328,32 @@ class Engine:
             self.call('fami_add_batch_f32', ptrs, counts, n)
         self._merge = []
         self._lane_priv = {}
+
+    def _all_to_all(self, n):
+        """every one of the n lanes continues after what the others have enqueued so far.  Through lane 0 as a hub (it waits for the
+        side lanes' events, then they wait for its event): two side streams waiting on EACH OTHER's events segfault
+        hipStreamEndCapture on this ROCm (tools/probes/capture_cross_wait.py: patterns 1, 2), a join immediately followed by a
+        fork does not (pattern 4)."""
+        side = [self._side[j - 1] for j in range(1, n)]
+        for st in side:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._main.wait_event(ev)
+        ev = torch.cuda.Event()
+        ev.record(self._main)
+        for st in side:
+            st.wait_event(ev)
+
+    def lanes_sync(self, n):
+        """Inside a forked region of n lanes: an all-to-all dependency instead of a join + fork through lane 0 (a module's fuse
+        sums read every lane's terms).  Its backward is the same all-to-all (the terms' backward reads every lane's gradients)."""
+        self.flush_reduces()
+        self._all_to_all(n)
+        if self.record:
+            def bwd():
+                self.flush_reduces()
+                self._all_to_all(n)
+            self.tape.append((bwd, (), self.lane, ()))
 
     def fork(self, n):
         """Lanes 1..n-1 start after everything enqueued on lane 0 so far; the backward of a fork is a join."""

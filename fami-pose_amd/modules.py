@@ -211,6 +211,43 @@ class HighResolutionModule(nn.Module):
         eng.join(nb)
         return ys, [eng.fuse(hs) for hs in handles]
 
+    def run_lanes(self, eng, xs, last=False):
+        """One module INSIDE a region the caller has forked (HRNetBody.run keeps the lanes of a stage forked across its modules):
+        lane j runs branch j and the fuse terms that read it; fused output i is summed on lane i behind an all-to-all of lane
+        events (Engine.lanes_sync) -- no join, no sums on lane 0.  -> (branch outputs, fused outputs, joined)"""
+        nb = self.num_branches
+        ys = []
+        handles = [[None] * nb for _ in self.fuse_layers]
+        for j in range(nb):
+            eng.set_lane(j)
+            y = xs[j]
+            for blk in self.branches[j]:
+                y = blk.run(eng, y)
+            ys.append(y)
+            for i, row in enumerate(self.fuse_layers):
+                if j == i:
+                    handles[i][j] = eng.fuse_term(y, None, 0)
+                elif j > i:
+                    handles[i][j] = eng.conv_fuse_term(y, row[j][0], row[j][1], j - i)
+                else:
+                    z = y
+                    chain = row[j]
+                    for k in range(len(chain) - 1):
+                        z = run_cbr(eng, chain[k], z)
+                    handles[i][j] = eng.conv_fuse_term(z, chain[-1][0], chain[-1][1], 0)
+        if last or len(handles) < nb:
+            # the stage's last module: its sums follow the stage's join on lane 0.  (With the all-to-all here the backward pass would
+            # open the stage with a fork and record the all-to-all's events right behind the fork's waits, no kernel in between --
+            # a pattern hipStreamEndCapture does not survive; the same goes for lanes without an output in front of the join.)
+            eng.join(nb)
+            return ys, [eng.fuse(hs) for hs in handles], True
+        eng.lanes_sync(nb)
+        outs = []
+        for i, hs in enumerate(handles):
+            eng.set_lane(i)
+            outs.append(eng.fuse(hs))
+        return ys, outs, False
+
     def run(self, eng, xs):
         return self.run_both(eng, xs)[1]
 
@@ -298,11 +335,19 @@ class HRNetBody(nn.Module):
             eng.wlane_scope = outer
             eng.wlane_pair = False
             ys = xs
+            nb = self.stage_branches[s]
+            persist = eng.persist_lanes and eng.fuse_lanes and nb > 1 and eng.fork(nb)      # the stage's lanes stay forked across its modules
+            joined = False
             for mi, mod in enumerate(getattr(self, 'stage%d' % s)):
-                yb, ys = mod.run_both(eng, ys)
+                if persist and not joined:
+                    yb, ys, joined = mod.run_lanes(eng, ys, last=(mi == len(getattr(self, 'stage%d' % s)) - 1))
+                else:
+                    yb, ys = mod.run_both(eng, ys)
                 if s == 4 and mi == 0:
                     # the reference's `feature = x3_list` is overwritten in place by stage4[0]'s
                     # branches (hrnet.py:156-157,323): HRNet.forward returns these branch outputs
                     stage4_in = list(yb)
+            if persist and not joined:
+                eng.join(nb)
         hm = run_conv(eng, self.final_layer, ys[0], out_f32=True)     # heatmaps are fp32 in every mode
         return hm, ys, stage4_in

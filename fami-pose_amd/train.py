@@ -395,6 +395,8 @@ class Trainer:
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
                      deterministic=getattr(model, 'deterministic', None))
+        if on_bucket is not None:
+            eng.persist_lanes = False       # bucket hooks fire between forked regions: keep a join per module
         # conv weight images of this step: the forward orientation in one launch now, the input-gradient orientation in a
         # second launch on a side lane beside the forward pass (first read by the backward pass, which waits for it)
         # ... and the DCN layers' backward weight images + their fixed-point scale bound (a one-workgroup reduction): they
