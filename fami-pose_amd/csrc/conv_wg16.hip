@@ -554,6 +554,7 @@ static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
 struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho, Wo, PR; size_t lds; };
 static int g_wg6_s2 = 1;      // fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on
+static int g_wg6_c42 = 1;
 static int g_wg6_c4 = 1;      // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
 static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
@@ -564,7 +565,10 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
   q.Wo = (W + 2 - 3) / st + 1;
   q.CIT = Ci % 48 == 0 ? 3 : (Ci % 64 == 0 ? 4 : 0);
   q.COT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
-  if (!q.CIT || !q.COT || (q.CIT == 3 && q.COT == 4) || (q.CIT == 4 && !g_wg6_c4)) return q;       // (3 x 4 is not instantiated: no layer of the path has it)
+  if (!q.CIT || !q.COT || (q.CIT == 3 && q.COT == 4) || (q.CIT == 4 && !g_wg6_c4)) return q;
+  // 64 x 64 blocks only fit the LDS twice with two-row units (five K steps, a barrier per 144 pixels, 17 spilled registers);
+  // 64 x 32 blocks take four-row units (nine K steps): fami_conv_tune_wgrad_lds(23006 / 23007) off / on
+  if (q.CIT == 4 && q.COT == 4 && g_wg6_c42) q.COT = 2;       // (3 x 4 is not instantiated: no layer of the path has it)
   // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple, two buffers in the LDS
   const int RG = (W + 2) * 2 * q.CIT;
   q.UR = 0;
@@ -572,7 +576,7 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
     if (q.Ho % ur != 0 || ur * q.Wo > 288) continue;
     const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 3;
     if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
-    if (q.CIT == 4 && KS != 5) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
+    if (q.CIT == 4 && !(KS == 5 || (KS == 9 && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
     const int XI = (PR * RG + 63) / 64, YI = KS * q.COT;
     if (XI > 8 * WG6_XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
     q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI; q.PR = PR;
@@ -905,7 +909,7 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
     ok6 = true;                                                                                                           \
   }
       FAMI_WG6_CASE(9, 3, 3) FAMI_WG6_CASE(8, 3, 3) FAMI_WG6_CASE(7, 3, 3) FAMI_WG6_CASE(5, 3, 3) FAMI_WG6_CASE(4, 3, 3)
-      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3)
+      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3) FAMI_WG6_CASE(9, 4, 2) FAMI_WG6_CASE(5, 4, 2)
 #undef FAMI_WG6_CASE
       if (ok6) {
         hipError_t err6 = hipGetLastError();
@@ -936,9 +940,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_s2 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
+  else if (on == 3006 || on == 3007) g_wg6_c42 = on - 3006;
   else if (on == 3004 || on == 3005) g_wg6_s2 = on - 3004;
   else if (on == 3002 || on == 3003) g_wg6_c4 = on - 3002;
   else if (on == 3000 || on == 3001) g_wg6 = on - 3000;           // (fami_conv_tune_wgrad_lds(23000 / 23001): the DMA-staged 48-channel kernel off / on)
