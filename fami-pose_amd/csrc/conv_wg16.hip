@@ -575,8 +575,8 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
   for (int ur = q.Ho; ur >= 1; --ur) {
     if (q.Ho % ur != 0 || ur * q.Wo > 288) continue;
     const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 3;
-    if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
-    if (q.CIT == 4 && !(KS == 5 || (KS == 9 && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
+    if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4 || (KS == 3 && q.CIT == 4 && q.COT == 2)) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
+    if (q.CIT == 4 && !(KS == 5 || ((KS == 9 || KS == 3) && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
     const int XI = (PR * RG + 63) / 64, YI = KS * q.COT;
     if (XI > 8 * WG6_XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
     q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI; q.PR = PR;
@@ -909,7 +909,7 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
     ok6 = true;                                                                                                           \
   }
       FAMI_WG6_CASE(9, 3, 3) FAMI_WG6_CASE(8, 3, 3) FAMI_WG6_CASE(7, 3, 3) FAMI_WG6_CASE(5, 3, 3) FAMI_WG6_CASE(4, 3, 3)
-      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3) FAMI_WG6_CASE(9, 4, 2) FAMI_WG6_CASE(5, 4, 2)
+      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3) FAMI_WG6_CASE(9, 4, 2) FAMI_WG6_CASE(5, 4, 2) FAMI_WG6_CASE(3, 4, 2)
 #undef FAMI_WG6_CASE
       if (ok6) {
         hipError_t err6 = hipGetLastError();

@@ -376,7 +376,7 @@ def test_dma_staged_weight_gradient_stride2(dev, half):
     sfx = '_' + half
     try:
         for it, (N, H, W, Ci, Co) in enumerate([(20, 96, 72, 48, 96), (20, 48, 36, 96, 192), (20, 24, 18, 192, 384), (3, 16, 24, 48, 48),
-                                                (2, 96, 72, 48, 48)]):
+                                                (2, 96, 72, 48, 48), (4, 192, 144, 64, 64)]):      # (the stem's second convolution: units of one output row)
             torch.manual_seed(it)
             Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
             x = torch.randn(N, H, W, Ci, device=dev).to(BF)
