@@ -749,6 +749,151 @@ static Wg1Plan wg1_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
   return q;
 }
 
+// ------------------------------------------------------------------ weight gradient of the stem's first convolution ("wgs", round 4)
+// conv1: 3 -> 64 channels, 3x3, stride 2 (hrnet.py:573-578).  K = 27 fits no 16-channel tile, so the launch fell back to the scalar-
+// operand kernel: 183 us -- the LAST weight gradient of the backward pass (it needs the last input gradient), i.e. on the step's
+// critical path in front of the final reduce and Adam.  Here: dW[k = tap * 3 + c][co] = sum_p Xcol[p][k] dY[p][co] over the flat
+// output-pixel axis, units of 288 pixels (whole output rows); the unit's dY rows (128 bytes per pixel, contiguous) come by LDS DMA,
+// its im2col tile Xcol [288][32] (27 used) is gathered by the threads two bytes at a time (x is 13 MB: the gather hits L2) into
+// registers while the previous unit is multiplied and stored to the other buffer behind it; wave w owns k tile w / 4, output tile w % 4.
+struct WgsArgs {
+  const void* x;    // [N,H,W,3]
+  const void* dy;   // [N,Ho,Wo,64]
+  float* part;      // [G][9][3][64]
+  int N, H, W, Ho, Wo;
+  int UR, upf;      // output rows per unit (UR * Wo = 288), units per frame
+  int nunits, NU;
+};
+#define WGS_IT 2      // (pixel, tap row) items per thread and unit: 288 * 3 = 864 <= 2 * 512
+
+template <typename H>
+__global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad_stem_kernel(WgsArgs p) {
+  typedef typename H16<H>::x8 hx8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int M = 288, KS = M / 32, PSX = 64, PSY = 128, XB = M * PSX, YI = M * PSY / 1024, BUFSZ = XB + M * PSY;
+  constexpr int YJ = (YI + WG16_WAVES - 1) / WG16_WAVES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int rsel = l16 >> 2, piece = l16 & 3;
+  int job;
+  {
+    const int n = gridDim.x, lin = blockIdx.x;
+    const int q = n >> 3, r = n & 7, xc = lin & 7, l = lin >> 3;
+    job = xc * q + (xc < r ? xc : r) + l;
+  }
+  const int u0 = job * p.nunits;
+  const int nunits = min(p.nunits, p.NU - u0);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  // zero both Xcol tiles once (columns 27 .. 31 stay zero; the gather rewrites the others)
+  for (int i = tid; i < 2 * (XB / 16); i += WG16_THREADS) {
+    const int b = i / (XB / 16), o = i - b * (XB / 16);
+    *reinterpret_cast<u32x4*>(smem + b * BUFSZ + o * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  const long xfb = (long)p.H * p.W * 3 * 2, yfb = (long)p.Ho * p.Wo * 64 * 2;
+  // gather plan: item = (pixel of the unit, tap row ky); nine consecutive 16-bit values of input row 2 oy + ky - 1 from column
+  // 2 ox - 1
+  int ipix[WGS_IT], iky[WGS_IT];
+#pragma unroll
+  for (int t = 0; t < WGS_IT; ++t) {
+    const int it = tid + t * WG16_THREADS;
+    ipix[t] = it < M * 3 ? it / 3 : -1;
+    iky[t] = it - (it / 3) * 3;
+  }
+  unsigned short gv[WGS_IT][9];
+  auto gather = [&](int ug) {
+    const int img = ug / p.upf, oy0 = (ug - img * p.upf) * p.UR;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) + (long)img * xfb, 0, (int)xfb, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < WGS_IT; ++t) {
+      const int pix = ipix[t] < 0 ? 0 : ipix[t];
+      const int oy = oy0 + pix / p.Wo, ox = pix - (pix / p.Wo) * p.Wo;
+      const int iy = 2 * oy + iky[t] - 1;
+      const bool rowok = ipix[t] >= 0 && (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const int ix = 2 * ox - 1 + e / 3;
+        const bool ok = rowok && (unsigned)ix < (unsigned)p.W;
+        gv[t][e] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, ok ? (unsigned)(((iy * p.W + ix) * 3 + e % 3) * 2) : 0x80000000u, 0, 0);
+      }
+    }
+  };
+  auto scatter = [&](char* buf) {
+#pragma unroll
+    for (int t = 0; t < WGS_IT; ++t)
+      if (ipix[t] >= 0) {
+        unsigned short* d = reinterpret_cast<unsigned short*>(buf + ipix[t] * PSX + iky[t] * 18);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) d[e] = gv[t][e];
+      }
+  };
+  auto dma_y = [&](int ug, unsigned buf) {
+    const int img = ug / p.upf, oy0 = (ug - img * p.upf) * p.UR;
+    const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const int i = wave + WG16_WAVES * j;
+      if (i < YI) wg6_dma16(ry, (unsigned)(oy0 * p.Wo * PSY + i * 1024 + lane * 16), buf + XB + i * 1024);
+    }
+  };
+  if (nunits > 0) {
+    gather(u0);
+    dma_y(u0, lds0);
+    __syncthreads();                 // (the zero fill is complete before the first scatter)
+    scatter(smem);
+  }
+  const int kt = wave >> 2, ct = wave & 3;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int pl0 = kq * 4 + rsel;
+  const int xa0 = pl0 * PSX + kt * 32 + piece * 8, ya0 = XB + pl0 * PSY + ct * 32 + piece * 8;
+  for (int u = 0; u < nunits; ++u) {
+    __syncthreads();                 // vmcnt(0) lgkmcnt(0) + barrier: unit u's dY rows have landed, its Xcol tile is stored, unit u - 1 is done
+    const bool more = u + 1 < nunits;
+    const char* xt = smem + (u & 1) * BUFSZ;
+    if (more) {
+      gather(u0 + u + 1);
+      dma_y(u0 + u + 1, lds0 + ((u + 1) & 1) * BUFSZ);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const char* xp = xt + xa0 + ks * 32 * PSX;
+      const char* yp = xt + ya0 + ks * 32 * PSY;
+      const hx8 a = frag_of<hx8>(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xp)),
+                                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(xp + 16 * PSX)));
+      const hx8 b = frag_of<hx8>(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yp)),
+                                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(yp + 16 * PSY)));
+      acc = H16<H>::mfma(a, b, acc);
+    }
+    if (more) scatter(smem + ((u + 1) & 1) * BUFSZ);
+  }
+  // D row = kq*4 + r (k = tap * 3 + c), col = l16 (co)  ->  slab [job][tap][c][co] = [job][k][co]
+  float* slab = p.part + (long)job * 27 * 64;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = kt * 16 + kq * 4 + r;
+    if (k < 27) slab[k * 64 + ct * 16 + l16] = acc[r];
+  }
+}
+
+struct WgsPlan { int ok, UR, upf, nunits, G; long NU; };
+static int g_wgs = 1;      // fami_conv_tune_wgrad_lds(25000 / 25001): off / on
+static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
+  WgsPlan q;
+  q.ok = 0;
+  if (!g_wgs || k != 3 || st != 2 || pad != 1 || dil != 1 || Ci != 3 || Co != 64) return q;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (288 % Wo != 0 || Ho % (288 / Wo) != 0) return q;
+  q.UR = 288 / Wo;
+  q.upf = Ho / q.UR;
+  q.NU = (long)N * q.upf;
+  long nu = (q.NU + 255) / 256;
+  q.nunits = (int)nu;
+  q.G = (int)((q.NU + nu - 1) / nu);
+  q.ok = (long)H * W * 6 < (1L << 31) && (long)Ho * Wo * 128 < (1L << 31) && q.G < 65536;
+  return q;
+}
+
 // ------------------------------------------------------------------ host side
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
@@ -822,7 +967,9 @@ long fami_wgrad16_slabs(int N, int H, int W, int Ci, int Co, int k, int st, int 
   const Wg16Plan q = wg16_plan(N, H, W, Ci, Co, k, st, pad, dil);
   const Wg6Plan q6 = wg6_plan(N, H, W, Ci, Co, k, st, pad, dil);      // (workspace sizing: whichever kernel takes the launch)
   const Wg1Plan q1 = wg1_plan(N, H, W, Ci, Co, k, st, pad, dil);
+  const WgsPlan qs = wgs_plan(N, H, W, Ci, Co, k, st, pad, dil);
   long g = q.ok ? q.G : 0;
+  if (qs.ok && qs.G > g) g = qs.G;
   if (q6.ok && q6.G > g) g = q6.G;
   if (q1.ok && q1.G > g) g = q1.G;
   return g;
@@ -863,6 +1010,29 @@ static int wg16_launch(const Wg16Plan& q, const void* x, const void* dy, float* 
 // -> number of partial slabs written to `part` ([G][k*k][Ci][Co] fp32), 0 if the shape is not eligible, < 0 on error
 int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, long ws_bytes, int N, int H, int W, int Ci,
                      int Co, int k, int st, int pad, int dil, hipStream_t s, const char* name, const XBN& xbn) {
+  if (!xbn.on && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    const WgsPlan qs = wgs_plan(N, H, W, Ci, Co, k, st, pad, dil);
+    if (qs.ok && ws_bytes >= (long)qs.G * 27 * 64 * (long)sizeof(float)) {
+      WgsArgs a;
+      a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+      a.UR = qs.UR; a.upf = qs.upf; a.nunits = qs.nunits; a.NU = (int)qs.NU;
+      static bool attrs = false;
+      if (!attrs) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_stem_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_stem_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrs = true;
+      }
+      const size_t ldss = (size_t)2 * (288 * 64 + 288 * 128);
+      if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad_stem_kernel<f16_t>), dim3(qs.G), dim3(WG16_THREADS), ldss, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_stem_kernel<bf16_t>), dim3(qs.G), dim3(WG16_THREADS), ldss, s, a);
+      hipError_t errs = hipGetLastError();
+      if (errs != hipSuccess) {
+        fami_set_error(name, hipGetErrorString(errs));
+        return FAMI_EHIP;
+      }
+      return qs.G;
+    }
+  }
   if (!xbn.on && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
     const Wg1Plan q1 = wg1_plan(N, H, W, Ci, Co, k, st, pad, dil);
     if (q1.ok && ws_bytes >= (long)q1.G * Ci * Co * (long)sizeof(float)) {
@@ -940,9 +1110,10 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
+  else if (on == 5000 || on == 5001) g_wgs = on - 5000;           // (fami_conv_tune_wgrad_lds(25000 / 25001): the stem conv1 kernel off / on)
   else if (on == 3006 || on == 3007) g_wg6_c42 = on - 3006;
   else if (on == 3004 || on == 3005) g_wg6_s2 = on - 3004;
   else if (on == 3002 || on == 3003) g_wg6_c4 = on - 3002;

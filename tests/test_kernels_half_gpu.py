@@ -399,3 +399,38 @@ def test_dma_staged_weight_gradient_stride2(dev, half):
             assert relerr(out[23005], out[23004].double()) < 3e-6
     finally:
         L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
+def test_stem_conv1_weight_gradient(dev, half):
+    """conv_wgrad_stem_kernel (conv_wg16.hip, round 4): the weight gradient of the stem's 3 -> 64 stride-2 convolution (hrnet.py:573-578)
+    as a GEMM over the flat output-pixel axis with a gathered im2col tile (K = 27) and DMA-staged dY rows.  Against fp64 and the
+    scalar-operand kernel it replaces; the second shape has image rows the kernel must zero-pad on every side."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W) in enumerate([(20, 384, 288), (3, 16, 288), (2, 8, 144)]):
+            torch.manual_seed(it)
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            x = torch.randn(N, H, W, 3, device=dev).to(BF)
+            dy = (torch.randn(N, Ho, Wo, 64, device=dev) * 0.1).to(BF)
+            geo = (N, H, W, 3, 64, 3, 3, 2, 1, 1)
+            nb = L.cdll.fami_conv2d_wgrad_workspace(*geo)
+            ws = torch.empty(nb // 4 + 4, device=dev)
+            wref = torch.zeros(64, 3, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=1, stride=2).backward(dy.double().permute(0, 3, 1, 2))
+            ref = wref.grad
+            out = {}
+            for code in (25000, 25001):
+                L.cdll.fami_conv_tune_wgrad_lds(-1)
+                L.cdll.fami_conv_tune_wgrad_lds(code)
+                dw = torch.empty(64, 3, 3, 3, device=dev)
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, 0, st)
+                torch.cuda.synchronize(dev)
+                assert relerr(dw, ref) < 3e-6, (it, code, relerr(dw, ref))
+                out[code] = dw
+            assert relerr(out[25001], out[25000].double()) < 3e-6
+    finally:
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
