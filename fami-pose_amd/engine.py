@@ -355,6 +355,14 @@ class Engine:
                 self._all_to_all(n)
             self.tape.append((bwd, (), self.lane, ()))
 
+    on_mark = None
+
+    def mark(self, name):
+        """A named point of the forward pass; the backward pass calls on_mark(name) when it gets back there (every operation
+        recorded after the mark has had its backward enqueued by then)."""
+        if self.record:
+            self.tape.append((lambda: self.on_mark(name) if self.on_mark is not None else None, (), self.lane, ()))
+
     def fork(self, n):
         """Lanes 1..n-1 start after everything enqueued on lane 0 so far; the backward of a fork is a join."""
         if not self.use_lanes or n < 2:

@@ -335,6 +335,8 @@ class HRNetBody(nn.Module):
             eng.wlane_scope = outer
             eng.wlane_pair = False
             ys = xs
+            if s == 2:
+                eng.mark('stage2')      # backward: every gradient but the stem stretch's is final here (train.Trainer: early Adam)
             nb = self.stage_branches[s]
             persist = eng.persist_lanes and eng.fuse_lanes and nb > 1 and eng.fork(nb)      # the stage's lanes stay forked across its modules
             joined = False

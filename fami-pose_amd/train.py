@@ -73,6 +73,16 @@ class FlatAdam:
         lib().call('fami_adam_f32', _p(self.p), _p(self.grad), _p(self.m), _p(self.v), self.p.numel(), _p(self.state),
                    self.betas[0], self.betas[1], self.eps, self.wd, s)
 
+    def prep(self, s=None):
+        """the step's scalars alone (step count, bias corrections): a step split into ranges prepares once, up front"""
+        lib().call('fami_adam_prep_f32', _p(self.state), self.betas[0], self.betas[1], _stream(self.p.device) if s is None else s)
+
+    def apply(self, lo, hi, s=None):
+        """the update of arena[lo:hi] with the prepared scalars"""
+        if hi > lo:
+            lib().call('fami_adam_f32', _p(self.p[lo:hi]), _p(self.grad[lo:hi]), _p(self.m[lo:hi]), _p(self.v[lo:hi]), hi - lo,
+                       _p(self.state), self.betas[0], self.betas[1], self.eps, self.wd, _stream(self.p.device) if s is None else s)
+
 
 class MultiStepLR:
     """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma, last_epoch) for the flat Adam: what
@@ -303,6 +313,8 @@ class Trainer:
         self.overflow = torch.zeros(2, dtype=torch.int32, device=self.dev) if self.loss_scale != 1.0 else None   # {raised, skipped steps}
         self.opt = FlatAdam(self.flat, lr=lr)
         self.grad = self.opt.grad
+        self._adam_split = self._find_adam_split(model)
+        self._adam_done = False
         self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -397,6 +409,24 @@ class Trainer:
                      deterministic=getattr(model, 'deterministic', None))
         if on_bucket is not None:
             eng.persist_lanes = False       # bucket hooks fire between forked regions: keep a join per module
+        early = {'ev': None}
+        split = self._adam_split if (on_bucket is None and not self.ddp) else None
+        if split is not None:
+            # Adam in two parts (see _find_adam_split): the scalars now, everything but the stem stretch when backward reaches the
+            # stage-2 boundary (side lane), the stem stretch behind the backward pass
+            self.opt.prep(eng.stream)
+
+            def on_mark(name):
+                if name == 'stage2' and early['ev'] is None:
+                    eng.flush_reduces()
+                    eng.sync_wgrad_lane()
+                    n = self.flat.numel()
+
+                    def upd(st):
+                        self.opt.apply(0, split[0], st)
+                        self.opt.apply(split[1], n, st)
+                    early['ev'] = eng.side_launch(upd)
+            eng.on_mark = on_mark
         # conv weight images of this step: the forward orientation in one launch now, the input-gradient orientation in a
         # second launch on a side lane beside the forward pass (first read by the backward pass, which waits for it)
         # ... and the DCN layers' backward weight images + their fixed-point scale bound (a one-workgroup reduction): they
@@ -493,6 +523,13 @@ class Trainer:
         if packed_bwd is not None:
             eng.wait_main(packed_bwd)
         eng.backward(on_params_done=hook)
+        if split is not None:
+            if early['ev'] is not None:
+                self.opt.apply(split[0], split[1], eng.stream)
+                eng.wait_main(early['ev'])
+            else:
+                self.opt.apply(0, self.flat.numel(), eng.stream)
+            self._adam_done = True
         self.conv_flops = eng.conv_flops        # nn.Conv2d FLOPs of one step (forward + both gradients; reporting)
         if on_bucket is not None:
             self._flushing = True
@@ -510,6 +547,31 @@ class Trainer:
         The scale is static: a count that keeps growing means the scale is too large for this model."""
         return 0 if self.overflow is None else int(self.overflow[1].item())
 
+    def _find_adam_split(self, model):
+        """(lo, hi): the arena range of the stem / layer1 / first-transition parameters, whose gradients are the LAST the backward
+        pass completes.  Everything outside it is final when backward reaches the boundary of stage 2 (modules.HRNetBody.run marks
+        it), so its Adam update can run on a side lane beside the rest of the backward pass instead of behind it (the one-launch
+        Adam is 0.33 ms of pure HBM traffic at the end of every step).  None: no such split (FAMI_EARLY_ADAM=0, fp16's checked step,
+        data-parallel plans, a frozen backbone)."""
+        if os.environ.get('FAMI_EARLY_ADAM', '1') == '0' or self.loss_scale != 1.0:
+            return None
+        hr = getattr(model, 'hrnet', None)
+        if hr is None or not hasattr(hr, 'stage2') or not hasattr(hr, 'conv1'):
+            return None
+        off = {id(p): o for p, o, n in self.table}
+        first = [p for p in hr.stage2.parameters() if id(p) in off]
+        if id(hr.conv1.weight) not in off or not first:
+            return None
+        lo, hi = off[id(hr.conv1.weight)], min(off[id(p)] for p in first)
+        return (lo, hi) if 0 <= lo < hi else None
+
+    def _opt_step(self):
+        if self._adam_done:
+            self._adam_done = False
+            return
+        self._unscale()
+        self.opt.step(self.overflow)
+
     def _unscale(self):
         """gradient arena *= 1 / (world * loss_scale): the data-parallel mean and the static loss scale in one pass."""
         f = 1.0 / ((self.world if self.ddp else 1) * self.loss_scale)
@@ -525,8 +587,7 @@ class Trainer:
             self.reducer.wait()
         else:
             outs = self._forward_backward(kf_x, sup_x, target, weight)
-        self._unscale()
-        self.opt.step(self.overflow)
+        self._opt_step()
         return outs
 
     # ------------------------------------------------------------------ hipGraph capture / replay
@@ -553,8 +614,7 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
-                self._unscale()
-                self.opt.step(self.overflow)
+                self._opt_step()
             plan = [('graph', g)]
         elif self.ddp_plan == 'serial':
             # graph 1 = forward + backward, then the bucketed all-reduce of the flat gradient arena (RCCL, outside any
