@@ -15,7 +15,7 @@ for arg in sys.argv[2:]:
     cols, rows = pickle.load(gzip.open(path))
     ix = {c: i for i, c in enumerate(cols)}
     S, E, NM, GX = ix['start'], ix['end'], ix['name'], ix['grid_x']
-    ends = [r[E] for r in rows if 'adam_kernel' in r[NM]]
+    ends = [r[S] for r in rows if 'adam_prep' in r[NM]] or [r[E] for r in rows if 'adam_kernel' in r[NM]]      # one per step
     steps = []
     for t0, t1 in zip(ends[-3:-1], ends[-2:]):          # the last two steps of the trace
         st = [r for r in rows if r[S] >= t0 and r[E] <= t1 + 1]

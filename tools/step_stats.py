@@ -1,5 +1,5 @@
 """ONE aggregation window for both in-step artefacts: from the kernel-trace pickles of a graph-mode
-bench run (tools/round_profile.sh) take the replayed steps only (the spans between the last `adam_kernel` launches: no
+bench run (tools/round_profile.sh) take the replayed steps only (the spans between the last `adam_prep` launches, one per step: no
 warm-up, no eager capture steps) and write
   * <out>_kernel_stats_<dtype>.txt : the per-kernel table (calls, total, average, share) and the per-(kernel, grid) rows
   * in_step.json                  : launches / kernel time / idle share per step and the dominant convolution's in-step average
@@ -18,9 +18,11 @@ for arg in sys.argv[3:]:
     cols, rows = pickle.load(gzip.open(path))
     ix = {c: i for i, c in enumerate(cols)}
     S, E, NM, GX, GY, GZ = ix['start'], ix['end'], ix['name'], ix['grid_x'], ix['grid_y'], ix['grid_z']
-    ends = [r[E] for r in rows if 'adam_kernel' in r[NM]]
+    # one adam_prep launch per step (at its top since the optimizer update runs in two parts, at its end before): the spans
+    # between consecutive ones are whole steps
+    ends = [r[S] for r in rows if 'adam_prep' in r[NM]] or [r[E] for r in rows if 'adam_kernel' in r[NM]]
     spans = list(zip(ends[-NSTEPS - 1:-1], ends[-NSTEPS:]))
-    win = [r for r in rows if any(r[S] >= t0 and r[E] <= t1 + 1 for t0, t1 in spans)]
+    win = [r for r in rows if any(r[S] >= t0 and r[S] < t1 for t0, t1 in spans)]
     wall = sum(t1 - t0 for t0, t1 in spans)
     tot = sum(r[E] - r[S] for r in win)
     by = collections.defaultdict(lambda: [0, 0])
@@ -43,7 +45,7 @@ for arg in sys.argv[3:]:
     # idle share and concurrency
     idle = 0
     for t0, t1 in spans:
-        st = [r for r in rows if r[S] >= t0 and r[E] <= t1 + 1]
+        st = [r for r in rows if r[S] >= t0 and r[S] < t1]
         ev = sorted([(r[S], 1) for r in st] + [(r[E], -1) for r in st])
         live, last = 0, t0
         for t, d in ev:

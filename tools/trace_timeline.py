@@ -5,7 +5,7 @@ cols, rows = pickle.load(gzip.open(sys.argv[1]))
 ix = {c: i for i, c in enumerate(cols)}
 S, E, NM, Q = ix['start'], ix['end'], ix['name'], ix['queue_id']
 # step boundaries: the adam kernel ends a step
-ends = [r[E] for r in rows if 'adam_kernel' in r[NM]]
+ends = [r[S] for r in rows if 'adam_prep' in r[NM]] or [r[E] for r in rows if 'adam_kernel' in r[NM]]      # one per step
 t1 = ends[-1]; t0 = ends[-2]
 step = [r for r in rows if r[S] >= t0 and r[E] <= t1 + 1]
 print('last step: %.3f ms, %d kernels, sum of kernel time %.3f ms' % ((t1 - t0) / 1e6, len(step), sum(r[E] - r[S] for r in step) / 1e6))
