@@ -404,30 +404,39 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       yoff[j] = pix < p.M ? (pix * p.Co + cob * (16 * COT) + c * 8) * 2 : (int)0x80000000;
     }
   }
+  // a unit's scalars (frame, rows, buffer descriptors) once per unit: the pieces of its copy are issued one per K step, and the
+  // divisions behind them were ~40 scalar instructions in front of every K step's MFMAs
+  struct UnitGeo { int yt, ui; wg6_i32x4 rx, ry; };
+  auto unit_geo = [&](int ug) {
+    UnitGeo g;
+    const int img = ug / p.upf;
+    g.ui = ug - img * p.upf;
+    g.yt = p.st * g.ui * p.UR - 1;                     // image row of the unit's first patch row
+    g.rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * xfb, (int)xfb);
+    g.ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
+    return g;
+  };
   // piece k of a unit's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
-  auto dma_piece = [&](int ug, unsigned buf, int k) {
-    const int img = ug / p.upf, ui = ug - img * p.upf;
-    const int yt = p.st * ui * p.UR - 1;               // image row of the unit's first patch row
+  auto dma_piece = [&](const UnitGeo& g, unsigned buf, int k) {
     if (k < WG6_XJ) {
       const int i = wave + WG16_WAVES * k;             // (wave-uniform)
       if (i < p.XI) {
-        const wg6_i32x4 rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * xfb, (int)xfb);
-        unsigned off = (unsigned)(yt * W * p.Ci * 2 + xoff[k]);
-        if ((unsigned)(yt + xrow[k]) >= (unsigned)p.H) off = 0x80000000u;
-        wg6_dma16(rx, off, buf + i * 1024);
+        unsigned off = (unsigned)(g.yt * W * p.Ci * 2 + xoff[k]);
+        if ((unsigned)(g.yt + xrow[k]) >= (unsigned)p.H) off = 0x80000000u;
+        wg6_dma16(g.rx, off, buf + i * 1024);
       }
     } else {
       const int i = wave + WG16_WAVES * (k - WG6_XJ);
       if (i < p.YI) {
-        const wg6_i32x4 ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
         const int yo = yoff[k - WG6_XJ];
-        wg6_dma16(ry, yo < 0 ? 0x80000000u : (unsigned)(ui * p.UR * Wo * p.Co * 2 + yo), buf + XB + i * 1024);
+        wg6_dma16(g.ry, yo < 0 ? 0x80000000u : (unsigned)(g.ui * p.UR * Wo * p.Co * 2 + yo), buf + XB + i * 1024);
       }
     }
   };
   if (nunits > 0) {
+    const UnitGeo g0 = unit_geo(u0g);
 #pragma unroll
-    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u0g, lds0, k);
+    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(g0, lds0, k);
   }
   WG6_STAMP();
 
@@ -466,6 +475,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     const bool more = u + 1 < nunits;
     const unsigned nbuf = lds0 + ((u + 1) & 1) * BUFSZ;
     const char* xt = smem + (u & 1) * BUFSZ;
+    const UnitGeo gn = unit_geo(more ? u0g + u + 1 : u0g + u);
     int py[2], pxx[2], pl[2], ya[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -513,10 +523,10 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) load((ks + 1) & 1);
         if (more) {
-          if (ks < WG6_XJ + WG6_YJ) dma_piece(u0g + u + 1, nbuf, ks);
+          if (ks < WG6_XJ + WG6_YJ) dma_piece(gn, nbuf, ks);
           if (ks == KS - 1) {
 #pragma unroll
-            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(u0g + u + 1, nbuf, k);
+            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(gn, nbuf, k);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
