@@ -425,8 +425,17 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       }
     }
   }
+  // a job's scalars (first input row, frame descriptor) once per step instead of once per DMA piece
+  struct JobGeo { int y0; t7_i32x4 rx; };
+  auto job_geo = [&](int jb) {
+    JobGeo g;
+    const int img = jb / p.bands;
+    g.y0 = (jb - img * p.bands) * p.RB;
+    g.rx = t7_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * fbytes, (int)fbytes);
+    return g;
+  };
   // piece k of the copy of (job, phase) (k < WJ: weight slab, else patch slice); wave-uniform guards
-  auto dma_piece = [&](int jb, int ph, unsigned buf, int k) {
+  auto dma_piece = [&](const JobGeo& g, int ph, unsigned buf, int k) {
     if (k < WJ) {
       const int i = wave + T6_WAVES * k;
       if (i < WI) {
@@ -441,17 +450,16 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       const int j = k - WJ;
       const int i = wave + T6_WAVES * j;
       if (i < p.PI) {
-        const int img = jb / p.bands, y0 = (jb - img * p.bands) * p.RB;
-        const t7_i32x4 rx = t7_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * fbytes, (int)fbytes);
-        unsigned off = (unsigned)(y0 * W * p.Ci * 2 + xoff[j] + ph * 96);
-        if ((unsigned)(y0 + xrow[j]) >= (unsigned)p.H) off = 0x80000000u;
-        t7_dma16(rx, off, buf + (WI + i) * 1024);
+        unsigned off = (unsigned)(g.y0 * W * p.Ci * 2 + xoff[j] + ph * 96);
+        if ((unsigned)(g.y0 + xrow[j]) >= (unsigned)p.H) off = 0x80000000u;
+        t7_dma16(g.rx, off, buf + (WI + i) * 1024);
       }
     }
   };
   if (job0 < job1) {
+    const JobGeo g0 = job_geo(job0);
 #pragma unroll
-    for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(job0, 0, lds0, k);
+    for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(g0, 0, lds0, k);
   }
 
   // ---- per-lane constants
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       ++nj;
     }
     const bool more = nj < job1;
+    const JobGeo gn = job_geo(more ? nj : jb);
     const unsigned nbuf = lds0 + ((step + 1) & 1) * BUFSZ;
     const char* cb = smem + (step & 1) * BUFSZ;
     if (pending >= 0) {
@@ -576,7 +585,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       for (int k = 0; k < NK; ++k) {
         const int s = k % PF;
         if (k + 1 < NK) ld(k + 1, (k + 1) % PF);
-        if (more && k < WJ + T7_PJ) dma_piece(nj, nph, nbuf, k);      // (NK = 14 >= WJ + T7_PJ = 12)
+        if (more && k < WJ + T7_PJ) dma_piece(gn, nph, nbuf, k);      // (NK = 14 >= WJ + T7_PJ = 12)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (O) {
 #pragma unroll
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       else body(No(), Yes());
     } else if (more) {                               // a wave without tiles still issues its share of the next step's copy
 #pragma unroll
-      for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(nj, nph, nbuf, k);
+      for (int k = 0; k < WJ + T7_PJ; ++k) dma_piece(gn, nph, nbuf, k);
     }
     if (nph == 0) {                                  // the job is complete: keep its results for the next step, clear the accumulators
 #pragma unroll
