@@ -83,6 +83,25 @@ __device__ __forceinline__ f32x4 t6_epi2(EpiPtr e, f32x4 v, long idx, int co0, f
   return v;
 }
 
+// The same arithmetic with every operand already on chip: zz = the BN input's four values, yy = the BN output's (rmode 1; both
+// requested a unit ahead), ct = this lane's rows of the workgroup's channel table in LDS ([mean | invstd | scale | shift][NT * 16]).
+template <typename H>
+__device__ __forceinline__ f32x4 t6_epi2p(f32x4 v, f32x4 zz, f32x4 yy, const float* ct, int cstride, int rmode, f32x4& s, f32x4& q) {
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(ct), is = *reinterpret_cast<const f32x4*>(ct + cstride);
+  if (rmode == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = yy[r] > 0.f ? v[r] : 0.f;
+  } else if (rmode == 2) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ct + 2 * cstride), b = *reinterpret_cast<const f32x4*>(ct + 3 * cstride);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(zz[r], a[r], b[r]) > 0.f ? v[r] : 0.f;
+  }
+  const f32x4 g = ld4_round<H>(v);
+  s += g;
+  q += g * ((zz - mu) * is);
+  return v;
+}
+
 // G: 16-byte granules per pixel (Ci / 8); NT: channel tiles per workgroup; MT: own pixel tiles per wave (a unit is 2 MT rows);
 // EX: 1 if the unit has tiles past the 8 MT-th; ACC: y += result; EM: EpiBN mode (0 | 1 | 2)
 template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM>
@@ -168,6 +187,30 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   dma_rows(UR + 2);
   T6_STAMP();
 
+  // ---- EpiBN mode 2: the workgroup's channel table (behind the patch) is written before the first barrier; the BN input's
+  // values of a unit are requested before the unit's MFMA loop and used in its (deferred) epilogue
+  typedef H hx4 __attribute__((ext_vector_type(4)));
+  float* const ctab = reinterpret_cast<float*>(patch + p.pj * (T6_WAVES * 1024));    // [4][NT * 16]
+  const H* zsrc = nullptr;
+  const H* yrsrc = nullptr;
+  int rmode = 0;
+  if (EM == 2) {
+    EpiPtr e = epi_late(__builtin_offsetof(ConvT6Args, e));
+    zsrc = reinterpret_cast<const H*>(e->z);
+    yrsrc = reinterpret_cast<const H*>(e->yr);
+    rmode = e->relu;
+    if (tid < NT * 16) {
+      const int co = ntg0 * 16 + tid;
+      const float mu = e->mean[co], is = e->invstd[co];
+      float a = 0.f, b = 0.f;
+      if (rmode == 2) epi_scale_shift(mu, is, e->gamma[co], e->beta[co], a, b);
+      ctab[tid] = mu;
+      ctab[NT * 16 + tid] = is;
+      ctab[2 * NT * 16 + tid] = a;
+      ctab[3 * NT * 16 + tid] = b;
+    }
+  }
+
   // ---- epilogue constants (loaded after the first barrier)
   const int nte = wave % NT;                          // channel tile of the extra pair (waves 0 .. REMP-1: tile 8 MT + wave / NT)
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -216,10 +259,42 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   const int wl = lane * 16, wle = lane * 16 + nte * 1024;
 
   f32x4 sv[MT][NT], sve = z4;
-  auto emit1 = [&](f32x4 v, H* yp, int co0, const f32x4& b4, const f32x4& k4, f32x4& s, f32x4& q) {
+  // EM == 2: what the epilogue of the unit in flight reads at the lane's outputs, requested before the unit's MFMA loop:
+  // the BN input, the BN output (rmode 1: zero registers otherwise), the gradient so far (ACC)
+  hx4 zp[MT][NT], zpe, rp[MT][NT], rpe, ap[MT][NT], ape;
+  auto prefetch = [&](int u) {
+    const long ub = (long)(img * p.H + y0 + UR * u) * W * p.Co;
+    const H* zb = zsrc + ub;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) zp[m][nt] = *reinterpret_cast<const hx4*>(zb + oown[m] + nt * 16);
+    if (has_e) zpe = *reinterpret_cast<const hx4*>(zb + oex);
+    if (rmode == 1) {
+      const H* rb = yrsrc + ub;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rp[m][nt] = *reinterpret_cast<const hx4*>(rb + oown[m] + nt * 16);
+      if (has_e) rpe = *reinterpret_cast<const hx4*>(rb + oex);
+    }
+    if (ACC) {
+      const H* ab = reinterpret_cast<const H*>(p.y) + ub;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ap[m][nt] = *reinterpret_cast<const hx4*>(ab + oown[m] + nt * 16);
+      if (has_e) ape = *reinterpret_cast<const hx4*>(ab + oex);
+    }
+  };
+  auto emit1 = [&](f32x4 v, H* yp, int ctl, const hx4& zq, const hx4& rq, const hx4& aq, const f32x4& b4, const f32x4& k4, f32x4& s, f32x4& q) {
     v += b4;
-    if (ACC) v += ld4(yp);
-    if (EM == 2) v = t6_epi2<H>(epi_late(__builtin_offsetof(ConvT6Args, e)), v, yp - reinterpret_cast<H*>(p.y), co0, s, q);
+    if (EM == 2) {
+      if (ACC) v += __builtin_convertvector(aq, f32x4);
+      v = t6_epi2p<H>(v, __builtin_convertvector(zq, f32x4), __builtin_convertvector(rq, f32x4), ctab + ctl, NT * 16, rmode, s, q);
+    } else if (ACC) {
+      v += ld4(yp);
+    }
     st4(yp, v);
     if (EM == 1) {
       const f32x4 d = ld4_round<H>(v) - k4;
@@ -233,8 +308,8 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        emit1(sv[m][nt], yb + oown[m] + nt * 16, (ntg0 + nt) * 16 + kq * 4, bias4[nt], ek[nt], es[nt], eq[nt]);
-    if (has_e) emit1(sve, yb + oex, (ntg0 + nte) * 16 + kq * 4, biase, eke, ese, eqe);
+        emit1(sv[m][nt], yb + oown[m] + nt * 16, nt * 16 + kq * 4, zp[m][nt], rp[m][nt], ap[m][nt], bias4[nt], ek[nt], es[nt], eq[nt]);
+    if (has_e) emit1(sve, yb + oex, nte * 16 + kq * 4, zpe, rpe, ape, biase, eke, ese, eqe);
   };
 
   // ---- units
@@ -242,13 +317,20 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p)
   T6_STAMP();
   for (int u = 0; u < nunits; ++u) {
     T6_STAMP();
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the unit's rows (and of the weights) has landed; the stores of unit u - 2 are long done
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's share of the unit's rows (and of the weights) has landed; the stores of unit u - 2 are long done (lgkmcnt(0): the channel table's writes)
     __builtin_amdgcn_s_barrier();         // ... and everybody else's
     asm volatile("" ::: "memory");        // no LDS read of the unit may move (or be hoisted out of the loop) above the wait
     T6_STAMP();
-    if (u + 1 < nunits) dma_rows(UR * (u + 2) + 2);
-    if (u == 0) load_consts();
-    if (u > 0) emit(u - 1);
+    if (EM == 2) {                        // the epilogue reads what was requested a unit ago: ahead of this unit's requests, so its wait is the one above
+      if (u > 0) emit(u - 1);
+      if (u + 1 < nunits) dma_rows(UR * (u + 2) + 2);
+      if (u == 0) load_consts();
+      prefetch(u);
+    } else {
+      if (u + 1 < nunits) dma_rows(UR * (u + 2) + 2);
+      if (u == 0) load_consts();
+      if (u > 0) emit(u - 1);
+    }
     T6_STAMP();
     f32x4 acc[MT][NT], acce = z4;
 #pragma unroll
@@ -693,7 +775,7 @@ static T6Plan t6_plan(int N, int H, int W, int Ci, int Co) {
     if (g_t6_rows > 0 && RB != g_t6_rows) continue;
     if (H % RB != 0) continue;
     const int instr = ((RB + 2) * RG + 63) / 64, pj = (instr + 7) / 8;
-    if (wbytes + (size_t)pj * 8192 + 8 * (NT + 1) * 32 * 4 > lds_cap) break;
+    if (wbytes + (size_t)pj * 8192 + 8 * (NT + 1) * 32 * 4 + 1024 > lds_cap) break;
     const long jobs = (long)N * (H / RB) * (Co / (16 * NT));
     const double cost = (double)((jobs + 255) / 256) * (RB / 2 + 3.0);     // rounds x (rows + prologue)
     if (cost < best - 1e-9) {
@@ -710,6 +792,7 @@ static T6Plan t6_plan(int N, int H, int W, int Ci, int Co) {
   q.lds = wbytes + (size_t)q.pj * 8192;
   const size_t red = (size_t)8 * (NT + 1) * 32 * 4;
   if ((size_t)q.pj * 8192 < red) q.lds = wbytes + red;
+  q.lds += 1024;                                   // EpiBN mode 2's channel table (behind pj * 8 KiB of patch)
   q.ok = 1;
   return q;
 }
@@ -856,7 +939,8 @@ int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const floa
   }
   return 1;
 }
-extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) { return (t6_plan(N, H, W, Ci, Co).ok || t7_plan(N, H, W, Ci, Co).ok) ? 1 : 0; }
+// 1: the 48-channel kernel takes it, 2: the phased kernel, 0: neither
+extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) { return t7_plan(N, H, W, Ci, Co).ok ? 2 : (t6_plan(N, H, W, Ci, Co).ok ? 1 : 0); }
 void fami_conv_t6_tune(int on) {
   if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 120; }
   else if (on >= 8700 && on < 8999) g_t7_target = on - 8700;

@@ -135,9 +135,14 @@ class Engine:
         # round-3 kernels: forward fusion f32 62.7 -> 62.3 ms, bf16 29.1 -> 29.0 ms (neutral, ~250 launches and as many
         # tensor reads fewer per step: on); backward fusion bf16 29.1 -> 29.3 ms, both 28.7 -> 29.1 ms (off, kept as a
         # tested option).
-        fz = os.environ.get('FAMI_FUSE_BN', 'fwd')
-        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd')
+        # Round 4, 'auto' (the default): forward everywhere, backward only where the weight-resident 48-channel kernel
+        # (conv_t6.hip) takes the input gradient -- it requests the BatchNorm input a unit ahead and reads the channel
+        # constants from LDS, +1.7 us on a 14.5 us launch against 5.7 us saved on the BatchNorm backward
+        # (tools/bench_epi2.py); on the other kernels the epilogue still costs more than the pass it removes.
+        fz = os.environ.get('FAMI_FUSE_BN', 'auto')
+        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
+        self.fuse_bn_bwd_auto = self.bn2 and self.half and fz == 'auto'
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
         # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
         # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
@@ -739,7 +744,9 @@ class Engine:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
                     rec = x.bnrec
-                    if (rec is not None and (self.fuse_bn_bwd or fuse_here) and x.uses == 0 and not x.nofuse and x.lanes is not None
+                    pays = (self.fuse_bn_bwd_auto and kh == 3 and stride == 1 and pad == 1 and dil == 1
+                            and self.L.cdll.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci) == 1)
+                    if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
                         # the epilogue applies the ReLU mask and takes the two sums of the BatchNorm backward

@@ -407,6 +407,7 @@ class Trainer:
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
                      deterministic=getattr(model, 'deterministic', None))
+        self.last_engine = eng              # (tests / tools read its counters)
         if on_bucket is not None:
             eng.persist_lanes = False       # bucket hooks fire between forked regions: keep a join per module
         early = {'ev': None}

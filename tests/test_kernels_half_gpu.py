@@ -236,7 +236,7 @@ def test_weight_resident_dma_conv(dev, half):
                         L.cdll.fami_conv_tune_lds((8100 if Ci == 48 else 8600) + rows)
                     if mt:
                         L.cdll.fami_conv_tune_lds(8200 + mt if Ci == 48 else 8700 + mt)
-                    assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == 1, (N, H, W, Ci, Co, rows)
+                    assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == (1 if Ci == 48 else 2), (N, H, W, Ci, Co, rows)
                 y, ys, dx, dxa = (torch.empty(N, H, W, Co, device=dev, dtype=BF), torch.empty(N, H, W, Co, device=dev, dtype=BF),
                                   torch.empty(N, H, W, Ci, device=dev, dtype=BF), dx0.clone())
                 slots = torch.zeros(L.cdll.fami_bn_slots_bytes(Co) // 8, device=dev, dtype=torch.float64)
