@@ -60,30 +60,7 @@ struct ConvT6Args {
 // EpiBN mode 2 on one lane's four output channels (conv_epi.h; conv_t4.hip's epilogue): v = dL/d(BN output) complete -> ReLU mask
 // (from the BN output, or recomputed from its input z exactly as the forward apply pass computes it), the masked value rounded to
 // the storage type is what gets stored; sum g and sum g * xhat are taken from the rounded values.
-template <typename H>
-__device__ __forceinline__ f32x4 t6_epi2(EpiPtr e, f32x4 v, long idx, int co0, f32x4& s, f32x4& q) {      // e: epi_late (conv_epi.h): the fields stay out of the main loop's SGPRs
-  const f32x4 zz = ld4(reinterpret_cast<const H*>(e->z) + idx);
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(e->mean + co0), is = *reinterpret_cast<const f32x4*>(e->invstd + co0);
-  if (e->relu == 1) {
-    const f32x4 yy = ld4(reinterpret_cast<const H*>(e->yr) + idx);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = yy[r] > 0.f ? v[r] : 0.f;
-  } else if (e->relu == 2) {
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(e->gamma + co0), be = *reinterpret_cast<const f32x4*>(e->beta + co0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a, b;
-      epi_scale_shift(mu[r], is[r], ga[r], be[r], a, b);
-      v[r] = __builtin_fmaf(zz[r], a, b) > 0.f ? v[r] : 0.f;
-    }
-  }
-  const f32x4 g = ld4_round<H>(v);
-  s += g;
-  q += g * ((zz - mu) * is);
-  return v;
-}
-
-// The same arithmetic with every operand already on chip: zz = the BN input's four values, yy = the BN output's (rmode 1; both
+// Every operand is on chip already: zz = the BN input's four values, yy = the BN output's (rmode 1; both
 // requested a unit ahead), ct = this lane's rows of the workgroup's channel table in LDS ([mean | invstd | scale | shift][NT * 16]).
 template <typename H>
 __device__ __forceinline__ f32x4 t6_epi2p(f32x4 v, f32x4 zz, f32x4 yy, const float* ct, int cstride, int rmode, f32x4& s, f32x4& q) {
@@ -584,6 +561,47 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
   typedef typename std::conditional<ACC, f32x4, hx4>::type SV;
   f32x4 acc[MT][NT], acce = z4;
   SV sv[MT][NT], sve;
+  // EpiBN mode 2 (as in conv3x3_t6_kernel): the channel table behind the two buffers, written before the first barrier; what a
+  // job's epilogue reads at the lane's outputs is requested in front of the job's last phase
+  float* const ctab = reinterpret_cast<float*>(smem + 2 * BUFSZ);     // [4][NT * 16]
+  const H* zsrc = nullptr;
+  const H* yrsrc = nullptr;
+  int rmode = 0;
+  if (EM == 2) {
+    EpiPtr e = epi_late(__builtin_offsetof(ConvT7Args, e));
+    zsrc = reinterpret_cast<const H*>(e->z);
+    yrsrc = reinterpret_cast<const H*>(e->yr);
+    rmode = e->relu;
+    if (tid < NT * 16) {
+      const int co = ntg0 * 16 + tid;
+      const float mu = e->mean[co], is = e->invstd[co];
+      float a = 0.f, b = 0.f;
+      if (rmode == 2) epi_scale_shift(mu, is, e->gamma[co], e->beta[co], a, b);
+      ctab[tid] = mu;
+      ctab[NT * 16 + tid] = is;
+      ctab[2 * NT * 16 + tid] = a;
+      ctab[3 * NT * 16 + tid] = b;
+    }
+  }
+  hx4 zp[MT][NT], zpe, ap[MT][NT], ape;        // (the BN output of rmode 1 is read in the epilogue: no registers left for it)
+  auto prefetch = [&](int jq) {
+    const int img = jq / p.bands, y0 = (jq - img * p.bands) * p.RB;
+    const long ub = (long)(img * p.H + y0) * W * p.Co;
+    const H* zb = zsrc + ub;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) zp[m][nt] = *reinterpret_cast<const hx4*>(zb + oown[m] + nt * 16);
+    if (EX) zpe = *reinterpret_cast<const hx4*>(zb + oex);
+    if (ACC) {
+      const H* ab = reinterpret_cast<const H*>(p.y) + ub;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) ap[m][nt] = *reinterpret_cast<const hx4*>(ab + oown[m] + nt * 16);
+      if (EX) ape = *reinterpret_cast<const hx4*>(ab + oex);
+    }
+  };
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -605,12 +623,14 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       }
     }
   };
-  auto emit1 = [&](const SV& v, H* yp, int co0, f32x4& s, f32x4& q) {
+  auto emit1 = [&](const SV& v, H* yp, int ctl, const hx4& zq, const hx4& aq, f32x4& s, f32x4& q) {
     if constexpr (EM == 2) {
       f32x4 t;
-      if constexpr (ACC) t = v + ld4(yp);
+      if constexpr (ACC) t = v + __builtin_convertvector(aq, f32x4);
       else t = __builtin_convertvector(v, f32x4);          // (rounded once already: masking commutes with the rounding)
-      st4(yp, t6_epi2<H>(epi_late(__builtin_offsetof(ConvT7Args, e)), t, yp - reinterpret_cast<H*>(p.y), co0, s, q));
+      f32x4 yy = z4;
+      if (rmode == 1) yy = ld4(yrsrc + (yp - reinterpret_cast<H*>(p.y)));
+      st4(yp, t6_epi2p<H>(t, __builtin_convertvector(zq, f32x4), yy, ctab + ctl, NT * 16, rmode, s, q));
     } else if constexpr (ACC) st4(yp, v + ld4(yp));
     else *reinterpret_cast<hx4*>(yp) = v;
   };
@@ -621,16 +641,16 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     for (int m = 0; m < MT; ++m)
       if (pvalid[m]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16, (ntg0 + nt) * 16 + kq * 4, es[nt], eq[nt]);
+        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16, nt * 16 + kq * 4, zp[m][nt], ap[m][nt], es[nt], eq[nt]);
       }
-    if (EX && pvalide) emit1(sve, yb + oex, (ntg0 + nte) * 16 + kq * 4, ese, eqe);
+    if (EX && pvalide) emit1(sve, yb + oex, nte * 16 + kq * 4, zpe, ape, ese, eqe);
   };
 
   // ---- (job, phase) steps: one wait + barrier each; the next step's copy is issued while this one is multiplied, across job
   // boundaries; a job's results are written after the NEXT step's barrier (no store in front of a wait)
   int jb = job0, ph = 0, step = 0, pending = -1;
   while (jb < job1) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's share of the step has landed
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's share of the step has landed (lgkmcnt(0): the channel table's writes)
     __builtin_amdgcn_s_barrier();         // ... everybody's, and every wave has left the previous step (the other buffer is free)
     asm volatile("" ::: "memory");
     int nj = jb, nph = ph + 1;
@@ -646,6 +666,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       emit(pending);
       pending = -1;
     }
+    if (EM == 2 && nph == 0) prefetch(jb);
     auto body = [&](auto ec, auto oc) {
       constexpr bool E = decltype(ec)::value;
       constexpr bool O = decltype(oc)::value;          // the wave has own tiles (only the 12x9 maps leave a wave without)
@@ -851,7 +872,7 @@ static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
     else continue;
     const int PI = ((RB + 2) * RG + 63) / 64;
     if (PI > 8 * T7_PJ) continue;
-    const size_t lds = 2 * (size_t)(42 + PI) * 1024;
+    const size_t lds = 2 * (size_t)(42 + PI) * 1024 + 1024;     // (+ EpiBN mode 2's channel table)
     if (lds > 160 * 1024) continue;
     const long jobs = (long)N * (H / RB) * (Co / 48);
     if (jobs > 512 && g_t7_rows == 0) continue;       // (more than one round of workgroups: the band kernel's two workgroups per CU win, e.g. 96 -> 48 @64x64 19.2 vs 14.3 us)

@@ -744,8 +744,11 @@ class Engine:
                     gx, acc = self.gbuf(x)
                     wpd = self.packed(weight, 1)
                     rec = x.bnrec
-                    pays = (self.fuse_bn_bwd_auto and kh == 3 and stride == 1 and pad == 1 and dil == 1
-                            and self.L.cdll.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci) == 1)
+                    pays = False
+                    if self.fuse_bn_bwd_auto and rec is not None and (kh, stride, pad, dil) == (3, 1, 1, 1):
+                        kind = self.L.cdll.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
+                        t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
+                        pays = kind == 1 or (kind == 2 and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
                     if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
