@@ -54,7 +54,7 @@ class RefNet(nn.Module):
         return self.last(self.down(self.b(self.a(x))))
 
 
-def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None):
+def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None, auto=False):
     """the same graph on the HIP engine -> dict of results (fp32, on the host)"""
     from fami_pose_amd.engine import Engine, T
     from fami_pose_amd.modules import BasicBlock, _cbr, run_cbr
@@ -69,7 +69,8 @@ def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None):
     eng = Engine(dev, dtype=dtype)
     if not eng.bn2:
         pytest.skip('two-launch BatchNorm disabled')
-    eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # the fusion is opt-in (FAMI_FUSE_BN): switch it per engine
+    eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # switch the fusion per engine (FAMI_FUSE_BN)
+    eng.fuse_bn_bwd_auto = bool(auto)                   # (the default's per-kernel choice for the backward statistics)
     if fuse_bwd is not None:
         eng.fuse_bn_bwd = bool(fuse_bwd)
     eng.use_xbn = bool(xbn)
@@ -133,6 +134,39 @@ def test_fused_bn_statistics(dev, shape, dt, lds_mode):
         for n, b in ref.named_buffers():
             if b.dtype.is_floating_point:
                 assert relerr(fused['b.' + n], b) < 1e-5, n
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_default_backward_fusion_follows_the_input_gradient_kernel(dev, dt):
+    """FAMI_FUSE_BN=auto (the 16-bit default): the backward statistics ride in the input gradient's epilogue exactly where the
+    DMA-staged kernels (conv_t6.hip) take it -- the 48-channel kernel at every such site (a.bn1: mask recomputed from the BN
+    input; a.bn2: residual, mask from the BN output, accumulating launch; b.bn1), the phased kernel not at all here (no
+    96-channel 3x3 in the net) -- and nowhere once those kernels are switched off.  Results against the unfused graph as in
+    test_fused_bn_statistics."""
+    from fami_pose_amd._lib import lib
+    N, C, H, W, C2 = 8, 48, 96, 72, 96
+    torch.manual_seed(77)
+    ref = RefNet(C, C2).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.3)
+                m.running_mean.normal_(0, 0.2)
+    x = torch.randn(N, C, H, W) + 0.5
+    gy = torch.randn(N, 8, (H + 1) // 2, (W + 1) // 2)
+    assert lib().cdll.fami_conv_t6_eligible(N, H, W, C, C) == 1
+    auto, na = _run(dev, ref, x, gy, DT[dt], True, fuse_bwd=False, auto=True)
+    plain, npl = _run(dev, ref, x, gy, DT[dt], True, fuse_bwd=False)
+    assert na['bwd'] == 3 and npl['bwd'] == 0 and na['fwd'] == npl['fwd']
+    ref32, _ = _run(dev, ref, x, gy, torch.float32, False)
+    ulp = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}[dt]
+    for k in auto:
+        ea, ep = relerr(auto[k], ref32[k]), relerr(plain[k], ref32[k])
+        assert ea < 1.5 * ep + ulp, (k, ea, ep)
+    lib().cdll.fami_conv_tune_lds(8000)               # (the autouse fixture restores the knobs)
+    off, no = _run(dev, ref, x, gy, DT[dt], True, fuse_bwd=False, auto=True)
+    assert no['bwd'] == 0
 
 
 @pytest.mark.parametrize('shape', [(2, 48, 24, 18, 96), (3, 96, 13, 11, 192), (2, 192, 12, 10, 384), (2, 64, 23, 20, 64),
