@@ -236,6 +236,29 @@ def test_glue_ops(dev):
     assert torch.equal(eng.to_nchw(eng.from_nchw(x.to(dev))).cpu(), x)
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(55296, 48), (4099, 48), (5000, 17), (300, 48), (12288, 288), (4608, 1536)], ids=lambda s: '%dx%d' % s)
+def test_channel_sum(dev, shape, dt):
+    """fami_channel_sum_* (bias gradients of the biased convolutions, Alignment_V15.py:60-101): out[c] (+)= sum_p x[p][c] against
+    an fp64 sum of the same stored values -- the four-channel form (C % 4 == 0, >= 4096 rows), the scalar form, and the
+    C > 256 walk."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    P, C = shape
+    torch.manual_seed(P + C)
+    tdt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[dt]
+    x = (torch.randn(P, C, device=dev) + 0.25).to(tdt)
+    ref = x.double().sum(0)
+    out = torch.full((C,), 3.0, device=dev)
+    ws = torch.empty(L.cdll.fami_channel_sum_workspace(C) // 4, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    L.call('fami_channel_sum_' + dt, x.data_ptr(), P, C, out.data_ptr(), 0, ws.data_ptr(), st)
+    tol = 2e-6 * x.double().abs().sum(0).max().item()
+    assert (out.double() - ref).abs().max().item() < tol
+    L.call('fami_channel_sum_' + dt, x.data_ptr(), P, C, out.data_ptr(), 1, ws.data_ptr(), st)
+    assert (out.double() - 2 * ref).abs().max().item() < 2 * tol
+
+
 def test_linear_chain(dev):
     torch.manual_seed(3)
     from fami_pose_amd.engine import T
