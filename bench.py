@@ -14,6 +14,7 @@ plus `roofline` (dominant kernel, live HIP-event timing) and, at N=1, `cpu_basel
 """
 import argparse
 import json
+import gc
 import os
 import sys
 import time
@@ -435,6 +436,7 @@ def main():
                          "allreduce_ms_expected_mesh": round(2 * wire / world / 153e9 * 1e3, 3),
                          "allreduce_wire_bytes": int(wire)})
         del trainer, model
+        gc.collect()                 # (the Trainer is a reference cycle: its hipGraph goes now, not inside the next capture)
         torch.cuda.empty_cache()
         return dt, loss, info
 

@@ -407,7 +407,8 @@ class Trainer:
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
                      deterministic=getattr(model, 'deterministic', None))
-        self.last_engine = eng              # (tests / tools read its counters)
+        self.last_nfused = eng.nfused       # (tools read the counters; not the engine itself: its callbacks point back here, and a
+                                            #  Trainer kept alive by that cycle is collected at a random time -- e.g. inside the next capture)
         if on_bucket is not None:
             eng.persist_lanes = False       # bucket hooks fire between forked regions: keep a join per module
         early = {'ev': None}
@@ -593,6 +594,21 @@ class Trainer:
 
     # ------------------------------------------------------------------ hipGraph capture / replay
     def _capture(self, kf_x, sup_x, target, weight):
+        """Capture with the cyclic garbage collector off: a collection that starts inside a capture may destroy an older Trainer's
+        graph (Engine / Trainer objects are reference cycles through their callbacks, so `del trainer` leaves them to the collector),
+        and destroying a graph while a stream captures in the global mode aborts the process (hipErrorStreamCaptureUnsupported out
+        of ~CUDAGraph).  torch.cuda.graph() no longer collects on entry in this PyTorch, so it is done here."""
+        import gc
+        was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._capture_plan(kf_x, sup_x, target, weight)
+        finally:
+            if was:
+                gc.enable()
+
+    def _capture_plan(self, kf_x, sup_x, target, weight):
         st = {'kf': kf_x.clone(), 'sup': sup_x.clone(), 'target': target.clone(), 'weight': weight.clone()}
         # warm-up on a side stream (allocator + pack caches).  The warm-up steps must not count as training steps: the
         # parameters, Adam state and module buffers (BN running statistics, batch counters) are restored afterwards, so

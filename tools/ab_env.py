@@ -30,7 +30,7 @@ for spec in sys.argv[3:]:
     tr = Trainer(model, lr=1e-3, use_mi=True, use_graph=True, targets_from_joints=True)
     for _ in range(3): tr.step(kf, sup, joints, vis)      # capture happens under this setting
     torch.cuda.synchronize()
-    print('%s: statistics passes in convolution epilogues %s' % (name, dict(tr.last_engine.nfused)), flush=True)
+    print('%s: statistics passes in convolution epilogues %s' % (name, dict(tr.last_nfused)), flush=True)
     trs.append((name, tr))
     for k, old in envs:
         if old is None: os.environ.pop(k, None)
