@@ -140,6 +140,32 @@ def test_smaller_last_batch_under_graph_replay(dev):
         tr.step(seq[0][0], seq[1][1], seq[0][2], seq[0][3])
 
 
+def test_no_garbage_collection_inside_a_capture(dev):
+    """A Trainer that went out of scope is a reference cycle (its Engine's callbacks point back at it), so its hipGraph is destroyed
+    by the cyclic collector -- and a graph destroyed while a stream captures aborts the process (the default bench run: f32 Trainer,
+    then the bf16 Trainer's capture).  Trainer._capture collects first and keeps the collector off until the capture has ended."""
+    import gc
+    from fami_pose_amd.train import Trainer
+    bt = _batch(dev, 30, 1)
+    model, _ = _model()
+    tr = Trainer(model.to(dev), use_graph=True, targets_from_joints=True)
+    tr.step(*bt)
+    del tr, model                                  # (left to the collector)
+    model, _ = _model()
+    tr = Trainer(model.to(dev), use_graph=True, targets_from_joints=True)
+    seen = []
+    inner = tr._forward_backward
+
+    def spy(*a, **k):
+        seen.append((torch.cuda.is_current_stream_capturing(), gc.isenabled()))
+        return inner(*a, **k)
+    tr._forward_backward = spy
+    assert gc.isenabled()
+    tr.step(*bt)
+    assert gc.isenabled()
+    assert (True, False) in seen and (True, True) not in seen
+
+
 def test_lr_schedule_drives_captured_adam(dev):
     """MultiStepLR (scheduler.py:14-35; TRAIN.LR_STEP / LR_FACTOR) writes the device-resident learning rate: the captured
     hipGraph keeps replaying and the very next update is gamma times smaller.  Changing betas re-captures."""
