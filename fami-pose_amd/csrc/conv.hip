@@ -887,6 +887,17 @@ __global__ __launch_bounds__(256) void conv_igemm_h(ConvArgsH p) {
       if (VEC) {
         const unsigned o = cbase < p.Ci ? aoff[mt] + kc * 64 : FAMI_OOB;
         a[mt] = __builtin_bit_cast(hx8, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+      } else if ((p.Ci & 3) == 0) {
+        // channel counts that are multiples of 4 but not of 8 (the 108 mask channels of the DCN predictors: their input gradient is on
+        // the head's serial chain): two 8-byte loads per fragment instead of eight 2-byte ones
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned o0 = cbase < p.Ci ? aoff[mt] + kc * 64 : FAMI_OOB;
+        const unsigned o1 = cbase + 4 < p.Ci ? aoff[mt] + kc * 64 + 8 : FAMI_OOB;
+        const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, o0, 0, 0));
+        const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, o1, 0, 0));
+        const u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+        a[mt] = __builtin_bit_cast(hx8, t);
       } else {
         s16x8 t;
 #pragma unroll

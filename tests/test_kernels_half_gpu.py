@@ -69,6 +69,8 @@ CASES = [
     (2, 16, 12, 256, 48, 3, 1, 1, 1, False),
     (2, 13, 9, 96, 192, 3, 2, 1, 1, False),      # odd sizes, stride 2
     (2, 24, 18, 48, 216, 3, 1, 3, 3, True),      # DCN offset predictor (dilation 3)
+    (2, 24, 18, 48, 108, 3, 1, 3, 3, True),      # DCN mask predictor: input gradient over 108 channels (8-byte operand fetch)
+    (2, 13, 9, 20, 108, 3, 2, 1, 1, True),       # ... the same fetch, stride 2 (parity-class input gradient), both directions
     (2, 24, 18, 48, 17, 1, 1, 0, 1, True),       # heatmap head (Co = 17, fp32 output)
     (3, 7, 5, 16, 16, 3, 2, 1, 1, True),
     (1, 5, 7, 20, 36, 3, 1, 1, 1, True),         # channel tails
