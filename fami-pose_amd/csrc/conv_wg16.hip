@@ -331,7 +331,8 @@ struct Wg6Args {
   int N, H, W, Ci, Co;
   int st, Ho, Wo;   // stride (1 | 2), output map
   int UR, upf;      // OUTPUT rows per unit, units per frame (Ho / UR)
-  int PR;           // patch rows of a unit (st (UR - 1) + 3)
+  int PR;           // patch rows of a unit (st (UR - 1) + 2 dil + 1)
+  int dil;          // dilation = padding (1; 3: the DCN predictors of the head, stride 1)
   int M;            // output pixels of a unit (UR * Wo)
   int nunits;       // units per workgroup (consecutive, frame-major)
   int NU;           // units in total (N * upf)
@@ -347,7 +348,8 @@ struct Wg6Args {
 
 // KS: K steps of 32 pixels per unit (ceil(M / 32): the dY rows past M are zeros); CIT x COT: 16-channel tiles of the workgroup's
 // channel block (3 x 3: the HRNet branches; 4 x 4 / 4 x 3: the 64-channel 3x3 convolutions of stage 1 and the 256 -> 48 transition)
-template <typename H, int KS, int CIT, int COT>
+// XJ: most patch DMA instructions per wave and unit (8 for the dilated launches: a unit of two output rows reads 2 + 2 dil patch rows)
+template <typename H, int KS, int CIT, int COT, int XJ = WG6_XJ>
 __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p) {
   typedef typename H16<H>::x8 hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -380,16 +382,16 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
   // channel slice included); dY granule -> byte offset from the unit's first pixel
   const long xfb = (long)p.H * W * p.Ci * 2, yfb = (long)p.Ho * Wo * p.Co * 2;     // one frame
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-  int xrow[WG6_XJ], xoff[WG6_XJ], yoff[WG6_YJ];
+  int xrow[XJ], xoff[XJ], yoff[WG6_YJ];
   {
     const int q0 = wave * 64 + lane;
     int r = q0 / p.RG, wi = q0 - r * p.RG;
 #pragma unroll
-    for (int j = 0; j < WG6_XJ; ++j) {
+    for (int j = 0; j < XJ; ++j) {
       const int pos = wi / GX, c = wi - pos * GX;
-      const bool ok = r < p.PR && pos >= 1 && pos <= W;
+      const bool ok = r < p.PR && pos >= p.dil && pos < W + p.dil;      // (dil = pad border positions on either side)
       xrow[j] = ok ? r : 0x40000000;                  // never a valid image row
-      xoff[j] = ((r * W + pos - 1) * p.Ci + cib * (16 * CIT) + c * 8) * 2;
+      xoff[j] = ((r * W + pos - p.dil) * p.Ci + cib * (16 * CIT) + c * 8) * 2;
       r += p.q512;
       wi += p.r512;
       if (wi >= p.RG) {
@@ -401,7 +403,9 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     for (int j = 0; j < WG6_YJ; ++j) {
       const int q = (wave + WG16_WAVES * j) * 64 + lane;
       const int pix = q / GY, c = q - pix * GY;
-      yoff[j] = pix < p.M ? (pix * p.Co + cob * (16 * COT) + c * 8) * 2 : (int)0x80000000;
+      // (a channel tail -- Co not a multiple of the block -- reads zeros; a granule that straddles Co picks up the next pixel's first
+      //  channels: they only reach accumulator columns >= Co, which are not stored)
+      yoff[j] = (pix < p.M && cob * (16 * COT) + c * 8 < p.Co) ? (pix * p.Co + cob * (16 * COT) + c * 8) * 2 : (int)0x80000000;
     }
   }
   // a unit's scalars (frame, rows, buffer descriptors) once per unit: the pieces of its copy are issued one per K step, and the
@@ -411,14 +415,14 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     UnitGeo g;
     const int img = ug / p.upf;
     g.ui = ug - img * p.upf;
-    g.yt = p.st * g.ui * p.UR - 1;                     // image row of the unit's first patch row
+    g.yt = p.st * g.ui * p.UR - p.dil;                 // image row of the unit's first patch row
     g.rx = wg6_rsrc(reinterpret_cast<const char*>(p.x) + (long)img * xfb, (int)xfb);
     g.ry = wg6_rsrc(reinterpret_cast<const char*>(p.dy) + (long)img * yfb, (int)yfb);
     return g;
   };
-  // piece k of a unit's copy (k < WG6_XJ: patch, else dY rows); wave-uniform guards
+  // piece k of a unit's copy (k < XJ: patch, else dY rows); wave-uniform guards
   auto dma_piece = [&](const UnitGeo& g, unsigned buf, int k) {
-    if (k < WG6_XJ) {
+    if (k < XJ) {
       const int i = wave + WG16_WAVES * k;             // (wave-uniform)
       if (i < p.XI) {
         unsigned off = (unsigned)(g.yt * W * p.Ci * 2 + xoff[k]);
@@ -426,9 +430,9 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
         wg6_dma16(g.rx, off, buf + i * 1024);
       }
     } else {
-      const int i = wave + WG16_WAVES * (k - WG6_XJ);
+      const int i = wave + WG16_WAVES * (k - XJ);
       if (i < p.YI) {
-        const int yo = yoff[k - WG6_XJ];
+        const int yo = yoff[k - XJ];
         wg6_dma16(g.ry, yo < 0 ? 0x80000000u : (unsigned)(g.ui * p.UR * Wo * p.Co * 2 + yo), buf + XB + i * 1024);
       }
     }
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
   if (nunits > 0) {
     const UnitGeo g0 = unit_geo(u0g);
 #pragma unroll
-    for (int k = 0; k < WG6_XJ + WG6_YJ; ++k) dma_piece(g0, lds0, k);
+    for (int k = 0; k < XJ + WG6_YJ; ++k) dma_piece(g0, lds0, k);
   }
   WG6_STAMP();
 
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
     pci[i] = ok ? q / TAPS : 0;
     ptap[i] = ok ? q - pci[i] * TAPS : -1;
     const int t = ok ? ptap[i] : 0;
-    poff[i] = ((t / 3) * PW + (t % 3)) * PS + pci[i] * 32 + piece * 8;
+    poff[i] = ((t / 3) * PW + (t % 3)) * p.dil * PS + pci[i] * 32 + piece * 8;
   }
   f32x4 acc[NPW][COT];
 #pragma unroll
@@ -523,10 +527,10 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) load((ks + 1) & 1);
         if (more) {
-          if (ks < WG6_XJ + WG6_YJ) dma_piece(gn, nbuf, ks);
+          if (ks < XJ + WG6_YJ) dma_piece(gn, nbuf, ks);
           if (ks == KS - 1) {
 #pragma unroll
-            for (int k = KS; k < WG6_XJ + WG6_YJ; ++k) dma_piece(gn, nbuf, k);
+            for (int k = KS; k < XJ + WG6_YJ; ++k) dma_piece(gn, nbuf, k);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
       const int co = cob * (16 * COT) + c * 16 + l16;
+      if (co >= p.Co) continue;                        // (channel tail)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ci = cib * (16 * CIT) + pci[i] * 16 + kq * 4 + r;
@@ -562,40 +567,47 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 
 static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
-struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho, Wo, PR; size_t lds; };
+struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho, Wo, PR, XJ, coBlocks; size_t lds; };
 static int g_wg6_s2 = 1;      // fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on
+static int g_wg6_dil = 1;     // fami_conv_tune_wgrad_lds(23008 / 23009): the dilated (48 -> 216 / 108, dilation 3) launches off / on
 static int g_wg6_c42 = 1;
 static int g_wg6_c4 = 1;      // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
 static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
   q.ok = 0;
-  if (!g_wg6 || k != 3 || !(st == 1 || (st == 2 && g_wg6_s2)) || pad != 1 || dil != 1) return q;
-  q.Ho = (H + 2 - 3) / st + 1;
-  q.Wo = (W + 2 - 3) / st + 1;
+  // dilated form (the DCN offset / mask predictors of the head, Alignment_V15.py:83-101: 48 -> 216 / 108, dilation = padding = 3,
+  // stride 1): 48-channel blocks with a channel tail, units of two output rows (2 + 2 dil patch rows)
+  const bool dilated = dil > 1;
+  if (!g_wg6 || k != 3 || !(st == 1 || (st == 2 && g_wg6_s2)) || pad != dil || (dilated && (!g_wg6_dil || st != 1 || dil > 3 || Ci % 48 != 0 || Co % 4 != 0))) return q;
+  q.Ho = (H + 2 * pad - 2 * dil - 1) / st + 1;
+  q.Wo = (W + 2 * pad - 2 * dil - 1) / st + 1;
   q.CIT = Ci % 48 == 0 ? 3 : (Ci % 64 == 0 ? 4 : 0);
-  q.COT = Co % 48 == 0 ? 3 : (Co % 64 == 0 ? 4 : 0);
+  q.COT = (Co % 48 == 0 || dilated) ? 3 : (Co % 64 == 0 ? 4 : 0);
+  q.XJ = dilated ? 8 : WG6_XJ;
   if (!q.CIT || !q.COT || (q.CIT == 3 && q.COT == 4) || (q.CIT == 4 && !g_wg6_c4)) return q;
   // 64 x 64 blocks only fit the LDS twice with two-row units (five K steps, a barrier per 144 pixels, 17 spilled registers);
   // 64 x 32 blocks take four-row units (nine K steps): fami_conv_tune_wgrad_lds(23006 / 23007) off / on
   if (q.CIT == 4 && q.COT == 4 && g_wg6_c42) q.COT = 2;       // (3 x 4 is not instantiated: no layer of the path has it)
   // rows per unit: about 288 pixels (nine K steps) of whole rows, H a multiple, two buffers in the LDS
-  const int RG = (W + 2) * 2 * q.CIT;
+  const int RG = (W + 2 * dil) * 2 * q.CIT;
   q.UR = 0;
   for (int ur = q.Ho; ur >= 1; --ur) {
     if (q.Ho % ur != 0 || ur * q.Wo > 288) continue;
-    const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 3;
+    const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 2 * dil + 1;
     if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4 || (KS == 3 && q.CIT == 4 && q.COT == 2)) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
     if (q.CIT == 4 && !(KS == 5 || ((KS == 9 || KS == 3) && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
     const int XI = (PR * RG + 63) / 64, YI = KS * q.COT;
-    if (XI > 8 * WG6_XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
+    if (XI > 8 * q.XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
+    if (dilated && KS != 5) continue;                    // (instantiated: five K steps)
     q.UR = ur; q.M = M; q.KS = KS; q.XI = XI; q.YI = YI; q.PR = PR;
     break;
   }
   if (!q.UR) return q;
   q.lds = 2 * (size_t)(q.XI + q.YI) * 1024;
   q.upf = q.Ho / q.UR;
-  q.blocks = (Ci / (16 * q.CIT)) * (Co / (16 * q.COT));
+  q.coBlocks = (Co + 16 * q.COT - 1) / (16 * q.COT);
+  q.blocks = (Ci / (16 * q.CIT)) * q.coBlocks;
   const long NU = (long)N * q.upf;
   // units per workgroup: about g_wg6_target workgroups in the launch (the other stream lanes use the CUs a launch leaves, and a
   // workgroup's 83 KB partial slab -- written, then read by the reduce -- is the kernel's largest HBM item).  Alone 240 is the
@@ -1071,25 +1083,26 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
       Wg6Args a;
       a.x = x; a.dy = dy; a.part = part; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
       a.st = st; a.Ho = q6.Ho; a.Wo = q6.Wo; a.PR = q6.PR;
-      a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = Co / (16 * q6.COT);
-      a.PW = W + 2; a.RG = (W + 2) * 2 * q6.CIT; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / q6.Wo; a.dxr = 32 % q6.Wo;
+      a.UR = q6.UR; a.upf = q6.upf; a.M = q6.M; a.nunits = q6.nunits; a.NU = N * q6.upf; a.coBlocks = q6.coBlocks; a.dil = dil;
+      a.PW = W + 2 * dil; a.RG = (W + 2 * dil) * 2 * q6.CIT; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG; a.dyq = 32 / q6.Wo; a.dxr = 32 % q6.Wo;
       a.XI = q6.XI; a.YI = q6.YI; a.dbg = g_wg6_dbg;
       const dim3 grid(q6.G, q6.blocks);
       bool ok6 = false;
-#define FAMI_WG6_CASE(ks, cit, cot)                                                                                       \
-  if (q6.KS == ks && q6.CIT == cit && q6.COT == cot) {                                                                    \
+#define FAMI_WG6_CASE(ks, cit, cot, xj)                                                                                   \
+  if (!ok6 && q6.KS == ks && q6.CIT == cit && q6.COT == cot && q6.XJ == xj) {                                                                    \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, ks, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, ks, cit, cot>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<bf16_t, ks, cit, cot, xj>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad6_kernel<f16_t, ks, cit, cot, xj>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, ks, cit, cot>), grid, dim3(WG16_THREADS), q6.lds, s, a);      \
-    else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, ks, cit, cot>), grid, dim3(WG16_THREADS), q6.lds, s, a);                    \
+    if (half_kind == 1) hipLaunchKernelGGL((conv_wgrad6_kernel<f16_t, ks, cit, cot, xj>), grid, dim3(WG16_THREADS), q6.lds, s, a);      \
+    else hipLaunchKernelGGL((conv_wgrad6_kernel<bf16_t, ks, cit, cot, xj>), grid, dim3(WG16_THREADS), q6.lds, s, a);                    \
     ok6 = true;                                                                                                           \
   }
-      FAMI_WG6_CASE(9, 3, 3) FAMI_WG6_CASE(8, 3, 3) FAMI_WG6_CASE(7, 3, 3) FAMI_WG6_CASE(5, 3, 3) FAMI_WG6_CASE(4, 3, 3)
-      FAMI_WG6_CASE(5, 4, 4) FAMI_WG6_CASE(5, 4, 3) FAMI_WG6_CASE(9, 4, 2) FAMI_WG6_CASE(5, 4, 2) FAMI_WG6_CASE(3, 4, 2)
+      FAMI_WG6_CASE(9, 3, 3, WG6_XJ) FAMI_WG6_CASE(8, 3, 3, WG6_XJ) FAMI_WG6_CASE(7, 3, 3, WG6_XJ) FAMI_WG6_CASE(5, 3, 3, WG6_XJ) FAMI_WG6_CASE(4, 3, 3, WG6_XJ)
+      FAMI_WG6_CASE(5, 4, 4, WG6_XJ) FAMI_WG6_CASE(5, 4, 3, WG6_XJ) FAMI_WG6_CASE(9, 4, 2, WG6_XJ) FAMI_WG6_CASE(5, 4, 2, WG6_XJ) FAMI_WG6_CASE(3, 4, 2, WG6_XJ)
+      FAMI_WG6_CASE(5, 3, 3, 8)
 #undef FAMI_WG6_CASE
       if (ok6) {
         hipError_t err6 = hipGetLastError();
@@ -1120,10 +1133,11 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_dil = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
   else if (on == 5000 || on == 5001) g_wgs = on - 5000;           // (fami_conv_tune_wgrad_lds(25000 / 25001): the stem conv1 kernel off / on)
+  else if (on == 3008 || on == 3009) g_wg6_dil = on - 3008;
   else if (on == 3006 || on == 3007) g_wg6_c42 = on - 3006;
   else if (on == 3004 || on == 3005) g_wg6_s2 = on - 3004;
   else if (on == 3002 || on == 3003) g_wg6_c4 = on - 3002;

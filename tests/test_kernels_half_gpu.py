@@ -368,6 +368,44 @@ def test_dma_staged_wide_1x1_weight_gradient(dev, half):
         L.cdll.fami_conv_tune_wgrad_lds(-1)
 
 
+def test_dma_staged_weight_gradient_dilated(dev, half):
+    """conv_wgrad6_kernel on the dilated predictors of the alignment head (Alignment_V15.py:83-101: 48 -> 216 offsets, 48 -> 108 masks,
+    dilation = padding = 3): units of two output rows over 2 + 2 dil patch rows, tap offsets scaled by the dilation, 48-channel
+    output blocks with a tail (216 = 4.5 blocks; 108 is not even a whole 8-channel granule: the straddling granule's extra channels
+    only reach columns that are not stored).  Against fp64 on the same operands and against conv_wgrad16_kernel."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W, Ci, Co, dil) in enumerate([(8, 96, 72, 48, 216, 3), (8, 96, 72, 48, 108, 3), (2, 24, 18, 48, 216, 3), (3, 24, 18, 48, 108, 3),
+                                                     (2, 16, 36, 96, 52, 2), (1, 96, 72, 48, 48, 3)]):
+            torch.manual_seed(it)
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)
+            geo = (N, H, W, Ci, Co, 3, 3, 1, dil, dil)
+            nb = L.cdll.fami_conv2d_wgrad_workspace(*geo)
+            ws = torch.empty(nb // 4 + 4, device=dev)
+            wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=dil, dilation=dil).backward(dy.double().permute(0, 3, 1, 2))
+            ref = wref.grad
+            dw0 = torch.randn(Co, Ci, 3, 3, device=dev)
+            out = {}
+            for code in (23008, 23009):
+                L.cdll.fami_conv_tune_wgrad_lds(-1)
+                L.cdll.fami_conv_tune_wgrad_lds(code)
+                dw, dwa = torch.empty(Co, Ci, 3, 3, device=dev), dw0.clone()
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, 0, st)
+                L.call('fami_conv2d_wgrad' + sfx, p(x), p(dy), p(dwa), p(ws), ws.numel() * 4, *geo, 1, st)
+                torch.cuda.synchronize(dev)
+                assert relerr(dw, ref) < 2e-6 and relerr(dwa - dw0, ref) < 2e-5, (it, code, relerr(dw, ref))
+                out[code] = dw
+            assert relerr(out[23009], out[23008].double()) < 2e-6
+    finally:
+        L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
 def test_dma_staged_weight_gradient_stride2(dev, half):
     """conv_wgrad6_kernel on the stride-2 3x3 convolutions of the fuse / transition chains (hrnet.py:117-150): the unit's patch is
     st (UR - 1) + 3 input rows, a pixel's tap sits at twice its output coordinates.  Against fp64 and conv_wgrad16_kernel."""
