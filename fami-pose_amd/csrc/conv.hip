@@ -2663,7 +2663,13 @@ int fami_conv_tune(int mt, int nt, int ks) {
 }
 // 1 routes eligible 3x3 stride-1 convolutions through the LDS-staged kernel, 0 through the direct kernels,
 // -1 = default (bf16: staged, f32: direct)
+void fami_conv_stem_tune(int on);
 int fami_conv_tune_lds(int on) {
+  if (on == 9000 || on == 9001) {            // conv_stem.hip (the stem's first convolution, 16-bit forward): off / on
+    fami_conv_stem_tune(on - 9000);
+    return FAMI_OK;
+  }
+  if (on < 0) fami_conv_stem_tune(-1);
   if (on == 10 || on == 11 || on == 20 || on == 21 || on == 30 || on == 31 || (on >= 40 && on <= 42) || (on >= 52 && on <= 54) || (on >= 60 && on <= 62) || on >= 100) {   // (30 / 31: split-product f32 instance) register-blocked kernel (conv_t4.hip): 10 / 11 off / on (20 / 21: its f32 instance);
     fami_conv_t4_tune(on);                   // 100 + tiles per band (100 = heuristic)
     return FAMI_OK;
@@ -3396,6 +3402,12 @@ static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, 
   return FAMI_OK;
 }
 
+// conv_stem.hip: the stem's 3 -> 64 stride-2 convolution with K dense over (tap, channel)
+int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
+                        int kh, int kw, int stride, int pad, int dil, int NTt, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi);
+void fami_conv_stem_tune(int on);
+
 // y[N,Ho,Wo,Co] (16-bit, or f32 when out_f32) (=|+=) relu?( conv(x[N,H,W,Ci]) + bias ) ; wp packed with mode 0
 template <typename HT>
 static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const float* bias, void* y, int N, int H, int W,
@@ -3421,6 +3433,11 @@ static int conv_fwd_h_impl(const char* nm, const HT* x, const HT* wp, const floa
   const long xb = (long)N * H * W * Ci * 2, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (Ci == 3 && !xbn.on) {
+    const int rc = fami_try_conv_stem1(std::is_same<HT, f16_t>::value ? 1 : 0, x, wp, bias, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil,
+                                       a.NTt, relu, accumulate, out_f32, s, nm, e);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1) {
     const int rc = try_conv3x3_lds<HT>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, out_f32, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;

@@ -441,6 +441,53 @@ def test_dma_staged_weight_gradient_stride2(dev, half):
         L.cdll.fami_conv_tune_wgrad_lds(-1)
 
 
+def test_stem_conv1_forward(dev, half):
+    """conv_stem1_fwd_kernel (conv_stem.hip): the stem's 3 -> 64 stride-2 convolution with K dense over (tap, channel) -- against fp64
+    on the same 16-bit operands and against the implicit-GEMM kernel it replaces (fami_conv_tune_lds(9000)); with the BatchNorm
+    statistics epilogue the slot rows must hold the shifted sums of the values AS STORED (odd sizes: border taps on every side,
+    a ragged last pixel tile)."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W, has_bias) in enumerate([(4, 384, 288, False), (3, 38, 26, True), (1, 17, 23, False)]):
+            torch.manual_seed(it)
+            Ci, Co = 3, 64
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.2
+            bias = torch.randn(Co, device=dev) * 0.1 if has_bias else None
+            pivot = torch.randn(Co, device=dev) * 0.05
+            wp = torch.empty(L.cdll.fami_packed_weight_elems_bf16(Co, Ci, 3, 3, 0), device=dev, dtype=BF)
+            L.call('fami_pack_conv_weight' + sfx, p(w), p(wp), Co, Ci, 3, 3, 0, st)
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.to(BF).double(), None if bias is None else bias.double(), stride=2,
+                           padding=1).permute(0, 2, 3, 1)
+            geo = (N, H, W, Ci, Co, 3, 3, 2, 1, 1)
+            nb = L.cdll.fami_bn_slots_bytes(Co)
+            out = {}
+            for code in (9000, 9001):
+                L.cdll.fami_conv_tune_lds(code)
+                y = torch.empty(N, Ho, Wo, Co, device=dev, dtype=BF)
+                ys = torch.empty_like(y)
+                slots = torch.zeros(nb, device=dev, dtype=torch.uint8)
+                L.call('fami_conv2d_fwd' + sfx, p(x), p(wp), p(bias), p(y), *geo, 0, 0, 0, st)
+                L.call('fami_conv2d_fwd_stats' + sfx, p(x), p(wp), p(bias), p(ys), *geo, p(slots), p(pivot), st)
+                torch.cuda.synchronize(dev)
+                assert relerr(y, ref) < ACT_TOL, (it, code, relerr(y, ref))
+                assert torch.equal(y, ys), (it, code)
+                rows = slots[:8 * 2 * Co * 8].view(torch.float64).view(8, 2, Co).sum(0)
+                piv = slots[8 * 2 * Co * 8:8 * 2 * Co * 8 + Co * 4].view(torch.float32)
+                assert torch.equal(piv, pivot)
+                d = ys.double().reshape(-1, Co) - pivot.double()
+                assert relerr(rows[0], d.sum(0)) < 1e-5 and relerr(rows[1], (d * d).sum(0)) < 1e-5, (it, code)
+                out[code] = y
+            assert relerr(out[9001], out[9000].double()) < ACT_TOL
+    finally:
+        L.cdll.fami_conv_tune_lds(-1)
+
+
 def test_stem_conv1_weight_gradient(dev, half):
     """conv_wgrad_stem_kernel (conv_wg16.hip, round 4): the weight gradient of the stem's 3 -> 64 stride-2 convolution (hrnet.py:573-578)
     as a GEMM over the flat output-pixel axis with a gathered im2col tile (K = 27) and DMA-staged dY rows.  Against fp64 and the
