@@ -2823,6 +2823,9 @@ int fami_conv2d_fwd_xbn_f32(const float* z, const float* wp, const float* bias, 
   return conv_fwd_f32_impl("fami_conv2d_fwd_xbn_f32", z, wp, bias, nullptr, y, N, H, W, Ci, Co, 3, 3, 1, 1, 1, 0, 0, e, s, xb);
 }
 }  // extern "C"
+int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
+                        int kh, int kw, int stride, int pad, int dil, int NTt, int relu, int accumulate, int out_f32, hipStream_t s,
+                        const char* name, const EpiBN& epi);      // conv_stem.hip
 static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, const float* bias, const float* addend,
                              float* y, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                              int relu, int accumulate, const EpiBN& e, hipStream_t s, const XBN& xbn) {
@@ -2842,6 +2845,10 @@ static int conv_fwd_f32_impl(const char* nm, const float* x, const float* wp, co
   const long xb = (long)N * H * W * Ci * 4, wb = (long)kh * kw * a.KC * a.NTt * 1024;
   FAMI_REQUIRE(P > 0 && P < (1L << 31) && xb < (1L << 31) && wb < (1L << 31), nm, "tensor >= 2 GiB");
   a.P = (int)P; a.x_bytes = (unsigned)xb; a.wp_bytes = (unsigned)wb;
+  if (Ci == 3 && !addend && !xbn.on) {
+    const int rc = fami_try_conv_stem1(2, x, wp, bias, y, N, H, W, Ci, Co, kh, kw, stride, pad, dil, a.NTt, relu, accumulate, 1, s, nm, e);
+    if (rc != 0) return rc < 0 ? rc : FAMI_OK;
+  }
   if (kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && !addend) {
     const int rc = try_conv3x3_lds<float>(x, wp, bias, y, N, H, W, Ci, Co, a.KC, a.NTt, +1, relu, accumulate, 1, s, nm, e, xbn);
     if (rc != 0) return rc < 0 ? rc : FAMI_OK;

@@ -129,18 +129,125 @@ __global__ __launch_bounds__(256) void conv_stem1_fwd_kernel(StemArgs p) {
   }
 }
 
+// f32 storage: the same walk on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32: lane (n | pixel, kq) holds ONE K-value per
+// step) -- 27 -> seven K steps of 4, kk = 4 step + kq; weights from the f32 fragment image ([tap][1][NTt][64][4]: W[n][ci] of tap t at
+// element n * 4 + ci).  The implicit GEMM spends nine steps of its 16-wide K group per pixel tile and 268 us on the launch (170 MB of
+// output: floor 34 us).
+template <int EM>
+__global__ __launch_bounds__(256) void conv_stem1_fwd_f32_kernel(StemArgs p) {
+  constexpr int NT = 4, NS = 7;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int W = p.W, HoWo = p.Ho * p.Wo;
+  int dyq[NS], dxq[NS], offq[NS];
+  float wf[NT][NS];
+  {
+    const float* wq = reinterpret_cast<const float*>(p.wp);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const int kk = q * 4 + kq;
+      const bool ok = kk < 27;
+      const int tap = ok ? kk / 3 : 0, ci = ok ? kk - tap * 3 : 0;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      dyq[q] = ok ? ky - 1 : 0x40000000;
+      dxq[q] = kx - 1;
+      offq[q] = ((ky - 1) * W + (kx - 1)) * 3 + ci;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wf[nt][q] = ok ? wq[(long)(tap * p.NTt + nt) * 256 + col * 4 + ci] : 0.f;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4[NT], ek[NT], es[NT], eq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co0 = nt * 16 + kq * 4;
+    bias4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + co0) : z4;
+    ek[nt] = (EM == 1 && p.e.pivot_src) ? *reinterpret_cast<const f32x4*>(p.e.pivot_src + co0) : z4;
+    es[nt] = eq[nt] = z4;
+  }
+  auto gather = [&](int t, float (&a)[NS], int& m, bool& valid) {
+    m = t * 16 + col;
+    valid = t < p.ntiles && m < p.P;
+    const int mm = valid ? m : 0;
+    const int n = mm / HoWo, r = mm - n * HoWo;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    const int base = ((n * p.H + 2 * oy) * W + 2 * ox) * 3;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      const int iy = 2 * oy + dyq[q], ix = 2 * ox + dxq[q];
+      const bool ok = valid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)W;
+      a[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)(base + offq[q]) * 4u : 0x80000000u, 0, 0));
+    }
+  };
+  auto emit = [&](const float (&a)[NS], int m, bool valid) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = z4;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][q], a[q], acc[nt], 0, 0, 0);
+    }
+    if (!valid) return;
+    float* yp = reinterpret_cast<float*>(p.y) + (long)m * 64 + kq * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 v = acc[nt] + bias4[nt];
+      st4(yp + nt * 16, v);
+      if (EM == 1) {
+        const f32x4 d = v - ek[nt];
+        es[nt] += d;
+        eq[nt] += d * d;
+      }
+    }
+  };
+  const int stride = gridDim.x * 4;
+  for (int t = blockIdx.x * 4 + wave; t < p.ntiles; t += 2 * stride) {
+    float a0[NS], a1[NS];
+    int m0, m1;
+    bool v0, v1;
+    gather(t, a0, m0, v0);
+    gather(t + stride, a1, m1, v1);
+    emit(a0, m0, v0);
+    emit(a1, m1, v1);
+  }
+  if (EM == 1) {
+    __shared__ float red[4][NT * 32];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = row16_sum(es[nt][r]), q = row16_sum(eq[nt][r]);
+        if (col == 0) {
+          red[wave][nt * 32 + kq * 4 + r] = s;
+          red[wave][nt * 32 + 16 + kq * 4 + r] = q;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x < NT * 32) {
+      const int tid = threadIdx.x, nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
+      const int co = nt * 16 + c16;
+      const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      const int eC = p.e.C;
+      double* srow = p.e.slots + (long)(blockIdx.x % p.e.ns) * 2 * eC;
+      unsafeAtomicAdd(srow + st * eC + co, (double)v);
+      if (st == 0 && blockIdx.x == 0) bn_slots_pivot(p.e.slots, eC)[co] = p.e.pivot_src ? p.e.pivot_src[co] : 0.f;
+    }
+  }
+}
+
 static int g_stem1 = 1;      // fami_conv_tune_lds(9000 / 9001): off / on
 extern "C" void fami_conv_stem_tune(int on) { g_stem1 = on < 0 ? 1 : (on ? 1 : 0); }      // (declared inside conv.hip's extern "C" block)
 
-// Returns 1 if launched, 0 if the shape is not this kernel's, < 0 on error.  half_kind: 0 bf16, 1 fp16.
+// Returns 1 if launched, 0 if the shape is not this kernel's, < 0 on error.  half_kind: 0 bf16, 1 fp16, 2 f32 (out_f32 is then the storage type).
 int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                         int kh, int kw, int stride, int pad, int dil, int NTt, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi) {
-  if (!g_stem1 || Ci != 3 || Co != 64 || kh != 3 || kw != 3 || stride != 2 || pad != 1 || dil != 1 || relu || accumulate || out_f32) return 0;
+  if (!g_stem1 || Ci != 3 || Co != 64 || kh != 3 || kw != 3 || stride != 2 || pad != 1 || dil != 1 || relu || accumulate || (out_f32 && half_kind != 2)) return 0;
   const int emode = epi.slots ? epi.mode : 0;
   if (emode != 0 && emode != 1) return 0;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long P = (long)N * Ho * Wo, xb = (long)N * H * W * 3 * 2;
+  const long P = (long)N * Ho * Wo, xb = (long)N * H * W * 3 * (half_kind == 2 ? 4 : 2);
   if (P >= (1L << 27) || xb >= (1L << 31)) return 0;
   StemArgs a;
   a.e = epi; a.emode = emode; a.x = x; a.wp = wp; a.y = y; a.bias = bias;
@@ -149,7 +256,10 @@ int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const floa
   if (g > 1024) g = 1024;
   if (g < 1) g = 1;
 #define FAMI_STEM_CASE(HT, em) hipLaunchKernelGGL((conv_stem1_fwd_kernel<HT, em>), dim3(g), dim3(256), 0, s, a)
-  if (half_kind == 1) { if (emode) FAMI_STEM_CASE(f16_t, 1); else FAMI_STEM_CASE(f16_t, 0); }
+  if (half_kind == 2) {
+    if (emode) hipLaunchKernelGGL((conv_stem1_fwd_f32_kernel<1>), dim3(g), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_stem1_fwd_f32_kernel<0>), dim3(g), dim3(256), 0, s, a);
+  } else if (half_kind == 1) { if (emode) FAMI_STEM_CASE(f16_t, 1); else FAMI_STEM_CASE(f16_t, 0); }
   else { if (emode) FAMI_STEM_CASE(bf16_t, 1); else FAMI_STEM_CASE(bf16_t, 0); }
 #undef FAMI_STEM_CASE
   hipError_t err = hipGetLastError();

@@ -259,6 +259,51 @@ def test_channel_sum(dev, shape, dt):
     assert (out.double() - 2 * ref).abs().max().item() < 2 * tol
 
 
+def test_stem_conv1_forward_f32(dev):
+    """conv_stem1_fwd_f32_kernel (conv_stem.hip): the stem's 3 -> 64 stride-2 convolution on the exact-f32 matrix instruction with K
+    dense over (tap, channel) -- against fp64, against the implicit-GEMM kernel it replaces (fami_conv_tune_lds(9000)), and the
+    statistics epilogue's slot rows against the sums of the stored values."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    try:
+        for it, (N, H, W, has_bias) in enumerate([(4, 384, 288, False), (3, 38, 26, True), (1, 17, 23, False)]):
+            torch.manual_seed(it)
+            Ci, Co = 3, 64
+            Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            x = torch.randn(N, H, W, Ci, device=dev)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.2
+            bias = torch.randn(Co, device=dev) * 0.1 if has_bias else None
+            pivot = torch.randn(Co, device=dev) * 0.05
+            wp = torch.empty(L.cdll.fami_packed_weight_elems(Co, Ci, 3, 3, 0), device=dev)
+            L.call('fami_pack_conv_weight_f32', p(w), p(wp), Co, Ci, 3, 3, 0, st)
+            ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None if bias is None else bias.double(), stride=2,
+                           padding=1).permute(0, 2, 3, 1)
+            geo = (N, H, W, Ci, Co, 3, 3, 2, 1, 1)
+            nb = L.cdll.fami_bn_slots_bytes(Co)
+            out = {}
+            for code in (9000, 9001):
+                L.cdll.fami_conv_tune_lds(code)
+                y = torch.empty(N, Ho, Wo, Co, device=dev)
+                ys = torch.empty_like(y)
+                slots = torch.zeros(nb, device=dev, dtype=torch.uint8)
+                L.call('fami_conv2d_fwd_f32', p(x), p(wp), p(bias), None, p(y), *geo, 0, 0, st)
+                L.call('fami_conv2d_fwd_stats_f32', p(x), p(wp), p(bias), p(ys), *geo, p(slots), p(pivot), st)
+                torch.cuda.synchronize(dev)
+                assert relerr(y, ref) < 2e-6, (it, code, relerr(y, ref))
+                assert torch.equal(y, ys), (it, code)
+                rows = slots[:8 * 2 * Co * 8].view(torch.float64).view(8, 2, Co).sum(0)
+                piv = slots[8 * 2 * Co * 8:8 * 2 * Co * 8 + Co * 4].view(torch.float32)
+                assert torch.equal(piv, pivot)
+                d = ys.double().reshape(-1, Co) - pivot.double()
+                assert relerr(rows[0], d.sum(0)) < 1e-5 and relerr(rows[1], (d * d).sum(0)) < 1e-5, (it, code)
+                out[code] = y
+            assert relerr(out[9001], out[9000].double()) < 2e-6
+    finally:
+        L.cdll.fami_conv_tune_lds(-1)
+
+
 def test_linear_chain(dev):
     torch.manual_seed(3)
     from fami_pose_amd.engine import T
