@@ -75,9 +75,12 @@ int fami_conv_t5_eligible(int N, int H, int W, int Ci, int Co);
 /* ... and the LDS-DMA-staged kernels of conv_t6.hip (round 4: 16-bit storage; 48 input channels: whole weight image LDS-resident,
  * patch and weights copied by LDS DMA -- fami_conv_tune_lds(8000 / 8001) off / on, 8100 + rows per band, 8201 / 8202 units of two /
  * four rows, 8400 + minimum jobs; 96 / 192 / 384 input channels in phases of 48 -- 8500 / 8501 off / on, 8600 + rows per band,
- * 8700 + workgroups per output-channel block)?  Weight gradients: fami_conv_tune_wgrad_lds(23000 / 23001) the DMA-staged 3x3
- * kernel off / on (23002 / 23003 its 64-channel blocks, 23100 + units per workgroup, 23400 + workgroup target), 24000 / 24001 the
- * DMA-staged wide 1x1 kernel off / on (24100 + workgroup target). */
+ * 8700 + workgroups per output-channel block)?  Returns 1 (the 48-channel kernel), 2 (the phased kernel) or 0.
+ * fami_conv_tune_lds(9000 / 9001): the stem's dense-K 3 -> 64 stride-2 forward kernel (conv_stem.hip, every storage type) off / on.
+ * Weight gradients: fami_conv_tune_wgrad_lds(23000 / 23001) the DMA-staged 3x3
+ * kernel off / on (23002 / 23003 its 64-channel blocks, 23004 / 23005 stride 2, 23008 / 23009 the dilated 48 -> 216 / 108
+ * predictors of the alignment head, 23100 + units per workgroup, 23400 + workgroup target), 24000 / 24001 the
+ * DMA-staged wide 1x1 kernel off / on (24100 + workgroup target), 25000 / 25001 the stem's 3 -> 64 weight-gradient kernel. */
 int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co);
 long fami_packed_weight_elems(int Co, int Ci, int kh, int kw, int mode);
 int fami_pack_conv_weight_f32(const float* w_oihw, float* wp, int Co, int Ci, int kh, int kw, int mode,
