@@ -143,6 +143,9 @@ class Engine:
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.fuse_bn_bwd_auto = self.bn2 and self.half and fz == 'auto'
+        # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
+        # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
+        self.fuse_bn_bwd_t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
         # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
         # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
@@ -747,7 +750,7 @@ class Engine:
                     pays = False
                     if self.fuse_bn_bwd_auto and rec is not None and (kh, stride, pad, dil) == (3, 1, 1, 1):
                         kind = self.L.cdll.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
-                        t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
+                        t7 = self.fuse_bn_bwd_t7
                         pays = kind == 1 or (kind == 2 and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
                     if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
