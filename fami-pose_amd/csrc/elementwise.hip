@@ -80,6 +80,60 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, T* __restrict__ 
   }
 }
 
+// torch.cat on channels of up to four tensors in ONE launch (Alignment_V15.py:139,143,160: the head concatenates two to four
+// 48-channel maps three times per step, forward and backward, on its one-lane chain -- a launch per source was 5 us each), and the
+// reverse: slices of the concatenated gradient (=|+=) into the sources' gradients.  Channel counts are multiples of 4.
+struct Cat4 { const void* src[4]; void* dst[4]; int c[4], acc[4]; int n; };
+template <typename T, bool SPLIT>
+__global__ void cat4_kernel(Cat4 a, const T* __restrict__ whole_src, T* __restrict__ whole_dst, long P, int Ct) {
+  const int CtV = Ct >> 2;
+  const long total = P * CtV;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CtV) * 4;
+    const long p = i / CtV;
+    int k = 0, base = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j + 1 < a.n && c >= base + a.c[k]) {
+        base += a.c[k];
+        ++k;
+      }
+    if (SPLIT) {
+      T* d = reinterpret_cast<T*>(a.dst[k]);
+      if (!d) continue;
+      d += p * a.c[k] + (c - base);
+      f32x4 v = ld4(whole_src + p * Ct + c);
+      if (a.acc[k]) v += ld4(d);
+      st4(d, v);
+    } else {
+      st4(whole_dst + p * Ct + c, ld4(reinterpret_cast<const T*>(a.src[k]) + p * a.c[k] + (c - base)));
+    }
+  }
+}
+template <typename T>
+static int cat4_impl(bool split, const void* const* ptrs, const int* cs, const int* accs, int n, const T* whole_src, T* whole_dst, long P,
+                     hipStream_t s, const char* nm) {
+  FAMI_REQUIRE(ptrs && cs && n >= 1 && n <= 4 && P > 0 && (split ? (const void*)whole_src : (const void*)whole_dst), nm, "bad argument");
+  Cat4 a;
+  int Ct = 0;
+  for (int k = 0; k < 4; ++k) {
+    a.src[k] = nullptr; a.dst[k] = nullptr; a.c[k] = 0; a.acc[k] = 0;
+    if (k < n) {
+      FAMI_REQUIRE(cs[k] > 0 && (cs[k] & 3) == 0 && (split || ptrs[k]) && (reinterpret_cast<uintptr_t>(ptrs[k]) & 7) == 0, nm,
+                   "channel counts must be multiples of 4, pointers 8-byte aligned");
+      if (split) { a.dst[k] = const_cast<void*>(ptrs[k]); a.acc[k] = accs ? accs[k] : 0; }
+      else a.src[k] = ptrs[k];
+      a.c[k] = cs[k];
+      Ct += cs[k];
+    }
+  }
+  a.n = n;
+  if (split) hipLaunchKernelGGL((cat4_kernel<T, true>), dim3(fami_ew_grid(P * Ct / 4)), dim3(256), 0, s, a, whole_src, (T*)nullptr, P, Ct);
+  else hipLaunchKernelGGL((cat4_kernel<T, false>), dim3(fami_ew_grid(P * Ct / 4)), dim3(256), 0, s, a, (const T*)nullptr, whole_dst, P, Ct);
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
+
 // out = alpha*a + beta*b (b may be null; out may alias a or b)
 // out[i][0..1] (=|+=) in[i][0..1] * (sx, sy): the legacy kornia.warp_affine translation scaling (MODEL.WARP_ALIGN_CORNERS
 // False: kornia <= 0.4 normalises the matrix for [0, W-1] but builds its grid with align_corners=False, so a translation
@@ -415,6 +469,17 @@ extern "C" {
   int fami_copy_channels_##sfx(const T* src, T* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,         \
                                int accumulate, hipStream_t s) {                                                        \
     return copy_channels_impl<T>(src, dst, P, Cs, src_off, Cd, dst_off, Cc, accumulate, s, "fami_copy_channels_" #sfx);\
+  }                                                                                                                    \
+  /* dst[P][c0 + .. + c(n-1)] = cat(src[0..n-1][P][c_k]); n <= 4, c_k % 4 == 0 */                                       \
+  int fami_concat_channels_##sfx(const T* const* src, const int* c, int n, T* dst, long P, hipStream_t s) {            \
+    return cat4_impl<T>(false, reinterpret_cast<const void* const*>(src), c, nullptr, n, (const T*)nullptr, dst, P, s, \
+                        "fami_concat_channels_" #sfx);                                                                \
+  }                                                                                                                    \
+  /* dst[k][P][c_k] (=|+=, accumulate[k]) the k-th channel slice of src[P][sum c]; dst[k] may be null (slice skipped) */ \
+  int fami_split_channels_##sfx(const T* src, T* const* dst, const int* c, const int* accumulate, int n, long P,       \
+                                hipStream_t s) {                                                                       \
+    return cat4_impl<T>(true, reinterpret_cast<const void* const*>(dst), c, accumulate, n, src, (T*)nullptr, P, s,     \
+                        "fami_split_channels_" #sfx);                                                                 \
   }                                                                                                                    \
   int fami_axpby_##sfx(const T* a, const T* b, T* out, long n, float alpha, float beta, hipStream_t s) {               \
     return axpby_impl<T>(a, b, out, n, alpha, beta, s, "fami_axpby_" #sfx);                                            \

@@ -146,6 +146,7 @@ class Engine:
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
         self.fuse_bn_bwd_t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
+        self.concat_one = os.environ.get('FAMI_CONCAT_ONE', '1') != '0'      # Engine.concat: one launch for up to four sources
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
         # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
         # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
@@ -1037,15 +1038,30 @@ class Engine:
         Ct = sum(x.shape[3] for x in xs)
         P = N * H * W
         y = self.act(N, H, W, Ct)
-        off = 0
-        for x in xs:
-            c = x.shape[3]
-            self.acall('fami_copy_channels', _p(x.data), _p(y), P, c, 0, Ct, off, c, 0)
-            off += c
+        n = len(xs)
+        # one launch for the lot (the head's three concatenations); distinct tensors only: the backward writes every slice at once
+        one = self.concat_one and 2 <= n <= 4 and all(x.shape[3] % 4 == 0 for x in xs) and len({id(x) for x in xs}) == n
+        cs = (ctypes.c_int * 4)(*[x.shape[3] for x in xs]) if one else None
+        if one:
+            self.acall('fami_concat_channels', (ctypes.c_void_p * 4)(*[x.data.data_ptr() for x in xs]), cs, n, _p(y), P)
+        else:
+            off = 0
+            for x in xs:
+                c = x.shape[3]
+                self.acall('fami_copy_channels', _p(x.data), _p(y), P, c, 0, Ct, off, c, 0)
+                off += c
         out = T(y, any(x.requires_grad for x in xs))
         if out.requires_grad:
             def bwd():
                 if out.grad is None:
+                    return
+                if one:
+                    dst, accs = (ctypes.c_void_p * 4)(), (ctypes.c_int * 4)()
+                    for k, x in enumerate(xs):
+                        if x.requires_grad:
+                            g, acc = self.gbuf(x)
+                            dst[k], accs[k] = g.data_ptr(), acc
+                    self.acall('fami_split_channels', _p(out.grad), dst, cs, accs, n, P)
                     return
                 o = 0
                 for x in xs:

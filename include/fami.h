@@ -210,6 +210,11 @@ int fami_pack_frames_f32(const float* kf_nchw, const float* sup_nchw, float* fra
                          fami_stream_t stream);
 int fami_copy_channels_f32(const float* src, float* dst, long P, int Cs, int src_off, int Cd, int dst_off, int Cc,
                            int accumulate, fami_stream_t stream);
+/* torch.cat on channels of n <= 4 tensors in one launch (c[k] % 4 == 0) and its backward: the k-th channel slice of src (=|+=) into
+ * dst[k] (null: skipped).  src / dst / c / accumulate are HOST arrays of length n. */
+int fami_concat_channels_f32(const float* const* src, const int* c, int n, float* dst, long P, fami_stream_t stream);
+int fami_split_channels_f32(const float* src, float* const* dst, const int* c, const int* accumulate, int n, long P,
+                             fami_stream_t stream);
 int fami_axpby_f32(const float* a, const float* b, float* out, long n, float alpha, float beta,
                    fami_stream_t stream);
 int fami_fill_f32(float* out, long n, float v, fami_stream_t stream);
@@ -420,6 +425,11 @@ int fami_pack_frames_bf16(const float* kf_nchw, const float* sup_nchw, fami_bf16
                           int W, fami_stream_t stream);
 int fami_copy_channels_bf16(const fami_bf16_t* src, fami_bf16_t* dst, long P, int Cs, int src_off, int Cd,
                             int dst_off, int Cc, int accumulate, fami_stream_t stream);
+/* torch.cat on channels of n <= 4 tensors in one launch (c[k] % 4 == 0) and its backward: the k-th channel slice of src (=|+=) into
+ * dst[k] (null: skipped).  src / dst / c / accumulate are HOST arrays of length n. */
+int fami_concat_channels_bf16(const fami_bf16_t* const* src, const int* c, int n, fami_bf16_t* dst, long P, fami_stream_t stream);
+int fami_split_channels_bf16(const fami_bf16_t* src, fami_bf16_t* const* dst, const int* c, const int* accumulate, int n, long P,
+                             fami_stream_t stream);
 int fami_axpby_bf16(const fami_bf16_t* a, const fami_bf16_t* b, fami_bf16_t* out, long n, float alpha, float beta,
                     fami_stream_t stream);
 int fami_widen_bf16(const fami_bf16_t* src, float* dst, long n, fami_stream_t stream);
@@ -527,6 +537,11 @@ int fami_pack_frames_f16(const float* kf_nchw, const float* sup_nchw, fami_f16_t
                           int W, fami_stream_t stream);
 int fami_copy_channels_f16(const fami_f16_t* src, fami_f16_t* dst, long P, int Cs, int src_off, int Cd,
                             int dst_off, int Cc, int accumulate, fami_stream_t stream);
+/* torch.cat on channels of n <= 4 tensors in one launch (c[k] % 4 == 0) and its backward: the k-th channel slice of src (=|+=) into
+ * dst[k] (null: skipped).  src / dst / c / accumulate are HOST arrays of length n. */
+int fami_concat_channels_f16(const fami_f16_t* const* src, const int* c, int n, fami_f16_t* dst, long P, fami_stream_t stream);
+int fami_split_channels_f16(const fami_f16_t* src, fami_f16_t* const* dst, const int* c, const int* accumulate, int n, long P,
+                             fami_stream_t stream);
 int fami_axpby_f16(const fami_f16_t* a, const fami_f16_t* b, fami_f16_t* out, long n, float alpha, float beta,
                     fami_stream_t stream);
 int fami_widen_f16(const fami_f16_t* src, float* dst, long n, fami_stream_t stream);

@@ -304,6 +304,37 @@ def test_stem_conv1_forward_f32(dev):
         L.cdll.fami_conv_tune_lds(-1)
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f16'])
+def test_concat_and_split_channels_in_one_launch(dev, dt):
+    """fami_concat_channels_* / fami_split_channels_* (torch.cat on channels of the head, Alignment_V15.py:139,143,160, and its
+    backward): two to four sources of different widths, a skipped slice, (=|+=) per slice -- bit for bit against torch."""
+    import ctypes
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    tdt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[dt]
+    torch.manual_seed(11)
+    P = 3 * 7 * 5
+    for cs in ((48, 48), (48, 96, 16), (48, 48, 48, 48), (4, 8)):
+        n = len(cs)
+        xs = [torch.randn(P, c, device=dev).to(tdt) for c in cs]
+        y = torch.empty(P, sum(cs), device=dev, dtype=tdt)
+        carr = (ctypes.c_int * 4)(*cs)
+        L.call('fami_concat_channels_' + dt, (ctypes.c_void_p * 4)(*[x.data_ptr() for x in xs]), carr, n, y.data_ptr(), P, st)
+        assert torch.equal(y, torch.cat(xs, 1))
+        g = torch.randn(P, sum(cs), device=dev).to(tdt)
+        old = [torch.randn(P, c, device=dev).to(tdt) for c in cs]
+        dst = [o.clone() for o in old]
+        accs = [k % 2 for k in range(n)]
+        skip = n - 1 if n > 2 else -1
+        ptrs = (ctypes.c_void_p * 4)(*[None if k == skip else d.data_ptr() for k, d in enumerate(dst)])
+        L.call('fami_split_channels_' + dt, g.data_ptr(), ptrs, carr, (ctypes.c_int * 4)(*accs), n, P, st)
+        torch.cuda.synchronize(dev)
+        for k, piece in enumerate(torch.split(g, list(cs), 1)):
+            want = old[k] if k == skip else ((old[k].float() + piece.float()).to(tdt) if accs[k] else piece)
+            assert torch.equal(dst[k], want), (cs, k)
+
+
 def test_linear_chain(dev):
     torch.manual_seed(3)
     from fami_pose_amd.engine import T
