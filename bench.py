@@ -141,18 +141,31 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
         ('conv3x3_t5_kernel<float, persistent split-product>' if t5 else 'conv3x3_t4_kernel<float, split-product>') if split else 'conv_igemm_f32')
     key = {'f32': ('conv3x3_t5_s3_f32' if t5 else 'conv3x3_t4_s3_f32') if split else 'conv_igemm_f32',
            'bf16': 'conv3x3_t6_bf16' if t6 else 'conv3x3_t4_bf16'}.get(dtype)
+    abytes = int(2 * x.numel() * x.element_size())
     out = {"bound": "mfma", "kernel": "%s (%d->%d 3x3 @%dx%d, N=%d frames)" % (kname, C, C, H, W, N),
            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
            "frac": round(ach / peak, 4), "traffic": pmc_traffic(key) if (N == 20 and C == 48 and H == 96 and key) else None,
-           "algorithmic_bytes": int(2 * x.numel() * x.element_size()), "avg_launch_us": round(ms * 1e3, 2)}
+           "algorithmic_bytes": abytes, "avg_launch_us": round(ms * 1e3, 2),
+           # the SAME launch against the other roof: x read once + y written once over the live time vs the HBM peak.  At 48
+           # channels the launch is below the ridge (216 FLOP/B against 312): its HBM floor is above its MFMA floor, so
+           # hbm_frac is the tighter of the two bounds there
+           "hbm_frac": round(abytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    if not half:
+        # f32 storage: `frac` prices the launch against the pipe it runs on (bf16 matrix pipe / 6 products);
+        # frac_vs_guide_peak against the guide's f32-input MFMA peak (157.3 TFLOP/s), which an exact-f32 kernel is bound by
+        out["frac_vs_guide_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
     rec_p = pmc_record(key) if (N == 20 and C == 48 and H == 96 and key) else None
     if rec_p and rec_p.get('mfma_busy') is not None:
         # north_star: "MFMA-busy reported against gfx950 peaks" -- SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) of
-        # the same launch, and the MFMA instruction count against 2 N H W C 9 C / 16384 (x 6 products in the split form)
-        out["mfma_busy"] = rec_p['mfma_busy']
-        out["mfma_insts"] = rec_p.get('sq_insts_mfma')
+        # the same launch, and the MFMA instruction count against 2 N H W C 9 C / 16384 (x 6 products in the split form).
+        # RECORDED values (a rocprofv3 --pmc run committed under profiles/), not measured in this process: they describe
+        # the kernel of `pmc_source`; `pmc_kernel_matches` says whether that is the kernel timed above.
+        want = kname.split('<')[0]
+        out["pmc_recorded"] = {"mfma_busy": rec_p['mfma_busy'], "mfma_insts": rec_p.get('sq_insts_mfma'),
+                               "source": rec_p.get('source'), "kernel": rec_p.get('workload'),
+                               "git_sha": rec_p.get('git_sha'),
+                               "kernel_matches_live_route": want in (rec_p.get('workload') or '')}
         out["mfma_insts_expected"] = int(flops / 16384 * (6 if split else 1)) if (half or split) else int(flops / 2048)
-        out["pmc_source"] = rec_p.get('source')
     if split:
         out["peak_note"] = ("dense bf16 MFMA peak %.0f / 6 products per f32 product; achieved counts each f32 "
                             "multiply-add once" % PEAK_BF16_MFMA_TFLOPS)
@@ -170,6 +183,8 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
         out["in_step_avg_us"] = rec['dominant_avg_us']
         out["frac_in_step"] = round(flops / (rec['dominant_avg_us'] * 1e-6) / 1e12 / peak, 4)
         out["in_step_source"] = rec.get('source')
+        if rec.get('profiled_step_ms'):
+            out["in_step_profiled_step_ms"] = rec['profiled_step_ms']      # main() divides by the timed step: in_step_profiler_inflation
     return out
 
 
@@ -426,7 +441,8 @@ def main():
                          "ddp_plan": plan_name, "ddp_plan_fallbacks": plan_notes, "bucket_mb": args.bucket_mb,
                          "buckets": len(trainer.reducer.ranges()),
                          "gradient_bytes": int(trainer.grad.numel() * 4),
-                         "gradient_payload": trainer.payload_name, **trainer.plan_summary(),
+                         "gradient_payload": trainer.payload_name, "allreduce_algo": trainer.reducer.algo,
+                         **trainer.plan_summary(),
                          "allreduce_ms_standalone": round(trainer.measure_allreduce_ms(), 3)})
             # what the exchange should cost over xGMI (point-to-point, 7 links x ~153 GB/s per GPU, MI355X_MICROARCH.md):
             # a ring is bound by one link, 2 (N-1)/N B / link; a direct reduce-scatter + all-gather over the full mesh
@@ -479,7 +495,14 @@ def main():
                 if os.environ.get('FAMI_F32_SPLIT', '1') != '0' else "f32 storage, v_mfma_f32_16x16x4_f32 everywhere")
         C, Hf, Wf = args.width, args.img_h // 4, args.img_w // 4
         G = 12 if C % 48 == 0 else C // 4
-        out["roofline"] = conv_roofline(dev, args.batch * (args.sup + 1), args.dtype, C=C, H=Hf, W=Wf)
+        def with_inflation(r, step_ms):
+            # the committed in-step averages come from a rocprofv3 kernel trace, which slows the step down: the ratio of the
+            # profiled step to the step timed here says by how much frac_in_step understates the kernel
+            if r.get("in_step_profiled_step_ms"):
+                r["in_step_profiler_inflation"] = round(r["in_step_profiled_step_ms"] / step_ms, 3)
+            return r
+        out["roofline"] = with_inflation(conv_roofline(dev, args.batch * (args.sup + 1), args.dtype, C=C, H=Hf, W=Wf),
+                                         dt / args.steps * 1e3)
 
         def step_roofline(dtype, flops, ms):
             # every nn.Conv2d FLOP of the step (forward + input gradient + weight gradient, counted by the engine as the
@@ -506,7 +529,8 @@ def main():
                         "same workload in the fp32 parity configuration",
                 "value": round(args.batch * world * o_steps / o_dt, 3), "unit": "clips/s", "steps": o_steps,
                 "ms_per_step": round(o_dt / o_steps * 1e3, 3), "loss": round(o_loss, 6),
-                "roofline": conv_roofline(dev, args.batch * (args.sup + 1), o_dtype, C=C, H=Hf, W=Wf),
+                "roofline": with_inflation(conv_roofline(dev, args.batch * (args.sup + 1), o_dtype, C=C, H=Hf, W=Wf),
+                                           o_dt / o_steps * 1e3),
                 "roofline_step": step_roofline(o_dtype, o_info["conv_flops_per_step"], o_dt / o_steps * 1e3),
                 "roofline_dcn": dcn_roofline(dev, args.batch, o_dtype, C=C, G=G, H=Hf, W=Wf)[0]}
         if frozen is not None:

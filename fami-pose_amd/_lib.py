@@ -66,6 +66,16 @@ class _Lib:
         for env, base in (('FAMI_WG16_TARGET', 21000), ('FAMI_WGS3_TARGET', 31000)):     # A/B: workgroup target of the weight-gradient kernels
             if os.environ.get(env):
                 self.cdll.fami_conv_tune_wgrad_lds(base + int(os.environ[env]))
+        # The two ablation switches below compute WRONG results on purpose (upper-bound experiments of tools/): they are refused
+        # unless FAMI_ALLOW_WRONG=1 says the caller knows, so a variable left over in a job environment cannot silently corrupt a
+        # training run.
+        wrong = [v for v in ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD') if os.environ.get(v, '0') not in ('', '0')]
+        if wrong and os.environ.get('FAMI_ALLOW_WRONG') != '1':
+            raise FamiError('%s set: these switches skip work and produce WRONG gradients (measurement ablations only); '
+                            'set FAMI_ALLOW_WRONG=1 to run them on purpose' % ', '.join(wrong))
+        if wrong:
+            import sys
+            print('[fami] WARNING: %s active -- results are WRONG by design (ablation run)' % ', '.join(wrong), file=sys.stderr, flush=True)
         if os.environ.get('FAMI_T5_ABL'):              # upper-bound experiment (WRONG results): only n chunks per convolution
             self.cdll.fami_conv_tune_lds(7600)
             self.cdll.fami_conv_tune_lds(7401)

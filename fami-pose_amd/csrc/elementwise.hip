@@ -564,21 +564,29 @@ int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const fl
 // array of n ints.  One launch per 32 pairs (the arguments travel in the kernarg segment).
 int fami_add_batch_f32(const long* ptrs, const int* counts, int n, hipStream_t s) {
   FAMI_REQUIRE(ptrs && counts && n > 0, "fami_add_batch_f32", "bad argument");
-  for (int i0 = 0; i0 < n; i0 += FAMI_AXPBY_BATCH) {
-    const int m = n - i0 < FAMI_AXPBY_BATCH ? n - i0 : FAMI_AXPBY_BATCH;
+  // The pairs of one launch run concurrently (one blockIdx.y each) with a plain read-modify-write, so a launch must not
+  // hold the same `out` twice: a repeated output closes the launch and opens the next one (same stream => the adds into one
+  // buffer happen in call order, and the result does not depend on how the pairs fall into launches).
+  int i0 = 0;
+  while (i0 < n) {
     AxpbyBatch b;
-    int maxn = 1;
-    for (int i = 0; i < FAMI_AXPBY_BATCH; ++i) {
-      const int j = i < m ? i0 + i : i0;
-      b.a[i] = reinterpret_cast<const float*>(ptrs[2 * j]);
-      b.out[i] = reinterpret_cast<float*>(ptrs[2 * j + 1]);
-      b.n[i] = i < m ? counts[j] : 0;
-      if (b.n[i] > maxn) maxn = b.n[i];
+    int m = 0, maxn = 1;
+    for (; m < FAMI_AXPBY_BATCH && i0 + m < n; ++m) {
+      float* o = reinterpret_cast<float*>(ptrs[2 * (i0 + m) + 1]);
+      bool repeated = false;
+      for (int k = 0; k < m; ++k) repeated |= (b.out[k] == o);
+      if (repeated) break;
+      b.a[m] = reinterpret_cast<const float*>(ptrs[2 * (i0 + m)]);
+      b.out[m] = o;
+      b.n[m] = counts[i0 + m];
+      if (b.n[m] > maxn) maxn = b.n[m];
     }
+    for (int i = m; i < FAMI_AXPBY_BATCH; ++i) { b.a[i] = b.a[0]; b.out[i] = b.out[0]; b.n[i] = 0; }
     int gx = (maxn + 255) / 256;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(add_batch_kernel, dim3(gx, m), dim3(256), 0, s, b);
     FAMI_CHECK_LAUNCH("fami_add_batch_f32");
+    i0 += m;
   }
   return FAMI_OK;
 }

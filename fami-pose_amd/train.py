@@ -211,11 +211,17 @@ class BucketReducer:
     gradient contribution has been enqueued; once every parameter overlapping a slice is complete the slice
     is handed to `on_bucket(lo, hi)` (an async all-reduce, or a graph cut during capture)."""
 
-    def __init__(self, grad, table, bucket_elems, process_group=None, payload=None, cast=None, widen=None):
+    def __init__(self, grad, table, bucket_elems, process_group=None, payload=None, cast=None, widen=None, algo=None):
         """payload: None (the fp32 slices themselves are reduced in place) or a 16-bit torch dtype: a slice is cast into a
         16-bit mirror of the arena, the mirror slice is all-reduced (half the bytes over xGMI: 129 MB instead of 258.6 MB
         per step for W48) and widened back into the fp32 arena in wait().  cast(src_f32, dst_16) / widen(src_16, dst_f32):
-        the device kernels of the caller (Trainer: fami_cast_add_* / fami_widen_*); default = torch copies (CPU tests)."""
+        the device kernels of the caller (Trainer: fami_cast_add_* / fami_widen_*); default = torch copies (CPU tests).
+        algo (default FAMI_DDP_ALGO or 'ring'): 'ring' = one all_reduce per slice (the library picks its algorithm; a ring
+        over xGMI is bound by ONE 153 GB/s link: ~3 ms for 258 MB); 'mesh' = the slice as reduce_scatter_tensor ->
+        all_gather_into_tensor, i.e. every rank owns 1/world of the slice, receives the other ranks' copies of it over
+        its 7 point-to-point links at once, sums, and sends the sum back the same way (~0.4 ms for 258 MB on
+        the full xGMI mesh).  The remainder of a slice that is not a multiple of `world` (< world elements, at most one
+        slice per step) goes through a plain all_reduce.  Replaces engine/defaults/trainer.py:57-58 (nn.DataParallel)."""
         self.payload = payload
         self._cast = cast or (lambda src, dst: dst.copy_(src))
         self._widen = widen or (lambda src, dst: dst.copy_(src))
@@ -226,6 +232,13 @@ class BucketReducer:
         self.bucket_elems = max(1, int(bucket_elems))
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.algo = (algo or os.environ.get('FAMI_DDP_ALGO') or 'ring').lower()
+        if self.algo not in ('ring', 'mesh'):
+            raise ValueError("FAMI_DDP_ALGO must be 'ring' or 'mesh', not %r" % self.algo)
+        self._shards = {}        # (lo, hi) -> this rank's 1/world of the slice (mesh plan; persistent: graph-plan replays reuse it)
+        # gloo runs queued collectives on a worker pool: the all-gather of a slice must not start before its
+        # reduce-scatter has finished, so the handle is waited for in between.  RCCL orders both on its own stream.
+        self._ordered = dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
         self.works = []
 
     def ranges(self):
@@ -262,16 +275,37 @@ class BucketReducer:
             self._on_bucket(*self._ranges[self._next])
             self._next += 1
 
+    def _exchange(self, buf, key):
+        """Sum `buf` (a slice of the arena or of its 16-bit mirror) over the ranks, asynchronously -> last work handle."""
+        if self.algo == 'ring' or self.world == 1:
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        n = buf.numel()
+        main = n - n % self.world
+        wk = None
+        if main:
+            shard = self._shards.get(key)
+            if shard is None or shard.numel() != main // self.world or shard.dtype != buf.dtype:
+                shard = self._shards[key] = torch.empty(main // self.world, dtype=buf.dtype, device=buf.device)
+            wk = dist.reduce_scatter_tensor(shard, buf[:main], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if not self._ordered:
+                wk.wait()
+            wk = dist.all_gather_into_tensor(buf[:main], shard, group=self.pg, async_op=True)
+        if main < n:
+            if wk is not None:
+                self.works.append((wk, None))
+            wk = dist.all_reduce(buf[main:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return wk
+
     def allreduce(self, lo, hi):
         if self.payload is None:
-            wk = dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            wk = self._exchange(self.grad[lo:hi], (lo, hi))
             self.works.append((wk, None))
             return wk
         if self._mirror is None:
             self._mirror = torch.empty(self.total, dtype=self.payload, device=self.grad.device)
         buf = self._mirror[lo:hi]
         self._cast(self.grad[lo:hi], buf)
-        wk = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        wk = self._exchange(buf, (lo, hi))
         self.works.append((wk, (lo, hi)))
         return wk
 
@@ -326,11 +360,11 @@ class Trainer:
         # on a single GPU; an all-reduce over one rank is the identity)
         self.ddp = self.world > 1 or (force_ddp and dist.is_initialized())
         # FAMI_DDP_PAYLOAD = f32 (default) | bf16 | f16: gradient bytes on the wire (the sum over ranks is then taken in
-        # that type; master gradients, the 1/world scale and Adam stay fp32)
-        # Default: the compute type's width -- a bf16 / fp16 model exchanges 16-bit gradients (129 MB instead of 258.6 MB per
-        # step for W48: xGMI is point-to-point, a ring all-reduce is bound by ONE link), the f32 model fp32 ones.
-        self.payload_name = os.environ.get('FAMI_DDP_PAYLOAD') or \
-            {torch.bfloat16: 'bf16', torch.float16: 'f16'}.get(getattr(model, 'act_dtype', torch.float32), 'f32')
+        # that type; master gradients, the 1/world scale and Adam stay fp32).  The reference all-reduces fp32 gradients
+        # (nn.DataParallel, trainer.py:57-58) and so does the default here in every compute mode: a 16-bit wire format
+        # halves the bytes (129 MB instead of 258.6 MB per step for W48) but sums over ranks with 8 / 11 significand bits,
+        # and no multi-GPU convergence run has validated that yet -- opt in with FAMI_DDP_PAYLOAD.
+        self.payload_name = os.environ.get('FAMI_DDP_PAYLOAD') or 'f32'
         pay = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[self.payload_name]
         if pay == torch.float16 and self.overflow is None:
             # without the loss-scale guard an fp16 sum that overflows on the wire would reach Adam as inf
@@ -403,7 +437,10 @@ class Trainer:
         return self._dcn_imgs
 
     # ------------------------------------------------------------------ the step (eager launch sequence)
-    def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None):
+    def _forward_backward(self, kf_x, sup_x, target, weight, on_bucket=None, fused_opt=False):
+        """Enqueue forward, loss and backward of one batch.  fused_opt (set only by _eager_step / _capture_plan): the Adam update
+        may be enqueued from INSIDE the backward pass in two parts (_find_adam_split) -- the call then mutates the parameters and
+        sets `_adam_done` for the `_opt_step` that must follow.  Direct callers (tools, tests) get a pure gradient computation."""
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
                      deterministic=getattr(model, 'deterministic', None))
@@ -412,7 +449,7 @@ class Trainer:
         if on_bucket is not None:
             eng.persist_lanes = False       # bucket hooks fire between forked regions: keep a join per module
         early = {'ev': None}
-        split = self._adam_split if (on_bucket is None and not self.ddp) else None
+        split = self._adam_split if (fused_opt and on_bucket is None and not self.ddp) else None
         if split is not None:
             # Adam in two parts (see _find_adam_split): the scalars now, everything but the stem stretch when backward reaches the
             # stage-2 boundary (side lane), the stem stretch behind the backward pass
@@ -507,11 +544,15 @@ class Trainer:
             if lanes:
                 eng._do_fork(3)        # (not taped: the seeds are enqueued here, ahead of the tape walk)
             pending = []
+            same = aux.get('mi_same', {})      # repeated terms (mi_6 is mi_2): one gradient pass with the summed coefficient
+            for k, j in same.items():
+                coef[j] += coef[k]
             for k, ((val, seed), c) in enumerate(zip(aux['mis'], coef)):
                 if lanes:
                     eng.set_lane(k % 3)
                 eng.call('fami_axpby_f32', _p(val), None, _p(self.loss_parts[1 + k:2 + k]), 1, 1.0, 0.0)
-                pending.append(seed(c * ls, None, True))
+                if k not in same:
+                    pending.append(seed(c * ls, None, True))
             if lanes:
                 eng._do_join(3)
             for fin in pending:        # the accumulations into the (shared) gradient buffers, in term order, on lane 0
@@ -588,7 +629,7 @@ class Trainer:
             outs = self._forward_backward(kf_x, sup_x, target, weight, on_bucket=self.reducer.allreduce)
             self.reducer.wait()
         else:
-            outs = self._forward_backward(kf_x, sup_x, target, weight)
+            outs = self._forward_backward(kf_x, sup_x, target, weight, fused_opt=True)
         self._opt_step()
         return outs
 
@@ -614,6 +655,7 @@ class Trainer:
         # parameters, Adam state and module buffers (BN running statistics, batch counters) are restored afterwards, so
         # the first step() of a graph-mode Trainer is exactly one optimisation step, like the eager one.
         snap = [t.clone() for t in (self.flat, self.opt.m, self.opt.v, self.opt.state)]
+        ovf = None if self.overflow is None else self.overflow.clone()     # {raised, skipped steps}: warm-up steps do not count
         bufs = [(b, b.clone()) for b in self.model.buffers()]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -626,11 +668,13 @@ class Trainer:
             dst.copy_(src)
         for b, src in bufs:
             b.copy_(src)
+        if ovf is not None:
+            self.overflow.copy_(ovf)
         torch.cuda.synchronize(self.dev)
         if not self.ddp:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'])
+                outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], fused_opt=True)
                 self._opt_step()
             plan = [('graph', g)]
         elif self.ddp_plan == 'serial':

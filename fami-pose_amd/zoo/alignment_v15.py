@@ -198,8 +198,10 @@ class Alignment_V15(EngineModule):
             # the six MI terms only READ the head's tensors: three stream lanes (each ~50-90 us of small dependent kernels
             # -- transposes, a 17-channel conv, the row softmax / KL pass; they were ~0.35 ms back to back on the head's
             # serial chain)
+            # mi_6 = feat_feat_mi(kf, all_agg) is the SAME term as mi_2 (Alignment_V15.py:171,179 call it twice on the same
+            # tensors): computed once; the output list still carries six scalars and each keeps its own gradient seed
             terms = [lambda: label_mi(all_agg), lambda: feat_mi(kf, all_agg), lambda: label_mi(agg_sup),
-                     lambda: feat_mi(agg_sup, all_agg), lambda: label_mi(kf), lambda: feat_mi(kf, all_agg)]
+                     lambda: feat_mi(agg_sup, all_agg), lambda: label_mi(kf)]
             forked = eng.fork(3) if eng.mi_lanes else False
             mis = []
             for i, fn in enumerate(terms):
@@ -208,7 +210,11 @@ class Alignment_V15(EngineModule):
                 mis.append(fn())
             if forked:
                 eng.join(3)
+            v6 = eng.empty(1)
+            eng.call('fami_axpby_f32', mis[1][0].data_ptr(), None, v6.data_ptr(), 1, 1.0, 0.0)
+            mis.append((v6, mis[1][1]))
             eng.aux['mis'] = mis
+            eng.aux['mi_same'] = {5: 1}       # term index -> the earlier term it repeats (Trainer: one seed with the summed coefficient)
             for val, seed in mis:
                 outs.append(val.reshape(()))
                 seeds.append(lambda g, seed=seed: seed(1.0, g.reshape(1).contiguous()))

@@ -236,7 +236,8 @@ int fami_relu_bwd_f32(const float* dy, const float* y, float* dx, long n, int ac
 int fami_pool_relu_bwd_f32(const float* dy, const float* y, float* out, int N, int Hl, int Wl, int C, int shift,
                            int relu, fami_stream_t stream);
 /* out_k += a_k for n pairs of fp32 tensors in one launch per 32 pairs (the engine's lane join: lane-private gradients of a
- * module that ran on several stream lanes).  ptrs: host array of 2 n longs (a_0, out_0, a_1, out_1, ...), counts: n ints. */
+ * module that ran on several stream lanes).  ptrs: host array of 2 n longs (a_0, out_0, a_1, out_1, ...), counts: n ints.
+ * The same `out` may appear several times: a repeated output starts a new launch, so its adds happen in call order. */
 int fami_add_batch_f32(const long* ptrs, const int* counts, int n, fami_stream_t stream);
 int fami_adam_prep_f32(float* state4, float beta1, float beta2, fami_stream_t stream);
 int fami_adam_f32(float* p, const float* g, float* m, float* v, long n, const float* state4, float beta1,

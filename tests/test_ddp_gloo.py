@@ -84,6 +84,35 @@ def _worker(rank, world, port, q):
         assert torch.equal(grad16, want16)
         assert (grad16 - want).abs().max() <= 2.0 ** -7 * want.abs().max()
 
+        # FAMI_DDP_ALGO=mesh: every slice as reduce_scatter_tensor -> all_gather_into_tensor (the direct exchange
+        # over the full xGMI mesh) + a plain all_reduce for the < world elements a slice has beyond a multiple of world.
+        # Sums of two terms are order independent: bitwise the ring result.  Odd slice lengths (bucket 127, total 587)
+        # exercise the remainder; the second begin() replays the plan on the persistent shard buffers (graph plans do).
+        for bucket in (128, 127, 1000):
+            gm = local.clone()
+            redm = BucketReducer(gm, table, bucket_elems=bucket, algo='mesh')
+            assert redm.algo == 'mesh'
+            for rep in range(2):
+                gm.copy_(local)
+                hookm = redm.begin()
+                for i in range(len(sizes) - 1, -1, -1):
+                    hookm([params[i]])
+                redm.flush()
+                redm.wait()
+                assert torch.equal(gm, grad), (bucket, rep)
+        gm16 = local.clone()
+        redm16 = BucketReducer(gm16, table, bucket_elems=127, payload=torch.bfloat16, algo='mesh')
+        hookm16 = redm16.begin()
+        for i in range(len(sizes) - 1, -1, -1):
+            hookm16([params[i]])
+        redm16.wait()
+        assert torch.equal(gm16, want16)
+        try:
+            BucketReducer(local.clone(), table, bucket_elems=128, algo='tree')
+            raise AssertionError('unknown algo accepted')
+        except ValueError:
+            pass
+
         # parameter / buffer broadcast from rank 0 (what Trainer.broadcast_parameters does with the flat arena)
         flat = torch.full((total,), float(rank + 1))
         dist.broadcast(flat, src=0)

@@ -27,17 +27,33 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
+    """backend 'gloo': both ranks share cuda:0 (the one-GPU test box).  'nccl': one rank per device over RCCL -- the
+    measured configuration (bench.py --gpus N); runs only where torch.cuda.device_count() >= world."""
     try:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
         os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.pop('FAMI_DDP_ALGO', None)
         import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
         import fami_pose_amd as fp
         from fami_pose_amd.train import Trainer
         from oracle import model as om
-        dev = torch.device('cuda:0')
+        if backend == 'nccl':
+            dev = torch.device('cuda', rank)
+            torch.cuda.set_device(dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dev = torch.device('cuda:0')
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+
+        def gather(t):
+            """-> [rank 0's t, rank 1's t, ...] on the host (RCCL moves device tensors only)."""
+            src = t.to(dev) if backend == 'nccl' else t.cpu()
+            out = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(out, src.contiguous())
+            return [o.cpu() for o in out]
 
         sd = om.realistic_init_(om.AlignmentOracle(om.make_cfg(48), True, S, (H, W)), 5).state_dict()
 
@@ -69,25 +85,33 @@ def _worker(rank, world, port, q):
         tr_b.reducer.allreduce = spy
         tr_b.step(kf, sup, joints, vis)
         assert torch.equal(pre, g_a), 'rank %d: pre-exchange gradients differ from the single-process run on its shard' % rank
-        both = [torch.empty_like(g_a.cpu()) for _ in range(world)]
-        dist.all_gather(both, g_a.cpu())
+        both = gather(g_a)
         mean = (both[0] + both[1]) * 0.5
         assert torch.equal(tr_b.grad.cpu(), mean), 'exchanged gradients are not the mean over ranks'
-        ps = [torch.empty_like(mean) for _ in range(world)]
-        dist.all_gather(ps, tr_b.flat.cpu())
+        ps = gather(tr_b.flat)
         assert torch.equal(ps[0], ps[1]), 'parameters diverged across ranks after Adam'
         assert not torch.equal(tr_b.flat, tr_a.flat)
         # BatchNorm statistics are per replica
-        rm = [torch.empty(64) for _ in range(world)]
-        dist.all_gather(rm, tr_b.model.hrnet.bn1.running_mean.cpu())
+        rm = gather(tr_b.model.hrnet.bn1.running_mean)
         assert not torch.equal(rm[0], rm[1])
 
+        # (2b) FAMI_DDP_ALGO=mesh (reduce_scatter_tensor -> all_gather_into_tensor per slice) == the all_reduce plan:
+        # a two-rank sum is order independent, so bitwise
+        os.environ['FAMI_DDP_ALGO'] = 'mesh'
+        tr_m = Trainer(model(), use_graph=False, targets_from_joints=True, bucket_mb=8)
+        assert tr_m.reducer.algo == 'mesh'
+        tr_m.step(kf, sup, joints, vis)
+        assert torch.equal(tr_m.grad, tr_b.grad), 'mesh exchange differs from the all_reduce exchange'
+        assert torch.equal(tr_m.flat, tr_b.flat)
+        del tr_m
+
         # (3) graph plans == eager plan (rank 0 also checks the serial plan; the single-rank RCCL test covers both)
-        for plan in ('overlap', 'serial'):
+        for plan, algo in (('overlap', 'ring'), ('serial', 'ring'), ('overlap', 'mesh')):
             os.environ['FAMI_DDP_PLAN'] = plan
+            os.environ['FAMI_DDP_ALGO'] = algo
             tr_c = Trainer(model(), use_graph=True, targets_from_joints=True, bucket_mb=8)
             tr_c.step(kf, sup, joints, vis)
-            assert torch.equal(tr_c.flat, tr_b.flat), plan
+            assert torch.equal(tr_c.flat, tr_b.flat), (plan, algo)
             summ = tr_c.plan_summary()
             if plan == 'overlap':
                 assert summ['graphs'] >= 4 and summ['allreduces'] == len(tr_c.reducer.ranges()), summ
@@ -104,11 +128,11 @@ def _worker(rank, world, port, q):
         q.put((rank, 'FAILED: %s\n%s' % (e, traceback.format_exc())))
 
 
-def test_two_ranks_on_one_gpu_equal_their_shards(dev):
+def _run(backend):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -118,3 +142,14 @@ def test_two_ranks_on_one_gpu_equal_their_shards(dev):
     for p in procs:
         p.join(60)
     assert res == {0: 'ok', 1: 'ok'}, res
+
+
+def test_two_ranks_on_one_gpu_equal_their_shards(dev):
+    _run('gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two MI355X: one rank per device over RCCL')
+def test_two_ranks_two_gpus_rccl(dev):
+    """The same assertions with the measured transport: one rank per GPU, RCCL over xGMI, the eager / overlap / serial plans
+    and the mesh exchange.  Skipped on the one-GPU test box; a multi-GPU node (the driver's scaling box) runs it."""
+    _run('nccl')

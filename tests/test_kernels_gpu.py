@@ -1026,6 +1026,19 @@ def test_batched_small_launches_equal_the_single_ones(dev):
     L.call('fami_add_batch_f32', ptrs, counts, len(a), st)
     torch.cuda.synchronize(dev)
     assert all(torch.equal(x, y) for x, y in zip(o, ref))
+    # the SAME output several times inside one 32-entry window (a shared module with few parameters on 3 lanes: ADVICE r4 --
+    # concurrent blocks raced on `o[i] += a[i]`): a repeated output opens a new launch, adds land in call order
+    outs = [torch.randn(n, device=dev) for n in (5, 4096, 300)]
+    adds = [(k % 3, torch.randn(outs[k % 3].numel(), device=dev)) for k in range(9)]       # 3 lanes x 3 parameters
+    want = [x.clone() for x in outs]
+    for j, t in adds:
+        want[j] += t
+    ptrs, counts = (ctypes.c_long * (2 * len(adds)))(), (ctypes.c_int * len(adds))()
+    for i, (j, t) in enumerate(adds):
+        ptrs[2 * i], ptrs[2 * i + 1], counts[i] = t.data_ptr(), outs[j].data_ptr(), t.numel()
+    L.call('fami_add_batch_f32', ptrs, counts, len(adds), st)
+    torch.cuda.synchronize(dev)
+    assert all(torch.equal(x, y) for x, y in zip(outs, want))
     # 40 updates over 3 modules (the same buffers several times: order matters), channel counts 16 / 64 / 300
     mods = [(torch.randn(c, device=dev), torch.rand(c, device=dev) + 0.5) for c in (16, 64, 300)]
     mods_ref = [(m.clone(), v.clone()) for m, v in mods]

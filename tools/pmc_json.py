@@ -13,6 +13,12 @@ for line in open(path):
         vals[m.group(1)] = float(m.group(2))
 assert vals, 'kernel %r not found in %s' % (sub, path)
 rec = {'workload': note, 'source': os.path.relpath(path, root), 'algorithmic_bytes': int(float(alg))}
+# which tree the counters describe (bench.py prints it beside the live timing so a stale record is visible): the GPU box has no
+# .git, so the commit travels in .fami_sha (written by tools/gpu.sh before the snapshot) or FAMI_GIT_SHA
+sha = os.environ.get('FAMI_GIT_SHA')
+if not sha and os.path.exists(os.path.join(root, '.fami_sha')):
+    sha = open(os.path.join(root, '.fami_sha')).read().strip()
+rec['git_sha'] = sha
 if 'FETCH_SIZE' in vals:
     rec['fetch_kb'] = vals['FETCH_SIZE']; rec['read_bytes_corrected'] = int(vals['FETCH_SIZE'] * 1024 * 2)
 if 'WRITE_SIZE' in vals:
