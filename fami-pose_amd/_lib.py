@@ -69,7 +69,7 @@ class _Lib:
         # The two ablation switches below compute WRONG results on purpose (upper-bound experiments of tools/): they are refused
         # unless FAMI_ALLOW_WRONG=1 says the caller knows, so a variable left over in a job environment cannot silently corrupt a
         # training run.
-        wrong = [v for v in ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD') if os.environ.get(v, '0') not in ('', '0')]
+        wrong = [v for v in ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_BN1') if os.environ.get(v, '0') not in ('', '0')]
         if wrong and os.environ.get('FAMI_ALLOW_WRONG') != '1':
             raise FamiError('%s set: these switches skip work and produce WRONG gradients (measurement ablations only); '
                             'set FAMI_ALLOW_WRONG=1 to run them on purpose' % ', '.join(wrong))

@@ -170,6 +170,8 @@ struct DcnArgs {
   T* y;               // [B,Ho,Wo,Co]
   int B, H, W, C, Ho, Wo, Co, G, kh, kw, stride, pad, dil;
   int cg, KS, NTt, P;  // KS = ceil(C*K / 16): 16-wide k groups of the contraction
+  int ostr, mstr;      // elements per pixel of the offset / mask tensors: 2GK / GK (two dense tensors) or 3GK / 3GK (ONE tensor
+                       // [P][2GK offsets | GK masks], the output of the merged predictor: msk == off + 2GK)
 };
 
 // Column index of the contraction, TAP-major: kidx = ((tap*G + g)*q4 + q)*4 + c4  (channel c = g*cg + q*4 + c4,
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
         const long m = m0 + pixv[u];
         const int tg = rv[u] / q4, tap = tg / p.G;
         const int gt = (tg - tap * p.G) * K + tap;  // tap-major item -> (group, tap) index of the offset tensor
-        ov[u] = ld2(p.off + (m * GK + gt) * 2);
-        if (p.msk) mv[u] = ld1(p.msk + m * GK + gt);
+        ov[u] = ld2(p.off + m * p.ostr + gt * 2);
+        if (p.msk) mv[u] = ld1(p.msk + m * p.mstr + gt);
       }
     }
     f32x4 a[DCN_U][4];
@@ -404,8 +406,12 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
   const int K = p.kh * p.kw, GK = p.G * K, q4 = p.cg >> 2, CK = p.C * K;
   const int KS16 = p.KS;
   const int nitem = KS16 * 4;  // 4-channel sample blocks per pixel, padded to whole k groups
-  T* soff = reinterpret_cast<T*>(smem);                                  // [DCN_PIX][GK*2]
-  T* smsk = soff + DCN_PIX * GK * 2;                                     // [DCN_PIX][GK]
+  // two dense tensors: soff [DCN_PIX][2GK] then smsk [DCN_PIX][GK]; one merged tensor (p.ostr == 3GK): rows of 3GK, the
+  // masks of a pixel behind its offsets -- the tile's rows are then ONE contiguous run of HBM
+  const bool merged = p.ostr == 3 * GK;
+  const int lo = merged ? 3 * GK : 2 * GK, lm = merged ? 3 * GK : GK;      // LDS row strides (elements)
+  T* soff = reinterpret_cast<T*>(smem);
+  T* smsk = merged ? soff + 2 * GK : soff + DCN_PIX * GK * 2;
   const int staged = (DCN_PIX * GK * 3 * (int)sizeof(T) + 15) & ~15;     // bytes
   int4* tapt = reinterpret_cast<int4*>(reinterpret_cast<char*>(smem) + staged);  // [nitem]
   float* red = smem;  // [4][NT*256], reuses the staged rows once every wave is done with them
@@ -414,15 +420,15 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
   const int m0 = bxl * DCN_PIX;
   const int rows = min(DCN_PIX, p.P - m0);
 
-  {  // offsets / masks of the tile: contiguous runs, 16-byte copies
-    const int nb = rows * GK * 2 * (int)sizeof(T);
-    const char* src = reinterpret_cast<const char*>(p.off + (long)m0 * GK * 2);
+  {  // offsets (/ + masks) of the tile: contiguous runs, 16-byte copies
+    const int nb = rows * lo * (int)sizeof(T);
+    const char* src = reinterpret_cast<const char*>(p.off + (long)m0 * p.ostr);
     char* dst = reinterpret_cast<char*>(soff);
     for (int i = tid * 16; i + 16 <= nb; i += 256 * 16) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
     for (int i = (nb & ~15) + tid * (int)sizeof(T); i < nb; i += 256 * (int)sizeof(T))
       *reinterpret_cast<T*>(dst + i) = *reinterpret_cast<const T*>(src + i);
   }
-  if (p.msk) {
+  if (p.msk && !merged) {
     const int nb = rows * GK * (int)sizeof(T);
     const char* src = reinterpret_cast<const char*>(p.msk + (long)m0 * GK);
     char* dst = reinterpret_cast<char*>(smsk);
@@ -458,8 +464,8 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
   const unsigned WCb = p.W * p.C * (unsigned)sizeof(T), Cb = p.C * (unsigned)sizeof(T);
   const int Hm1 = p.H - 1, Wm1 = p.W - 1;
   const float Hf1 = sgpr_f((float)(p.H + 1)), Wf1 = sgpr_f((float)(p.W + 1));
-  const T* myoff = soff + row * GK * 2;
-  const T* mymsk = smsk + row * GK;
+  const T* myoff = soff + row * lo;
+  const T* mymsk = smsk + row * lm;
   __syncthreads();
 
   f32x4 acc[NT];
@@ -598,6 +604,7 @@ struct DcnWinArgs {
   int B, H, W, C, Ho, Wo, Co, G, K, kw, pad, dil;
   int TH, TW, tilesX, tilesY, R, WR, WC, PS;  // window rows / cols, LDS elements per window pixel (C + 16 bytes)
   int NQ, NTt, nsub;
+  int ostr, mstr;                             // elements per pixel of off / msk (see DcnArgs)
   unsigned mul_row, mul_px;                   // exact-division multipliers (>> 24) by the pieces per window row / per pixel
   int abl;                                    // ablation bits (benchmarks): 1 no MFMA, 2 no LDS gather, 4 no offset stream, 8 no window fill
 };
@@ -665,10 +672,10 @@ __global__ __launch_bounds__(512 * KSPLIT) void dcn_fwd_win_kernel(DcnWinArgs<T>
     if (abl & 4) { r.o0 = r.o1 = r.mk = f32x4{0.25f, 0.5f, 0.75f, 0.125f}; return; }
     int it0 = 16 * Q + 4 * kq;
     if (it0 + 4 > GK) it0 = GK - 4;                // padding items: any valid address (their weights are zero)
-    const T* po = p.off + m * GK2 + it0 * 2;
+    const T* po = p.off + m * p.ostr + it0 * 2;
     r.o0 = ld4(po);
     r.o1 = ld4(po + 4);
-    r.mk = p.msk ? ld4(p.msk + m * GK + it0) : f32x4{1.f, 1.f, 1.f, 1.f};
+    r.mk = p.msk ? ld4(p.msk + m * p.mstr + it0) : f32x4{1.f, 1.f, 1.f, 1.f};
   };
   OM om0, om1;
   om0.o0 = om0.o1 = om0.mk = om1.o0 = om1.o1 = om1.mk = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -910,6 +917,7 @@ struct DcnBwdArgs {
   long long* gfix;
   const unsigned* amax_bits;
   const float* wnorm;   // 1 float: max over columns k of sum_co |W[co][k]| (tail of the backward weight image)
+  int ostr, mstr;       // elements per pixel of off / goff and msk / gmsk (see DcnArgs)
   int fixl;             // 1 / 2: the LDS region accumulates in 64- / 32-bit fixed point (per-workgroup scale), flushed to gx as f32
   int abl;              // benchmarks (fami_dcn_tune(1024 + bits)): 1 = no region flush, 2 = no LDS adds, 4 = constant scale (no maxima pass)
 };
@@ -1119,8 +1127,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
       const int gt = chunk * gtl_n + gtl;
       const int g = gt / K, tap = gt - g * K;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      const f32x2 o = ld2(p.off + (m * GK + gt) * 2);
-      const float mk = p.msk ? ld1(p.msk + m * GK + gt) : 1.f;
+      const f32x2 o = ld2(p.off + m * p.ostr + gt * 2);
+      const float mk = p.msk ? ld1(p.msk + m * p.mstr + gt) : 1.f;
       const float sy = (float)(py * p.stride - p.pad + ky * p.dil) + o.x;
       const float sx = (float)(px * p.stride - p.pad + kx * p.dil) + o.y;
       const float fy = floorf(sy), fx = floorf(sx);
@@ -1258,13 +1266,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
         }
       }
       if (p.goff) {
-        T* qo = p.goff + (m * GK + gt) * 2;
+        T* qo = p.goff + m * p.ostr + gt * 2;
         f32x2 go = {gpy, gpx};
         if (p.acc_off) go += ld2(qo);
         st2(qo, go);
       }
       if (p.gmsk) {
-        T* qm = p.gmsk + m * GK + gt;
+        T* qm = p.gmsk + m * p.mstr + gt;
         st1(qm, p.acc_off ? ld1(qm) + gm : gm);
       }
     }
@@ -1462,9 +1470,13 @@ static inline long dcn_f32_image_elems(int Co, int C, int kh, int kw, int G) {
 template <typename T>
 static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp, const float* bias, T* y, int B, int H,
                         int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s,
-                        const char* nm) {
+                        const char* nm, bool merged = false) {
   FAMI_REQUIRE(x && off && wp && y && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
   DcnArgs<T> a;
+  // merged: `off` is ONE tensor [P][2GK offsets | GK masks] (the merged predictor's output); msk is derived here
+  a.ostr = (merged ? 3 : 2) * G * kh * kw;
+  a.mstr = (merged ? 3 : 1) * G * kh * kw;
+  if (merged) msk = off + 2 * G * kh * kw;
   a.x = x; a.off = off; a.msk = msk; a.wp = wp; a.bias = bias; a.y = y;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
   a.stride = stride; a.pad = pad; a.dil = dil;
@@ -1492,6 +1504,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
       w.pad = pad; w.dil = dil;
       w.TH = q.TH; w.TW = q.TW; w.tilesX = q.tilesX; w.tilesY = q.tilesY; w.R = q.R; w.WR = q.WR; w.WC = q.WC; w.PS = q.PS;
       w.NQ = q.NQ; w.NTt = a.NTt; w.nsub = q.nsub; w.mul_row = q.mul_row; w.mul_px = q.mul_px; w.abl = g_dcn_abl;
+      w.ostr = a.ostr; w.mstr = a.mstr;
       const dim3 grid(q.tilesX * q.tilesY * B);
       switch (a.NTt) {
         case 1: dcn_fwd_win_launch<T, 1>(w, grid, q.lds, s); break;
@@ -1557,9 +1570,16 @@ template <typename T>
 static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, float* gx,
                         T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
                         int pad, int dil, int acc_off, hipStream_t s, const char* nm, long long* gfix = nullptr,
-                        const unsigned* amax_bits = nullptr) {
+                        const unsigned* amax_bits = nullptr, bool merged = false) {
   FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
   DcnBwdArgs<T> a;
+  // merged: off / goff are ONE tensor each, [P][2GK offsets | GK masks] (merged predictor output and its gradient)
+  a.ostr = (merged ? 3 : 2) * G * kh * kw;
+  a.mstr = (merged ? 3 : 1) * G * kh * kw;
+  if (merged) {
+    msk = off + 2 * G * kh * kw;
+    gmsk = goff ? goff + 2 * G * kh * kw : nullptr;
+  }
   a.gfix = gfix; a.amax_bits = amax_bits;
   a.x = x; a.off = off; a.msk = msk; a.dy = dy; a.wpb = wpb; a.col = col; a.gx = gx; a.goff = goff; a.gmsk = gmsk;
   a.B = B; a.H = H; a.W = W; a.C = C; a.Co = Co; a.G = G; a.kh = kh; a.kw = kw;
@@ -1612,19 +1632,20 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
 template <typename T>
 static int dcn_bwd_det_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, T* gx,
                             T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
-                            int pad, int dil, int acc_off, int acc_x, void* ws, hipStream_t s, const char* nm) {
+                            int pad, int dil, int acc_off, int acc_x, void* ws, hipStream_t s, const char* nm,
+                            bool merged = false) {
   FAMI_REQUIRE(ws && dy, nm, "bad argument");
   const long n = (long)B * H * W * C;
   long long* gfix = gx ? reinterpret_cast<long long*>(ws) : nullptr;
   unsigned* amax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + n * 8);
-  if (!gx) return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm);
+  if (!gx) return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, nullptr, nullptr, merged);
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   hipLaunchKernelGGL(zero_u64_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(gfix), n, amax);
   FAMI_CHECK_LAUNCH(nm);
   const long ndy = (long)B * Ho * Wo * Co;
   hipLaunchKernelGGL(absmax_kernel<T>, dim3(fami_ew_grid(ndy) < 256 ? fami_ew_grid(ndy) : 256), dim3(256), 0, s, dy, ndy, amax);
   FAMI_CHECK_LAUNCH(nm);
-  const int rc = dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, gfix, amax);
+  const int rc = dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, gfix, amax, merged);
   if (rc != FAMI_OK) return rc;
   hipLaunchKernelGGL(fix_to_act_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, gfix, gx, n, amax, acc_x);
   FAMI_CHECK_LAUNCH(nm);
@@ -1742,6 +1763,26 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
                              int pad, int dil, int acc_off, int acc_x, void* ws, hipStream_t s) {                      \
     return dcn_bwd_det_impl<T>(x, off, msk, dy, wpb, col, gx, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, \
                                acc_off, acc_x, ws, s, "fami_dcn_bwd_det_" #sfx);                                       \
+  }                                                                                                                    \
+  /* The same three entry points for offsets and masks held in ONE tensor om [B,Ho,Wo,3GK] = per pixel (2GK offsets |   */ \
+  /* GK masks): the output of the two predictor convolutions of Alignment_V15.py:144-158 run as one 48 -> 324 convolution */ \
+  /* (gom: its gradient, same layout).                                                                                   */ \
+  int fami_dcn_fwd_om_##sfx(const T* x, const T* om, const float* wp, const float* bias, T* y, int B, int H, int W,    \
+                            int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s) {       \
+    return dcn_fwd_impl<T>(x, om, nullptr, wp, bias, y, B, H, W, C, Co, G, kh, kw, stride, pad, dil, s,                \
+                           "fami_dcn_fwd_om_" #sfx, true);                                                             \
+  }                                                                                                                    \
+  int fami_dcn_bwd_om_##sfx(const T* x, const T* om, const T* dy, const float* wpb, T* col, float* gx, T* gom, int B,  \
+                            int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,          \
+                            int acc_om, hipStream_t s) {                                                               \
+    return dcn_bwd_impl<T>(x, om, nullptr, dy, wpb, col, gx, gom, nullptr, B, H, W, C, Co, G, kh, kw, stride, pad, dil,\
+                           acc_om, s, "fami_dcn_bwd_om_" #sfx, nullptr, nullptr, true);                                \
+  }                                                                                                                    \
+  int fami_dcn_bwd_det_om_##sfx(const T* x, const T* om, const T* dy, const float* wpb, T* col, T* gx, T* gom, int B,  \
+                                int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,      \
+                                int acc_om, int acc_x, void* ws, hipStream_t s) {                                      \
+    return dcn_bwd_det_impl<T>(x, om, nullptr, dy, wpb, col, gx, gom, nullptr, B, H, W, C, Co, G, kh, kw, stride, pad, \
+                               dil, acc_om, acc_x, ws, s, "fami_dcn_bwd_det_om_" #sfx, true);                          \
   }
 FAMI_ALIGN_ABI(f32, float)
 FAMI_ALIGN_ABI(bf16, bf16_t)

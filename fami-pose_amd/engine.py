@@ -28,6 +28,10 @@ def _p(t):
 
 
 _ABL_WGRAD = os.environ.get('FAMI_ABL_WGRAD', '0') != '0'
+# Upper-bound experiments for "BatchNorm apply inside the consumer" (WRONG results, refused by _lib unless
+# FAMI_ALLOW_WRONG=1 when present at load; read per Engine): FAMI_ABL_BN1 bit 1 = the apply pass of every conv1 -> bn1 -> ReLU -> conv2 edge is skipped (conv2 reads z),
+# bit 2 = the backward apply pass of the same BatchNorms is skipped (the gradient passes through unchanged).  What the step would
+# gain if the consumer-side transform were free.
 _SFX = {torch.float32: '_f32', torch.bfloat16: '_bf16', torch.float16: '_f16'}
 
 
@@ -56,6 +60,50 @@ class T:
     @property
     def shape(self):
         return tuple(self.data.shape)
+
+
+class CatParam:
+    """Several parameters that are ADJACENT in memory, seen as one tensor concatenated on axis 0 -- no copy: the view spans
+    their storage.  The offset and the mask predictor of a DCN layer (Alignment_V15.py:79-100) run as ONE 48 -> 324 convolution
+    this way (one forward, one input gradient, one weight gradient instead of two each) while the module tree and the
+    state_dict keep the two nn.Conv2d.  train.flatten_parameters lays the flat parameter (and so the gradient) arena out so that
+    the parts are adjacent; anywhere else (parameters allocated one by one) `adjacent()` is False and callers take the
+    two-convolution path."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.shape = (sum(p.shape[0] for p in self.parts),) + tuple(self.parts[0].shape[1:])
+
+    @property
+    def requires_grad(self):
+        return all(p.requires_grad for p in self.parts)
+
+    def adjacent(self):
+        ps = self.parts
+        if any(not p.data.is_contiguous() or p.dtype != torch.float32 or p.shape[1:] != ps[0].shape[1:] for p in ps):
+            return False
+        if len({p.requires_grad for p in ps}) != 1:
+            return False
+        return all(b.data_ptr() == a.data_ptr() + a.numel() * 4 for a, b in zip(ps, ps[1:]))
+
+    @property
+    def data(self):
+        a = self.parts[0].data
+        return torch.as_strided(a, self.shape, a.stride())
+
+    def numel(self):
+        return sum(p.numel() for p in self.parts)
+
+
+def _real_params(ps):
+    """parameters of a tape entry with CatParams replaced by their parts (bucket hooks and counters work on real parameters)"""
+    out = []
+    for p in ps:
+        if isinstance(p, CatParam):
+            out.extend(p.parts)
+        else:
+            out.append(p)
+    return out
 
 
 class Engine:
@@ -147,6 +195,9 @@ class Engine:
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
         self.fuse_bn_bwd_t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
         self.concat_one = os.environ.get('FAMI_CONCAT_ONE', '1') != '0'      # Engine.concat: one launch for up to four sources
+        # the two predictor convolutions of a DCN layer as one (CatParam; needs the Trainer's arena layout): FAMI_MERGE_PREDICTORS
+        self.merge_predictors = os.environ.get('FAMI_MERGE_PREDICTORS', '1') != '0'
+        self.fuse_term_bn2 = os.environ.get('FAMI_FUSE_TERM_BN2', '1') != '0'
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
         # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
         # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
@@ -172,6 +223,7 @@ class Engine:
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
         self._red_longs = self.L.cdll.fami_wgrad_reduce_desc_longs()
+        self.abl_bn1 = int(os.environ.get('FAMI_ABL_BN1', '0'))      # upper-bound experiment, see the comment at the top of the file
         self.sync_stream()
         self._zero_begin()
 
@@ -398,7 +450,16 @@ class Engine:
                 t.lanes = {self.lane}
             else:
                 t.lanes.add(self.lane)
-        self.tape.append((fn, params, self.lane, inputs))
+        self.tape.append((fn, _real_params(params), self.lane, inputs))
+
+    def cat_usable(self, *cats):
+        """May these CatParams stand in for their parts in this step?  Adjacent in memory, and -- when gradients are recorded --
+        with a gradient buffer of their own that spans the parts' buffers (train.Trainer registers those views)."""
+        if not self.merge_predictors or not all(c.adjacent() for c in cats):
+            return False
+        if self.record and any(c.requires_grad for c in cats):
+            return self.grad_views is not None and all(id(c) in self.grad_views for c in cats)
+        return True
 
     def call(self, name, *args):
         self.L.call(name, *args, self.stream)
@@ -806,6 +867,8 @@ class Engine:
               and tuple(nxt.weight.shape[1:]) == (Co, 3, 3) and nxt.stride[0] == 1 and nxt.padding[0] == 1
               and nxt.dilation[0] == 1 and okq(N, Ho, Wo, Co, nxt.weight.shape[0]))
         if not ok:
+            if self.abl_bn1 and bn.training and self.fuse_bn_fwd and self.bn_fusable(P, Co):
+                return self._abl_bn1(x, conv, bn, st, pd, dl, Co)
             return self.conv_bn(x, conv, bn, relu=True)
         slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
         z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
@@ -832,6 +895,21 @@ class Engine:
             self.record_bwd(bwd, [bn.weight, bn.bias], (z,))
         return out
 
+    _abl_skip = 0
+
+    def _abl_bn1(self, x, conv, bn, st, pd, dl, Co):
+        """FAMI_ABL_BN1 (WRONG results, timing only): conv -> statistics in its epilogue -> BatchNorm whose apply pass (bit 1:
+        a one-workgroup finalize runs instead and the output aliases z) and / or backward apply pass (bit 2: the gradient
+        passes through) are skipped."""
+        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+        z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
+        self._abl_skip = self.abl_bn1
+        try:
+            y = self.bn(z, bn, relu=True, pre=slots)
+        finally:
+            self._abl_skip = 0
+        return y
+
     def bn(self, x, bn, relu=False, residual=None, pre=None):
         """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update.
         pre: slot rows the producing convolution's epilogue has filled (Engine.conv_bn): apply pass only."""
@@ -846,7 +924,11 @@ class Engine:
                 self._lane_guard(('running statistics', id(bn)))
             mom = 0.1 if bn.momentum is None else bn.momentum
             bn2 = self.bn2
-            if pre is not None:
+            if pre is not None and (self._abl_skip & 1):
+                y = x.data
+                self.call('fami_bn_finalize_slots_f32', _p(pre), P, C, _p(mean), _p(invstd), _p(None if deferred else bn.running_mean),
+                          _p(None if deferred else bn.running_var), float(mom), float(bn.eps))
+            elif pre is not None:
                 self.acall('fami_bn_apply_slots', _p(x.data), _p(None if residual is None else residual.data), _p(y),
                            _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
                            _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
@@ -879,8 +961,16 @@ class Engine:
                 rec = out.bnrec = {'z': x.data, 'y': y, 'mean': mean, 'invstd': invstd, 'gamma': bn.weight.data,
                                    'beta': bn.bias.data, 'rmode': rmode, 'pre_bwd': None}
 
+            abl_bwd = bool(self._abl_skip & 2)
+            if abl_bwd:
+                rec = out.bnrec = None
+
             def bwd():
                 if out.grad is None:
+                    return
+                if abl_bwd:                  # FAMI_ABL_BN1 bit 2 (WRONG, timing only): no backward passes at all
+                    if x.requires_grad:
+                        x.grad = out.grad
                     return
                 if not training:
                     raise NotImplementedError("backward through eval-mode BatchNorm is outside the training hot path")
@@ -971,16 +1061,28 @@ class Engine:
                 if need_p:
                     gg, accp = self.pgrad(bn.weight)
                     gb, _ = self.pgrad(bn.bias)
-                ws = self.ws(self.L.cdll.fami_bn_workspace(C))
                 st = h['stats']
+                # two-launch form (statistics into fp64 slot rows, finalize folded into the apply pass) where the BatchNorm is
+                # large enough for it -- the three-launch form's one-workgroup finalize sat between the two passes of all 53
+                # fuse-term BatchNorms of a step (5 us each); FAMI_FUSE_TERM_BN2=0 restores it
+                two = self.bn2 and self.fuse_term_bn2 and self.bn_fusable(Pk, C)
+                ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if two else self.ws(self.L.cdll.fami_bn_workspace(C))
                 if shift == 0:
-                    self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
-                               _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
+                    if two:
+                        self.acall('fami_bn_bwd2', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]), _p(bn.weight.data),
+                                   _p(bn.bias.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
+                    else:
+                        self.acall('fami_bn_bwd', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]),
+                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 1, accx, accp, 0, _p(ws))
                 else:
                     low = self.like(x.data)
                     self.acall('fami_pool_relu_bwd', _p(dy), _p(y), _p(low), N, H >> shift, W >> shift, C, shift, 1)
-                    self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
-                               _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
+                    if two:
+                        self.acall('fami_bn_bwd2', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]), _p(bn.weight.data),
+                                   _p(bn.bias.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
+                    else:
+                        self.acall('fami_bn_bwd', _p(low), _p(x.data), None, _p(st[0]), _p(st[1]),
+                                   _p(bn.weight.data), _p(gx), _p(gg), _p(gb), None, Pk, C, 0, accx, accp, 0, _p(ws))
             self.record_bwd(bwd, [bn.weight, bn.bias] if bn is not None else [], (x,))
         return h
 
@@ -1161,7 +1263,9 @@ class Engine:
         return out
 
     def dcn(self, x, off, msk, weight, bias, G, pad=3, dil=3):
-        """torchvision DeformConv2d(C,Co,3,padding=3,dilation=3)(x, off, msk) (Alignment_V15.py:146-158)."""
+        """torchvision DeformConv2d(C,Co,3,padding=3,dilation=3)(x, off, msk) (Alignment_V15.py:146-158).
+        msk None: `off` is the merged predictor's output [B,H,W,3GK] = per pixel (2GK offsets | GK masks)."""
+        om = msk is None
         B, H, W, C = x.shape
         Co, _, kh, kw = weight.shape
         K = kh * kw
@@ -1176,9 +1280,13 @@ class Engine:
             wp = self.empty(n)
             self.acall('fami_dcn_pack_weight', _p(weight.data), _p(wp), Co, C, kh, kw, G)   # 16-bit modes: + the 16-bit image
         y = self.act(B, H, W, Co)
-        self.acall('fami_dcn_fwd', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
-                   C, Co, G, kh, kw, 1, pad, dil)
-        rg = x.requires_grad or off.requires_grad or msk.requires_grad or self.rq(weight)
+        if om:
+            assert off.shape[3] == 3 * G * K
+            self.acall('fami_dcn_fwd_om', _p(x.data), _p(off.data), _p(wp), _p(bias.data), _p(y), B, H, W, C, Co, G, kh, kw, 1, pad, dil)
+        else:
+            self.acall('fami_dcn_fwd', _p(x.data), _p(off.data), _p(msk.data), _p(wp), _p(bias.data), _p(y), B, H, W,
+                       C, Co, G, kh, kw, 1, pad, dil)
+        rg = x.requires_grad or off.requires_grad or (not om and msk.requires_grad) or self.rq(weight)
         out = T(y, rg)
         wl = self.wlane_scope and self.head_wlane
         if rg:
@@ -1198,14 +1306,19 @@ class Engine:
                 acco = accx = 0
                 if off.requires_grad:
                     goff, acco = self.gbuf(off)
-                    gmsk, accm = self.gbuf(msk)
-                    assert acco == accm
+                    if not om:
+                        gmsk, accm = self.gbuf(msk)
+                        assert acco == accm
                 if self.deterministic:
                     if x.requires_grad:
                         gx, accx = self.gbuf(x)
                     ws = self.ws(self.L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C))
-                    self.acall('fami_dcn_bwd_det', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
-                               _p(gx), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco, accx, _p(ws))
+                    if om:
+                        self.acall('fami_dcn_bwd_det_om', _p(x.data), _p(off.data), _p(dy), _p(wpb), _p(col), _p(gx), _p(goff),
+                                   B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco, accx, _p(ws))
+                    else:
+                        self.acall('fami_dcn_bwd_det', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                                   _p(gx), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco, accx, _p(ws))
                 else:
                     if x.requires_grad:
                         gx, accx = self.gbuf(x)
@@ -1215,8 +1328,12 @@ class Engine:
                             gx32 = gx
                             if not accx:
                                 self.fill(gx)
-                    self.acall('fami_dcn_bwd', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
-                               _p(gx32), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
+                    if om:
+                        self.acall('fami_dcn_bwd_om', _p(x.data), _p(off.data), _p(dy), _p(wpb), _p(col), _p(gx32), _p(goff),
+                                   B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
+                    else:
+                        self.acall('fami_dcn_bwd', _p(x.data), _p(off.data), _p(msk.data), _p(dy), _p(wpb), _p(col),
+                                   _p(gx32), _p(goff), _p(gmsk), B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco)
                     if gx is not None and gx32 is not gx:
                         self.acall('fami_cast_add', _p(gx32), _p(gx), gx.numel(), accx)
                 if self.rq(weight):
@@ -1229,7 +1346,7 @@ class Engine:
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
                     if saved is not None:
                         self.stream = saved
-            self.record_bwd(bwd, [weight, bias], (x, off, msk))
+            self.record_bwd(bwd, [weight, bias], (x, off) if om else (x, off, msk))
         return out
 
     # ------------------------------------------------------------------ MI estimators (Alignment_V15.py:250-277)

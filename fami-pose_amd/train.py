@@ -129,25 +129,38 @@ class MultiStepLR:
 def flatten_parameters(model):
     """Move every trainable parameter into one flat arena (views keep names/shapes). -> (flat, [(param, off, n)])"""
     ps = [p for p in model.parameters() if p.requires_grad]
+    # groups the model wants adjacent (engine.CatParam: the two predictor convolutions of a DCN layer run as one): the later
+    # members move directly behind the first one
+    groups = [g for g in (model.adjacent_parameters() if hasattr(model, 'adjacent_parameters') else [])
+              if all(q.requires_grad for q in g)]
+    follow = {id(g[0]): g[1:] for g in groups}
+    moved = {id(q) for g in groups for q in g[1:]}
+    ordered = []
+    for p in ps:
+        if id(p) in moved:
+            continue
+        ordered.append(p)
+        ordered.extend(follow.get(id(p), ()))
     total = sum(p.numel() for p in ps)
     flat = torch.empty(total, dtype=torch.float32, device=ps[0].device)
-    table, off = [], 0
-    for p in ps:
+    where, off = {}, 0
+    for p in ordered:                      # the arena's layout
         n = p.numel()
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view(p.shape)
         if hasattr(p, '_fami_packed'):          # a packed image cached while the parameter was frozen is stale now
             del p._fami_packed
-        table.append((p, off, n))
+        where[id(p)] = off
         off += n
-    return flat, table
+    # the table stays in model.parameters() order: torch.optim.Adam numbers its state that way (checkpoint.py)
+    return flat, [(p, where[id(p)], p.numel()) for p in ps]
 
 
 class WeightPacker:
     """MFMA-fragment images of every trainable nn.Conv2d weight (forward and dgrad orientation), rebuilt from the
     flat fp32 parameter arena in ONE launch per step (fami_pack_conv_weights_batch_*) instead of ~600."""
 
-    def __init__(self, model, flat, table, dtype):
+    def __init__(self, model, flat, table, dtype, cats=None):
         import numpy as np
         L = lib().cdll
         from .engine import _SFX
@@ -156,9 +169,15 @@ class WeightPacker:
         convs = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Conv2d)}
         recs, self.views, off = [], {}, 0
         spans = []
+        # merged convolutions (engine.CatParam over adjacent weights): ONE image of the concatenated weight, keyed by the
+        # CatParam; the parts get no image of their own
+        cats = {id(c.parts[0]): c for c in (cats or ()) if len(c.shape) == 4}
+        skip = {id(q) for c in cats.values() for q in c.parts[1:]}
         for prm, src, _ in table:
-            if id(prm) not in convs:
+            if id(prm) not in convs or id(prm) in skip:
                 continue
+            if id(prm) in cats:
+                prm = cats[id(prm)]
             Co, Ci, kh, kw = prm.shape
             for mode in (0, 1):
                 n = elems(Co, Ci, kh, kw, mode)
@@ -177,7 +196,7 @@ class WeightPacker:
         names = {id(p): n for n, p in model.named_parameters()}
         early = ('hrnet.conv1.', 'hrnet.conv2.', 'hrnet.layer1.', 'hrnet.transition1.', 'hrnet.stage2.', 'conv1.', 'conv2.',
                  'layer1.', 'transition1.', 'stage2.')
-        order = [prm for prm, _, _ in table if id(prm) in convs]
+        order = [prm for prm, _, _ in table if id(prm) in convs and id(prm) not in skip]
         self.n_early = 0
         for prm in order:
             if names.get(id(prm), '').startswith(early):
@@ -350,6 +369,16 @@ class Trainer:
         self._adam_split = self._find_adam_split(model)
         self._adam_done = False
         self.views = {id(p): self.grad[o:o + n].view(p.shape) for p, o, n in self.table}
+        # merged parameters (engine.CatParam): adjacent in the arena by construction -- one gradient view spanning the parts
+        self.cats = []
+        if hasattr(model, 'merged_predictors'):
+            offs = {id(p): o for p, o, n in self.table}
+            for pair in model.merged_predictors().values():
+                for c in pair:
+                    if c.adjacent() and c.requires_grad and id(c.parts[0]) in offs:
+                        o = offs[id(c.parts[0])]
+                        self.views[id(c)] = self.grad[o:o + c.numel()].view(c.shape)
+                        self.cats.append(c)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         if data_parallel is False:          # a single-process trainer inside an initialised process group (tests, tools)
@@ -375,7 +404,7 @@ class Trainer:
             cast=lambda src, dst: lib().call('fami_cast_add_' + sfx, _p(src), _p(dst), src.numel(), 0, _stream(self.dev)),
             widen=lambda src, dst: lib().call('fami_widen_' + sfx, _p(src), _p(dst), src.numel(), _stream(self.dev)))
         self.reducer.world = self.world
-        self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype)
+        self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype, cats=self.cats)
         # data-parallel launch plan: 'overlap' (default) = hipGraph segments cut at the bucket boundaries with each
         # bucket's all-reduce issued between two segment replays (graph replay AND overlap with the rest of backward);
         # 'serial' = one graph for forward + backward, then every all-reduce; FAMI_DDP_GRAPH=0 = no graphs at all

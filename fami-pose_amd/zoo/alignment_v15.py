@@ -123,10 +123,31 @@ class Alignment_V15(EngineModule):
             logging.getLogger(__name__).error('=> please download pre-trained models first!')
 
     # ------------------------------------------------------------------ forward (Alignment_V15.py:113-183)
+    def merged_predictors(self):
+        """{k: (CatParam(weights), CatParam(biases))}: the offset and the mask predictor of DCN layer k (Alignment_V15.py:79-100;
+        both read the same tensor at :144-158) as ONE convolution with 2GK + GK output channels.  Views, not copies: usable only
+        while the parts are adjacent in memory (train.flatten_parameters lays the arena out that way, `adjacent_parameters`)."""
+        if getattr(self, '_cat', None) is None:
+            from ..engine import CatParam
+            self._cat = {}
+            for k in (1, 2, 3, 4):
+                oc, mc = getattr(self, 'dcn_offset_%d' % k).conv, getattr(self, 'dcn_mask_%d' % k).conv
+                self._cat[k] = (CatParam([oc.weight, mc.weight]), CatParam([oc.bias, mc.bias]))
+        return self._cat
+
+    def adjacent_parameters(self):
+        """parameter groups a flat arena must keep adjacent, in this order (train.flatten_parameters)"""
+        return [c.parts for pair in self.merged_predictors().values() for c in pair]
+
     def _dcn(self, eng, k, src, x):
+        d = getattr(self, 'dcn_%d' % k)
+        wcat, bcat = self.merged_predictors()[k]
+        if eng.cat_usable(wcat, bcat):
+            oc = getattr(self, 'dcn_offset_%d' % k).conv
+            om = eng.conv(src, wcat, bcat, oc.stride[0], oc.padding[0], oc.dilation[0])
+            return eng.dcn(x, om, None, d.weight, d.bias, self.G, d.padding, d.dilation)
         off = getattr(self, 'dcn_offset_%d' % k).run(eng, src)
         msk = getattr(self, 'dcn_mask_%d' % k).run(eng, src)
-        d = getattr(self, 'dcn_%d' % k)
         return eng.dcn(x, off, msk, d.weight, d.bias, self.G, d.padding, d.dilation)
 
     def _translation(self, eng, diff):

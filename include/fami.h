@@ -299,6 +299,19 @@ int fami_dcn_bwd_det_f32(const float* x, const float* off, const float* msk, con
                          int kh, int kw, int stride, int pad, int dil, int acc_off, int acc_x, void* ws,
                          fami_stream_t stream);
 
+/* The three DCN entry points above for offsets and masks held in ONE tensor om [B,Ho,Wo,3GK] -- per pixel the 2GK offsets
+ * followed by the GK masks: what the offset and the mask predictor of a DCN layer (Alignment_V15.py:79-100, called at
+ * :144-158) produce when they run as one 48 -> 324 convolution (weights concatenated on the output-channel axis; the
+ * state_dict keeps the two modules).  gom: the gradient wrt om, same layout (=|+= per acc_om).  Same kernels, other strides. */
+int fami_dcn_fwd_om_f32(const float* x, const float* om, const float* wp, const float* bias, float* y, int B, int H, int W,
+                       int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
+int fami_dcn_bwd_om_f32(const float* x, const float* om, const float* dy, const float* wpb, float* col, float* gx, float* gom,
+                       int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_om,
+                       fami_stream_t stream);
+int fami_dcn_bwd_det_om_f32(const float* x, const float* om, const float* dy, const float* wpb, float* col, float* gx,
+                           float* gom, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad,
+                           int dil, int acc_om, int acc_x, void* ws, fami_stream_t stream);
+
 /* ---- dense layers of the translation regressor: nn.Linear x3 (Alignment_V15.py:69-71) ------- */
 int fami_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int N,
                         fami_stream_t stream);
@@ -459,6 +472,14 @@ int fami_dcn_bwd_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_b
 int fami_dcn_bwd_det_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_bf16_t* msk, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col,
                          fami_bf16_t* gx, fami_bf16_t* goff, fami_bf16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
                          int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
+int fami_dcn_fwd_om_bf16(const fami_bf16_t* x, const fami_bf16_t* om, const float* wp, const float* bias, fami_bf16_t* y, int B, int H, int W,
+                       int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
+int fami_dcn_bwd_om_bf16(const fami_bf16_t* x, const fami_bf16_t* om, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col, float* gx, fami_bf16_t* gom,
+                       int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_om,
+                       fami_stream_t stream);
+int fami_dcn_bwd_det_om_bf16(const fami_bf16_t* x, const fami_bf16_t* om, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col, fami_bf16_t* gx,
+                           fami_bf16_t* gom, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad,
+                           int dil, int acc_om, int acc_x, void* ws, fami_stream_t stream);
 
 
 /* ======================================================================================================
@@ -571,6 +592,14 @@ int fami_dcn_bwd_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_
 int fami_dcn_bwd_det_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_t* msk, const fami_f16_t* dy, const float* wpb, fami_f16_t* col,
                          fami_f16_t* gx, fami_f16_t* goff, fami_f16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
                          int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
+int fami_dcn_fwd_om_f16(const fami_f16_t* x, const fami_f16_t* om, const float* wp, const float* bias, fami_f16_t* y, int B, int H, int W,
+                       int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
+int fami_dcn_bwd_om_f16(const fami_f16_t* x, const fami_f16_t* om, const fami_f16_t* dy, const float* wpb, fami_f16_t* col, float* gx, fami_f16_t* gom,
+                       int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, int acc_om,
+                       fami_stream_t stream);
+int fami_dcn_bwd_det_om_f16(const fami_f16_t* x, const fami_f16_t* om, const fami_f16_t* dy, const float* wpb, fami_f16_t* col, fami_f16_t* gx,
+                           fami_f16_t* gom, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad,
+                           int dil, int acc_om, int acc_x, void* ws, fami_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -420,6 +420,19 @@ def test_dcn_fwd_bwd(dev, cfg, dcn_gather):
     assert relerr(nchw(mt.grad), msk.grad) < 5e-5
     assert relerr(eng.param_grads[id(wd)], w.grad) < 5e-5
     assert relerr(eng.param_grads[id(bd)], b.grad) < 5e-5
+    # offsets and masks in ONE tensor [B,H,W,3GK] = per pixel (2GK offsets | GK masks) -- the output of the merged 48 -> 324
+    # predictor (fami_dcn_fwd_om_* / fami_dcn_bwd_om_*): the same kernels with other strides, so BITWISE the two-tensor
+    # result in the forward pass and in the offset / mask gradients (the input gradient is a sum of float atomics)
+    eng2 = _eng(dev)
+    om = T(torch.cat([ot.data, mt.data], 3).contiguous(), True)
+    xt2 = T(xt.data, True)
+    y2 = eng2.dcn(xt2, om, None, wd, bd, G, 3, 3)
+    assert torch.equal(y2.data, yt.data)
+    y2.grad = nhwc(g).to(dev)
+    eng2.backward()
+    assert torch.equal(om.grad[..., :18 * G], ot.grad) and torch.equal(om.grad[..., 18 * G:], mt.grad)
+    assert relerr(nchw(xt2.grad), x.grad) < 5e-5
+    assert relerr(eng2.param_grads[id(wd)], w.grad) < 5e-5
 
 
 def test_softmax_kl(dev):

@@ -329,3 +329,35 @@ def test_bench_workload_train_step_matches_the_oracle(dev):
         tg_.step(*args)
     torch.cuda.synchronize(dev)
     assert torch.equal(te.flat, tg_.flat) and torch.equal(te.opt.m, tg_.opt.m) and torch.equal(te.opt.v, tg_.opt.v)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_merged_predictors_match_the_two_convolution_path(dev, mode, monkeypatch):
+    """The offset and the mask predictor of every DCN layer (Alignment_V15.py:79-100, both applied to the same tensor at :144-158)
+    run as ONE 48 -> 324 dilated convolution inside Trainer.step (engine.CatParam over weights the flat arena keeps adjacent; the
+    DCN kernels read offsets and masks from one tensor).  Against the two-convolution path (FAMI_MERGE_PREDICTORS=0): the same
+    loss and the same gradients on every predictor / DCN / upstream parameter up to the summation order of other kernel
+    routes, twelve convolution-family launches and four bias sums fewer, identical state_dict layout."""
+    from fami_pose_amd.train import Trainer
+    from fami_pose_amd._lib import lib
+    bt = _batch(dev, 41)
+    grads, losses, calls = [], [], []
+    for merge in ('1', '0'):
+        monkeypatch.setenv('FAMI_MERGE_PREDICTORS', merge)
+        model, _ = _model(7)
+        model = model.to(dev).set_deterministic(True).set_compute_dtype(mode)
+        tr = Trainer(model, use_graph=False, targets_from_joints=True)
+        assert len(tr.cats) == 8                                           # (built either way: the arena layout does not depend on the switch)
+        n0 = lib().ncalls
+        tr.step(*bt)
+        calls.append(lib().ncalls - n0)
+        losses.append(tr.loss_value())
+        grads.append({n: tr.views[id(p)].clone() for n, p in model.named_parameters() if id(p) in tr.views})
+    assert calls[1] - calls[0] >= 12, calls
+    tol = 2e-5 if mode == 'f32' else 3e-2
+    assert losses[0] == pytest.approx(losses[1], rel=1e-6 if mode == 'f32' else 1e-3)
+    for name in ('dcn_offset_1.conv.weight', 'dcn_mask_1.conv.weight', 'dcn_offset_3.conv.bias', 'dcn_mask_4.conv.bias',
+                 'dcn_mask_4.conv.weight', 'dcn_2.weight', 'combined_feat_layers.layers.0.conv1.weight',
+                 'sup_agg_block.layers.0.conv1.weight'):
+        a, b = grads[0][name], grads[1][name]
+        assert ((a - b).norm() / b.norm()).item() < tol, name

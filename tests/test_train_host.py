@@ -151,3 +151,39 @@ def test_resumed_schedule_does_not_decay_twice(tmp_path):
     opt3 = FlatAdam(torch.zeros(4), lr=1e-3)
     load_adam_state_dict(SimpleNamespace(opt=opt3, table=[(p, 0, 4)]), osd)
     assert MultiStepLR(opt3, [8, 12, 16], 0.1, last_epoch=10).get_last_lr()[0] == pytest.approx(1e-4)
+
+
+def test_flat_arena_keeps_merged_predictor_weights_adjacent():
+    """The offset and the mask predictor of a DCN layer (Alignment_V15.py:79-100) run as ONE convolution on the HIP path
+    (engine.CatParam): flatten_parameters must lay the arena out so that the two weights (and the two biases) are adjacent, the
+    merged view must equal torch.cat of the parts, and the parameter TABLE must stay in model.parameters() order --
+    torch.optim.Adam numbers its state that way, so reference checkpoints keep loading (checkpoint.py)."""
+    import fami_pose_amd as fp
+    from fami_pose_amd.train import flatten_parameters
+    model = fp.build_model(fp.default_cfg(48, image_size=(96, 128), num_sup=2), 'train')
+    torch.manual_seed(3)
+    for p in model.parameters():
+        p.data.normal_()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    cats = model.merged_predictors()
+    assert not any(c.adjacent() for pair in cats.values() for c in pair)      # parameters allocated one by one: two-conv path
+    flat, table = flatten_parameters(model)
+    assert [id(p) for p, _, _ in table] == [id(p) for p in model.parameters() if p.requires_grad]
+    assert sorted(o for _, o, _ in table) != [o for _, o, _ in table]         # (the layout did move something)
+    spans = sorted((o, o + n) for _, o, n in table)
+    assert spans[0][0] == 0 and spans[-1][1] == flat.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n                          # values survive the move
+    G = model.G
+    for k, (wc, bc) in cats.items():
+        assert wc.adjacent() and bc.adjacent()
+        assert wc.shape == (27 * G, 48, 3, 3) and bc.shape == (27 * G,)
+        off, msk = getattr(model, 'dcn_offset_%d' % k).conv, getattr(model, 'dcn_mask_%d' % k).conv
+        assert torch.equal(wc.data, torch.cat([off.weight.data, msk.weight.data], 0))
+        assert torch.equal(bc.data, torch.cat([off.bias.data, msk.bias.data], 0))
+        assert wc.data.data_ptr() == off.weight.data_ptr() and wc.requires_grad
+    # state_dict is untouched by all of this
+    assert set(model.state_dict().keys()) >= {'dcn_offset_1.conv.weight', 'dcn_mask_1.conv.weight', 'dcn_offset_4.conv.bias'}
+    # a frozen part: no merged view
+    model.dcn_mask_2.conv.weight.requires_grad_(False)
+    assert not cats[2][0].adjacent()
