@@ -226,7 +226,8 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
     wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
     L.call('fami_dcn_pack_weight_bwd_f32', w.data_ptr(), wpb.data_ptr(), C, C, 3, 3, G, s.cuda_stream)
     dy = torch.randn(B, H, W, C, device=dev).to(tdt)
-    col = torch.empty(B * H * W, C * 9, device=dev, dtype=tdt)
+    colw = L.cdll.fami_dcn_bwd_col_width(C, C, G, 3, 3, 1, 3, int(sz), 0)      # (the register-fed kernel's own column order, padded)
+    col = torch.empty(B * H * W, colw, device=dev, dtype=tdt)
     gx = torch.zeros(B, H, W, C, device=dev)
     goff, gmsk = torch.empty_like(off), torch.empty_like(msk)
 
@@ -237,13 +238,15 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
     msb = _time_launches(launch_b, s, reps)
     nb = (2 * C + 6 * G * 9 + C) * H * W * sz * B
     achb = nb / (msb * 1e-3) / 1e9
-    bwd = {"bound": "hbm", "kernel": "dcn_bwd_kernel (%dch, %d groups, %dx%d, B=%d, %s; 64-bit fixed-point LDS scatter, f32 atomic flush)" % (C, G, H, W, B, dtype),
+    bwd = {"bound": "hbm", "kernel": "%s (%dch, %d groups, %dx%d, B=%d, %s; %d-bit fixed-point LDS scatter, f32 atomic flush)" % (
+               "dcn_bwd2_kernel <register-fed>" if L.cdll.fami_dcn_bwd_col_permuted(C, C, G, 3, 3, 1, 3, int(sz), 0) else "dcn_bwd_kernel", C, G, H, W, B, dtype, 64 if dtype == 'f32' else 32),
            "achieved": round(achb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achb / PEAK_HBM_GBS, 4),
            "traffic": pmc_traffic('dcn_bwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
            "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
     # the deterministic (64-bit fixed-point) form of the same backward: zero + |dy| max + kernel + conversion pass
     gxd = torch.empty(B, H, W, C, device=dev, dtype=tdt)
     ws = torch.empty(L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C) // 4 + 4, device=dev)
+    col = torch.empty(B * H * W, C * 9, device=dev, dtype=tdt)          # (the deterministic form writes the OIHW column order)
 
     def launch_d():
         L.call('fami_dcn_bwd_det_' + dtype, x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),

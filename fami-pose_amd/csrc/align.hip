@@ -15,6 +15,7 @@
 // feeds the samples to the MFMA from the registers of the lane that gathered them; dcn_fwd_kernel (fallback,
 // A/B partner) stages them in an LDS column tile first.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ bilinear shift
 template <typename T>
@@ -1331,6 +1332,329 @@ __global__ __launch_bounds__(256) void dcn_bwd_kernel(DcnBwdArgs<T> p) {
   }
 }
 
+// ------------------------------------------------------------------ DCN backward, register-fed form (round 5; default)
+// dcn_bwd_kernel above spends its time in vector instructions (PMC: 36 M wave instructions per B = 4 launch, 770 per
+// 64 (pixel, group, tap) items: three runtime integer divisions and 64-bit address arithmetic per item, per-corner
+// predication around every load and every LDS add, the column gradient through an LDS tile with three barriers per 16
+// pixels, every channel chunk of a tile in a workgroup of its own that repeats phase A's loads).  This kernel is the
+// forward's register-fed scheme (dcn_fwd_direct_kernel) run backwards:
+//   * a wave owns a 2 x 8 sub-tile of an 8 x 8 pixel tile and walks the chunk's (tap, group) items four at a time -- lane
+//     (pixel, kq) owns item 4q + kq of quad q.  The column gradient of the quad, gcol^T[16 columns][16 pixels] = W^T dy^T, comes
+//     out of the matrix core in exactly that shape: accumulator register r of lane (pixel, kq) is channel r of item 4q + kq at
+//     its pixel.  No LDS tile, no barrier between the GEMM and the gather; the dy fragments stay in registers for the whole
+//     kernel (f32: v_mfma_f32_16x16x4_f32 with the reduction index permuted so that a lane's Co / 4 values are contiguous in
+//     memory; 16-bit storage: v_mfma_f32_16x16x32 on the matrix pipe, the weights rounded to the storage type as in the forward);
+//   * the lane gathers its item's four corners exactly as the forward does (clamped addresses, zeroed weights for corners
+//     outside the map, 32-bit byte offsets, a decode table instead of divisions), forms the modulated sample (weight-gradient
+//     operand `col`, written as one 16-byte store per lane in the kernel's own column order: fami_dcn_col_dw_unpermute_f32 puts
+//     the weight gradient back into OIHW order), the mask gradient, the two offset gradients, and
+//   * scatters gcol x mask x bilinear weight into the workgroup's fixed-point LDS region with UNCONDITIONAL adds: region cells
+//     outside the map are simply never flushed, so no corner needs a predicate; a sample whose corners leave the region
+//     (offset beyond DCN2_RO pixels) or whose |mask| exceeds the fixed-point bound takes per-corner global atomics.
+// Channel chunks (GC groups per workgroup) only bound the region's LDS footprint, so that 4-6 workgroups share a CU.
+#define DCN2_RO 3      // offset reach of the LDS region beyond the taps (as DCN_RO of the general kernel)
+template <typename T>
+struct DcnBwd2Args {
+  const T* x;
+  const T* off;
+  const T* msk;        // may be null => 1
+  const T* dy;
+  const float* wimg;   // f32 storage: [nchunk][NQ][NCO][64][4]; 16-bit: [nchunk][NQ][NS][64][8] (fp32 values, converted in the kernel)
+  T* col;              // [P][colw] or null
+  float* gx;           // fp32, accumulated with atomics, or null
+  T* goff;
+  T* gmsk;
+  const float* wnorm;
+  int B, H, W, C, Ho, Wo, Co, G, K, kw, pad, dil, ostr, mstr, acc_off;
+  int GC, nchunk, NQ, colw;
+  int tilesX, tilesY, RH, RW, CS;     // region rows / columns, cells per region position (GC * 4 + 1: neighbours in different banks)
+};
+
+// item li of a chunk (tap-major: li = tap * GC + gl) -> column block of the original weight.view(Co, C*K) order
+__device__ __host__ __forceinline__ int dcn2_kidx(int li, int r, int chunk, int GC, int K) {
+  const int tap = li / GC, gl = li - tap * GC;
+  return ((chunk * GC + gl) * 4 + r) * K + tap;
+}
+// f32 image: wimg[(((chunk*NQ + q)*NCO + j4)*64 + lane)*4 + t] = W[co = (lane>>4)*NCO*4 + j4*4 + t][column of row lane&15 of quad q]
+// 16-bit image: wimg[(((chunk*NQ + q)*NS + m)*64 + lane)*8 + i] = W[co = m*32 + (lane>>4)*8 + i][same column]   (0 past Co / past the items)
+__global__ void dcn_pack_wb2_kernel(const float* __restrict__ w, float* __restrict__ img, int Co, int C, int K, int GC,
+                                    int nchunk, int NQ, int NJ, int half) {
+  const int per = half ? 512 : 256;
+  const long total = (long)nchunk * NQ * NJ * per;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % per);
+    long r = i / per;
+    const int j = (int)(r % NJ);
+    r /= NJ;
+    const int q = (int)(r % NQ), chunk = (int)(r / NQ);
+    const int lane = half ? e >> 3 : e >> 2, t = half ? e & 7 : e & 3;
+    const int row = lane & 15, kq = lane >> 4;
+    const int co = half ? j * 32 + kq * 8 + t : kq * NJ * 4 + j * 4 + t;
+    const int li = 4 * q + (row >> 2);
+    float v = 0.f;
+    if (co < Co && li < GC * K) v = w[(long)co * C * K + dcn2_kidx(li, row & 3, chunk, GC, K)];
+    img[i] = v;
+  }
+}
+// dw[co][c*K + tap] (=|+=) dwp[co][column of the kernel's order]   (dwp: [Co][colw] from the 1x1 weight gradient over `col`)
+__global__ void dcn_dw_unpermute_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int K, int GC,
+                                        int nchunk, int NQ, int colw, int CK, int accumulate) {
+  const long total = (long)Co * nchunk * NQ * 16;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i & 15);
+    long r = i >> 4;
+    const int q = (int)(r % NQ);
+    r /= NQ;
+    const int chunk = (int)(r % nchunk), co = (int)(r / nchunk);
+    const int li = 4 * q + (row >> 2);
+    if (li >= GC * K) continue;
+    const int k = dcn2_kidx(li, row & 3, chunk, GC, K);
+    const float v = dwp[(long)co * colw + (chunk * NQ + q) * 16 + row];
+    float* d = dw + (long)co * CK + k;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// floor(v + 0.5) as an integer in one instruction (v_cvt_rpi_i32_f32; __float2int_rn is v_rndne + v_cvt)
+__device__ __forceinline__ int dcn2_rint(float v) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ void dcn2_add64(long long* a, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)(long long)dcn2_rint(v));
+}
+
+template <typename T, int NCO, bool FIX32>
+__global__ __launch_bounds__(256, 3) void dcn_bwd2_kernel(DcnBwd2Args<T> p) {
+  constexpr bool HALF = sizeof(T) == 2;
+  constexpr int FIXB = FIX32 ? 20 : 30;            // bits of one contribution at the bound (see dcn_bwd_kernel)
+  constexpr int NS = (NCO + 1) / 2;                // 32-wide reduction steps of the 16-bit matrix instruction
+  extern __shared__ __attribute__((aligned(16))) char smem2[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, kq = lane >> 4;
+  const int nli = p.GC * p.K, Cc = p.GC * 4, CS = p.CS;
+  const int rcells = p.RH * p.RW * CS;
+  long long* reg64 = reinterpret_cast<long long*>(smem2);
+  int* reg32 = reinterpret_cast<int*>(smem2);
+  char* after = smem2 + (((size_t)rcells * (FIX32 ? 4 : 8) + 15) & ~(size_t)15);
+  int4* tapt = reinterpret_cast<int4*>(after);                                  // [NQ * 4]
+  float* wmax = reinterpret_cast<float*>(after + (size_t)p.NQ * 4 * sizeof(int4));   // [4]
+  int t, chunk;
+  xcd_tile(1, t, chunk);      // neighbouring tiles and all chunks of a tile on one XCD
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY, b = t / p.tilesY;
+  const int oy = ty * 8 + 2 * wave + (px >> 3), ox = tx * 8 + (px & 7);
+  const bool pv = oy < p.Ho && ox < p.Wo;
+  const long m = pv ? ((long)b * p.Ho + oy) * p.Wo + ox : (long)b * p.Ho * p.Wo;
+  const int ry0 = ty * 8 - p.pad - DCN2_RO, rx0 = tx * 8 - p.pad - DCN2_RO;
+
+  if (FIX32) { for (int i = tid; i < rcells; i += 256) reg32[i] = 0; }
+  else { for (int i = tid; i < rcells; i += 256) reg64[i] = 0ll; }
+  for (int it = tid; it < p.NQ * 4; it += 256) {
+    int4 e = {0, 0, 0, 0};
+    if (it < nli) {
+      const int tap = it / p.GC, gl = it - tap * p.GC;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      e = int4{(chunk * Cc + gl * 4) * (int)sizeof(T), ky * p.dil, kx * p.dil, (chunk * p.GC + gl) * p.K + tap};
+    }
+    tapt[it] = e;
+  }
+  // ---- dy fragments of this lane's pixel (kept for the whole kernel) and the tile's max |dy| (fixed-point scale)
+  typedef typename std::conditional<HALF, T, __bf16>::type HT;
+  typedef HT hx8 __attribute__((ext_vector_type(8)));
+  f32x4 dyf[HALF ? 1 : NCO];
+  hx8 dyh[HALF ? NS : 1];
+  float mdy = 0.f;
+  if constexpr (HALF) {
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int co0 = s2 * 32 + kq * 8;
+      hx8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (HT)0.f;
+      if (pv && co0 < p.Co) v = *reinterpret_cast<const hx8*>(p.dy + m * p.Co + co0);
+      dyh[s2] = v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mdy = fmaxf(mdy, fabsf((float)v[i]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NCO; ++j) {
+      dyf[j] = pv ? ld4(p.dy + m * p.Co + kq * NCO * 4 + j * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      mdy = fmaxf(fmaxf(mdy, fmaxf(fabsf(dyf[j][0]), fabsf(dyf[j][1]))), fmaxf(fabsf(dyf[j][2]), fabsf(dyf[j][3])));
+    }
+  }
+  mdy = wave_max(mdy);
+  if (lane == 0) wmax[wave] = mdy;
+  __syncthreads();
+  float fscale, finv;
+  {
+    mdy = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float bound = mdy * (p.msk ? DCN_MASK_BOUND : 1.f) * p.wnorm[0];
+    int e = -60;
+    if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);   // every |gcol * mask| < 2^e
+    e = e < -60 ? -60 : (e > 90 ? 90 : e);
+    fscale = ldexpf(1.f, FIXB - e);
+    finv = ldexpf(1.f, e - FIXB);
+  }
+
+  const char* xbase = reinterpret_cast<const char*>(p.x) + (long)b * p.H * p.W * p.C * sizeof(T);
+  float* gxb = p.gx ? p.gx + (long)b * p.H * p.W * p.C : nullptr;
+  const unsigned WCb = p.W * p.C * (unsigned)sizeof(T), Cb = p.C * (unsigned)sizeof(T);
+  const int Hm1 = p.H - 1, Wm1 = p.W - 1;
+  const float Hf1 = sgpr_f((float)(p.H + 1)), Wf1 = sgpr_f((float)(p.W + 1));
+  const int sy0 = oy - p.pad, sx0 = ox - p.pad;
+  const T* offp = p.off + m * p.ostr;
+  const T* mskp = p.msk ? p.msk + m * p.mstr : nullptr;
+
+  // per-lane bases (32-bit element offsets inside the loop)
+  T* const goffp = p.goff ? p.goff + m * p.ostr : nullptr;
+  T* const gmskp = p.gmsk ? p.gmsk + m * p.mstr : nullptr;
+  T* const colp = (p.col && pv) ? p.col + m * p.colw + chunk * p.NQ * 16 + kq * 4 : nullptr;
+  const int rwcs = p.RW * CS;
+  // offsets / mask of the quad in flight are requested one quad ahead
+  int4 te = tapt[kq];
+  f32x2 ov = pv ? ld2(offp + te.w * 2) : f32x2{0.f, 0.f};
+  float mv = (pv && mskp) ? ld1(mskp + te.w) : (pv ? 1.f : 0.f);
+  for (int q = 0; q < p.NQ; ++q) {
+    const int li = 4 * q + kq;
+    const bool iv = pv && li < nli;
+    const int4 tc = te;
+    const f32x2 o = ov;
+    const float mk = iv ? mv : 0.f;
+    // ---- the item's sample position and its four corner loads FIRST: they do not depend on the column gradient, so the matrix
+    // instructions below run while the loads are in flight
+    const float sy = (float)(sy0 + tc.y) + o.x, sx = (float)(sx0 + tc.z) + o.y;
+    const float fy = floorf(sy), fx = floorf(sx);
+    const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const int y0 = (int)__builtin_amdgcn_fmed3f(fy, -2.f, Hf1), x0 = (int)__builtin_amdgcn_fmed3f(fx, -2.f, Wf1);
+    const bool yv0 = (unsigned)y0 <= (unsigned)Hm1, yv1 = (unsigned)(y0 + 1) <= (unsigned)Hm1;
+    const bool xv0 = (unsigned)x0 <= (unsigned)Wm1, xv1 = (unsigned)(x0 + 1) <= (unsigned)Wm1;
+    const unsigned r0 = __umul24(min(max(y0, 0), Hm1), WCb), r1 = __umul24(min(max(y0 + 1, 0), Hm1), WCb);
+    const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)tc.x, c1 = __umul24(min(max(x0 + 1, 0), Wm1), Cb) + (unsigned)tc.x;
+    const f32x4 a00 = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0))), a01 = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
+    const f32x4 a10 = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0))), a11 = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
+    if (q + 1 < p.NQ) {
+      te = tapt[4 * (q + 1) + kq];
+      ov = pv ? ld2(offp + te.w * 2) : f32x2{0.f, 0.f};
+      mv = (pv && mskp) ? ld1(mskp + te.w) : (pv ? 1.f : 0.f);
+    }
+    // ---- column gradient of the quad: gc[r] = sum_co dy[pixel][co] W[co][channel r of item li]   (independent accumulators)
+    f32x4 gc;
+    if constexpr (HALF) {
+      const float* wb = p.wimg + ((long)(chunk * p.NQ + q) * NS) * 512 + lane * 8;
+      f32x4 g2[NS];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wb + s2 * 512), w1 = *reinterpret_cast<const f32x4*>(wb + s2 * 512 + 4);
+        const hx8 wv = {(HT)w0[0], (HT)w0[1], (HT)w0[2], (HT)w0[3], (HT)w1[0], (HT)w1[1], (HT)w1[2], (HT)w1[3]};
+        g2[s2] = H16<HT>::mfma(wv, dyh[s2], f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      gc = g2[0];
+#pragma unroll
+      for (int s2 = 1; s2 < NS; ++s2) gc += g2[s2];
+    } else {
+      const float* wb = p.wimg + ((long)(chunk * p.NQ + q) * NCO) * 256 + lane * 4;
+      f32x4 wv[NCO], g2[NCO];
+#pragma unroll
+      for (int j = 0; j < NCO; ++j) wv[j] = *reinterpret_cast<const f32x4*>(wb + j * 256);
+#pragma unroll
+      for (int j = 0; j < NCO; ++j) g2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int j = 0; j < NCO; ++j) g2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j][tt], dyf[j][tt], g2[j], 0, 0, 0);
+      gc = g2[0];
+#pragma unroll
+      for (int j = 1; j < NCO; ++j) gc += g2[j];
+    }
+    const float wy0 = yv0 ? hy : 0.f, wy1 = yv1 ? ly : 0.f, wx0 = xv0 ? hx : 0.f, wx1 = xv1 ? lx : 0.f;
+    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+    // corner order of the oracle's sum (and of the forward)
+    const f32x4 val = ((a00 * w00 + a01 * w01) + a10 * w10) + a11 * w11;
+    if (colp) st4(colp + q * 16, val * mk);
+    // d sample / d position: zero-padded corners, the derivative of each 1-D weight keeps its sign
+    const f32x4 z00 = (yv0 && xv0) ? a00 : f32x4{0.f, 0.f, 0.f, 0.f}, z01 = (yv0 && xv1) ? a01 : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 z10 = (yv1 && xv0) ? a10 : f32x4{0.f, 0.f, 0.f, 0.f}, z11 = (yv1 && xv1) ? a11 : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 gv = gc * mk;
+    const f32x4 dpy = hx * (z10 - z00) + lx * (z11 - z01);
+    const f32x4 dpx = hy * (z01 - z00) + ly * (z11 - z10);
+    float gm = 0.f, gpy = 0.f, gpx = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      gm += gc[c] * val[c];
+      gpy += gv[c] * dpy[c];
+      gpx += gv[c] * dpx[c];
+    }
+    if (iv) {
+      if (goffp) {
+        T* qo = goffp + tc.w * 2;
+        f32x2 go = {gpy, gpx};
+        if (p.acc_off) go += ld2(qo);
+        st2(qo, go);
+      }
+      if (gmskp) {
+        T* qm = gmskp + tc.w;
+        st1(qm, p.acc_off ? ld1(qm) + gm : gm);
+      }
+    }
+    // ---- input gradient
+    if (gxb && iv) {
+      const int ry = (int)fy - ry0, rx = (int)fx - rx0;       // (fy, fx inside the clamp whenever the region test passes)
+      const bool inreg = fy == (float)y0 && fx == (float)x0 && ry >= 0 && ry + 1 < p.RH && rx >= 0 && rx + 1 < p.RW &&
+                         fabsf(mk) <= DCN_MASK_BOUND;
+      const int cl = (tc.x / (int)sizeof(T)) - chunk * Cc;      // channel within the chunk
+      if (inreg) {
+        const f32x4 gs = gv * fscale;
+        const int cell = (ry * p.RW + rx) * CS + cl;
+        const float u00 = hy * hx, u01 = hy * lx, u10 = ly * hx, u11 = ly * lx;   // cells outside the map are never flushed
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (FIX32) {
+            atomicAdd(reg32 + cell + c, dcn2_rint(gs[c] * u00));
+            atomicAdd(reg32 + cell + CS + c, dcn2_rint(gs[c] * u01));
+            atomicAdd(reg32 + cell + rwcs + c, dcn2_rint(gs[c] * u10));
+            atomicAdd(reg32 + cell + rwcs + CS + c, dcn2_rint(gs[c] * u11));
+          } else {
+            dcn2_add64(reg64 + cell + c, gs[c] * u00);
+            dcn2_add64(reg64 + cell + CS + c, gs[c] * u01);
+            dcn2_add64(reg64 + cell + rwcs + c, gs[c] * u10);
+            dcn2_add64(reg64 + cell + rwcs + CS + c, gs[c] * u11);
+          }
+        }
+      } else {
+        float* g00 = gxb + tc.x / (int)sizeof(T);
+        const long o00 = ((long)y0 * p.W + x0) * p.C;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (yv0 && xv0) unsafeAtomicAdd(g00 + o00 + c, gv[c] * w00);
+          if (yv0 && xv1) unsafeAtomicAdd(g00 + o00 + p.C + c, gv[c] * w01);
+          if (yv1 && xv0) unsafeAtomicAdd(g00 + o00 + (long)p.W * p.C + c, gv[c] * w10);
+          if (yv1 && xv1) unsafeAtomicAdd(g00 + o00 + (long)p.W * p.C + p.C + c, gv[c] * w11);
+        }
+      }
+    }
+  }
+  if (!gxb) return;
+  __syncthreads();
+  // ---- region -> gx (f32 atomics; positions outside the map hold what zero padding discards)
+  // consecutive lanes = consecutive channels of one position: the atomics of a wave instruction fall into a few cache lines (one
+  // position per lane -- 64 lines per instruction -- ran the whole kernel at 300 us: the atomic units work per line request)
+  const float rcc = 1.f / (float)Cc, rrw = 1.f / (float)p.RW;      // exact quotients of (n + 0.5) * (1 / d) for n < 2^20
+  for (int e = tid; e < p.RH * p.RW * Cc; e += 256) {
+    const int pos = (int)(((float)e + 0.5f) * rcc), c = e - pos * Cc;
+    const long long v = FIX32 ? (long long)reg32[pos * CS + c] : reg64[pos * CS + c];
+    if (v == 0ll) continue;
+    const int ry = (int)(((float)pos + 0.5f) * rrw), rx = pos - ry * p.RW;
+    const int gy = ry0 + ry, gxx = rx0 + rx;
+    if ((unsigned)gy >= (unsigned)p.H || (unsigned)gxx >= (unsigned)p.W) continue;
+    unsafeAtomicAdd(gxb + ((long)gy * p.W + gxx) * p.C + chunk * Cc + c, (float)v * finv);
+  }
+}
+
 // ------------------------------------------------------------------ host side (templates over the storage type)
 template <typename T>
 static int shift_fwd_impl(const T* src, const float* t, T* out, int B, int H, int W, int C, hipStream_t s,
@@ -1539,8 +1863,66 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   return FAMI_OK;
 }
 
-static int g_dcn_bwd_abl = 0;       // fami_dcn_tune(1024 + bits): ablations of the backward kernel (benchmarks)
+// ---- register-fed backward (dcn_bwd2_kernel): plan shared by the weight pack, the launch and the callers' `col` width
+static int g_dcn_bwd2 = 1;          // fami_dcn_tune(2048 / 2049): off / on
+static int g_dcn_bwd2_cap = 36;     // fami_dcn_tune(4096 + KB): LDS budget of the fixed-point region (decides the groups per workgroup; benchmarks -- set BEFORE the weight pack)
+static int g_dcn_bwd_abl = 0;       // fami_dcn_tune(1024 + bits): ablations of the general backward kernel (benchmarks)
 static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = fixed-point LDS adds (64-bit for f32, 32-bit for 16-bit storage), 2 = 64-bit for every type
+// the register-fed kernel takes the default scatter (64-bit cells for f32 storage, 32-bit for the 16-bit types); every other
+// setting of the knobs above selects a form only the general kernel has
+static inline bool dcn_bwd2_on(int esz) {
+  return g_dcn_bwd2 && g_dcn_bwd_scatter != 0 && !(esz == 2 && g_dcn_bwd_scatter == 2) && !g_dcn_bwd_abl;
+}
+struct DcnBwd2Plan { int ok, GC, nchunk, NQ, colw, NJ, RH, RW, CS; size_t lds; };
+static DcnBwd2Plan dcn_bwd2_plan(int C, int Co, int G, int kh, int kw, int stride, int dil, int esz) {
+  DcnBwd2Plan q;
+  q.ok = 0; q.colw = C * kh * kw;
+  const int K = kh * kw;
+  if (!g_dcn_bwd2 || stride != 1 || G <= 0 || C != 4 * G || (Co % 16) != 0 || Co > 96 || K > 64) return q;
+  q.RH = 7 + (kh - 1) * dil + 2 + 2 * DCN2_RO;
+  q.RW = 7 + (kw - 1) * dil + 2 + 2 * DCN2_RO;
+  // groups per workgroup: the largest divisor of G whose fixed-point region (64-bit cells for f32 storage, 32-bit for the
+  // 16-bit types) stays within g_dcn_bwd2_cap KB at the head's dilation of 3.  The kernel is latency-bound, so the budget buys
+  // resident waves: measured on the B = 4, 96 x 72, 48-channel launch (tools/bench_dcn_bwd.py, region budget 64 / 48 / 36 / 24 KB):
+  // f32 102.6 / 89.9 / 82.3 / 98.4 us (groups per workgroup 4 / 3 / 2 / 1: below 2 the item quads are a quarter padding),
+  // bf16 107.6 / 108.0 / 72.5 / 74.8 us (6 / 6 / 4 / 3) -- against 166 / 127 us for dcn_bwd_kernel.  Default 36 KB: five
+  // workgroups (20 waves) per CU.  Chosen WITHOUT looking at the actual dilation: the weight image (packed before any launch)
+  // depends on it.
+  const int RHc = 7 + (kh - 1) * 3 + 2 + 2 * DCN2_RO, RWc = 7 + (kw - 1) * 3 + 2 + 2 * DCN2_RO;
+  q.GC = 0;
+  for (int gc = G; gc >= 1; --gc) {
+    if (G % gc) continue;
+    if ((size_t)RHc * RWc * (gc * 4 + 1) * (esz == 4 ? 8 : 4) <= (size_t)g_dcn_bwd2_cap * 1024) { q.GC = gc; break; }
+  }
+  if (!q.GC) return q;
+  q.nchunk = G / q.GC;
+  q.NQ = (q.GC * K + 3) / 4;
+  q.colw = q.nchunk * q.NQ * 16;
+  q.NJ = esz == 4 ? Co / 16 : (Co + 31) / 32;
+  q.CS = q.GC * 4 + 1;
+  q.lds = (((size_t)q.RH * q.RW * q.CS * (esz == 4 ? 8 : 4) + 15) & ~(size_t)15) + (size_t)q.NQ * 4 * 16 + 16;
+  q.ok = q.lds <= 64 * 1024;     // (a larger dilation than the head's: the general kernel)
+  if (!q.ok) q.colw = C * kh * kw;
+  return q;
+}
+static inline long dcn_bwd_old_image_elems(int Co, int C, int kh, int kw) {
+  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256 + 4;
+}
+// image of the register-fed kernel for storage size esz (4 | 2): floats
+static inline long dcn_bwd2_image_elems(const DcnBwd2Plan& q, int esz) {
+  return q.ok ? (long)q.nchunk * q.NQ * q.NJ * (esz == 4 ? 256 : 512) : 0;
+}
+template <typename T, int NCO>
+static void dcn_bwd2_launch(const DcnBwd2Args<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+  constexpr bool F32 = sizeof(T) == 2;       // 16-bit storage: 32-bit fixed-point region
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)dcn_bwd2_kernel<T, NCO, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dcn_bwd2_kernel<T, NCO, F32>), grid, dim3(256), lds, s, a);
+}
+
 static int dcn_bwd_chunk_groups(int G, int cg, int K) {
   // smallest group count whose column span cg*K*GC is a multiple of 16 and divides G
   for (int gc = 1; gc <= G; ++gc)
@@ -1588,6 +1970,35 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   a.Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   a.cg = C / G;
   const int K = kh * kw;
+  {
+    // register-fed kernel (default): the non-deterministic fixed-point scatter on the shapes it is built for
+    const DcnBwd2Plan q = dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, (int)sizeof(T));
+    if (q.ok && !gfix && dcn_bwd2_on((int)sizeof(T))) {
+      // (32-bit byte offsets inside a frame, 24-bit row / column products; no fallback here: the callers sized `col` for this kernel)
+      FAMI_REQUIRE((long)H * W * C * sizeof(T) < (1L << 32) && (long)W * C * sizeof(T) < (1L << 24), nm, "frame too large");
+      DcnBwd2Args<T> n;
+      n.x = x; n.off = off; n.msk = msk; n.dy = dy; n.col = col; n.gx = gx; n.goff = goff; n.gmsk = gmsk;
+      const long oldn = dcn_bwd_old_image_elems(Co, C, kh, kw);
+      n.wnorm = wpb + oldn - 4;
+      const DcnBwd2Plan q4 = dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, 4);
+      n.wimg = wpb + oldn + (sizeof(T) == 4 ? 0 : dcn_bwd2_image_elems(q4, 4));
+      n.B = B; n.H = H; n.W = W; n.C = C; n.Ho = a.Ho; n.Wo = a.Wo; n.Co = Co; n.G = G; n.K = K; n.kw = kw;
+      n.pad = pad; n.dil = dil; n.ostr = a.ostr; n.mstr = a.mstr; n.acc_off = acc_off;
+      n.GC = q.GC; n.nchunk = q.nchunk; n.NQ = q.NQ; n.colw = q.colw;
+      n.tilesX = fami_cdiv(a.Wo, 8); n.tilesY = fami_cdiv(a.Ho, 8); n.RH = q.RH; n.RW = q.RW; n.CS = q.CS;
+      const dim3 grid(n.tilesX * n.tilesY * B, q.nchunk);
+      switch (Co / 16) {
+        case 1: dcn_bwd2_launch<T, 1>(n, grid, q.lds, s); break;
+        case 2: dcn_bwd2_launch<T, 2>(n, grid, q.lds, s); break;
+        case 3: dcn_bwd2_launch<T, 3>(n, grid, q.lds, s); break;
+        case 4: dcn_bwd2_launch<T, 4>(n, grid, q.lds, s); break;
+        case 5: dcn_bwd2_launch<T, 5>(n, grid, q.lds, s); break;
+        default: dcn_bwd2_launch<T, 6>(n, grid, q.lds, s); break;
+      }
+      FAMI_CHECK_LAUNCH(nm);
+      return FAMI_OK;
+    }
+  }
   a.GC = (a.cg % 4 == 0) ? dcn_bwd_chunk_groups(G, a.cg, K) : 0;
   a.KSo = fami_cdiv(Co, 16);
   if (a.GC == 0 || a.KSo > 6) {
@@ -1700,10 +2111,12 @@ int fami_dcn_pack_weight_f16(const float* w_oihw, float* wp, int Co, int C, int 
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
   if (gather < 0) {   // every DCN knob back to its default
-    g_dcn_bwd_abl = 0; g_dcn_bwd_scatter = -1; g_dcn_ksplit = 1; g_dcn_abl = 0; g_dcn_win_r = 0; g_dcn_pf = 0; g_dcn_gather = -1;
+    g_dcn_bwd_abl = 0; g_dcn_bwd_scatter = -1; g_dcn_ksplit = 1; g_dcn_abl = 0; g_dcn_win_r = 0; g_dcn_pf = 0; g_dcn_gather = -1; g_dcn_bwd2 = 1; g_dcn_bwd2_cap = 36;
     return FAMI_OK;
   }
-  if (gather >= 1024) g_dcn_bwd_abl = gather - 1024;
+  if (gather >= 4096) g_dcn_bwd2_cap = gather - 4096;
+  else if (gather >= 2048) g_dcn_bwd2 = gather - 2048;
+  else if (gather >= 1024) g_dcn_bwd_abl = gather - 1024;
   else if (gather >= 512) g_dcn_bwd_scatter = gather - 512;
   else if (gather >= 256) g_dcn_ksplit = gather - 256;
   else if (gather >= 64) g_dcn_abl = gather - 64;
@@ -1715,7 +2128,39 @@ int fami_dcn_tune(int gather) {
 
 // the image of dcn_pack_wb_kernel + 4 floats: [0] = max_k sum_co |W[co][k]| (fixed-point scale bound of dcn_bwd_kernel)
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G) {
-  return (long)fami_cdiv((long)C * kh * kw, 16) * fami_cdiv(Co, 16) * 256 + 4;
+  // + the two images of the register-fed kernel (f32 storage / 16-bit storage: other chunking, other MFMA shape); sized for the
+  // head's geometry (stride 1, dilation = padding): the plan does not depend on anything else
+  long n = dcn_bwd_old_image_elems(Co, C, kh, kw);
+  for (int esz = 4; esz >= 2; esz -= 2) {
+    const int keep = g_dcn_bwd2;
+    g_dcn_bwd2 = 1;
+    n += dcn_bwd2_image_elems(dcn_bwd2_plan(C, Co, G, kh, kw, 1, 3, esz), esz);
+    g_dcn_bwd2 = keep;
+  }
+  return n;
+}
+/* columns of the `col` matrix fami_dcn_bwd_* writes for this geometry and storage size: C*kh*kw (weight.view(Co, C*K) order) on
+ * the general kernel, more (the register-fed kernel's own column order, padded) otherwise -- then the 1x1 weight gradient over
+ * col is [Co][cols] and fami_dcn_col_dw_unpermute_f32 brings it into OIHW order */
+long fami_dcn_bwd_col_width(int C, int Co, int G, int kh, int kw, int stride, int dil, int elem_bytes, int deterministic) {
+  if (deterministic || !dcn_bwd2_on(elem_bytes)) return (long)C * kh * kw;
+  return dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, elem_bytes).colw;
+}
+/* 1: col is in the register-fed kernel's column order (fami_dcn_col_dw_unpermute_f32 needed), 0: weight.view(Co, C*K) order.  (The
+ * widths alone do not tell: with four groups per workgroup the permuted matrix is exactly C*K wide.) */
+int fami_dcn_bwd_col_permuted(int C, int Co, int G, int kh, int kw, int stride, int dil, int elem_bytes, int deterministic) {
+  if (deterministic || !dcn_bwd2_on(elem_bytes)) return 0;
+  return dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, elem_bytes).ok ? 1 : 0;
+}
+int fami_dcn_col_dw_unpermute_f32(const float* dwp, float* dw, int Co, int C, int G, int kh, int kw, int stride, int dil,
+                                  int elem_bytes, int accumulate, hipStream_t s) {
+  FAMI_REQUIRE(dwp && dw, "fami_dcn_col_dw_unpermute_f32", "bad argument");
+  const DcnBwd2Plan q = dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, elem_bytes);
+  FAMI_REQUIRE(q.ok, "fami_dcn_col_dw_unpermute_f32", "geometry not on the register-fed backward kernel");
+  hipLaunchKernelGGL(dcn_dw_unpermute_kernel, dim3(fami_ew_grid((long)Co * q.colw)), dim3(256), 0, s, dwp, dw, Co, kh * kw, q.GC,
+                     q.nchunk, q.NQ, q.colw, C * kh * kw, accumulate);
+  FAMI_CHECK_LAUNCH("fami_dcn_col_dw_unpermute_f32");
+  return FAMI_OK;
 }
 
 // weight image of the backward column-gradient GEMM (see dcn_pack_wb_kernel)
@@ -1728,6 +2173,20 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32");
   hipLaunchKernelGGL(dcn_wnorm_kernel, dim3(1), dim3(256), 0, s, w_oihw, wpb + total, Co, C * K);
   FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32/norm");
+  float* img = wpb + total + 4;
+  for (int esz = 4; esz >= 2; esz -= 2) {
+    const int keep = g_dcn_bwd2;
+    g_dcn_bwd2 = 1;
+    const DcnBwd2Plan q = dcn_bwd2_plan(C, Co, G, kh, kw, 1, 3, esz);
+    g_dcn_bwd2 = keep;
+    const long n = dcn_bwd2_image_elems(q, esz);
+    if (n > 0) {
+      hipLaunchKernelGGL(dcn_pack_wb2_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, w_oihw, img, Co, C, K, q.GC, q.nchunk, q.NQ, q.NJ,
+                         esz == 2 ? 1 : 0);
+      FAMI_CHECK_LAUNCH("fami_dcn_pack_weight_bwd_f32/register-fed image");
+      img += n;
+    }
+  }
   return FAMI_OK;
 }
 

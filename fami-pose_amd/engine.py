@@ -1301,7 +1301,11 @@ class Engine:
                     nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
                     wpb = self.empty(nwp)
                     self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
-                col = self.act(P, CK) if self.rq(weight) else None
+                # columns of the modulated-sample matrix: C*K (OIHW order) or the register-fed kernel's own order, padded
+                esz = 2 if self.half else 4
+                colw = self.L.cdll.fami_dcn_bwd_col_width(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic))
+                permuted = bool(self.L.cdll.fami_dcn_bwd_col_permuted(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic)))
+                col = self.act(P, colw) if self.rq(weight) else None
                 gx = gx32 = goff = gmsk = None
                 acco = accx = 0
                 if off.requires_grad:
@@ -1339,8 +1343,13 @@ class Engine:
                 if self.rq(weight):
                     saved = self._enter_wlane() if wl else None      # leaves of the backward graph (see __init__)
                     g, acc = self.pgrad(weight)
-                    geo = (1, 1, P, CK, Co, 1, 1, 1, 0, 1)
-                    self.wgrad(col, dy, g, geo, acc)
+                    if not permuted:
+                        self.wgrad(col, dy, g, (1, 1, P, CK, Co, 1, 1, 1, 0, 1), acc)
+                    else:
+                        dwp = self.empty(Co, colw)
+                        self.wgrad(col, dy, dwp, (1, 1, P, colw, Co, 1, 1, 1, 0, 1), 0)
+                        self.flush_reduces(self.stream)      # (the deferred slab reduce writes dwp)
+                        self.call('fami_dcn_col_dw_unpermute_f32', _p(dwp), _p(g), Co, C, G, kh, kw, 1, dil, esz, acc)
                     gb, accb = self.pgrad(bias)
                     ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))

@@ -281,6 +281,16 @@ int fami_dcn_tune(int mode);            /* benchmarks / tests: forward kernel 0 
 long fami_dcn_packed_weight_bwd_elems(int Co, int C, int kh, int kw, int G);
 int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C, int kh, int kw, int G,
                                  fami_stream_t stream);
+/* Column count of the `col` matrix the fami_dcn_bwd_* / fami_dcn_bwd_om_* entry points write for this geometry and storage
+ * size (elem_bytes 4 | 2): C*kh*kw in weight.view(Co, C*K) order on the general kernel (always in the deterministic form), or
+ * more -- the register-fed kernel writes the modulated samples in its own (chunk, tap, group, channel) column order, padded to
+ * whole 16-column blocks (fami_dcn_bwd_col_permuted says which; the widths can coincide).  In that case the caller's 1x1 weight
+ * gradient over col is [Co][cols], and
+ * fami_dcn_col_dw_unpermute_f32 (=|+=) brings it into the OIHW order of DeformConv2d.weight (Alignment_V15.py:83-101). */
+long fami_dcn_bwd_col_width(int C, int Co, int G, int kh, int kw, int stride, int dil, int elem_bytes, int deterministic);
+int fami_dcn_bwd_col_permuted(int C, int Co, int G, int kh, int kw, int stride, int dil, int elem_bytes, int deterministic);
+int fami_dcn_col_dw_unpermute_f32(const float* dwp, float* dw, int Co, int C, int G, int kh, int kw, int stride, int dil,
+                                  int elem_bytes, int accumulate, fami_stream_t stream);
 /* autograd of DeformConv2d wrt input / offsets / masks (fused: column gradient dy x W stays in LDS).
  * col [P, C*K] (out, may be NULL) = modulated samples, column order (channel, tap) == weight.view(Co, C*K):
  * dW[co, kidx] = sum_p dy[p,co] * col[p,kidx], the caller runs that GEMM (fami_conv2d_wgrad_f32, 1x1).

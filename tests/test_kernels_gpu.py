@@ -843,8 +843,9 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
     g = torch.randn_like(y) * dyscale
     g[0, :, 3, 4] *= 50.0                                    # one hot pixel: the workgroup's bound is far above the typical value
     y.backward(g)
-    for mode in (0, 1):
+    for mode, regfed in ((0, 1), (1, 1), (1, 0)):         # (1, 1): the register-fed kernel (default); (1, 0): the general kernel's fixed-point form
         lib().cdll.fami_dcn_tune(512 + mode)
+        lib().cdll.fami_dcn_tune(2048 + regfed)
         try:
             eng = _eng(dev)
             wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(torch.zeros(C, device=dev))
@@ -858,8 +859,10 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
             # away from the hot pixel the gradient is 50x smaller than the bound assumes: still resolved
             far = (nchw(xt.grad).cpu()[1] - x.grad[1]).abs().max() / x.grad[1].abs().max()
             assert far.item() < 5e-6, mode
+            assert relerr(nchw(ot.grad), off.grad) < 5e-5 and relerr(nchw(mt.grad), msk.grad) < 5e-5
+            assert relerr(eng.param_grads[id(wd)], w.grad) < 5e-5
         finally:
-            lib().cdll.fami_dcn_tune(513)
+            lib().cdll.fami_dcn_tune(-1)
 
 
 @pytest.mark.parametrize("shape", [(20, 96, 72, 48, 48), (3, 48, 36, 96, 96), (2, 24, 18, 192, 192), (2, 12, 9, 384, 384),

@@ -211,7 +211,8 @@ def test_frozen_weight_image_is_not_reused_after_training(dev):
         y1 = model(kf, sup)[0].clone()
     fresh, _ = _model()
     fresh.load_state_dict(model.state_dict())
-    fresh = fresh.to(dev).set_deterministic(True)         # same launch plan as `model` (bitwise comparison below)
+    fresh = fresh.to(dev).set_deterministic(True)         # same launch plan as `model` (bitwise comparison below) ...
+    Trainer(fresh, use_graph=False, targets_from_joints=True)   # ... incl. the arena layout: adjacent predictor weights run as one convolution
     fresh.hrnet.freeze_weight()
     with torch.no_grad():
         y2 = fresh(kf, sup)[0]

@@ -47,7 +47,7 @@ for gather, pf, nm in ((0, 0, 'lds-column'), (1, 0, 'direct 1x7'), (2, 0, 'lds-w
 L.cdll.fami_dcn_tune(-1); L.cdll.fami_dcn_tune(16)
 
 dy = torch.randn(B, H, W, C, device=dev)
-col = torch.empty(P, C * 9, device=dev)
+col = torch.empty(P, max(C * 9, L.cdll.fami_dcn_bwd_col_width(C, C, G, 3, 3, 1, 3, 4, 0)), device=dev)      # (the register-fed kernel pads its column order)
 gx = torch.zeros(B, H, W, C, device=dev)
 goff = torch.empty_like(off)
 gmsk = torch.empty_like(msk)

@@ -58,7 +58,7 @@ else:
     else:
         wpb = torch.empty(L.cdll.fami_dcn_packed_weight_bwd_elems(C, C, 3, 3, G), device=dev)
         L.call('fami_dcn_pack_weight_bwd_f32', w.data_ptr(), wpb.data_ptr(), C, C, 3, 3, G, st)
-        col = torch.empty(B * H * W, C * 9, device=dev, dtype=tdt)
+        col = torch.empty(B * H * W, max(C * 9, L.cdll.fami_dcn_bwd_col_width(C, C, G, 3, 3, 1, 3, x.element_size(), 0)), device=dev, dtype=tdt)
         gx = torch.zeros(B, H, W, C, device=dev)
         goff, gmsk = torch.empty_like(off), torch.empty_like(msk)
         fn = lambda: L.call('fami_dcn_bwd_' + dt, x.data_ptr(), off.data_ptr(), msk.data_ptr(), y.data_ptr(), wpb.data_ptr(), col.data_ptr(), gx.data_ptr(), goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, st)
