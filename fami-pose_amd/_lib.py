@@ -43,6 +43,22 @@ class FamiError(RuntimeError):
     pass
 
 
+ROUTE_HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'fami_route.h')
+
+
+def _route_struct(path=ROUTE_HEADER_PATH):
+    """ctypes mirror of fami_route_t, built from the header's own field list (ints and longs only)."""
+    src = open(path).read()
+    body = re.search(r'typedef struct fami_route_t \{(.*?)\} fami_route_t;', src, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', ' ', body, flags=re.S)
+    fields = [(m.group(2), ctypes.c_int if m.group(1) == 'int' else ctypes.c_long)
+              for m in re.finditer(r'\b(int|long)\s+(\w+)\s*;', body)]
+    return type('fami_route_t', (ctypes.Structure,), {'_fields_': fields})
+
+
+Route = _route_struct()
+
+
 class _Lib:
     def __init__(self):
         if not os.path.isfile(LIB_PATH):
@@ -51,6 +67,8 @@ class _Lib:
                 "`make -C fami-pose_amd/csrc`. There is no CPU fallback." % LIB_PATH)
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.ncalls = 0                     # entry-point calls so far (a graph capture uses it to detect empty segments)
+        import threading
+        self._tls = threading.local()       # .bound: the fami_route_t THIS thread has bound (absent / None: process default)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():
             fn = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
@@ -83,7 +101,35 @@ class _Lib:
         if os.environ.get('FAMI_T5_WG'):               # A/B: workgroups of the persistent grid / 8 (99: one job per workgroup)
             self.cdll.fami_conv_tune_lds(7500 + int(os.environ['FAMI_T5_WG']))
 
+    def new_route(self):
+        """-> a fami_route_t with the library defaults (include/fami_route.h): the kernel-routing state an Engine owns."""
+        r = Route()
+        if self.cdll.fami_route_init(ctypes.byref(r)) != 0 or r.size != ctypes.sizeof(Route) or \
+                self.cdll.fami_route_size() != ctypes.sizeof(Route):
+            raise FamiError('fami_route_t layout differs between include/fami_route.h and libfami_hip.so -- rebuild the library')
+        return r
+
+    def bind(self, route):
+        """Entry points called from this thread route by `route` (None: the process default) until the next bind.  The binding is
+        thread-local on both sides; the bound object is kept alive here."""
+        if route is not getattr(self._tls, 'bound', None):
+            rc = self.cdll.fami_route_bind(None if route is None else ctypes.byref(route))
+            if rc != 0:
+                raise FamiError('fami_route_bind failed (%d): %s' % (rc, self.cdll.fami_last_error().decode()))
+            self._tls.bound = route
+
+    def call_routed(self, route, name, *args):
+        """call() under `route` (an Engine's): bound first, left bound."""
+        self.bind(route)
+        self.ncalls += 1
+        rc = getattr(self.cdll, name)(*args)
+        if self.protos[name][0] is ctypes.c_int and rc != 0:
+            raise FamiError('%s failed (%d): %s' % (name, rc, self.cdll.fami_last_error().decode()))
+        return rc
+
     def call(self, name, *args):
+        """An entry point under the process default route (callers with a route of their own: call_routed)."""
+        self.bind(None)
         self.ncalls += 1
         rc = getattr(self.cdll, name)(*args)
         if self.protos[name][0] is ctypes.c_int and rc != 0:

@@ -1685,9 +1685,9 @@ static int shift_bwd_impl(const T* gout, const T* src, const float* t, T* gsrc, 
   return FAMI_OK;
 }
 
-static int g_dcn_gather = -1;  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, 2 = dcn_fwd_win_kernel where eligible, -1 default (= 1)
-static int g_dcn_abl = 0;
-static int g_dcn_win_r = 0;    // fami_dcn_tune(32 + r): force the window's offset reach (benchmarks); 0 = largest that fits, up to 4
+// [fami_route_t] g_dcn_gather (default -1)  // fami_dcn_tune: 0 = dcn_fwd_kernel (LDS column tile), 1 = dcn_fwd_direct_kernel, 2 = dcn_fwd_win_kernel where eligible, -1 default (= 1)
+// [fami_route_t] g_dcn_abl (default 0)
+// [fami_route_t] g_dcn_win_r (default 0)  // fami_dcn_tune(32 + r): force the window's offset reach (benchmarks); 0 = largest that fits, up to 4
 
 // LDS-window forward: tile / window plan.  Eligible: stride 1, 4 channels per offset group (every HRNet width),
 // G*K a multiple of 4, C a multiple of 16 bytes' worth of elements, window (+ decode table) within 156 KB.
@@ -1743,7 +1743,7 @@ static void dcn_fwd_win_launch1(const DcnWinArgs<T>& a, dim3 grid, size_t lds, h
   }
   hipLaunchKernelGGL((dcn_fwd_win_kernel<T, NT, ABL, KSPLIT>), grid, dim3(512 * KSPLIT), lds, s, a);
 }
-static int g_dcn_ksplit = 1;   // fami_dcn_tune(256 + k): 2 = the 16-wave K-split build (measured slower: 35.5 vs 29.8 us)
+// [fami_route_t] g_dcn_ksplit (default 1)  // fami_dcn_tune(256 + k): 2 = the 16-wave K-split build (measured slower: 35.5 vs 29.8 us)
 template <typename T, int NT>
 static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   if (NT == 3 && sizeof(T) == 4 && a.abl) {   // tools/bench_dcn_win.py
@@ -1752,7 +1752,7 @@ static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hi
   } else if (g_dcn_ksplit == 2) dcn_fwd_win_launch1<T, NT, false, 2>(a, grid, lds, s);
   else dcn_fwd_win_launch1<T, NT, false, 1>(a, grid, lds, s);
 }
-static int g_dcn_pf = 0;       // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
+// [fami_route_t] g_dcn_pf (default 0)  // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
 
 template <typename T, int NT, int PF, int MINW>
 static void dcn_fwd_direct_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -1864,10 +1864,10 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
 }
 
 // ---- register-fed backward (dcn_bwd2_kernel): plan shared by the weight pack, the launch and the callers' `col` width
-static int g_dcn_bwd2 = 1;          // fami_dcn_tune(2048 / 2049): off / on
-static int g_dcn_bwd2_cap = 36;     // fami_dcn_tune(4096 + KB): LDS budget of the fixed-point region (decides the groups per workgroup; benchmarks -- set BEFORE the weight pack)
-static int g_dcn_bwd_abl = 0;       // fami_dcn_tune(1024 + bits): ablations of the general backward kernel (benchmarks)
-static int g_dcn_bwd_scatter = -1;  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = fixed-point LDS adds (64-bit for f32, 32-bit for 16-bit storage), 2 = 64-bit for every type
+// [fami_route_t] g_dcn_bwd2 (default 1)  // fami_dcn_tune(2048 / 2049): off / on
+// [fami_route_t] g_dcn_bwd2_cap (default 36)  // fami_dcn_tune(4096 + KB): LDS budget of the fixed-point region (decides the groups per workgroup; benchmarks -- set BEFORE the weight pack)
+// [fami_route_t] g_dcn_bwd_abl (default 0)  // fami_dcn_tune(1024 + bits): ablations of the general backward kernel (benchmarks)
+// [fami_route_t] g_dcn_bwd_scatter (default -1)  // fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = fixed-point LDS adds (64-bit for f32, 32-bit for 16-bit storage), 2 = 64-bit for every type
 // the register-fed kernel takes the default scatter (64-bit cells for f32 storage, 32-bit for the 16-bit types); every other
 // setting of the knobs above selects a form only the general kernel has
 static inline bool dcn_bwd2_on(int esz) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "route.h"
 
 #define FAMI_OK 0
 #define FAMI_EARG (-1)    // bad argument

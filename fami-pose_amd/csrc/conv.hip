@@ -2408,9 +2408,9 @@ static void launch_reduce_plain(const float* part, float* dw, int Co, int Ci, in
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fami_cdiv(n, 64)), dim3(256), 0, s, part, dw, n, psplit, accumulate);
 }
 
-static int g_prio = 0;      // fami_conv_tune_stages(120 / 121): s_setprio in the f32 MFMA kernels off / on
-static int g_lin_conv = 1;  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
-static int g_par = 1;       // fami_conv_tune_stages(110 / 111): parity-class stride-2 input gradient off / on
+// [fami_route_t] g_prio (default 0)  // fami_conv_tune_stages(120 / 121): s_setprio in the f32 MFMA kernels off / on
+// [fami_route_t] g_lin_conv (default 1)  // fami_conv_tune_stages(100 / 101): linear-address form of the f32 implicit GEMM off / on
+// [fami_route_t] g_par (default 1)  // fami_conv_tune_stages(110 / 111): parity-class stride-2 input gradient off / on
 // pixel tiles of MT*16 pixels: all of them, or (stride-2 dgrad by parity class) the sum over the four classes
 static long igemm_tiles(const ConvArgs& a, int MT) {
   if (!a.par) return fami_cdiv(a.P, MT * 16);
@@ -2454,14 +2454,14 @@ static int launch_igemm(const ConvArgs& a, int MT, int NT, int KS, int ST, hipSt
   return -1;
 }
 
-static int g_force_mt = 0, g_force_nt = 0, g_force_ks = 0;  // tuning overrides (fami_conv_tune)
-static int g_stages = 0;                                     // pipeline depth override (fami_conv_tune_stages)
+// [fami_route_t] g_force_mt (default 0), g_force_nt (default 0), g_force_ks (default 0)  // tuning overrides (fami_conv_tune)
+// [fami_route_t] g_stages (default 0)  // pipeline depth override (fami_conv_tune_stages)
 
-static int g_use32 = 1;  // fami_conv_tune(-1, ...) disables the 32x32-tile f32 kernel (benchmarks / tests)
+// [fami_route_t] g_use32 (default 1)  // fami_conv_tune(-1, ...) disables the 32x32-tile f32 kernel (benchmarks / tests)
 
 // 32x32x2 path: eligible when the weight image carries the 32-tile section (N >= 32, K % 4 == 0)
-static int g_xcd_w = 1;  // same switch for the weight-gradient kernels (fami_conv_tune_xcd bit 1)
-static int g_xcd = -1;  // fami_conv_tune_xcd: 0 natural tile order, 1 XCD-contiguous, -1 default (= 1: PMC FETCH_SIZE of the
+// [fami_route_t] g_xcd_w (default 1)  // same switch for the weight-gradient kernels (fami_conv_tune_xcd bit 1)
+// [fami_route_t] g_xcd (default -1)  // fami_conv_tune_xcd: 0 natural tile order, 1 XCD-contiguous, -1 default (= 1: PMC FETCH_SIZE of the
                         // 48->48 3x3 @96x72 N=20 launch drops from 46.6 MB to 13.7 MB, time -1..-2 %; tools/bench_xcd.py)
 
 static int run_igemm32(ConvArgs a, int mode, hipStream_t s, const char* name) {
@@ -2551,15 +2551,15 @@ static int run_igemm(ConvArgs a, int mode, hipStream_t s, const char* name) {
 // training step -- where the branch lanes run several convs at once and share the L2s -- the bf16 step is 4 % faster
 // with it (42.3 -> 40.6 ms) and the f32 step 4 % slower (77.3 -> 80.7 ms; interleaved A/B, tools/ab_step.py).
 // Default (-1): bf16 staged, f32 direct.  fami_conv_tune_lds(0/1) forces one path for both (tests exercise both).
-static int g_use_lds = -1;
-static int g_lds_sim = 0;  // fami_conv_tune_lds(2): LDS kernel in its split-operand cost-simulation form (benchmarks)
-static int g_wgrad_nsub = 2; // sub-chunks per workgroup of the 16-bit LDS wgrad (fewer, larger partial slabs): 2 = half the slab
+// [fami_route_t] g_use_lds (default -1)
+// [fami_route_t] g_lds_sim (default 0)  // fami_conv_tune_lds(2): LDS kernel in its split-operand cost-simulation form (benchmarks)
+// [fami_route_t] g_wgrad_nsub (default 2)  // sub-chunks per workgroup of the 16-bit LDS wgrad (fewer, larger partial slabs): 2 = half the slab
                              // traffic and reduce pass, bf16 step 34.6 -> 33.3 ms in both A/B orders; 3 and 4 equal to 2
-static int g_wgrad_ps = 0;   // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
-static int g_wgrad_mt = 0;   // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
-static int g_wgrad_lds = 1;  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
-static int g_wgrad_lds_f32 = 2;  // f32 LDS weight gradient: 0 never, 1 whenever eligible, 2 only where it measured faster
-static int g_wgrad_lin = 1;      // fami_conv_tune_wgrad_lds(50 / 51): linear-address per-tap f32 kernel off / on
+// [fami_route_t] g_wgrad_ps (default 0)  // fami_conv_tune_wgrad_lds(1000 + n): pixel-split target of the per-tap f32 wgrad (benchmarks)
+// [fami_route_t] g_wgrad_mt (default 0)  // fami_conv_tune_wgrad_lds(100 + mt): cap on input-channel tiles per f32 wgrad workgroup
+// [fami_route_t] g_wgrad_lds (default 1)  // fami_conv_tune_wgrad_lds(0): bf16 weight gradients on the scalar-operand kernels
+// [fami_route_t] g_wgrad_lds_f32 (default 2)  // f32 LDS weight gradient: 0 never, 1 whenever eligible, 2 only where it measured faster
+// [fami_route_t] g_wgrad_lin (default 1)  // fami_conv_tune_wgrad_lds(50 / 51): linear-address per-tap f32 kernel off / on
 
 // LDS-staged path: plan + launch.  Returns 1 if launched, 0 if the shape is not eligible, <0 on error.
 template <typename T>

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_stem1_fwd_f32_kernel(StemArgs p) {
   }
 }
 
-static int g_stem1 = 1;      // fami_conv_tune_lds(9000 / 9001): off / on
+// [fami_route_t] g_stem1 (default 1)  // fami_conv_tune_lds(9000 / 9001): off / on
 extern "C" void fami_conv_stem_tune(int on) { g_stem1 = on < 0 ? 1 : (on ? 1 : 0); }      // (declared inside conv.hip's extern "C" block)
 
 // Returns 1 if launched, 0 if the shape is not this kernel's, < 0 on error.  half_kind: 0 bf16, 1 fp16, 2 f32 (out_f32 is then the storage type).

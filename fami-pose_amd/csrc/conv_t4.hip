@@ -512,28 +512,28 @@ __global__ __launch_bounds__(WV * 64, S3 ? 2 : (NT == 3 ? 4 : 3)) void conv3x3_t
 }
 
 // ---- register-blocked LDS kernel (16-bit): plan + launch.  Returns 1 if launched, 0 if not eligible, <0 on error.
-static int g_use_t4 = 1;
-static int g_t4_dil = 1;      // fami_conv_tune_lds(40 / 41): dilated 3x3 convolutions on the band kernels off / on
-static int g_use_t4_f32 = 0;   // fami_conv_tune_lds(20 / 21): the f32 instance off / on.  Off by default: per launch it wins where
+// [fami_route_t] g_use_t4 (default 1)
+// [fami_route_t] g_t4_dil (default 1)  // fami_conv_tune_lds(40 / 41): dilated 3x3 convolutions on the band kernels off / on
+// [fami_route_t] g_use_t4_f32 (default 0)  // fami_conv_tune_lds(20 / 21): the f32 instance off / on.  Off by default: per launch it wins where
                                // the launch fills the chip (below), inside the f32 step it does not (61.2 vs 61.7 ms, and 61.4 vs 60.9
                                // when every shape takes it: noise) -- the exact-f32 MFMA step is bound by the matrix pipe itself   // fami_conv_tune_lds(10 / 11): off / on (default on for every eligible 16-bit 3x3)
-static int g_t4_bt = 0;    // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
+// [fami_route_t] g_t4_bt (default 0)  // fami_conv_tune_lds(100 + bt): force the tiles per band (benchmarks)
 static long long* g_t4_dbg = nullptr;   // fami_conv_t4_debug (FAMI_T4_TRACE builds)
-static int g_t4_s3_narrow = 0;      // fami_conv_tune_lds(102030 / 102031): two channel tiles per workgroup on launches of < 200 workgroups off / on.
+// [fami_route_t] g_t4_s3_narrow (default 0)  // fami_conv_tune_lds(102030 / 102031): two channel tiles per workgroup on launches of < 200 workgroups off / on.
                                     // Per launch 55 -> 43 us (24x18 @192 ch) and 70 -> 57 (12x9 @384 ch); f32 step 49.0 -> 49.7 and 48.9 -> 49.6 ms: off.
-static int g_t4_s3_fill = 2;        // fami_conv_tune_lds(102000 / 102001 / 102002): more, smaller bands on launches that leave CUs empty: off / all / tiny ones.
+// [fami_route_t] g_t4_s3_fill (default 2)  // fami_conv_tune_lds(102000 / 102001 / 102002): more, smaller bands on launches that leave CUs empty: off / all / tiny ones.
                                     // Per launch it wins (24x18 @192 ch 55 -> 45 us, 48x36 @96 ch 40.6 -> 35.6); inside the step other lanes
                                     // already fill those CUs and the smaller bands only add staging: 50.8 -> 51.4 and 49.5 -> 50.4 ms.  2 = only launches of
                                     // < 128 workgroups: the head's 4-frame convolutions (72 workgroups), which the trace shows running alone.
-static int g_t4_s3_pc = 0;          // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
-static int g_t4_s3_mt_minft = 64;   // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
-static int g_t4_s3_mt = 3;     // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
+// [fami_route_t] g_t4_s3_pc (default 0)  // fami_conv_tune_lds(60 / 61): producer / consumer form of the split-product instance off / on
+// [fami_route_t] g_t4_s3_mt_minft (default 64)  // ... only for frames of at least this many tiles (24x18 maps: 27 tiles = one band of 24 + one of 3)
+// [fami_route_t] g_t4_s3_mt (default 3)  // fami_conv_tune_lds(52 / 53): pixel tiles per wave of the split-product instance.  3 (bands of <= 24 tiles, 15 LDS
                                // fragment reads per 27 MFMAs instead of 12 per 18; 256 VGPRs, 12-64 bytes of scratch): per launch 48 ch @96x72
                                // 54 -> 51.5 us, 96 ch @48x36 56 -> 40.6, but 192 ch @24x18 55 -> 71 (hence the frame-size rule); f32 step
                                // 53.5 -> 52.3 ms.  4 tiles per wave (and 3 with 64-wide channel blocks) spill hundreds of bytes: not built.
-static int g_t4_s3_minwg = 0;  // fami_conv_tune_lds(2000 + n): the split-product instance only for launches of >= n workgroups (benchmarks)
-static int g_s3_default = 1;   // fami_tune_defaults: what fami_conv_tune_lds(-1) restores (FAMI_F32_SPLIT=0 -> 0)
-static int g_use_t4_s3 = 1;    // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
+// [fami_route_t] g_t4_s3_minwg (default 0)  // fami_conv_tune_lds(2000 + n): the split-product instance only for launches of >= n workgroups (benchmarks)
+// [fami_route_t] g_s3_default (default 1)  // fami_tune_defaults: what fami_conv_tune_lds(-1) restores (FAMI_F32_SPLIT=0 -> 0)
+// [fami_route_t] g_use_t4_s3 (default 1)  // fami_conv_tune_lds(30 / 31): f32 storage on the bf16 matrix pipe (split products, see the kernel) off / on
 
 // ---- the split-product f32 instance: plan + launch
 static int try_conv3x3_t4_s3(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,

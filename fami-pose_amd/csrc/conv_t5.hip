@@ -636,13 +636,13 @@ __global__ __launch_bounds__(T5_THREADS, 2) void conv3x3_t5_kernel(ConvT5Args p)
 // ------------------------------------------------------------------ plan + launch
 static long long* g_t5_dbg = nullptr;   // fami_conv_t5_debug (FAMI_T5_TRACE builds)
 extern "C" void fami_conv_t5_debug(void* buf) { g_t5_dbg = reinterpret_cast<long long*>(buf); }
-static int g_use_t5 = 1;        // fami_conv_tune_lds(7000 / 7001): off / on
-static int g_t5_rows = 0;       // fami_conv_tune_lds(7100 + R): force the rows per band (benchmarks)
-static int g_t5_maxwg = 256;    // fami_conv_tune_lds(7500 + n): at most 8 n workgroups in the persistent grid (benchmarks; 7599: one job per workgroup)
-static int g_t5_h16 = 0;        // fami_conv_tune_lds(7010 / 7011): the 16-bit instances off / on
-static int g_t5_abl = 0;        // fami_conv_tune_lds(7700 + n): ablation, see ConvT5Args.abl_chunks
-static int g_t5_min_jobs = 200; // fami_conv_tune_lds(7600 + n): only launches of >= n jobs
-static int g_t5_min_tiles = 0;  // fami_conv_tune_lds(7400 + n): only frames of >= 8 n tiles (7401: >= 1)  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
+// [fami_route_t] g_use_t5 (default 1)  // fami_conv_tune_lds(7000 / 7001): off / on
+// [fami_route_t] g_t5_rows (default 0)  // fami_conv_tune_lds(7100 + R): force the rows per band (benchmarks)
+// [fami_route_t] g_t5_maxwg (default 256)  // fami_conv_tune_lds(7500 + n): at most 8 n workgroups in the persistent grid (benchmarks; 7599: one job per workgroup)
+// [fami_route_t] g_t5_h16 (default 0)  // fami_conv_tune_lds(7010 / 7011): the 16-bit instances off / on
+// [fami_route_t] g_t5_abl (default 0)  // fami_conv_tune_lds(7700 + n): ablation, see ConvT5Args.abl_chunks
+// [fami_route_t] g_t5_min_jobs (default 200)  // fami_conv_tune_lds(7600 + n): only launches of >= n jobs
+// [fami_route_t] g_t5_min_tiles (default 0)  // fami_conv_tune_lds(7400 + n): only frames of >= 8 n tiles (7401: >= 1)  // fami_conv_tune_lds(7400 + n): only frames of >= n tiles (benchmarks / routing experiments)
 
 struct T5Plan { int ok, NT, R, bands, cblocks, njobs, G, npos; size_t lds; };
 template <bool S3>

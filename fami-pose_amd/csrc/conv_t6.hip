@@ -772,10 +772,10 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
 }
 
 // ---- plan + launch
-static int g_use_t6 = 1;        // fami_conv_tune_lds(8000 / 8001): off / on
-static int g_t6_rows = 0;       // fami_conv_tune_lds(8100 + RB): force the rows per band (benchmarks)
-static int g_t6_min_jobs = 96;  // fami_conv_tune_lds(8400 + n): only launches of >= n jobs
-static int g_t6_mt = 0;         // fami_conv_tune_lds(8201 / 8202): units of two / four rows (0: four where the band allows)
+// [fami_route_t] g_use_t6 (default 1)  // fami_conv_tune_lds(8000 / 8001): off / on
+// [fami_route_t] g_t6_rows (default 0)  // fami_conv_tune_lds(8100 + RB): force the rows per band (benchmarks)
+// [fami_route_t] g_t6_min_jobs (default 96)  // fami_conv_tune_lds(8400 + n): only launches of >= n jobs
+// [fami_route_t] g_t6_mt (default 0)  // fami_conv_tune_lds(8201 / 8202): units of two / four rows (0: four where the band allows)
 static long long* g_t6_dbg = nullptr;
 extern "C" void fami_conv_t6_debug(void* buf) { g_t6_dbg = reinterpret_cast<long long*>(buf); }
 
@@ -852,9 +852,9 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
 }
 
 struct T7Plan { int ok, RB, bands, TU, MT, EX, PI, jpw, G; size_t lds; };
-static int g_t7_target = 120;   // fami_conv_tune_lds(8700 + n): workgroups per output-channel block (jobs are dealt consecutively)
-static int g_use_t7 = 1;        // fami_conv_tune_lds(8500 / 8501): off / on
-static int g_t7_rows = 0;       // fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks)
+// [fami_route_t] g_t7_target (default 120)  // fami_conv_tune_lds(8700 + n): workgroups per output-channel block (jobs are dealt consecutively)
+// [fami_route_t] g_use_t7 (default 1)  // fami_conv_tune_lds(8500 / 8501): off / on
+// [fami_route_t] g_t7_rows (default 0)  // fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks)
 static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
   T7Plan q;
   q.ok = 0;

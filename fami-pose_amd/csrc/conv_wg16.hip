@@ -568,11 +568,11 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad6_kernel(Wg6Args p)
 static long long* g_wg6_dbg = nullptr;
 extern "C" void fami_wgrad6_debug(void* buf) { g_wg6_dbg = reinterpret_cast<long long*>(buf); }
 struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho, Wo, PR, XJ, coBlocks; size_t lds; };
-static int g_wg6_s2 = 1;      // fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on
-static int g_wg6_dil = 1;     // fami_conv_tune_wgrad_lds(23008 / 23009): the dilated (48 -> 216 / 108, dilation 3) launches off / on
-static int g_wg6_c42 = 1;
-static int g_wg6_c4 = 1;      // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
-static int g_wg6 = 1, g_wg6_nu = 0, g_wg6_target = 80;      // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
+// [fami_route_t] g_wg6_s2 (default 1)  // fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on
+// [fami_route_t] g_wg6_dil (default 1)  // fami_conv_tune_wgrad_lds(23008 / 23009): the dilated (48 -> 216 / 108, dilation 3) launches off / on
+// [fami_route_t] g_wg6_c42 (default 1)
+// [fami_route_t] g_wg6_c4 (default 1)  // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
+// [fami_route_t] g_wg6 (default 1), g_wg6_nu (default 0), g_wg6_target (default 80)  // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
   q.ok = 0;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad1_kernel(Wg1Args p)
 }
 
 struct Wg1Plan { int ok, nunits, G, blocks; long NU; };
-static int g_wg1 = 1, g_wg1_target = 192;     // inside the bf16 step (tools/ab_env.py): 48 / 96 / 192 workgroups 22.63 / 22.54 / 22.45 ms against 22.96 without the kernel      // fami_conv_tune_wgrad_lds(24000 / 24001): off / on; 24100 + n: workgroup target
+// [fami_route_t] g_wg1 (default 1), g_wg1_target (default 192)  // inside the bf16 step (tools/ab_env.py): 48 / 96 / 192 workgroups 22.63 / 22.54 / 22.45 ms against 22.96 without the kernel      // fami_conv_tune_wgrad_lds(24000 / 24001): off / on; 24100 + n: workgroup target
 static Wg1Plan wg1_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg1Plan q;
   q.ok = 0;
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(WG16_THREADS, 1) void conv_wgrad_stem_kernel(WgsArg
 }
 
 struct WgsPlan { int ok, UR, upf, nunits, G; long NU; };
-static int g_wgs = 1;      // fami_conv_tune_wgrad_lds(25000 / 25001): off / on
+// [fami_route_t] g_wgs (default 1)  // fami_conv_tune_wgrad_lds(25000 / 25001): off / on
 static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   WgsPlan q;
   q.ok = 0;
@@ -920,8 +920,8 @@ static WgsPlan wgs_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
 // Geometry covered: k x k with k in {1, 3}, stride 1 | 2, any dilation, padding = dilation * (k - 1) / 2 (centred kernels:
 // every convolution of the path), Ci % 16 == 0, Co % 4 == 0 (output-channel tails are zero-filled on the way into LDS).
 struct Wg16Plan { int ok, CIT, COT, taps, BT, bpf, nsub, G, Ho, Wo, ciBlocks, coBlocks; size_t lds; int xps, yps, xbytes; };
-static int g_wg16_abl = 0;
-static int g_wg16 = 1, g_wg16_bt = 0, g_wg16_target = 0, g_wg16_general = 1, g_wg16_bt18 = 0;   // 18-tile aligned runs: per launch 27.6 -> 25.0 us (48 ch @96x72), inside the bf16 step 26.10 -> 26.24 / 25.99 -> 26.09 ms: off
+// [fami_route_t] g_wg16_abl (default 0)
+// [fami_route_t] g_wg16 (default 1), g_wg16_bt (default 0), g_wg16_target (default 0), g_wg16_general (default 1), g_wg16_bt18 (default 0)  // 18-tile aligned runs: per launch 27.6 -> 25.0 us (48 ch @96x72), inside the bf16 step 26.10 -> 26.24 / 25.99 -> 26.09 ms: off
 static Wg16Plan wg16_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg16Plan q;
   q.ok = 0;

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WS3_THREADS) void conv_wgrad_s3_kernel(Wgs3Args p) 
 
 // ------------------------------------------------------------------ host side
 struct Wgs3Plan { int ok, CIT, COT, NYS, BT, bpf, nsub, G, ciBlocks, coBlocks, xpl, ypl, yrows; size_t lds; };
-static int g_wgs3 = 1, g_wgs3_bt = 0, g_wgs3_target = 0;
+// [fami_route_t] g_wgs3 (default 1), g_wgs3_bt (default 0), g_wgs3_target (default 0)
 static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
   Wgs3Plan q;
   q.ok = 0;
@@ -381,7 +381,7 @@ int fami_try_wgrad_s3(const float* x, const float* dy, float* part, long ws_byte
   return q.G;
 }
 // benchmarks / tests: 0 / 1 off / on, 100 + bt forces the tiles per run, 1000 + n the workgroup target, < 0 defaults
-static int g_wgs3_default = 1;   // fami_tune_defaults (FAMI_F32_SPLIT)
+// [fami_route_t] g_wgs3_default (default 1)  // fami_tune_defaults (FAMI_F32_SPLIT)
 void fami_wgrad_s3_default(int on) { g_wgs3_default = on ? 1 : 0; }
 void fami_wgrad_s3_tune(int on) {
   if (on < 0) { g_wgs3 = g_wgs3_default; g_wgs3_bt = 0; g_wgs3_target = 0; }

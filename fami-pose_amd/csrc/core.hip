@@ -12,6 +12,38 @@ extern "C" void fami_set_error(const char* where, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", where ? where : "?", what ? what : "?");
 }
 
+// ---- routing state (include/fami_route.h): one process default + the route each thread has bound
+static fami_route_t make_default_route() {
+  fami_route_t q;
+  fami_route_set_defaults(&q);
+  return q;
+}
+static fami_route_t g_process_route = make_default_route();
+static thread_local fami_route_t* t_bound_route = nullptr;
+extern "C" fami_route_t* fami_rt(void) { return t_bound_route ? t_bound_route : &g_process_route; }
+extern "C" long fami_route_size(void) { return (long)sizeof(fami_route_t); }
+// library defaults; the f32 arithmetic choice (split products on the bf16 matrix pipe or the exact-f32 MFMA) is the PROCESS
+// default's -- what FAMI_F32_SPLIT / fami_tune_defaults stored there
+extern "C" int fami_route_init(fami_route_t* r) {
+  FAMI_REQUIRE(r, "fami_route_init", "null route");
+  fami_route_set_defaults(r);
+  r->s3_default = g_process_route.s3_default;
+  r->use_t4_s3 = r->s3_default;
+  r->wgs3_default = g_process_route.wgs3_default;
+  r->wgs3 = r->wgs3_default;
+  return FAMI_OK;
+}
+// entry points called by THIS thread route by *r from now on (r stays owned by the caller and must outlive the binding);
+// NULL: back to the process default
+extern "C" int fami_route_bind(fami_route_t* r) {
+  if (r && r->size != (int)sizeof(fami_route_t)) {
+    fami_set_error("fami_route_bind", "route not initialised by fami_route_init of this library (size mismatch)");
+    return FAMI_EARG;
+  }
+  t_bound_route = r;
+  return FAMI_OK;
+}
+
 // One WAVE per output element (lanes stride K, coalesced rows of x and w, wave reduction): a thread per output walked K = 144
 // dependent global loads one at a time -- 52 us for the regressor's first layer (M = 4), on the head's serial chain.
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict_
 #define BN_SMALL_P 16384
 // one workgroup per 4 channels is serial over pixels: measured slower than the three-launch path for everything but
 // tiny tensors (the translation regressor's 16-channel maps below 24x18), where launch count is all that matters
-static long g_bn_small_elems = 32768;   // fami_bn_tune_small: tensors up to this many elements take the one-launch kernels
+// [fami_route_t] g_bn_small_elems (default 32768)  // fami_bn_tune_small: tensors up to this many elements take the one-launch kernels
 static inline bool bn_small_ok(long P, int C) { return P * C <= g_bn_small_elems; }
 
 __device__ __forceinline__ f32x4 block_sum4(f32x4 v, float* sm) {  // sm: 4 * 4 floats

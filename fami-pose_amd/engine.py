@@ -106,9 +106,29 @@ def _real_params(ps):
     return out
 
 
+class _RoutedQueries:
+    """The library's size / eligibility queries (workspace bytes, slot rows, which kernel would take a shape) under an engine's route:
+    they depend on the routing state, so the route is bound before the raw call, as it is before every launch."""
+
+    def __init__(self, L, eng):
+        self._L, self._eng = L, eng
+
+    def __getattr__(self, name):
+        fn, L, eng = getattr(self._L.cdll, name), self._L, self._eng
+
+        def query(*args):
+            L.bind(eng.route)
+            return fn(*args)
+        return query
+
+
 class Engine:
-    def __init__(self, device, grad_views=None, record=True, dtype=torch.float32, deterministic=None):
+    def __init__(self, device, grad_views=None, record=True, dtype=torch.float32, deterministic=None, route=None):
+        """route: the kernel-routing state (include/fami_route.h, `lib().new_route()`) this engine's launches dispatch by; bound to
+        the calling thread before every entry point, so engines with different routes interleave in one process.  None: the
+        process default route (what the fami_*_tune shims of tests and benchmarks write)."""
         assert dtype in _SFX
+        self.route = route
         self.dt = dtype                # activation storage dtype
         self.sfx = _SFX[dtype]
         self.half = dtype != torch.float32     # 16-bit storage (bf16 | fp16): 16x16x32 MFMA convolutions
@@ -117,6 +137,7 @@ class Engine:
         # form (fami_dcn_bwd_det_*).  Default from FAMI_DETERMINISTIC (0).
         self.deterministic = (os.environ.get('FAMI_DETERMINISTIC', '0') != '0') if deterministic is None else bool(deterministic)
         self.L = lib()
+        self.Q = _RoutedQueries(self.L, self)
         self.record = record           # False: forward only (no tape, no gradient flags)
         self.dev = device
         self.tape = []
@@ -222,7 +243,7 @@ class Engine:
         self.defer_reduce = os.environ.get('FAMI_DEFER_REDUCE', '1') != '0'
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
-        self._red_longs = self.L.cdll.fami_wgrad_reduce_desc_longs()
+        self._red_longs = self.Q.fami_wgrad_reduce_desc_longs()
         self.abl_bn1 = int(os.environ.get('FAMI_ABL_BN1', '0'))      # upper-bound experiment, see the comment at the top of the file
         self.sync_stream()
         self._zero_begin()
@@ -462,7 +483,7 @@ class Engine:
         return True
 
     def call(self, name, *args):
-        self.L.call(name, *args, self.stream)
+        self.L.call_routed(self.route, name, *args, self.stream)
 
     # ------------------------------------------------------------------ weight gradients with deferred slab reduces
     def wgrad(self, x_data, dy, g, geo, acc, xbn=None):
@@ -470,7 +491,7 @@ class Engine:
         xbn: x_data is the input of a not materialised BatchNorm+ReLU (mean, invstd, gamma, beta)."""
         if _ABL_WGRAD:          # upper-bound experiment (FAMI_ABL_WGRAD=1, WRONG gradients): no weight-gradient kernels at all
             return
-        nb = self.L.cdll.fami_conv2d_wgrad_workspace(*geo)
+        nb = self.Q.fami_conv2d_wgrad_workspace(*geo)
         ws = self.ws(nb)
         assert xbn is None or self.defer_reduce
         if not self.defer_reduce:
@@ -502,7 +523,7 @@ class Engine:
             flat = (ctypes.c_long * (self._red_longs * n))()
             for i, d in enumerate(items):
                 flat[i * self._red_longs:(i + 1) * self._red_longs] = d[:]
-            self.L.call('fami_wgrad_reduce_batch', flat, n, st)
+            self.L.call_routed(self.route, 'fami_wgrad_reduce_batch', flat, n, st)
             self._red[st] = []
             self._red_dw[st] = set()
 
@@ -519,7 +540,7 @@ class Engine:
 
     def acall(self, name, *args):
         """Call the activation-dtype instance of an entry point."""
-        self.L.call(name + self.sfx, *args, self.stream)
+        self.L.call_routed(self.route, name + self.sfx, *args, self.stream)
 
     def new_grad(self, t):
         g = torch.empty(t.data.shape, dtype=torch.float32 if t.f32grad else self.dt, device=self.dev)
@@ -640,7 +661,7 @@ class Engine:
             # nothing in the step reads the running statistics: on a side lane, joined by join_side() (the caller)
             if self.use_lanes:
                 self._side_events.append(self.side_launch(
-                    lambda st: self.L.call('fami_bn_running_update_batch_f32', ptrs, meta, n, st)))
+                    lambda st: self.L.call_routed(self.route, 'fami_bn_running_update_batch_f32', ptrs, meta, n, st)))
             else:
                 self.call('fami_bn_running_update_batch_f32', ptrs, meta, n)
 
@@ -673,11 +694,11 @@ class Engine:
             if hit is not None and hit[0] == w._version and hit[2] == w.data_ptr():
                 return hit[1]
         if self.half:
-            n = self.L.cdll.fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode)
+            n = self.Q.fami_packed_weight_elems_bf16(Co, Ci, kh, kw, mode)
             wp = self.act(n)
             self.acall('fami_pack_conv_weight', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
         else:
-            n = self.L.cdll.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
+            n = self.Q.fami_packed_weight_elems(Co, Ci, kh, kw, mode)
             wp = self.empty(n)
             self.call('fami_pack_conv_weight_f32', _p(w.data), _p(wp), Co, Ci, kh, kw, mode)
         if cacheable:
@@ -800,7 +821,7 @@ class Engine:
                     self.conv_flops += flops
                 if self.rq(bias):
                     g, acc = self.pgrad(bias)
-                    ws = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
+                    ws = self.ws(self.Q.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
                 if saved is not None:
                     self.stream = saved
@@ -811,14 +832,14 @@ class Engine:
                     rec = x.bnrec
                     pays = False
                     if self.fuse_bn_bwd_auto and rec is not None and (kh, stride, pad, dil) == (3, 1, 1, 1):
-                        kind = self.L.cdll.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
+                        kind = self.Q.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
                         t7 = self.fuse_bn_bwd_t7
                         pays = kind == 1 or (kind == 2 and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
                     if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
                         # the epilogue applies the ReLU mask and takes the two sums of the BatchNorm backward
-                        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Ci))
+                        slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Ci))
                         self.acall('fami_conv2d_dgrad_bnstats', _p(dy), _p(wpd), _p(gx), *geo, acc, _p(rec['z']),
                                    _p(rec['y'] if rec['rmode'] == 1 else None), _p(rec['mean']), _p(rec['invstd']),
                                    _p(rec['gamma']), _p(rec['beta']), rec['rmode'], _p(slots))
@@ -833,7 +854,7 @@ class Engine:
 
     def bn_fusable(self, P, C):
         """Can the statistics passes of a train-mode BatchNorm over [P, C] run in a convolution epilogue?"""
-        return C % 4 == 0 and 4 <= C <= 1024 and not self.L.cdll.fami_bn_is_small(P, C)
+        return C % 4 == 0 and 4 <= C <= 1024 and not self.Q.fami_bn_is_small(P, C)
 
     def conv_bn(self, x, conv, bn, relu=False, residual=None):
         """nn.Conv2d -> nn.BatchNorm2d (-> + residual) (-> ReLU): basic_model.py:34-63, basic_layer.py:25-26.  With a
@@ -844,7 +865,7 @@ class Engine:
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
         if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
-            slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+            slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
             z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
             return self.bn(z, bn, relu=relu, residual=residual, pre=slots)
         return self.bn(self.conv(x, conv.weight, conv.bias, st, pd, dl), bn, relu=relu, residual=residual)
@@ -861,7 +882,7 @@ class Engine:
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
         P = N * Ho * Wo
-        okq = self.L.cdll.fami_conv2d_xbn_ok if self.half else self.L.cdll.fami_conv2d_xbn_ok_f32
+        okq = self.Q.fami_conv2d_xbn_ok if self.half else self.Q.fami_conv2d_xbn_ok_f32
         ok = (self.use_xbn and self.bn2 and self.defer_reduce and bn.training and self.fuse_bn_fwd
               and self.defer_bn is None and bn.running_mean is not None and self.bn_fusable(P, Co)
               and tuple(nxt.weight.shape[1:]) == (Co, 3, 3) and nxt.stride[0] == 1 and nxt.padding[0] == 1
@@ -870,7 +891,7 @@ class Engine:
             if self.abl_bn1 and bn.training and self.fuse_bn_fwd and self.bn_fusable(P, Co):
                 return self._abl_bn1(x, conv, bn, st, pd, dl, Co)
             return self.conv_bn(x, conv, bn, relu=True)
-        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+        slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
         z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
         self._lane_guard(('running statistics', id(bn)))
         mean, invstd = self.empty(Co), self.empty(Co)
@@ -891,7 +912,7 @@ class Engine:
                     gb, _ = self.pgrad(bn.bias)
                 self.acall('fami_bn_bwd2', _p(out.grad), _p(z.data), None, _p(mean), _p(invstd), _p(bn.weight.data),
                            _p(bn.bias.data), _p(gx), _p(gg), _p(gb), None, P, Co, 2, accx, accp, 0,
-                           _p(self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))))
+                           _p(self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))))
             self.record_bwd(bwd, [bn.weight, bn.bias], (z,))
         return out
 
@@ -901,7 +922,7 @@ class Engine:
         """FAMI_ABL_BN1 (WRONG results, timing only): conv -> statistics in its epilogue -> BatchNorm whose apply pass (bit 1:
         a one-workgroup finalize runs instead and the output aliases z) and / or backward apply pass (bit 2: the gradient
         passes through) are skipped."""
-        slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+        slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
         z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
         self._abl_skip = self.abl_bn1
         try:
@@ -934,7 +955,7 @@ class Engine:
                            _p(None if deferred else bn.running_mean), _p(None if deferred else bn.running_var), P, C,
                            int(relu), float(mom), float(bn.eps), _p(pre))
             else:
-                ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if bn2 else self.ws(self.L.cdll.fami_bn_workspace(C))
+                ws = self.zeros_bytes(self.Q.fami_bn_slots_bytes(C)) if bn2 else self.ws(self.Q.fami_bn_workspace(C))
                 self.acall('fami_bn_train_fwd2' if bn2 else 'fami_bn_train_fwd', _p(x.data),
                            _p(None if residual is None else residual.data), _p(y),
                            _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
@@ -991,9 +1012,9 @@ class Engine:
                 elif self.bn2:
                     self.acall('fami_bn_bwd2', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
                                _p(bn.weight.data), _p(bn.bias.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, rmode, accx,
-                               accp, accr, _p(self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C))))
+                               accp, accr, _p(self.zeros_bytes(self.Q.fami_bn_slots_bytes(C))))
                 else:
-                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                    ws = self.ws(self.Q.fami_bn_workspace(C))
                     self.acall('fami_bn_bwd', _p(out.grad), _p(x.data), _p(y), _p(mean), _p(invstd),
                                _p(bn.weight.data), _p(gx), _p(gg), _p(gb), _p(gr), P, C, int(relu), accx, accp, accr,
                                _p(ws))
@@ -1010,7 +1031,7 @@ class Engine:
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
         if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
-            slots = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(Co))
+            slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
             z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
             return self.fuse_term(z, bn, shift, pre=slots)
         return self.fuse_term(self.conv(x, conv.weight, conv.bias, st, pd, dl), bn, shift)
@@ -1031,7 +1052,7 @@ class Engine:
                     self.call('fami_bn_finalize_slots_f32', _p(pre), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
                               _p(bn.running_var), float(mom), float(bn.eps))
                 else:
-                    ws = self.ws(self.L.cdll.fami_bn_workspace(C))
+                    ws = self.ws(self.Q.fami_bn_workspace(C))
                     self.acall('fami_bn_stats', _p(x.data), Pk, C, _p(mean), _p(invstd), _p(bn.running_mean),
                                _p(bn.running_var), float(mom), float(bn.eps), _p(ws))
                 self.bn_trained.append(bn)
@@ -1066,7 +1087,7 @@ class Engine:
                 # large enough for it -- the three-launch form's one-workgroup finalize sat between the two passes of all 53
                 # fuse-term BatchNorms of a step (5 us each); FAMI_FUSE_TERM_BN2=0 restores it
                 two = self.bn2 and self.fuse_term_bn2 and self.bn_fusable(Pk, C)
-                ws = self.zeros_bytes(self.L.cdll.fami_bn_slots_bytes(C)) if two else self.ws(self.L.cdll.fami_bn_workspace(C))
+                ws = self.zeros_bytes(self.Q.fami_bn_slots_bytes(C)) if two else self.ws(self.Q.fami_bn_workspace(C))
                 if shift == 0:
                     if two:
                         self.acall('fami_bn_bwd2', _p(dy), _p(x.data), _p(y), _p(st[0]), _p(st[1]), _p(bn.weight.data),
@@ -1256,7 +1277,7 @@ class Engine:
                     gs, accs = self.gbuf(x)
                 if t.requires_grad:
                     gt, acct = self.gbuf(t)
-                ws = self.ws(self.L.cdll.fami_shift_workspace(B))
+                ws = self.ws(self.Q.fami_shift_workspace(B))
                 self.acall('fami_shift_bilinear_bwd', _p(out.grad), _p(x.data), _p(t.data), _p(gs), _p(gt), B, H,
                            W, C, accs, acct, _p(ws))
             self.record_bwd(bwd, (), (x, t))
@@ -1276,7 +1297,7 @@ class Engine:
                 self.wait_main(ev)
                 self.dcn_fwd_ready = None
         else:
-            n = self.L.cdll.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
+            n = self.Q.fami_dcn_packed_weight_elems(Co, C, kh, kw, G)
             wp = self.empty(n)
             self.acall('fami_dcn_pack_weight', _p(weight.data), _p(wp), Co, C, kh, kw, G)   # 16-bit modes: + the 16-bit image
         y = self.act(B, H, W, Co)
@@ -1298,13 +1319,13 @@ class Engine:
                 CK = C * K
                 wpb = (getattr(self, 'prepacked_dcn_bwd', None) or {}).get(id(weight))     # packed at the start of the step (Trainer)
                 if wpb is None:
-                    nwp = self.L.cdll.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
+                    nwp = self.Q.fami_dcn_packed_weight_bwd_elems(Co, C, kh, kw, G)
                     wpb = self.empty(nwp)
                     self.call('fami_dcn_pack_weight_bwd_f32', _p(weight.data), _p(wpb), Co, C, kh, kw, G)
                 # columns of the modulated-sample matrix: C*K (OIHW order) or the register-fed kernel's own order, padded
                 esz = 2 if self.half else 4
-                colw = self.L.cdll.fami_dcn_bwd_col_width(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic))
-                permuted = bool(self.L.cdll.fami_dcn_bwd_col_permuted(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic)))
+                colw = self.Q.fami_dcn_bwd_col_width(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic))
+                permuted = bool(self.Q.fami_dcn_bwd_col_permuted(C, Co, G, kh, kw, 1, dil, esz, int(self.deterministic)))
                 col = self.act(P, colw) if self.rq(weight) else None
                 gx = gx32 = goff = gmsk = None
                 acco = accx = 0
@@ -1316,7 +1337,7 @@ class Engine:
                 if self.deterministic:
                     if x.requires_grad:
                         gx, accx = self.gbuf(x)
-                    ws = self.ws(self.L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C))
+                    ws = self.ws(self.Q.fami_dcn_bwd_det_workspace(B, H, W, C))
                     if om:
                         self.acall('fami_dcn_bwd_det_om', _p(x.data), _p(off.data), _p(dy), _p(wpb), _p(col), _p(gx), _p(goff),
                                    B, H, W, C, Co, G, kh, kw, 1, pad, dil, acco, accx, _p(ws))
@@ -1351,7 +1372,7 @@ class Engine:
                         self.flush_reduces(self.stream)      # (the deferred slab reduce writes dwp)
                         self.call('fami_dcn_col_dw_unpermute_f32', _p(dwp), _p(g), Co, C, G, kh, kw, 1, dil, esz, acc)
                     gb, accb = self.pgrad(bias)
-                    ws2 = self.ws(self.L.cdll.fami_channel_sum_workspace(Co))
+                    ws2 = self.ws(self.Q.fami_channel_sum_workspace(Co))
                     self.acall('fami_channel_sum', _p(dy), P, Co, _p(gb), accb, _p(ws2))
                     if saved is not None:
                         self.stream = saved

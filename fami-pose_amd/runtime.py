@@ -15,7 +15,7 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, owner, body, n_in, *tensors):
         inputs, params = tensors[:n_in], tensors[n_in:]
         eng = Engine(inputs[0].device, grad_views=getattr(owner, '_grad_views', None), record=True,
-                     dtype=owner.act_dtype, deterministic=owner.deterministic)
+                     dtype=owner.act_dtype, deterministic=owner.deterministic, route=owner.route)
         outs, seeds = body(eng, *inputs)
         owner._advance_bn_counters(eng)
         ctx.eng, ctx.seeds, ctx.params, ctx.n_in = eng, seeds, params, n_in
@@ -54,6 +54,14 @@ class EngineModule(nn.Module):
         return self
 
     deterministic = None           # None: FAMI_DETERMINISTIC decides; True / False: this model's engines
+    route = None                   # kernel-routing state of this model's engines (None: the library's process default)
+
+    def set_route(self, route):
+        """Give this model's engines a routing state of their own (`lib().new_route()`, fields documented in
+        include/fami_route.h): models with different routes run interleaved in one process, each launch dispatched by its own."""
+        self.route = route
+        return self
+
 
     def set_deterministic(self, on=True):
         """Run-to-run reproducible kernels for this model (the DCN input-gradient scatter takes its fixed-point form)."""
@@ -70,7 +78,7 @@ class EngineModule(nn.Module):
         inputs = tuple(t.float().contiguous() for t in inputs)
         params = self._trainable() if torch.is_grad_enabled() else []
         if not params:
-            eng = Engine(inputs[0].device, record=False, dtype=self.act_dtype, deterministic=self.deterministic)
+            eng = Engine(inputs[0].device, record=False, dtype=self.act_dtype, deterministic=self.deterministic, route=self.route)
             outs, _ = body(eng, *inputs)
             self._advance_bn_counters(eng)
             return tuple(outs)

@@ -353,6 +353,7 @@ class Trainer:
                  process_group=None, use_graph=True, targets_from_joints=False, sigma=3, force_ddp=False,
                  loss_scale=None, pck=True, data_parallel=None):
         self.model = model
+        self.route = getattr(model, 'route', None)      # kernel-routing state (None: process default), as the model's engines
         self.targets_from_joints, self.sigma = targets_from_joints, sigma
         self.dev = next(model.parameters()).device
         if self.dev.type != 'cuda':
@@ -401,8 +402,8 @@ class Trainer:
         sfx = {torch.bfloat16: 'bf16', torch.float16: 'f16'}.get(pay)
         self.reducer = BucketReducer(
             self.grad, self.table, bucket_mb * (1 << 20) // 4, self.pg, payload=pay,
-            cast=lambda src, dst: lib().call('fami_cast_add_' + sfx, _p(src), _p(dst), src.numel(), 0, _stream(self.dev)),
-            widen=lambda src, dst: lib().call('fami_widen_' + sfx, _p(src), _p(dst), src.numel(), _stream(self.dev)))
+            cast=lambda src, dst: self._lc('fami_cast_add_' + sfx, _p(src), _p(dst), src.numel(), 0, _stream(self.dev)),
+            widen=lambda src, dst: self._lc('fami_widen_' + sfx, _p(src), _p(dst), src.numel(), _stream(self.dev)))
         self.reducer.world = self.world
         self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype, cats=self.cats)
         # data-parallel launch plan: 'overlap' (default) = hipGraph segments cut at the bucket boundaries with each
@@ -419,6 +420,10 @@ class Trainer:
             model._ensure_nbt(self.dev)      # BatchNorm counters move into their arena BEFORE any snapshot is taken
         if self.ddp:
             self.broadcast_parameters()
+
+    def _lc(self, name, *args):
+        """a library entry point under this trainer's route (weight packs and plans must see what its engines see)"""
+        return lib().call_routed(self.route, name, *args)
 
     # ------------------------------------------------------------------ data parallel
     def broadcast_parameters(self):
@@ -454,6 +459,7 @@ class Trainer:
             from .zoo.alignment_v15 import DeformConv2d
             G = getattr(self.model, 'G', None)
             imgs = []
+            lib().bind(self.route)       # (the image size follows the route's plan of the register-fed backward kernel)
             if G is not None:
                 for m in self.model.modules():
                     if isinstance(m, DeformConv2d):
@@ -472,7 +478,7 @@ class Trainer:
         sets `_adam_done` for the `_opt_step` that must follow.  Direct callers (tools, tests) get a pure gradient computation."""
         model = self.model
         eng = Engine(self.dev, grad_views=self.views, dtype=self.act_dtype,
-                     deterministic=getattr(model, 'deterministic', None))
+                     deterministic=getattr(model, 'deterministic', None), route=self.route)
         self.last_nfused = eng.nfused       # (tools read the counters; not the engine itself: its callbacks point back here, and a
                                             #  Trainer kept alive by that cycle is collected at a random time -- e.g. inside the next capture)
         if on_bucket is not None:
@@ -508,12 +514,12 @@ class Trainer:
             # the DCN layers' FORWARD weight images (three small launches per layer) sat on the head's serial chain too:
             # packed on a side lane at the start of the step, joined before the head
             for w, _, geo, fbuf in dcn:
-                lib().call(pack_fwd_fn, _p(w.data), _p(fbuf), *geo, st)
+                self._lc(pack_fwd_fn, _p(w.data), _p(fbuf), *geo, st)
 
         def pack_bwd(st):
             self.packer.run(st, 1)
             for w, buf, geo, _ in dcn:
-                lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
+                self._lc('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
         if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
             if self.packer.n_early > 0 and os.environ.get('FAMI_PACK_EARLY', '1') != '0':
                 self.packer.run(eng.stream, 'early')
@@ -526,7 +532,7 @@ class Trainer:
             self.packer.run(eng.stream)
             pack_dcn_fwd(eng.stream)
             for w, buf, geo, _ in dcn:
-                lib().call('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, eng.stream)
+                self._lc('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, eng.stream)
             packed_fwd = packed_bwd = None
         eng.prepacked = self.packer.views
         eng.prepacked_dcn_bwd = {id(w): buf for w, buf, _, _ in dcn}
@@ -649,9 +655,9 @@ class Trainer:
         f = 1.0 / ((self.world if self.ddp else 1) * self.loss_scale)
         if self.overflow is not None:
             # static loss scaling (fp16): the same pass also looks for inf / NaN; Adam then skips the step
-            lib().call('fami_unscale_check_f32', _p(self.grad), self.grad.numel(), f, _p(self.overflow), _stream(self.dev))
+            self._lc('fami_unscale_check_f32', _p(self.grad), self.grad.numel(), f, _p(self.overflow), _stream(self.dev))
         elif f != 1.0:
-            lib().call('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), f, 0.0, _stream(self.dev))
+            self._lc('fami_axpby_f32', _p(self.grad), None, _p(self.grad), self.grad.numel(), f, 0.0, _stream(self.dev))
 
     def _eager_step(self, kf_x, sup_x, target, weight):
         if self.ddp:
@@ -761,7 +767,7 @@ class Trainer:
             try:
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], on_bucket=cut)
                 # a (possibly tiny) tail always exists: the stem's gradients complete after the last bucket boundary
-                lib().call('fami_axpby_f32', _p(self.loss_parts), None, _p(self.loss_parts), 7, 1.0, 0.0, _stream(self.dev))
+                self._lc('fami_axpby_f32', _p(self.loss_parts), None, _p(self.loss_parts), 7, 1.0, 0.0, _stream(self.dev))
             finally:
                 cur[0].capture_end()
             plan.append(('graph', cur[0]))

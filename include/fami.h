@@ -29,6 +29,20 @@ extern "C" {
 
 typedef void* fami_stream_t; /* hipStream_t */
 
+/* ---- routing state: which kernel form an entry point dispatches to ---------------------------------------------------
+ * "no global mutable state besides a kernel cache => re-entrant per stream".  Every such switch is a NAMED FIELD
+ * of fami_route_t (fami_route.h documents each: default, meaning, the measurement behind it).  A caller that wants routes of its
+ * own (the Python Engine does) keeps a fami_route_t, initialises it with fami_route_init -- library defaults, f32 arithmetic as
+ * the process default has it -- edits fields, and binds it to its thread with fami_route_bind before enqueueing work; the
+ * binding is thread-local, so engines with different routes interleave in one process and threads do not see each other's.
+ * With nothing bound, entry points use the process default route.  The fami_*_tune* / fami_tune_reset functions further down
+ * are SHIMS kept for tests and benchmarks: they write the corresponding fields of whichever route the calling thread has bound
+ * (or of the process default); the code numbers in their comments are the shim's encoding, not the interface. */
+#include "fami_route.h"
+long fami_route_size(void);                 /* sizeof(fami_route_t) of this build */
+int fami_route_init(fami_route_t* route);   /* library defaults */
+int fami_route_bind(fami_route_t* route);   /* this thread's calls route by *route until rebound; NULL = process default */
+
 const char* fami_version(void);
 const char* fami_last_error(void);
 /* info[0]=CUs, [1]=wavefront, [2]=LDS bytes/workgroup, [3]=clock kHz */
@@ -63,8 +77,8 @@ int fami_conv_tune_xcd(int mode);      /* benchmarks: bit 0 = XCD-contiguous wor
 int fami_conv_tune_stages(int stages); /* benchmarks only: register-pipeline depth 2..4, 0 = default;
                                         * 100 / 101 = linear-address form of the f32 implicit GEMM off / on (default on);
                                         * 110 / 111 = stride-2 input gradient: all taps / the pixel's parity class only (default) */
-/* Every fami_*_tune knob back to its default (tests: autouse fixture).  The knobs are process-wide and only select
- * between kernels that compute the same function. */
+/* Every field of the calling thread's route (bound or process default) back to its default (tests: autouse fixture).  The
+ * fields only select between kernels that compute the same function. */
 int fami_tune_reset(void);
 /* The library's default f32 arithmetic for 3x3 stride-1 convolutions (1 = split products on the bf16 matrix pipe,
  * 0 = exact-f32 MFMA, < 0 = keep) -- stored as the default that fami_tune_reset / fami_conv_tune_lds(-1) restore --

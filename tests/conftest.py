@@ -35,6 +35,7 @@ def _reset_tune_knobs(request):
     if request.node.get_closest_marker('gpu') is not None:
         from fami_pose_amd._lib import loaded, lib
         if loaded():
+            lib().bind(None)              # (a test that bound a route of its own: back to the process default, then reset THAT)
             lib().cdll.fami_tune_reset()
 
 

@@ -1075,3 +1075,63 @@ def test_batched_small_launches_equal_the_single_ones(dev):
     torch.cuda.synchronize(dev)
     for (m, v), (mr, vr) in zip(mods, mods_ref):
         assert torch.equal(m, mr) and torch.equal(v, vr)
+
+
+def test_two_engines_with_different_routes_interleave(dev):
+    """no process-global routing state.  Two engines in one process, each with a fami_route_t of its own
+    (include/fami_route.h) -- A sends the 48-channel 16-bit 3x3 convolution to the band kernel (conv_t4.hip: use_t6 = 0) and the
+    DCN backward to the general kernel (dcn_bwd2 = 0), B keeps the defaults (weight-resident DMA kernel, register-fed DCN backward) --
+    issue launches ALTERNATELY.  Every result must be bitwise what the same engine produces when it runs alone under the
+    process-wide tune shims set to the same values, and the process default route must be untouched."""
+    from fami_pose_amd._lib import lib
+    from fami_pose_amd.engine import Engine, T
+    L = lib()
+    ra, rb = L.new_route(), L.new_route()
+    ra.use_t6, ra.dcn_bwd2 = 0, 0
+    assert rb.use_t6 == 1 and rb.dcn_bwd2 == 1 and ra.size == rb.size > 0
+    torch.manual_seed(21)
+    N, H, W, C, G = 2, 24, 72, 48, 12
+    xc = torch.randn(20, 96, 72, C, device=dev).to(torch.bfloat16)          # (the bench launch: the weight-resident kernel takes it)
+    assert L.cdll.fami_conv_t6_eligible(20, 96, 72, C, C) == 1
+    x = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+    conv = nn.Conv2d(C, C, 3, 1, 1, bias=False).to(dev)
+    off = (torch.randn(N, H, W, 18 * G, device=dev)).to(torch.bfloat16)
+    msk = torch.randn(N, H, W, 9 * G, device=dev).to(torch.bfloat16)
+    wd, bd = nn.Parameter(torch.randn(C, C, 3, 3, device=dev) * 0.1), nn.Parameter(torch.zeros(C, device=dev))
+    gy = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+
+    def run(engines):
+        """one conv forward + one DCN forward / backward per engine, launches of the engines interleaved"""
+        outs = [dict() for _ in engines]
+        ts = []
+        for e, o in zip(engines, outs):
+            o['y'] = e.conv(T(xc), conv.weight, None, 1, 1, 1).data
+        for e, o in zip(engines, outs):
+            xt, ot, mt = T(x, True), T(off, True), T(msk, True)
+            yt = e.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+            yt.grad = gy
+            ts.append((xt, ot, mt))
+        for e, o, (xt, ot, mt) in zip(engines, outs, ts):
+            e.backward()
+            o['goff'], o['gmsk'], o['dw'] = ot.grad, mt.grad, e.param_grads[id(wd)].clone()
+        torch.cuda.synchronize(dev)
+        return outs
+
+    mk = lambda r: Engine(dev, dtype=torch.bfloat16, route=r, deterministic=False)
+    oa, ob = run([mk(ra), mk(rb)])
+    # references: one engine at a time on the process default route, set through the shims
+    L.bind(None)
+    L.cdll.fami_conv_tune_lds(8000)
+    L.cdll.fami_dcn_tune(2048)
+    try:
+        (ra_ref,) = run([mk(None)])
+    finally:
+        L.cdll.fami_tune_reset()
+    (rb_ref,) = run([mk(None)])
+    for k in ('y', 'goff', 'gmsk'):
+        assert torch.equal(oa[k], ra_ref[k]) and torch.equal(ob[k], rb_ref[k]), k
+    assert not torch.equal(oa['y'], ob['y'])                    # the two routes really are different kernels (other summation order)
+    assert (oa['y'].float() - ob['y'].float()).abs().max().item() < 0.1
+    assert relerr(oa['dw'], ob['dw']) < 2e-2
+    fresh = L.new_route()
+    assert fresh.use_t6 == 1 and fresh.dcn_bwd2 == 1           # nobody wrote the defaults
