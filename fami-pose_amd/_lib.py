@@ -8,6 +8,7 @@ import ctypes
 import os
 import re
 
+from . import options
 import torch  # loads torch's HIP runtime first; libfami_hip.so binds to the same libamdhip64 (soname match)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -78,28 +79,28 @@ class _Lib:
         # (v_mfma_f32_16x16x4_f32) instead of the split-product kernels on the bf16 matrix pipe (conv_t4.hip S3,
         # conv_wgs3.hip; same accuracy class)
         # stored as the library's default state: fami_tune_reset / fami_conv_tune_lds(-1) restore it
-        self.cdll.fami_tune_defaults(0 if os.environ.get('FAMI_F32_SPLIT', '1') == '0' else 1)
-        if os.environ.get('FAMI_T5', '1') == '0':      # A/B: the round-3 band kernel instead of the persistent one (conv_t5.hip)
+        self.cdll.fami_tune_defaults(1 if options.flag('FAMI_F32_SPLIT') else 0)
+        if not options.flag('FAMI_T5'):      # A/B: the round-3 band kernel instead of the persistent one (conv_t5.hip)
             self.cdll.fami_conv_tune_lds(7000)
         for env, base in (('FAMI_WG16_TARGET', 21000), ('FAMI_WGS3_TARGET', 31000)):     # A/B: workgroup target of the weight-gradient kernels
-            if os.environ.get(env):
-                self.cdll.fami_conv_tune_wgrad_lds(base + int(os.environ[env]))
+            if options.get(env):
+                self.cdll.fami_conv_tune_wgrad_lds(base + options.number(env))
         # The two ablation switches below compute WRONG results on purpose (upper-bound experiments of tools/): they are refused
         # unless FAMI_ALLOW_WRONG=1 says the caller knows, so a variable left over in a job environment cannot silently corrupt a
         # training run.
-        wrong = [v for v in ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_BN1') if os.environ.get(v, '0') not in ('', '0')]
-        if wrong and os.environ.get('FAMI_ALLOW_WRONG') != '1':
+        wrong = [v for v in options.WRONG if options.flag(v)]
+        if wrong and options.get('FAMI_ALLOW_WRONG') != '1':
             raise FamiError('%s set: these switches skip work and produce WRONG gradients (measurement ablations only); '
                             'set FAMI_ALLOW_WRONG=1 to run them on purpose' % ', '.join(wrong))
         if wrong:
             import sys
             print('[fami] WARNING: %s active -- results are WRONG by design (ablation run)' % ', '.join(wrong), file=sys.stderr, flush=True)
-        if os.environ.get('FAMI_T5_ABL'):              # upper-bound experiment (WRONG results): only n chunks per convolution
+        if options.get('FAMI_T5_ABL'):              # upper-bound experiment (WRONG results): only n chunks per convolution
             self.cdll.fami_conv_tune_lds(7600)
             self.cdll.fami_conv_tune_lds(7401)
-            self.cdll.fami_conv_tune_lds(7700 + int(os.environ['FAMI_T5_ABL']))
-        if os.environ.get('FAMI_T5_WG'):               # A/B: workgroups of the persistent grid / 8 (99: one job per workgroup)
-            self.cdll.fami_conv_tune_lds(7500 + int(os.environ['FAMI_T5_WG']))
+            self.cdll.fami_conv_tune_lds(7700 + options.number('FAMI_T5_ABL'))
+        if options.get('FAMI_T5_WG'):               # A/B: workgroups of the persistent grid / 8 (99: one job per workgroup)
+            self.cdll.fami_conv_tune_lds(7500 + options.number('FAMI_T5_WG'))
 
     def new_route(self):
         """-> a fami_route_t with the library defaults (include/fami_route.h): the kernel-routing state an Engine owns."""

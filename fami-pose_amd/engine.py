@@ -14,10 +14,10 @@ write fp32 in either mode; parameters, BatchNorm statistics, weight gradients, t
 dense layers ([M,K] tensors) and everything at the NCHW boundary are always fp32.
 """
 import ctypes
-import os
 
 import torch
 
+from . import options
 from ._lib import lib
 
 BN_EPS = 1e-5
@@ -27,7 +27,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-_ABL_WGRAD = os.environ.get('FAMI_ABL_WGRAD', '0') != '0'
+_ABL_WGRAD = options.flag('FAMI_ABL_WGRAD', '0')
 # Upper-bound experiments for "BatchNorm apply inside the consumer" (WRONG results, refused by _lib unless
 # FAMI_ALLOW_WRONG=1 when present at load; read per Engine): FAMI_ABL_BN1 bit 1 = the apply pass of every conv1 -> bn1 -> ReLU -> conv2 edge is skipped (conv2 reads z),
 # bit 2 = the backward apply pass of the same BatchNorms is skipped (the gradient passes through unchanged).  What the step would
@@ -135,7 +135,7 @@ class Engine:
         # deterministic: every kernel of the step is run-to-run reproducible.  The one order-dependent reduction of the
         # path is the DCN input-gradient scatter (float atomics); this flag routes it through the 64-bit fixed-point
         # form (fami_dcn_bwd_det_*).  Default from FAMI_DETERMINISTIC (0).
-        self.deterministic = (os.environ.get('FAMI_DETERMINISTIC', '0') != '0') if deterministic is None else bool(deterministic)
+        self.deterministic = (options.flag('FAMI_DETERMINISTIC', '0')) if deterministic is None else bool(deterministic)
         self.L = lib()
         self.Q = _RoutedQueries(self.L, self)
         self.record = record           # False: forward only (no tape, no gradient flags)
@@ -148,7 +148,7 @@ class Engine:
         self.bn_trained = []           # BatchNorm modules that consumed a training batch this forward
         self.prepacked = None          # optional {(id(param), mode): packed weight image} filled by the Trainer
         # stream lanes: independent sub-graphs (the parallel HRNet branches) run on side streams between fork()/join()
-        self.use_lanes = os.environ.get('FAMI_LANES', '1') != '0'
+        self.use_lanes = options.flag('FAMI_LANES', '1')
         self.lane = 0
         self._main = None              # torch stream object of lane 0
         self._side = []                # torch side streams (lanes 1..)
@@ -162,38 +162,38 @@ class Engine:
         # weight-gradient lane (opt-in, FAMI_WGRAD_LANE=1): conv wgrad kernels are leaves of the backward graph, so they
         # can run on their own stream beside the dgrad -> BN chain.  Measured on MI355X: no gain (f32 75.5 vs 75.5 ms,
         # bf16 45.9 vs 44.6 ms per step) -- every kernel already fills the chip -- hence off by default.
-        self.regressor_lanes = os.environ.get('FAMI_REGRESSOR_LANES', '1') != '0'   # shared-weight regressors on lanes
-        self.mi_lanes = self.use_lanes and os.environ.get('FAMI_MI_LANES', '1') != '0'   # the six MI terms of the loss on three lanes
-        self.fuse_lanes = os.environ.get('FAMI_FUSE_LANES', '1') != '0'   # fuse terms on the lane of their source branch
+        self.regressor_lanes = options.flag('FAMI_REGRESSOR_LANES', '1')   # shared-weight regressors on lanes
+        self.mi_lanes = self.use_lanes and options.flag('FAMI_MI_LANES', '1')   # the six MI terms of the loss on three lanes
+        self.fuse_lanes = options.flag('FAMI_FUSE_LANES', '1')   # fuse terms on the lane of their source branch
         # lanes stay forked across the modules of an HRNet stage (modules.HRNetBody.run): a module's fuse sum i runs on lane i behind
         # events of the other lanes instead of on lane 0 behind a join.  The Trainer switches it off when gradient buckets are
         # all-reduced during backward (their hooks fire between forked regions).
-        self.persist_lanes = os.environ.get('FAMI_PERSIST_LANES', '1') != '0'
-        self.use_wlane = self.use_lanes and os.environ.get('FAMI_WGRAD_LANE', '0') != '0'
+        self.persist_lanes = options.flag('FAMI_PERSIST_LANES', '1')
+        self.use_wlane = self.use_lanes and options.flag('FAMI_WGRAD_LANE', '0')
         self._wstream = None
         self._wstream2 = None      # second weight-gradient stream (wlane_pair scopes: the stem / layer1 / transition stretch)
         self._wflip = False
         self.wlane_pair = False
-        self.stem_wlanes = int(os.environ.get('FAMI_STEM_WGRAD_LANES', '1'))      # 2: measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38): the stretch is bandwidth-contended, not lane-bound
+        self.stem_wlanes = options.number('FAMI_STEM_WGRAD_LANES', '1')      # 2: measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38): the stretch is bandwidth-contended, not lane-bound
         self._wdirty = False
         # ... but for the HEAD it pays (FAMI_HEAD_WGRAD_LANE, default 1): between the first DCN forward and the last DCN backward
         # the step is one serial chain of kernels (rocprof trace: 3.5 ms with exactly one kernel in flight), and the weight
         # gradients in it are leaves.  A model body brackets that part with wlane_scope = True.
-        self.head_wlane = self.use_lanes and os.environ.get('FAMI_HEAD_WGRAD_LANE', '1') != '0'
+        self.head_wlane = self.use_lanes and options.flag('FAMI_HEAD_WGRAD_LANE', '1')
         self.wlane_scope = False
         # the same for the backbone's serial head and tail: stem, layer1 and the transitions run before the branches fork
         # (their backward after the branches have joined), FAMI_STEM_WGRAD_LANE
         # round 3: measured neutral (f32 49.1 -> 49.3, bf16 26.6 -> 26.5 ms).  Round 4, interleaved graph replays on one box
         # (tools/ab_env.py): f32 equal on two boxes (46.39 / 46.15, 47.96 / 48.04); bf16 with the 128-workgroup weight gradients
         # 25.50 -> 25.10 ms: on in the 16-bit modes
-        self.stem_wlane = os.environ.get('FAMI_STEM_WGRAD_LANE', '1' if self.half else '0') != '0'
+        self.stem_wlane = options.flag('FAMI_STEM_WGRAD_LANE', '1' if self.half else '0')
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:
                                        # the caching allocator must not recycle a block across lanes within a step
         # two-launch BatchNorm (fami_bn_train_fwd2 / fami_bn_bwd2: fp64 slot atomics, finalize folded into the apply pass).
         # Sums arrive in atomic order, so the deterministic mode keeps the three-launch forms.
-        self.bn2 = (not self.deterministic) and os.environ.get('FAMI_BN2', '1') != '0'
+        self.bn2 = (not self.deterministic) and options.flag('FAMI_BN2', '1')
         # BatchNorm statistics folded into the neighbouring convolutions' epilogues (conv.hip EpiBN): the forward
         # statistics into the producing convolution, the backward statistics into the input-gradient convolution that
         # makes the last contribution to the BatchNorm output's gradient.  FAMI_FUSE_BN = 0 | fwd | bwd | 1 (both).
@@ -208,17 +208,17 @@ class Engine:
         # (conv_t6.hip) takes the input gradient -- it requests the BatchNorm input a unit ahead and reads the channel
         # constants from LDS, +1.7 us on a 14.5 us launch against 5.7 us saved on the BatchNorm backward
         # (tools/bench_epi2.py); on the other kernels the epilogue still costs more than the pass it removes.
-        fz = os.environ.get('FAMI_FUSE_BN', 'auto')
+        fz = options.get('FAMI_FUSE_BN', 'auto')
         self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto')
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.fuse_bn_bwd_auto = self.bn2 and self.half and fz == 'auto'
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
-        self.fuse_bn_bwd_t7 = int(os.environ.get('FAMI_FUSE_BN_T7', '1'))
-        self.concat_one = os.environ.get('FAMI_CONCAT_ONE', '1') != '0'      # Engine.concat: one launch for up to four sources
+        self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '1')
+        self.concat_one = options.flag('FAMI_CONCAT_ONE', '1')      # Engine.concat: one launch for up to four sources
         # the two predictor convolutions of a DCN layer as one (CatParam; needs the Trainer's arena layout): FAMI_MERGE_PREDICTORS
-        self.merge_predictors = os.environ.get('FAMI_MERGE_PREDICTORS', '1') != '0'
-        self.fuse_term_bn2 = os.environ.get('FAMI_FUSE_TERM_BN2', '1') != '0'
+        self.merge_predictors = options.flag('FAMI_MERGE_PREDICTORS', '1')
+        self.fuse_term_bn2 = options.flag('FAMI_FUSE_TERM_BN2', '1')
         # BatchNorm + ReLU applied by the CONSUMER convolution while it stages its input (Engine.conv_bn_relu_into, conv_epi.h
         # XBN): 104 launches and one tensor write + read per BasicBlock less.  FAMI_XBN = 0 | 1; default: on in f32 storage,
         # off in the 16-bit modes.  Measured on MI355X (interleaved A/B of the step, both orders, 10 rounds): f32 50.95 ->
@@ -228,23 +228,23 @@ class Engine:
         # Late round 4: off again in the 16-bit modes -- the DMA-staged kernels (conv_t6.hip, conv_wgrad6_kernel) copy their operands
         # global -> LDS without passing registers, so they take a materialised input; with every weight gradient on them the
         # bf16 step is 23.23 -> 22.64 ms (tools/ab_env.py, one box) against the consumer-side transform on the band kernels.
-        self.use_xbn = os.environ.get('FAMI_XBN', '0' if self.half else '1') != '0'
+        self.use_xbn = options.flag('FAMI_XBN', '0' if self.half else '1')
         # Tried in round 4: backward fusion only on the SERIAL stretches of the step (stem, layer1: one lane, nothing beside it --
         # 3.6 ms of the f32 backward pass), `serial_scope` set by HRNetBody.run.  Interleaved bench runs on one box: f32 48.16
         # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  FAMI_SERIAL_FUSE=1
         # keeps it available.
         self.serial_scope = False
-        self.serial_fuse = os.environ.get('FAMI_SERIAL_FUSE', '0') != '0'
+        self.serial_fuse = options.flag('FAMI_SERIAL_FUSE', '0')
         self.nfused = {'fwd': 0, 'bwd': 0, 'xbn': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched
         # 16 at a time per stream (fami_wgrad_reduce_batch) at the joins / bucket boundaries / the end of backward --
         # 303 tiny launches per step otherwise sit between every weight gradient and the next kernel of its lane
-        self.defer_reduce = os.environ.get('FAMI_DEFER_REDUCE', '1') != '0'
+        self.defer_reduce = options.flag('FAMI_DEFER_REDUCE', '1')
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
         self._red_longs = self.Q.fami_wgrad_reduce_desc_longs()
-        self.abl_bn1 = int(os.environ.get('FAMI_ABL_BN1', '0'))      # upper-bound experiment, see the comment at the top of the file
+        self.abl_bn1 = options.number('FAMI_ABL_BN1', '0')      # upper-bound experiment, see the comment at the top of the file
         self.sync_stream()
         self._zero_begin()
 
@@ -279,7 +279,7 @@ class Engine:
         if len(side) < n - 1:
             raise RuntimeError('could not obtain %d distinct side streams' % (n - 1))
         self._side = side
-        if os.environ.get('FAMI_DEBUG_STREAMS'):
+        if options.flag('FAMI_DEBUG_STREAMS'):
             print('[fami] lanes: main %#x side %s capturing %s' % (main, [hex(t.cuda_stream) for t in side[:n - 1]],
                                                                   torch.cuda.is_current_stream_capturing()), flush=True)
         return side

@@ -10,9 +10,9 @@ Reference: posetimation/layers/basic_model.py:25-63 (BasicBlock), :66-113
 (conv_bn_relu); posetimation/backbones/hrnet.py:17-172 (HighResolutionModule),
 :186-332 (HRNet), :521-690 (HRNetPlus).
 """
-import os
-
 import torch.nn as nn
+
+from . import options
 
 BN_MOMENTUM = 0.1
 
@@ -182,7 +182,7 @@ class HighResolutionModule(nn.Module):
         join / fork pair between the two halves (a lane join costs the chip an idle gap on every lane but the slowest).
         -> (branch outputs, fused outputs)"""
         nb = self.num_branches
-        if nb == 1 or not eng.fuse_lanes or os.environ.get('FAMI_MERGE_FORK', '1') == '0':
+        if nb == 1 or not eng.fuse_lanes or not options.flag('FAMI_MERGE_FORK'):
             ys = self.run_branches(eng, xs)
             return ys, self.run_fuse(eng, ys)
         forked = eng.fork(nb)

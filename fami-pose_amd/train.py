@@ -19,11 +19,10 @@ zero_grad / backward / Adam step) -- the reference loop itself is not importable
   With world_size > 1 the backward is cut into one graph per bucket so the
   collectives run between graph launches on RCCL's stream.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
+from . import options
 from ._lib import lib
 from .engine import Engine, _p
 
@@ -251,7 +250,7 @@ class BucketReducer:
         self.bucket_elems = max(1, int(bucket_elems))
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.algo = (algo or os.environ.get('FAMI_DDP_ALGO') or 'ring').lower()
+        self.algo = (algo or options.get('FAMI_DDP_ALGO')).lower()
         if self.algo not in ('ring', 'mesh'):
             raise ValueError("FAMI_DDP_ALGO must be 'ring' or 'mesh', not %r" % self.algo)
         self._shards = {}        # (lo, hi) -> this rank's 1/world of the slice (mesh plan; persistent: graph-plan replays reuse it)
@@ -394,7 +393,7 @@ class Trainer:
         # (nn.DataParallel, trainer.py:57-58) and so does the default here in every compute mode: a 16-bit wire format
         # halves the bytes (129 MB instead of 258.6 MB per step for W48) but sums over ranks with 8 / 11 significand bits,
         # and no multi-GPU convergence run has validated that yet -- opt in with FAMI_DDP_PAYLOAD.
-        self.payload_name = os.environ.get('FAMI_DDP_PAYLOAD') or 'f32'
+        self.payload_name = options.get('FAMI_DDP_PAYLOAD')
         pay = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[self.payload_name]
         if pay == torch.float16 and self.overflow is None:
             # without the loss-scale guard an fp16 sum that overflows on the wire would reach Adam as inf
@@ -410,8 +409,8 @@ class Trainer:
         # bucket's all-reduce issued between two segment replays (graph replay AND overlap with the rest of backward);
         # 'serial' = one graph for forward + backward, then every all-reduce; FAMI_DDP_GRAPH=0 = no graphs at all
         # (eager launches, all-reduces fired from the Engine.backward hooks)
-        self.ddp_plan = os.environ.get('FAMI_DDP_PLAN', 'overlap')
-        self.use_graph = use_graph and (not self.ddp or os.environ.get('FAMI_DDP_GRAPH', '1') != '0')
+        self.ddp_plan = options.get('FAMI_DDP_PLAN')
+        self.use_graph = use_graph and (not self.ddp or options.flag('FAMI_DDP_GRAPH'))
         self.loss_parts = torch.zeros(7, device=self.dev)     # mse, mi_1..6 (device scalars of the last step)
         self.pck = pck
         self.acc = None           # [2, J+3] device floats of the last step: PCK of final_hm / kf_bb_hm (see accuracy())
@@ -520,8 +519,8 @@ class Trainer:
             self.packer.run(st, 1)
             for w, buf, geo, _ in dcn:
                 self._lc('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
-        if eng.use_lanes and os.environ.get('FAMI_PACK_SPLIT', '1') != '0':
-            if self.packer.n_early > 0 and os.environ.get('FAMI_PACK_EARLY', '1') != '0':
+        if eng.use_lanes and options.flag('FAMI_PACK_SPLIT'):
+            if self.packer.n_early > 0 and options.flag('FAMI_PACK_EARLY'):
                 self.packer.run(eng.stream, 'early')
                 eng.late_weights_ready = eng.side_launch(lambda st: self.packer.run(st, 'late'))   # HRNetBody.run waits before stage 3
             else:
@@ -631,7 +630,7 @@ class Trainer:
         it), so its Adam update can run on a side lane beside the rest of the backward pass instead of behind it (the one-launch
         Adam is 0.33 ms of pure HBM traffic at the end of every step).  None: no such split (FAMI_EARLY_ADAM=0, fp16's checked step,
         data-parallel plans, a frozen backbone)."""
-        if os.environ.get('FAMI_EARLY_ADAM', '1') == '0' or self.loss_scale != 1.0:
+        if not options.flag('FAMI_EARLY_ADAM') or self.loss_scale != 1.0:
             return None
         hr = getattr(model, 'hrnet', None)
         if hr is None or not hasattr(hr, 'stage2') or not hasattr(hr, 'conv1'):

@@ -188,3 +188,28 @@ def test_input_pipeline_host_logic_matches_reference_golden():
             assert (v2[j] == 0).all() if outside else np.array_equal(v2[j], g['vis'][b, j])
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         D.crop_clip(torch.zeros(2, 8, 8, 3, dtype=torch.uint8), [4, 4], [0.1, 0.1], 0, (8, 8))
+
+
+def test_every_environment_switch_goes_through_the_one_parser():
+    """The host layer reads FAMI_* switches only through fami_pose_amd/options.py, whose table is the complete list (name,
+    default, meaning); kernel-routing state is not environment at all but the fami_route_t struct (include/fami_route.h)."""
+    import glob
+    import re
+    from fami_pose_amd import options
+    from fami_pose_amd._lib import Route
+    pkg = os.path.dirname(os.path.abspath(options.__file__))
+    used = set()
+    for f in glob.glob(os.path.join(pkg, '**', '*.py'), recursive=True):
+        src = open(f).read()
+        if not f.endswith('options.py'):
+            assert not re.search(r"os\.environ[^\n]*FAMI_", src), f          # no direct read anywhere else
+        used |= set(re.findall(r"options\.(?:get|flag|number)\('(FAMI_[A-Z0-9_]+)'", src))
+    assert used and used <= set(options.SWITCHES), sorted(used - set(options.SWITCHES))
+    with pytest.raises(KeyError):
+        options.get('FAMI_NOT_A_SWITCH')
+    assert options.flag('FAMI_LANES') and not options.flag('FAMI_WGRAD_LANE')
+    # the route struct mirrors the header: ints / longs only, first field its own size
+    names = [n for n, _ in Route._fields_]
+    assert names[0] == 'size' and len(names) > 60 and {'use_t6', 'dcn_bwd2', 'wg6_target', 'bn_small_elems'} <= set(names)
+    hdr = open(os.path.join(os.path.dirname(pkg), 'include', 'fami_route.h')).read()
+    assert all(re.search(r'\b%s;' % n, hdr) for n in names)
