@@ -1425,7 +1425,10 @@ __device__ __forceinline__ void dcn2_add64(long long* a, float v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)(long long)dcn2_rint(v));
 }
 
-template <typename T, int NCO, bool FIX32>
+// STG: the offset / mask gradients of a wave's 16 pixels are collected in a wave-private LDS buffer and written with consecutive
+// lanes on consecutive elements at the end (PMC: one 8- / 4-byte store per lane and item was 218 MB of write requests per f32
+// launch against 90 MB of algorithmic writes -- every partial store its own 32-byte sector); costs 13.8 KB of LDS per workgroup
+template <typename T, int NCO, bool FIX32, bool STG>
 __global__ __launch_bounds__(256, 3) void dcn_bwd2_kernel(DcnBwd2Args<T> p) {
   constexpr bool HALF = sizeof(T) == 2;
   constexpr int FIXB = FIX32 ? 20 : 30;            // bits of one contribution at the bound (see dcn_bwd_kernel)
@@ -1441,6 +1444,8 @@ __global__ __launch_bounds__(256, 3) void dcn_bwd2_kernel(DcnBwd2Args<T> p) {
   char* after = smem2 + (((size_t)rcells * (FIX32 ? 4 : 8) + 15) & ~(size_t)15);
   int4* tapt = reinterpret_cast<int4*>(after);                                  // [NQ * 4]
   float* wmax = reinterpret_cast<float*>(after + (size_t)p.NQ * 4 * sizeof(int4));   // [4]
+  const int grun = 3 * nli;                                                          // staged gradient elements per pixel: 2 nli offsets | nli masks
+  T* gst = reinterpret_cast<T*>(after + (size_t)p.NQ * 4 * sizeof(int4) + 16) + (STG ? wave * 16 * grun : 0);   // [16 px][grun]
   int t, chunk;
   xcd_tile(1, t, chunk);      // neighbouring tiles and all chunks of a tile on one XCD
   const int tx = t % p.tilesX;
@@ -1589,7 +1594,13 @@ __global__ __launch_bounds__(256, 3) void dcn_bwd2_kernel(DcnBwd2Args<T> p) {
       gpy += gv[c] * dpy[c];
       gpx += gv[c] * dpx[c];
     }
-    if (iv) {
+    if (STG) {
+      if (li < nli) {                                  // (pixels outside the map stage zeros that are never written out)
+        const int gtl = tc.w - chunk * nli;            // (group, tap) index within the chunk: the memory order of the run
+        st2(gst + px * grun + gtl * 2, f32x2{gpy, gpx});
+        st1(gst + px * grun + 2 * nli + gtl, gm);
+      }
+    } else if (iv) {
       if (goffp) {
         T* qo = goffp + tc.w * 2;
         f32x2 go = {gpy, gpx};
@@ -1635,6 +1646,33 @@ __global__ __launch_bounds__(256, 3) void dcn_bwd2_kernel(DcnBwd2Args<T> p) {
           if (yv1 && xv0) unsafeAtomicAdd(g00 + o00 + (long)p.W * p.C + c, gv[c] * w10);
           if (yv1 && xv1) unsafeAtomicAdd(g00 + o00 + (long)p.W * p.C + p.C + c, gv[c] * w11);
         }
+      }
+    }
+  }
+  if (STG && (p.goff || p.gmsk)) {
+    // ---- the wave's staged offset / mask gradients -> goff / gmsk: lane l takes element l, l + 64, ... of the 16 runs
+    // (the wave wrote them itself: no barrier, only the LDS counter)
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    const int tyw = ty * 8 + 2 * wave;
+    const float rrun2 = 1.f / (float)(2 * nli), rrun1 = 1.f / (float)nli;
+    if (p.goff) {
+      for (int e = lane; e < 16 * 2 * nli; e += 64) {
+        const int q16 = (int)(((float)e + 0.5f) * rrun2), i = e - q16 * 2 * nli;
+        const int oyq = tyw + (q16 >> 3), oxq = tx * 8 + (q16 & 7);
+        if (oyq >= p.Ho || oxq >= p.Wo) continue;
+        T* dst = p.goff + (((long)b * p.Ho + oyq) * p.Wo + oxq) * p.ostr + chunk * 2 * nli + i;
+        const float v = ld1(gst + q16 * grun + i);
+        st1(dst, p.acc_off ? ld1(dst) + v : v);
+      }
+    }
+    if (p.gmsk) {
+      for (int e = lane; e < 16 * nli; e += 64) {
+        const int q16 = (int)(((float)e + 0.5f) * rrun1), i = e - q16 * nli;
+        const int oyq = tyw + (q16 >> 3), oxq = tx * 8 + (q16 & 7);
+        if (oyq >= p.Ho || oxq >= p.Wo) continue;
+        T* dst = p.gmsk + (((long)b * p.Ho + oyq) * p.Wo + oxq) * p.mstr + chunk * nli + i;
+        const float v = ld1(gst + q16 * grun + 2 * nli + i);
+        st1(dst, p.acc_off ? ld1(dst) + v : v);
       }
     }
   }
@@ -1873,7 +1911,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
 static inline bool dcn_bwd2_on(int esz) {
   return g_dcn_bwd2 && g_dcn_bwd_scatter != 0 && !(esz == 2 && g_dcn_bwd_scatter == 2) && !g_dcn_bwd_abl;
 }
-struct DcnBwd2Plan { int ok, GC, nchunk, NQ, colw, NJ, RH, RW, CS; size_t lds; };
+struct DcnBwd2Plan { int ok, GC, nchunk, NQ, colw, NJ, RH, RW, CS, stg; size_t lds; };
 static DcnBwd2Plan dcn_bwd2_plan(int C, int Co, int G, int kh, int kw, int stride, int dil, int esz) {
   DcnBwd2Plan q;
   q.ok = 0; q.colw = C * kh * kw;
@@ -1900,7 +1938,9 @@ static DcnBwd2Plan dcn_bwd2_plan(int C, int Co, int G, int kh, int kw, int strid
   q.colw = q.nchunk * q.NQ * 16;
   q.NJ = esz == 4 ? Co / 16 : (Co + 31) / 32;
   q.CS = q.GC * 4 + 1;
-  q.lds = (((size_t)q.RH * q.RW * q.CS * (esz == 4 ? 8 : 4) + 15) & ~(size_t)15) + (size_t)q.NQ * 4 * 16 + 16;
+  q.stg = g_dcn_bwd2_stage;
+  q.lds = (((size_t)q.RH * q.RW * q.CS * (esz == 4 ? 8 : 4) + 15) & ~(size_t)15) + (size_t)q.NQ * 4 * 16 + 16 +
+          (q.stg ? (size_t)4 * 16 * 3 * q.GC * K * esz : 0);
   q.ok = q.lds <= 64 * 1024;     // (a larger dilation than the head's: the general kernel)
   if (!q.ok) q.colw = C * kh * kw;
   return q;
@@ -1912,15 +1952,20 @@ static inline long dcn_bwd_old_image_elems(int Co, int C, int kh, int kw) {
 static inline long dcn_bwd2_image_elems(const DcnBwd2Plan& q, int esz) {
   return q.ok ? (long)q.nchunk * q.NQ * q.NJ * (esz == 4 ? 256 : 512) : 0;
 }
-template <typename T, int NCO>
-static void dcn_bwd2_launch(const DcnBwd2Args<T>& a, dim3 grid, size_t lds, hipStream_t s) {
+template <typename T, int NCO, bool STG>
+static void dcn_bwd2_launch1(const DcnBwd2Args<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   constexpr bool F32 = sizeof(T) == 2;       // 16-bit storage: 32-bit fixed-point region
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dcn_bwd2_kernel<T, NCO, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd2_kernel<T, NCO, F32, STG>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_bwd2_kernel<T, NCO, F32>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dcn_bwd2_kernel<T, NCO, F32, STG>), grid, dim3(256), lds, s, a);
+}
+template <typename T, int NCO>
+static void dcn_bwd2_launch(const DcnBwd2Args<T>& a, dim3 grid, size_t lds, hipStream_t s, int stg) {
+  if (stg) dcn_bwd2_launch1<T, NCO, true>(a, grid, lds, s);
+  else dcn_bwd2_launch1<T, NCO, false>(a, grid, lds, s);
 }
 
 static int dcn_bwd_chunk_groups(int G, int cg, int K) {
@@ -1988,12 +2033,12 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
       n.tilesX = fami_cdiv(a.Wo, 8); n.tilesY = fami_cdiv(a.Ho, 8); n.RH = q.RH; n.RW = q.RW; n.CS = q.CS;
       const dim3 grid(n.tilesX * n.tilesY * B, q.nchunk);
       switch (Co / 16) {
-        case 1: dcn_bwd2_launch<T, 1>(n, grid, q.lds, s); break;
-        case 2: dcn_bwd2_launch<T, 2>(n, grid, q.lds, s); break;
-        case 3: dcn_bwd2_launch<T, 3>(n, grid, q.lds, s); break;
-        case 4: dcn_bwd2_launch<T, 4>(n, grid, q.lds, s); break;
-        case 5: dcn_bwd2_launch<T, 5>(n, grid, q.lds, s); break;
-        default: dcn_bwd2_launch<T, 6>(n, grid, q.lds, s); break;
+        case 1: dcn_bwd2_launch<T, 1>(n, grid, q.lds, s, q.stg); break;
+        case 2: dcn_bwd2_launch<T, 2>(n, grid, q.lds, s, q.stg); break;
+        case 3: dcn_bwd2_launch<T, 3>(n, grid, q.lds, s, q.stg); break;
+        case 4: dcn_bwd2_launch<T, 4>(n, grid, q.lds, s, q.stg); break;
+        case 5: dcn_bwd2_launch<T, 5>(n, grid, q.lds, s, q.stg); break;
+        default: dcn_bwd2_launch<T, 6>(n, grid, q.lds, s, q.stg); break;
       }
       FAMI_CHECK_LAUNCH(nm);
       return FAMI_OK;
@@ -2111,10 +2156,11 @@ int fami_dcn_pack_weight_f16(const float* w_oihw, float* wp, int Co, int C, int 
 // 16 + 2 / 16 + 0 = the (2 k groups in flight, 4 waves per SIMD) build of the direct kernel / the default build
 int fami_dcn_tune(int gather) {
   if (gather < 0) {   // every DCN knob back to its default
-    g_dcn_bwd_abl = 0; g_dcn_bwd_scatter = -1; g_dcn_ksplit = 1; g_dcn_abl = 0; g_dcn_win_r = 0; g_dcn_pf = 0; g_dcn_gather = -1; g_dcn_bwd2 = 1; g_dcn_bwd2_cap = 36;
+    g_dcn_bwd_abl = 0; g_dcn_bwd_scatter = -1; g_dcn_ksplit = 1; g_dcn_abl = 0; g_dcn_win_r = 0; g_dcn_pf = 0; g_dcn_gather = -1; g_dcn_bwd2 = 1; g_dcn_bwd2_cap = 36; g_dcn_bwd2_stage = 1;
     return FAMI_OK;
   }
-  if (gather >= 4096) g_dcn_bwd2_cap = gather - 4096;
+  if (gather >= 8192) g_dcn_bwd2_stage = gather - 8192;
+  else if (gather >= 4096) g_dcn_bwd2_cap = gather - 4096;
   else if (gather >= 2048) g_dcn_bwd2 = gather - 2048;
   else if (gather >= 1024) g_dcn_bwd_abl = gather - 1024;
   else if (gather >= 512) g_dcn_bwd_scatter = gather - 512;

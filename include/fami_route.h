@@ -21,6 +21,7 @@ typedef struct fami_route_t {
   int  dcn_pf;                /* default 0.  fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks) */
   int  dcn_bwd2;              /* default 1.  fami_dcn_tune(2048 / 2049): off / on */
   int  dcn_bwd2_cap;          /* default 36.  fami_dcn_tune(4096 + KB): LDS budget of the fixed-point region (decides the groups per workgroup; benchmarks -- set BEFORE the weight pack) */
+  int  dcn_bwd2_stage;        /* default 1.  fami_dcn_tune(8192 / 8193): offset / mask gradients staged in LDS and written with consecutive lanes on consecutive elements -- PMC WRITE_SIZE per B = 4 launch 218 -> 123 MB (f32), 181 -> 78 MB (bf16); time 84.4 -> 88.6 us (f32), 72.6 -> 71.7 us (bf16) */
   int  dcn_bwd_abl;           /* default 0.  fami_dcn_tune(1024 + bits): ablations of the general backward kernel (benchmarks) */
   int  dcn_bwd_scatter;       /* default -1.  fami_dcn_tune(512 + m): 0 = f32 compare-and-swap LDS adds, 1 / default = fixed-point LDS adds (64-bit for f32, 32-bit for 16-bit storage), 2 = 64-bit for every type */
   /* ---- conv.hip */

@@ -843,9 +843,11 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
     g = torch.randn_like(y) * dyscale
     g[0, :, 3, 4] *= 50.0                                    # one hot pixel: the workgroup's bound is far above the typical value
     y.backward(g)
-    for mode, regfed in ((0, 1), (1, 1), (1, 0)):         # (1, 1): the register-fed kernel (default); (1, 0): the general kernel's fixed-point form
+    # (1, 1): the register-fed kernel (default); (1, 0): the general kernel's fixed-point form; (1, 3): register-fed WITHOUT the LDS staging of the offset / mask gradients
+    for mode, regfed in ((0, 1), (1, 1), (1, 0), (1, 3)):
         lib().cdll.fami_dcn_tune(512 + mode)
-        lib().cdll.fami_dcn_tune(2048 + regfed)
+        lib().cdll.fami_dcn_tune(2048 + (regfed & 1))
+        lib().cdll.fami_dcn_tune(8193 - (regfed >> 1))
         try:
             eng = _eng(dev)
             wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(torch.zeros(C, device=dev))

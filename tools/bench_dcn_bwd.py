@@ -40,6 +40,11 @@ for dt, tdt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
                                         None, gx.data_ptr(), goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream))
             out.append('regfed-no-col %.1f' % us)
     L.cdll.fami_dcn_tune(2049)
+    L.cdll.fami_dcn_tune(8192)          # WITHOUT the LDS staging of the offset / mask gradients (default: staged in LDS, written with consecutive lanes on consecutive elements
+    us = time_it(lambda: L.call('fami_dcn_bwd_' + dt, x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
+                                col.data_ptr(), gx.data_ptr(), goff.data_ptr(), gmsk.data_ptr(), B, H, W, C, C, G, 3, 3, 1, 3, 3, 0, s.cuda_stream))
+    out.append('regfed-unstaged %.1f' % us)
+    L.cdll.fami_dcn_tune(8193)
     for abl in (0, 1, 2, 3, 4, 7):
         L.cdll.fami_dcn_tune(1024 + abl)
         us = time_it(lambda: L.call('fami_dcn_bwd_' + dt, x.data_ptr(), off.data_ptr(), msk.data_ptr(), dy.data_ptr(), wpb.data_ptr(),
