@@ -213,3 +213,11 @@ def test_every_environment_switch_goes_through_the_one_parser():
     assert names[0] == 'size' and len(names) > 60 and {'use_t6', 'dcn_bwd2', 'wg6_target', 'bn_small_elems'} <= set(names)
     hdr = open(os.path.join(os.path.dirname(pkg), 'include', 'fami_route.h')).read()
     assert all(re.search(r'\b%s;' % n, hdr) for n in names)
+    # ... and the LIBRARY agrees with the header field by field: fami_route_init must produce the default each field's comment
+    # documents (a stale object file compiled against an older layout passes the size check -- padding -- and shifts every field)
+    from fami_pose_amd._lib import lib
+    r = lib().new_route()
+    doc = {m.group(1): int(m.group(2)) for m in re.finditer(r'\b(\w+);\s*/\* default (-?\d+)', hdr)}
+    assert len(doc) >= len(names) - 1
+    wrong = {n: (getattr(r, n), v) for n, v in doc.items() if getattr(r, n) != v}
+    assert not wrong, wrong
