@@ -18,6 +18,7 @@ import os.path as osp
 import torch
 import torch.nn as nn
 
+from .. import options
 from ..modules import ChainOfBasicBlocks, conv_bn_relu, run_conv
 from ..runtime import EngineModule
 from .hrnet import HRNetPlus, _hyper_parameters
@@ -153,6 +154,13 @@ class Alignment_V15(EngineModule):
     def _translation(self, eng, diff):
         seq = self.feat_global_offset_layers
         z = seq[0].run(eng, diff)
+        if options.number('FAMI_ABL_REGTAIL'):
+            # upper-bound experiment (WRONG results, refused without FAMI_ALLOW_WRONG=1): the regressor ends after its first
+            # n - 1 stride-2 stages; what a fused kernel for the rest of the chain could save at most
+            from ..engine import T
+            for i in range(1, options.number('FAMI_ABL_REGTAIL')):
+                z = seq[i].run(eng, z)
+            return T(torch.zeros(diff.shape[0], 2, device=eng.dev))
         for i in range(1, 6):
             z = seq[i].run(eng, z)
         z = eng.flatten_chw(z)
