@@ -95,16 +95,9 @@ def _worker(rank, world, port, q, backend='gloo'):
         rm = gather(tr_b.model.hrnet.bn1.running_mean)
         assert not torch.equal(rm[0], rm[1])
 
-        # (2b) FAMI_DDP_ALGO=mesh (reduce_scatter_tensor -> all_gather_into_tensor per slice) == the all_reduce plan:
-        # a two-rank sum is order independent, so bitwise
-        os.environ['FAMI_DDP_ALGO'] = 'mesh'
-        tr_m = Trainer(model(), use_graph=False, targets_from_joints=True, bucket_mb=8)
-        assert tr_m.reducer.algo == 'mesh'
-        tr_m.step(kf, sup, joints, vis)
-        assert torch.equal(tr_m.grad, tr_b.grad), 'mesh exchange differs from the all_reduce exchange'
-        assert torch.equal(tr_m.flat, tr_b.flat)
-        del tr_m
-
+        # (2b) FAMI_DDP_ALGO=mesh (reduce_scatter_tensor -> all_gather_into_tensor per slice) is held to the all_reduce
+        # plan below through the overlap graph plan (a two-rank sum is order independent, so bitwise), and in the eager form by
+        # tests/test_ddp_gloo.py on CPU
         # (3) graph plans == eager plan (rank 0 also checks the serial plan; the single-rank RCCL test covers both)
         for plan, algo in (('overlap', 'ring'), ('serial', 'ring'), ('overlap', 'mesh')):
             os.environ['FAMI_DDP_PLAN'] = plan
