@@ -99,7 +99,10 @@ def _worker(rank, world, port, q, backend='gloo'):
         # plan below through the overlap graph plan (a two-rank sum is order independent, so bitwise), and in the eager form by
         # tests/test_ddp_gloo.py on CPU
         # (3) graph plans == eager plan (rank 0 also checks the serial plan; the single-rank RCCL test covers both)
-        for plan, algo in (('overlap', 'ring'), ('serial', 'ring'), ('overlap', 'mesh')):
+        # (the serial plan -- one graph, every exchange, one graph -- runs over RCCL in test_ddp_path_single_rank_rccl; with two
+        # ranks it is covered on CPU by tests/test_ddp_gloo.py: each capture here costs ~25 s of two processes sharing one GPU)
+        plans = (('overlap', 'ring'), ('overlap', 'mesh')) if backend == 'gloo' else (('overlap', 'ring'), ('serial', 'ring'), ('overlap', 'mesh'))
+        for plan, algo in plans:
             os.environ['FAMI_DDP_PLAN'] = plan
             os.environ['FAMI_DDP_ALGO'] = algo
             tr_c = Trainer(model(), use_graph=True, targets_from_joints=True, bucket_mb=8)
