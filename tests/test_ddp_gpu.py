@@ -99,8 +99,9 @@ def _worker(rank, world, port, q, backend='gloo'):
         # plan below through the overlap graph plan (a two-rank sum is order independent, so bitwise), and in the eager form by
         # tests/test_ddp_gloo.py on CPU
         # (3) graph plans == eager plan (rank 0 also checks the serial plan; the single-rank RCCL test covers both)
-        # (the serial plan -- one graph, every exchange, one graph -- runs over RCCL in test_ddp_path_single_rank_rccl; with two
-        # ranks it is covered on CPU by tests/test_ddp_gloo.py: each capture here costs ~25 s of two processes sharing one GPU)
+        # (the serial plan -- one graph, every exchange, one graph -- runs its launch sequence over RCCL with one rank in
+        # test_ddp_path_single_rank_rccl and with two ranks in the RCCL variant of this test wherever two devices exist: each
+        # capture here costs ~25 s of two processes sharing one GPU)
         plans = (('overlap', 'ring'), ('overlap', 'mesh')) if backend == 'gloo' else (('overlap', 'ring'), ('serial', 'ring'), ('overlap', 'mesh'))
         for plan, algo in plans:
             os.environ['FAMI_DDP_PLAN'] = plan
