@@ -186,7 +186,8 @@ class Engine:
         # round 3: measured neutral (f32 49.1 -> 49.3, bf16 26.6 -> 26.5 ms).  Round 4, interleaved graph replays on one box
         # (tools/ab_env.py): f32 equal on two boxes (46.39 / 46.15, 47.96 / 48.04); bf16 with the 128-workgroup weight gradients
         # 25.50 -> 25.10 ms: on in the 16-bit modes
-        self.stem_wlane = options.flag('FAMI_STEM_WGRAD_LANE', '1' if self.half else '0')
+        # round 5 (tools/ab_env.py, two runs of 6 / 10 rounds on two boxes): f32 45.68 -> 45.43 and 45.31 -> 45.17 ms with it: on in every mode
+        self.stem_wlane = options.flag('FAMI_STEM_WGRAD_LANE')
         self._sliced = []              # parents of batch_slice views: their gradient buffers are created (zero-filled) on
                                        # lane 0 before backward starts, so no lane ever races a slice write against the fill
         self._keep = []                # every buffer handed out this step stays alive until the step has been enqueued:

@@ -19,7 +19,7 @@ SWITCHES = {
     'FAMI_MERGE_FORK': ('1', 'branches and the fuse terms that read them in one forked region (modules.HighResolutionModule.run_both)'),
     'FAMI_WGRAD_LANE': ('0', 'every weight gradient on its own stream (measured slower: the kernels fill the chip)'),
     'FAMI_HEAD_WGRAD_LANE': ('1', 'weight gradients of the serial aggregation / DCN stack on their own stream'),
-    'FAMI_STEM_WGRAD_LANE': (None, 'the same for stem / layer1 / transitions; default on in the 16-bit modes, off in f32'),
+    'FAMI_STEM_WGRAD_LANE': ('1', 'the same for stem / layer1 / transitions (round 5: on in f32 too, -0.3 ... -0.5 %)'),
     'FAMI_STEM_WGRAD_LANES': ('1', 'number of weight-gradient streams of that stretch (2 measured neutral)'),
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
