@@ -807,6 +807,19 @@ static inline int bn_grid(long P, int C) {
   if (g < 1) g = 1;
   return (int)g;
 }
+// the statistics passes of the two-launch forms write no partial array (fp64 slot atomics), so their grid is not tied to BN_MAXG:
+// fami_bn_tune_small(-(1000 + n)) sets the cap (route field bn2_maxg)
+// Measured inside the step (tools/ab_env.py, caps 512 / 1024 / 2048 / 4096): f32 storage 45.50 / 45.45 / 45.30 ms and 46.68 / - / 46.64 /
+// 46.57 on a second box, config 4 (512x384, 8 frames) 116.8 / - / 116.5 / 116.2 ms; bf16 20.02 / 20.01 / 20.14 ms -- the f32 tensors of
+// the stem stretch are twice the bytes and want more loads in flight: four times the cap in f32 storage.
+static inline int bn_grid2(long P, int C, int esz) {
+  const int rows = 256 / (C >> 2);
+  long g = (P + (long)rows * 2 * BN_U - 1) / ((long)rows * 2 * BN_U);
+  const long cap = (long)g_bn2_maxg * (esz == 4 ? 4 : 1);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
 static inline bool bn_shape_ok(long P, int C) { return P > 0 && C >= 4 && (C % 4) == 0 && C <= 1024; }
 
 // ------------------------------------------------------------------ host side (templates over the storage type)
@@ -923,7 +936,7 @@ static int bn_train_fwd2_impl(const T* x, const T* residual, T* y, const float* 
     FAMI_CHECK_LAUNCH(nm);
     return FAMI_OK;
   }
-  const int G = bn_grid(P, C), NS = bn_slots(C);
+  const int G = bn_grid2(P, C, (int)sizeof(T)), NS = bn_slots(C);
   const int rows = 256 / (C >> 2);
   if (!pre) {   // pre: the producing convolution's epilogue has filled the slot rows and the pivots already
     hipLaunchKernelGGL(bn_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, x,
@@ -955,7 +968,7 @@ static int bn_bwd2_impl(const T* dy, const T* x, const T* y, const float* mean, 
     FAMI_CHECK_LAUNCH(nm);
     return FAMI_OK;
   }
-  const int G = bn_grid(P, C), NS = bn_slots(C);
+  const int G = bn_grid2(P, C, (int)sizeof(T)), NS = bn_slots(C);
   const int rows = 256 / (C >> 2);
   if (!pre) {   // pre: the input-gradient convolution that produced dy summed dz and dz*xhat in its epilogue
     hipLaunchKernelGGL(bn_bwd_partial2_kernel<T>, dim3(G), dim3(256), (size_t)rows * 2 * C * sizeof(float), s, dy, x, y, mean,
@@ -993,7 +1006,12 @@ extern "C" {
 
 long fami_bn_workspace(int C) { return (long)BN_MAXG * 2 * C * (long)sizeof(float); }
 long fami_bn_slots_bytes(int C) { return bn_slots_bytes(C); }
-int fami_bn_tune_small(long elems) { g_bn_small_elems = elems < 0 ? 32768 : elems; return FAMI_OK; }
+int fami_bn_tune_small(long elems) {
+  if (elems <= -1000) { g_bn2_maxg = (int)(-elems - 1000); return FAMI_OK; }      // benchmarks: grid cap of the two-launch statistics passes
+  if (elems < 0) { g_bn_small_elems = 32768; g_bn2_maxg = 512; return FAMI_OK; }
+  g_bn_small_elems = elems;
+  return FAMI_OK;
+}
 int fami_bn_is_small(long P, int C) { return bn_small_ok(P, C) ? 1 : 0; }
 long fami_channel_sum_workspace(int C) { return (long)BN_MAXG * C * (long)sizeof(float); }
 

@@ -98,6 +98,7 @@ typedef struct fami_route_t {
   int  wgs3_default;          /* default 1.  fami_tune_defaults (FAMI_F32_SPLIT) */
   /* ---- norm.hip */
   long bn_small_elems;        /* default 32768.  fami_bn_tune_small: tensors up to this many elements take the one-launch kernels */
+  int  bn2_maxg;              /* default 512.  fami_bn_tune_small(-(1000 + n)): most workgroups of the statistics passes of the two-launch BatchNorm forms (bn_partial2 / bn_bwd_partial2) in 16-bit storage; four times as many in f32 storage */
 } fami_route_t;
 
 #ifdef __cplusplus

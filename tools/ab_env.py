@@ -1,5 +1,5 @@
 """A/B of library knobs on ONE box with less noise than bench.py runs: captures the training step once per setting (hipGraph) and
-replays the graphs alternately.  usage: ab_env.py <dtype> <rounds> "<name>:<tune call>,<tune call>" ...   tune call = lds:N | wgrad:N | env:NAME=VALUE
+replays the graphs alternately.  usage: ab_env.py <dtype> <rounds> "<name>:<tune call>,<tune call>" ...   tune call = lds:N | wgrad:N | dcn:N | bn:N | env:NAME=VALUE
 e.g. ab_env.py bf16 6 "t256:wgrad:21256" "t128:wgrad:21128" """
 import os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,10 @@ from fami_pose_amd.train import Trainer
 dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
 dtype, rounds = sys.argv[1], int(sys.argv[2])
 L = lib().cdll
-args = types.SimpleNamespace(width=48, img_w=288, img_h=384, sup=4, freeze_backbone=False, dtype=dtype, deterministic=False)
-kf, sup, joints, vis = bench.synth_batch(4, 4, 384, 288, 17, dev, 19970808)
+# workload: the headline's by default; AB_H / AB_W / AB_SUP / AB_WIDTH / AB_BATCH select another BASELINE config
+EH, EW, ES, EC, EB = (int(os.environ.get(k, d)) for k, d in (('AB_H', 384), ('AB_W', 288), ('AB_SUP', 4), ('AB_WIDTH', 48), ('AB_BATCH', 4)))
+args = types.SimpleNamespace(width=EC, img_w=EW, img_h=EH, sup=ES, freeze_backbone=False, dtype=dtype, deterministic=False)
+kf, sup, joints, vis = bench.synth_batch(EB, ES, EH, EW, 17, dev, 19970808)
 trs = []
 for spec in sys.argv[3:]:
     name, calls = spec.split(':', 1)
@@ -25,7 +27,7 @@ for spec in sys.argv[3:]:
             envs.append((k, os.environ.get(k)))
             os.environ[k] = v
         else:
-            (L.fami_conv_tune_lds if kind == 'lds' else L.fami_conv_tune_wgrad_lds)(int(val))
+            {'lds': L.fami_conv_tune_lds, 'wgrad': L.fami_conv_tune_wgrad_lds, 'dcn': L.fami_dcn_tune, 'bn': L.fami_bn_tune_small}[kind](int(val))
     model = bench.build(args, dev)
     tr = Trainer(model, lr=1e-3, use_mi=True, use_graph=True, targets_from_joints=True)
     for _ in range(3): tr.step(kf, sup, joints, vis)      # capture happens under this setting
