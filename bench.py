@@ -136,8 +136,9 @@ def conv_roofline(dev, N, dtype, reps=30, C=48, H=96, W=72):
     split = (not half) and os.environ.get('FAMI_F32_SPLIT', '1') != '0'
     t5 = split and os.environ.get('FAMI_T5', '1') != '0' and bool(L.cdll.fami_conv_t5_eligible(N, H, W, C, C))
     peak = PEAK_BF16_MFMA_TFLOPS if half else (round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1) if split else PEAK_F32_MFMA_TFLOPS)
-    t6 = half and bool(L.cdll.fami_conv_t6_eligible(N, H, W, C, C))      # round 4: weight-resident, LDS-DMA-staged kernel (conv_t6.hip)
-    kname = (('conv3x3_t6_kernel<%s, weight-resident, LDS DMA>' if t6 else 'conv3x3_t4_kernel<%s>') % dtype) if half else (
+    t6 = L.cdll.fami_conv_t6_eligible(N, H, W, C, C) if half else 0      # round 4: weight-resident, LDS-DMA-staged kernels (conv_t6.hip)
+    kname = (({1: 'conv3x3_t6_kernel<%s, weight-resident, LDS DMA>', 2: 'conv3x3_t7_kernel<%s, 48-channel phases, LDS DMA>',
+               3: 'conv3x3_t7_kernel<%s, 32-channel phases, LDS DMA>'}.get(t6, 'conv3x3_t4_kernel<%s>')) % dtype) if half else (
         ('conv3x3_t5_kernel<float, persistent split-product>' if t5 else 'conv3x3_t4_kernel<float, split-product>') if split else 'conv_igemm_f32')
     key = {'f32': ('conv3x3_t5_s3_f32' if t5 else 'conv3x3_t4_s3_f32') if split else 'conv_igemm_f32',
            'bf16': 'conv3x3_t6_bf16' if t6 else 'conv3x3_t4_bf16'}.get(dtype)

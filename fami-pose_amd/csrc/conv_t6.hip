@@ -430,9 +430,9 @@ struct ConvT7Args {
   int KC, NTt;
   int sgn, accumulate;
   int RB, bands;      // output rows per band (H % RB == 0), bands per frame
-  int PW, RG;         // W + 2, 16-byte granules per patch row of a slice (6 PW)
+  int PW, RG;         // W + 2, 16-byte granules per patch row of a slice (G PW)
   int q512, r512;     // 512 / RG, 512 % RG
-  int nph;            // phases (Ci / 48)
+  int nph;            // phases (Ci / (8 G))
   int TU, npix;       // 16-pixel tiles of a band (the last may be ragged), pixels of a band (RB * W)
   int REMP;           // (tile, channel tile) pairs of the tiles past the 8 MT-th
   int PI;             // patch DMA instructions (1 KiB) of a phase
@@ -440,11 +440,19 @@ struct ConvT7Args {
 };
 #define T7_PJ 6       // most patch DMA instructions per wave and phase (PI <= 48)
 
-template <typename H, int NT, int MT, int EX, bool ACC, int EM>
+// G: 16-byte granules of a phase's channel slice (6: 48 channels, NT = 3 -- the W48 branches; 4: 32 channels, NT = 4 -- the 64 /
+// 128 / 256 / 512-channel layers of HRNet-W64 and the 64 -> 64 convolutions of stage 1, round 5).  G = 4: a K chunk is one tap
+// (lane quarter kq = the slice's granule kq), a weight-slab block is a block of the packed image as it stands, and the 64-byte
+// positions would put the 16 lanes of a ds_read_b128 group on 8 bank quads (2-way conflicts at any padding, tools/probes note in
+// DESIGN 4) -- so granule c of linear patch position P sits at slot c ^ ((P >> 1) & 2): the four positions of a group that share
+// a quad block (P mod 4 equal) then take four different slots.  The copy un-swizzles at the source (a lane's LDS slot is fixed,
+// its source granule is slot ^ key), the reads compute the slot from P (4 VALU per fragment).
+template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM>
 __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p) {
   typedef typename H16<H>::x8 frag;
-  constexpr int G = 6, NK = (9 * G + 3) / 4, PSB = G * 16, PF = 2;
-  constexpr int WI = NK * NT;                      // weight DMA instructions of a phase (42)
+  constexpr int NK = (9 * G + 3) / 4, PSB = G * 16, PF = 2;
+  constexpr bool SWZ = G == 4;
+  constexpr int WI = NK * NT;                      // weight DMA instructions of a phase (42 | 36)
   constexpr int WJ = (WI + T6_WAVES - 1) / T6_WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -472,7 +480,9 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     int r = q0 / p.RG, wi = q0 - r * p.RG;
 #pragma unroll
     for (int j = 0; j < T7_PJ; ++j) {
-      const int pos = wi / G, c = wi - pos * G;
+      const int pos = wi / G;
+      int c = wi - pos * G;
+      if (SWZ) c ^= ((r * PW + pos) >> 1) & 2;      // (the slot is fixed by the copy's LDS address: fetch the granule that belongs there)
       const bool ok = r < p.RB + 2 && pos >= 1 && pos <= W;
       xrow[j] = ok ? r - 1 : 0x40000000;            // image row relative to the band's first row; never valid for a border column
       xoff[j] = (((r - 1) * W + pos - 1) * p.Ci + c * 8) * 2;
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       const int j = k - WJ;
       const int i = wave + T6_WAVES * j;
       if (i < p.PI) {
-        unsigned off = (unsigned)(g.y0 * W * p.Ci * 2 + xoff[j] + ph * 96);
+        unsigned off = (unsigned)(g.y0 * W * p.Ci * 2 + xoff[j] + ph * PSB);
         if ((unsigned)(g.y0 + xrow[j]) >= (unsigned)p.H) off = 0x80000000u;
         t7_dma16(g.rx, off, buf + (WI + i) * 1024);
       }
@@ -522,14 +532,24 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
   }
 
   // ---- per-lane constants
-  int koff[NK];
+  int koff[NK];                                    // byte offset of the lane quarter's (tap, granule) from the pixel's own position; SWZ: the tap's shift in POSITIONS
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     int kg = 4 * k + kq;
     if (kg >= 9 * G) kg = 4 * G;
     const int tap = kg / G, c8 = kg - tap * G;
-    koff[k] = (p.sgn * ((tap / 3 - 1) * PW + (tap % 3 - 1)) * G + c8) * 16;
+    const int sh = p.sgn * ((tap / 3 - 1) * PW + (tap % 3 - 1));
+    koff[k] = SWZ ? sh : (sh * G + c8) * 16;
   }
+  // LDS byte address of a fragment: base = the pixel's own position (SWZ: its linear position index)
+  auto faddr = [&](int base_, int k) {
+    if constexpr (SWZ) {
+      const int P = base_ + koff[k];
+      return WI * 1024 + P * PSB + ((kq ^ ((P >> 1) & 2)) << 4);
+    } else {
+      return base_ + koff[k];
+    }
+  };
   const int nte = wave % NT;
   const bool has_e = EX && wave < p.REMP;
   bool own[MT], pvalid[MT], pvalide = false;       // own: the wave has this tile (wave-uniform); pvalid: the lane's pixel is inside the band
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     pvalid[m] = own[m] && j < p.npix;
     if (j >= p.npix) j = p.npix - 1;                // ragged last tile: re-read the band's last pixel (never stored)
     const int rr = j / W, xx = j - rr * W;
-    base[m] = WI * 1024 + ((rr + 1) * PW + xx + 1) * PSB;
+    base[m] = SWZ ? (rr + 1) * PW + xx + 1 : WI * 1024 + ((rr + 1) * PW + xx + 1) * PSB;
     oown[m] = j * p.Co + ntg0 * 16 + kq * 4;
   }
   if (EX) {
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     pvalide = has_e && je < p.npix;
     if (je >= p.npix) je = p.npix - 1;
     const int rre = je / W, xxe = je - rre * W;
-    basee = WI * 1024 + ((rre + 1) * PW + xxe + 1) * PSB;
+    basee = SWZ ? (rre + 1) * PW + xxe + 1 : WI * 1024 + ((rre + 1) * PW + xxe + 1) * PSB;
     oex = je * p.Co + (ntg0 + nte) * 16 + kq * 4;
   }
   const int wl = lane * 16, wle = lane * 16 + nte * 1024;
@@ -606,9 +626,21 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[m][nt] = z4;
-  f32x4 es[NT], eq[NT], ese = z4, eqe = z4;
+  // EpiBN sums of the workgroup: an LDS table [NT][sum | sum-of-products][16] behind the channel table, added to with ds_add_f32 once per
+  // job and wave (round 5: the per-lane accumulators -- 8 NT + 8 registers live across every phase of every job -- spilled in the
+  // MT = 2 instances: 160-400 bytes of scratch; inside the W64 step the spilling instances cost more than the kernel saved)
+  float* const lstat = ctab + 4 * NT * 16;
+  if (EM != 0 && tid < NT * 32) lstat[tid] = 0.f;     // (ordered before the first add by the first step's barrier)
+  auto stat_add = [&](int nt, const f32x4& s4, const f32x4& q4) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) es[nt] = eq[nt] = z4;
+    for (int r = 0; r < 4; ++r) {
+      const float s = row16_sum(s4[r]), q = row16_sum(q4[r]);
+      if (col == 0) {
+        __hip_atomic_fetch_add(lstat + nt * 32 + kq * 4 + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(lstat + nt * 32 + 16 + kq * 4 + r, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
   auto save1 = [&](f32x4 v, SV& out, int co0, bool valid, f32x4& s, f32x4& q) {
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co0);
     if constexpr (ACC) out = v;
@@ -638,12 +670,18 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     const int img = jb / p.bands, y0 = (jb - img * p.bands) * p.RB;
     H* yb = reinterpret_cast<H*>(p.y) + (long)(img * p.H + y0) * W * p.Co;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-      if (pvalid[m]) {
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 s4 = z4, q4 = z4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) emit1(sv[m][nt], yb + oown[m] + nt * 16, nt * 16 + kq * 4, zp[m][nt], ap[m][nt], es[nt], eq[nt]);
-      }
-    if (EX && pvalide) emit1(sve, yb + oex, nte * 16 + kq * 4, zpe, ape, ese, eqe);
+      for (int m = 0; m < MT; ++m)
+        if (pvalid[m]) emit1(sv[m][nt], yb + oown[m] + nt * 16, nt * 16 + kq * 4, zp[m][nt], ap[m][nt], s4, q4);
+      if (EM == 2) stat_add(nt, s4, q4);
+    }
+    if (EX) {
+      f32x4 s4 = z4, q4 = z4;
+      if (pvalide) emit1(sve, yb + oex, nte * 16 + kq * 4, zpe, ape, s4, q4);
+      if (EM == 2 && has_e) stat_add(nte, s4, q4);       // (has_e is wave-uniform; lanes of a ragged tile add zeros)
+    }
   };
 
   // ---- (job, phase) steps: one wait + barrier each; the next step's copy is issued while this one is multiplied, across job
@@ -670,17 +708,19 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     auto body = [&](auto ec, auto oc) {
       constexpr bool E = decltype(ec)::value;
       constexpr bool O = decltype(oc)::value;          // the wave has own tiles (only the 12x9 maps leave a wave without)
+      // (the extra pair's weight fragment is the wave's own a[s][nte] when the wave has own tiles: selected, not loaded again)
+      constexpr bool AE = E && !O;
       frag a[PF][NT], b[PF][MT], ae[PF], be[PF];
       auto ld = [&](int k, int s) {
         if constexpr (O) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const frag*>(cb + base[m] + koff[k]);
+          for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const frag*>(cb + faddr(base[m], k));
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) a[s][nt] = *reinterpret_cast<const frag*>(cb + (k * NT + nt) * 1024 + wl);
         }
         if constexpr (E) {
-          be[s] = *reinterpret_cast<const frag*>(cb + basee + koff[k]);
-          ae[s] = *reinterpret_cast<const frag*>(cb + k * NT * 1024 + wle);
+          be[s] = *reinterpret_cast<const frag*>(cb + faddr(basee, k));
+          if constexpr (AE) ae[s] = *reinterpret_cast<const frag*>(cb + k * NT * 1024 + wle);
         }
       };
       ld(0, 0);
@@ -688,7 +728,13 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
       for (int k = 0; k < NK; ++k) {
         const int s = k % PF;
         if (k + 1 < NK) ld(k + 1, (k + 1) % PF);
-        if (more && k < WJ + T7_PJ) dma_piece(gn, nph, nbuf, k);      // (NK = 14 >= WJ + T7_PJ = 12)
+        if (more && k < WJ + T7_PJ) dma_piece(gn, nph, nbuf, k);      // (G = 6: NK = 14 >= WJ + T7_PJ = 12; G = 4: the last two pieces go with the last chunk)
+        if constexpr (NK < WJ + T7_PJ) {
+          if (more && k == NK - 1) {
+#pragma unroll
+            for (int kk = NK; kk < WJ + T7_PJ; ++kk) dma_piece(gn, nph, nbuf, kk);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (O) {
 #pragma unroll
@@ -696,7 +742,15 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = H16<H>::mfma(a[s][nt], b[s][m], acc[m][nt]);
         }
-        if constexpr (E) acce = H16<H>::mfma(ae[s], be[s], acce);
+        if constexpr (E) {
+          if constexpr (AE) acce = H16<H>::mfma(ae[s], be[s], acce);
+          else {
+            frag aw = a[s][0];
+#pragma unroll
+            for (int nt = 1; nt < NT; ++nt) aw = nte == nt ? a[s][nt] : aw;      // (wave-uniform)
+            acce = H16<H>::mfma(aw, be[s], acce);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -711,13 +765,20 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
     }
     if (nph == 0) {                                  // the job is complete: keep its results for the next step, clear the accumulators
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 s4 = z4, q4 = z4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          save1(acc[m][nt], sv[m][nt], (ntg0 + nt) * 16 + kq * 4, pvalid[m], es[nt], eq[nt]);
+        for (int m = 0; m < MT; ++m) {
+          save1(acc[m][nt], sv[m][nt], (ntg0 + nt) * 16 + kq * 4, pvalid[m], s4, q4);
           acc[m][nt] = z4;
         }
-      if (EX) save1(acce, sve, (ntg0 + nte) * 16 + kq * 4, pvalide, ese, eqe);
+        if (EM == 1 && !ACC && own[0]) stat_add(nt, s4, q4);      // (own[0] is wave-uniform)
+      }
+      if (EX) {
+        f32x4 s4 = z4, q4 = z4;
+        save1(acce, sve, (ntg0 + nte) * 16 + kq * 4, pvalide, s4, q4);
+        if (EM == 1 && !ACC && has_e) stat_add(nte, s4, q4);
+      }
       acce = z4;
       pending = jb;
     }
@@ -729,40 +790,11 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
 
   if (EM != 0) {
     EpiPtr e = epi_late(__builtin_offsetof(ConvT7Args, e));
-    __syncthreads();                                   // every wave is done with the buffers
-    float* ered = reinterpret_cast<float*>(smem);      // [waves][NT*32] own tiles, then [waves][32] extra pairs
-    float* erex = ered + T6_WAVES * NT * 32;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s = row16_sum(es[nt][r]), q = row16_sum(eq[nt][r]);
-        if (col == 0) {
-          ered[wave * (NT * 32) + nt * 32 + kq * 4 + r] = s;
-          ered[wave * (NT * 32) + nt * 32 + 16 + kq * 4 + r] = q;
-        }
-      }
-    }
-    if (EX) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s = row16_sum(ese[r]), q = row16_sum(eqe[r]);
-        if (col == 0) {
-          erex[wave * 32 + kq * 4 + r] = s;
-          erex[wave * 32 + 16 + kq * 4 + r] = q;
-        }
-      }
-    }
-    __syncthreads();
+    __syncthreads();                                   // every wave's adds are in the table
     if (tid < NT * 32) {
       const int nt = tid >> 5, st = (tid >> 4) & 1, c16 = tid & 15;
       const int co = (ntg0 + nt) * 16 + c16;
-      float v = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < T6_WAVES; ++wv) v += ered[wv * (NT * 32) + tid];
-      if (EX) {
-        for (int wv = nt; wv < p.REMP; wv += NT) v += erex[wv * 32 + (tid & 31)];
-      }
+      const float v = lstat[tid];
       const int eC = e->C;
       double* srow = e->slots + (long)(wg % e->ns) * 2 * eC;
       unsafeAtomicAdd(srow + st * eC + co, (double)v);
@@ -851,15 +883,21 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
   return 1;
 }
 
-struct T7Plan { int ok, RB, bands, TU, MT, EX, PI, jpw, G; size_t lds; };
-// [fami_route_t] g_t7_target (default 120)  // fami_conv_tune_lds(8700 + n): workgroups per output-channel block (jobs are dealt consecutively)
+struct T7Plan { int ok, RB, bands, TU, MT, EX, PI, jpw, G, SG, NT; size_t lds; };      // SG: granules of a phase's slice (6 | 4); NT: channel tiles per workgroup (3 | 4)
+// [fami_route_t] g_t7_c64 (default 1)  // fami_conv_tune_lds(8502 / 8503): the 32-channel-phase instances (64-multiple layers: HRNet-W64, stage 1's 64 -> 64) off / on
+// [fami_route_t] g_t7_target (default 240)  // fami_conv_tune_lds(8700 + n): workgroups of a launch (jobs are dealt consecutively).  Round 4: 120; round 5 (statistics in an LDS table, no spills): bf16 step 19.90 / 19.87 / 19.80 / 19.80 / 19.79 ms at 120 / 160 / 200 / 240 / 290, W64 fp16 29.52 -> 29.20 at 240
 // [fami_route_t] g_use_t7 (default 1)  // fami_conv_tune_lds(8500 / 8501): off / on
 // [fami_route_t] g_t7_rows (default 0)  // fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks)
 static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
   T7Plan q;
   q.ok = 0;
-  if (!g_use_t7 || Ci < 96 || Ci % 48 != 0 || Co % 48 != 0) return q;
-  const int RG = (W + 2) * 6;
+  if (!g_use_t7) return q;
+  if (Ci >= 96 && Ci % 48 == 0 && Co % 48 == 0) { q.SG = 6; q.NT = 3; }
+  else if (g_t7_c64 && Ci >= 64 && Ci % 64 == 0 && Co % 64 == 0) { q.SG = 4; q.NT = 4; }
+  else return q;
+  const int CB = 16 * q.NT;                           // output channels of a workgroup
+  const int WIK = ((9 * q.SG + 3) / 4) * q.NT;        // KiB of a phase's weight slab
+  const int RG = (W + 2) * q.SG;
   double best = 1e30;
   for (int RB = 1; RB <= H; ++RB) {
     if (H % RB != 0) continue;
@@ -872,12 +910,13 @@ static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
     else continue;
     const int PI = ((RB + 2) * RG + 63) / 64;
     if (PI > 8 * T7_PJ) continue;
-    const size_t lds = 2 * (size_t)(42 + PI) * 1024 + 1024;     // (+ EpiBN mode 2's channel table)
+    const size_t lds = 2 * (size_t)(WIK + PI) * 1024 + 1024 + 512;     // (+ EpiBN mode 2's channel table, the workgroup's statistics table)
     if (lds > 160 * 1024) continue;
-    const long jobs = (long)N * (H / RB) * (Co / 48);
+    if (EX && (TU - 8 * MT) * q.NT > 8) continue;     // (the tiles past the 8 MT-th are dealt one (tile, channel tile) pair per wave)
+    const long jobs = (long)N * (H / RB) * (Co / CB);
     if (jobs > 512 && g_t7_rows == 0) continue;       // (more than one round of workgroups: the band kernel's two workgroups per CU win, e.g. 96 -> 48 @64x64 19.2 vs 14.3 us)
     // rounds x (MFMA tiles of the busiest SIMD + a fixed cost per phase-set)
-    const int per_simd = TU <= 8 ? (TU > 4 ? 2 : 1) * 3 : (MT * 6 + (EX ? 1 : 0));
+    const int per_simd = TU <= 8 ? (TU > 4 ? 2 : 1) * q.NT : (MT * 2 * q.NT + (EX ? 1 : 0));
     const double c2 = (double)((jobs + 255) / 256) * (per_simd + 2.0);      // ~ time of the launch
     if (c2 < best - 1e-9) {
       best = c2;
@@ -889,7 +928,7 @@ static T7Plan t7_plan(int N, int H, int W, int Ci, int Co) {
   q.bands = H / q.RB;
   {
     const long njobs = (long)N * q.bands;
-    long tgt = g_t7_target / (Co / 48);
+    long tgt = g_t7_target / (Co / CB);
     if (tgt < 1) tgt = 1;
     q.jpw = (int)((njobs + tgt - 1) / tgt);
     q.G = (int)((njobs + q.jpw - 1) / q.jpw);
@@ -903,26 +942,28 @@ static int t7_launch(const T7Plan& q, const void* x, const void* wp, const float
   a.e = epi; a.emode = epi.slots ? epi.mode : 0;
   a.x = x; a.wimg = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt; a.sgn = sgn; a.accumulate = accumulate;
-  a.RB = q.RB; a.bands = q.bands; a.PW = W + 2; a.RG = (W + 2) * 6; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG;
-  a.nph = Ci / 48; a.TU = q.TU; a.npix = q.RB * W; a.REMP = q.TU > 8 * q.MT ? (q.TU - 8 * q.MT) * 3 : 0; a.PI = q.PI; a.jpw = q.jpw;
-  const dim3 grid(q.G, Co / 48);
+  a.RB = q.RB; a.bands = q.bands; a.PW = W + 2; a.RG = (W + 2) * q.SG; a.q512 = 512 / a.RG; a.r512 = 512 % a.RG;
+  a.nph = Ci / (8 * q.SG); a.TU = q.TU; a.npix = q.RB * W; a.REMP = q.TU > 8 * q.MT ? (q.TU - 8 * q.MT) * q.NT : 0; a.PI = q.PI; a.jpw = q.jpw;
+  const dim3 grid(q.G, Co / (16 * q.NT));
   bool ok = false;
   const bool acc_ = accumulate != 0;
-#define FAMI_T7_CASE(mt, ex, ac, em)                                                                                      \
-  if (!ok && q.MT == mt && q.EX == ex && acc_ == ac && a.emode == em) {                                                \
+#define FAMI_T7_CASE_G(sg, nt, mt, ex, ac, em)                                                                            \
+  if (!ok && q.SG == sg && q.MT == mt && q.EX == ex && acc_ == ac && a.emode == em) {                                  \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t7_kernel<HT, sg, nt, mt, ex, ac, em>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((conv3x3_t7_kernel<HT, 3, mt, ex, ac, em>), grid, dim3(T6_THREADS), q.lds, s, a);                  \
+    hipLaunchKernelGGL((conv3x3_t7_kernel<HT, sg, nt, mt, ex, ac, em>), grid, dim3(T6_THREADS), q.lds, s, a);             \
     ok = true;                                                                                                            \
   }
+#define FAMI_T7_CASE(mt, ex, ac, em) FAMI_T7_CASE_G(6, 3, mt, ex, ac, em) FAMI_T7_CASE_G(4, 4, mt, ex, ac, em)
   FAMI_T7_CASE(1, 1, false, 0) FAMI_T7_CASE(1, 1, false, 1) FAMI_T7_CASE(1, 1, true, 0) FAMI_T7_CASE(1, 1, false, 2) FAMI_T7_CASE(1, 1, true, 2)
   FAMI_T7_CASE(1, 0, false, 0) FAMI_T7_CASE(1, 0, false, 1) FAMI_T7_CASE(1, 0, true, 0) FAMI_T7_CASE(1, 0, false, 2) FAMI_T7_CASE(1, 0, true, 2)
   FAMI_T7_CASE(2, 1, false, 0) FAMI_T7_CASE(2, 1, false, 1) FAMI_T7_CASE(2, 1, true, 0) FAMI_T7_CASE(2, 1, false, 2) FAMI_T7_CASE(2, 1, true, 2)
   FAMI_T7_CASE(2, 0, false, 0) FAMI_T7_CASE(2, 0, false, 1) FAMI_T7_CASE(2, 0, true, 0) FAMI_T7_CASE(2, 0, false, 2) FAMI_T7_CASE(2, 0, true, 2)
 #undef FAMI_T7_CASE
+#undef FAMI_T7_CASE_G
   return ok ? 1 : 0;
 }
 
@@ -960,10 +1001,15 @@ int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const floa
   }
   return 1;
 }
-// 1: the 48-channel kernel takes it, 2: the phased kernel, 0: neither
-extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) { return t7_plan(N, H, W, Ci, Co).ok ? 2 : (t6_plan(N, H, W, Ci, Co).ok ? 1 : 0); }
+// 1: the 48-channel kernel takes it, 2: the phased kernel (48-channel phases), 3: the phased kernel with 32-channel phases, 0: neither
+extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) {
+  const T7Plan q7 = t7_plan(N, H, W, Ci, Co);
+  if (q7.ok) return q7.SG == 4 ? 3 : 2;
+  return t6_plan(N, H, W, Ci, Co).ok ? 1 : 0;
+}
 void fami_conv_t6_tune(int on) {
-  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 120; }
+  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 240; g_t7_c64 = 1; }
+  else if (on == 8502 || on == 8503) g_t7_c64 = on - 8502;
   else if (on >= 8700 && on < 8999) g_t7_target = on - 8700;
   else if (on == 8500 || on == 8501) g_use_t7 = on - 8500;
   else if (on >= 8600 && on < 8700) g_t7_rows = on - 8600;

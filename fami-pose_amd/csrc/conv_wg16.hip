@@ -572,6 +572,7 @@ struct Wg6Plan { int ok, UR, upf, M, KS, nunits, G, XI, YI, blocks, CIT, COT, Ho
 // [fami_route_t] g_wg6_dil (default 1)  // fami_conv_tune_wgrad_lds(23008 / 23009): the dilated (48 -> 216 / 108, dilation 3) launches off / on
 // [fami_route_t] g_wg6_c42 (default 1)
 // [fami_route_t] g_wg6_c4 (default 1)  // fami_conv_tune_wgrad_lds(23002 / 23003): the 64-channel blocks off / on
+// [fami_route_t] g_wg6_target_c4 (default 160)  // fami_conv_tune_wgrad_lds(26000 + n): workgroup target of the launches with 64-channel input blocks (0: wg6_target); bf16 W48 step 19.47 / 19.39 / 19.43 / 19.34 ms at 80 / 120 / 160 / 240, W64 fp16 29.82 / 29.50 / 29.38 at 80 / 140 / 180
 // [fami_route_t] g_wg6 (default 1), g_wg6_nu (default 0), g_wg6_target (default 80)  // fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target
 static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil) {
   Wg6Plan q;
@@ -596,7 +597,7 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
     if (q.Ho % ur != 0 || ur * q.Wo > 288) continue;
     const int M = ur * q.Wo, KS = (M + 31) / 32, PR = st * (ur - 1) + 2 * dil + 1;
     if (!(KS == 9 || KS == 8 || KS == 7 || KS == 5 || KS == 4 || (KS == 3 && q.CIT == 4 && q.COT == 2)) || KS * 32 - M > 24) continue;      // (a quarter of the last step may be padding, not more)
-    if (q.CIT == 4 && !(KS == 5 || ((KS == 9 || KS == 3) && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
+    if (q.CIT == 4 && !(KS == 5 || ((KS == 9 || KS == 4 || KS == 3) && q.COT == 2))) continue;                                                              // (instantiated: 64-channel blocks with five K steps)
     const int XI = (PR * RG + 63) / 64, YI = KS * q.COT;
     if (XI > 8 * q.XJ || YI > 8 * WG6_YJ || 2 * (size_t)(XI + YI) * 1024 > 160 * 1024) continue;
     if (dilated && KS != 5) continue;                    // (instantiated: five K steps)
@@ -613,7 +614,10 @@ static Wg6Plan wg6_plan(int N, int H, int W, int Ci, int Co, int k, int st, int 
   // workgroup's 83 KB partial slab -- written, then read by the reduce -- is the kernel's largest HBM item).  Alone 240 is the
   // fastest (19.9 us with the reduce at 48 channels against 21.1 / 25.0 / 31.1 at 160 / 96 / 64); inside the bf16 step
   // (tools/ab_env.py) 80: 22.44 ms against 22.58 (120) and 23.08 (240); 48 and 64 equal to 80
-  long nu = g_wg6_nu > 0 ? g_wg6_nu : (NU * q.blocks + g_wg6_target - 1) / g_wg6_target;
+  // ... of 64-channel blocks (round 5): HRNet-W64's launches are 1.8 x the work of W48's -- inside the W64 fp16 step 80 / 120 / 160 / 240 / 320
+  // workgroups 29.77 / 29.45 / 29.42 / 29.79 / 30.55 ms
+  const int tgt6 = q.CIT == 4 && g_wg6_target_c4 > 0 ? g_wg6_target_c4 : g_wg6_target;
+  long nu = g_wg6_nu > 0 ? g_wg6_nu : (NU * q.blocks + tgt6 - 1) / tgt6;
   if (nu < 1) nu = 1;
   if (nu > NU) nu = NU;
   q.nunits = (int)nu;
@@ -1101,7 +1105,7 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
     ok6 = true;                                                                                                           \
   }
       FAMI_WG6_CASE(9, 3, 3, WG6_XJ) FAMI_WG6_CASE(8, 3, 3, WG6_XJ) FAMI_WG6_CASE(7, 3, 3, WG6_XJ) FAMI_WG6_CASE(5, 3, 3, WG6_XJ) FAMI_WG6_CASE(4, 3, 3, WG6_XJ)
-      FAMI_WG6_CASE(5, 4, 4, WG6_XJ) FAMI_WG6_CASE(5, 4, 3, WG6_XJ) FAMI_WG6_CASE(9, 4, 2, WG6_XJ) FAMI_WG6_CASE(5, 4, 2, WG6_XJ) FAMI_WG6_CASE(3, 4, 2, WG6_XJ)
+      FAMI_WG6_CASE(5, 4, 4, WG6_XJ) FAMI_WG6_CASE(5, 4, 3, WG6_XJ) FAMI_WG6_CASE(9, 4, 2, WG6_XJ) FAMI_WG6_CASE(5, 4, 2, WG6_XJ) FAMI_WG6_CASE(4, 4, 2, WG6_XJ) FAMI_WG6_CASE(3, 4, 2, WG6_XJ)      /* (4, 4, 2: 512 channels @12x9, HRNet-W64's fourth branch) */
       FAMI_WG6_CASE(5, 3, 3, 8)
 #undef FAMI_WG6_CASE
       if (ok6) {
@@ -1133,7 +1137,8 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_dil = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg1 = 1; g_wg1_target = 192; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_dil = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg6_target_c4 = 160; g_wg1 = 1; g_wg1_target = 192; }
+  else if (on >= 6000 && on < 7000) g_wg6_target_c4 = on - 6000;  // (26000 + workgroup target of the launches with 64-channel blocks; 0: the common target)
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)
   else if (on >= 4100 && on < 5000) g_wg1_target = on - 4100;     // (24100 + workgroup target)
   else if (on == 5000 || on == 5001) g_wgs = on - 5000;           // (fami_conv_tune_wgrad_lds(25000 / 25001): the stem conv1 kernel off / on)

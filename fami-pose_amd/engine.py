@@ -210,12 +210,18 @@ class Engine:
         # constants from LDS, +1.7 us on a 14.5 us launch against 5.7 us saved on the BatchNorm backward
         # (tools/bench_epi2.py); on the other kernels the epilogue still costs more than the pass it removes.
         fz = options.get('FAMI_FUSE_BN', 'auto')
-        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto')
+        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto', 'fwd3')
+        self.fuse_bn_fwd3 = fz == 'fwd3'       # (probe: forward statistics only in the epilogues of the DMA-staged 3x3 kernels)
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
         self.fuse_bn_bwd_auto = self.bn2 and self.half and fz == 'auto'
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
         self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '1')
+        # ... and the forward statistics stay a pass of their own behind the 32-channel-phase instances of that kernel (layers of
+        # 64-multiple channels: HRNet-W64's branches, stage 1's 64 -> 64).  W64 fp16 step, tools/ab_env.py on one box: epilogues
+        # everywhere 29.40 ms, forward only 29.05, none 28.59
+        self.fuse_bn_c64 = options.flag('FAMI_FUSE_BN_C64', '0')
+        self.fuse_bn_skip = set(filter(None, options.get('FAMI_FUSE_BN_SKIP', '').replace('+', ',').split(',')))      # probes: '1x1', 's2'
         self.concat_one = options.flag('FAMI_CONCAT_ONE', '1')      # Engine.concat: one launch for up to four sources
         # the two predictor convolutions of a DCN layer as one (CatParam; needs the Trainer's arena layout): FAMI_MERGE_PREDICTORS
         self.merge_predictors = options.flag('FAMI_MERGE_PREDICTORS', '1')
@@ -857,6 +863,16 @@ class Engine:
         """Can the statistics passes of a train-mode BatchNorm over [P, C] run in a convolution epilogue?"""
         return C % 4 == 0 and 4 <= C <= 1024 and not self.Q.fami_bn_is_small(P, C)
 
+    def conv_fuses_stats(self, N, Ho, Wo, Ci, Co, kh, st, pd, dl):
+        """Does the forward statistics pass of the BatchNorm behind this convolution go into its epilogue (given bn_fusable)?"""
+        if ('1x1' in self.fuse_bn_skip and kh == 1) or ('s2' in self.fuse_bn_skip and st == 2):
+            return False
+        if self.fuse_bn_fwd3:
+            return self.half and (kh, st, pd, dl) == (3, 1, 1, 1) and self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) in (1, 2)
+        if self.half and not self.fuse_bn_c64 and (kh, st, pd, dl) == (3, 1, 1, 1):
+            return self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) != 3
+        return True
+
     def conv_bn(self, x, conv, bn, relu=False, residual=None):
         """nn.Conv2d -> nn.BatchNorm2d (-> + residual) (-> ReLU): basic_model.py:34-63, basic_layer.py:25-26.  With a
         train-mode BatchNorm over a large enough tensor the statistics pass is the convolution's epilogue."""
@@ -865,7 +881,8 @@ class Engine:
         st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
-        if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
+        if (bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co)
+                and self.conv_fuses_stats(N, Ho, Wo, conv.weight.shape[1], Co, kh, st, pd, dl)):
             slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
             z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
             return self.bn(z, bn, relu=relu, residual=residual, pre=slots)
@@ -1031,7 +1048,8 @@ class Engine:
         st, pd, dl = conv.stride[0], conv.padding[0], conv.dilation[0]
         Ho = (H + 2 * pd - dl * (kh - 1) - 1) // st + 1
         Wo = (W + 2 * pd - dl * (kw - 1) - 1) // st + 1
-        if bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co):
+        if (bn.training and self.fuse_bn_fwd and self.bn_fusable(N * Ho * Wo, Co)
+                and self.conv_fuses_stats(N, Ho, Wo, conv.weight.shape[1], Co, kh, st, pd, dl)):
             slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
             z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
             return self.fuse_term(z, bn, shift, pre=slots)

@@ -71,9 +71,10 @@ typedef struct fami_route_t {
   int  t6_rows;               /* default 0.  fami_conv_tune_lds(8100 + RB): force the rows per band (benchmarks) */
   int  t6_min_jobs;           /* default 96.  fami_conv_tune_lds(8400 + n): only launches of >= n jobs */
   int  t6_mt;                 /* default 0.  fami_conv_tune_lds(8201 / 8202): units of two / four rows (0: four where the band allows) */
-  int  t7_target;             /* default 120.  fami_conv_tune_lds(8700 + n): workgroups per output-channel block (jobs are dealt consecutively) */
+  int  t7_target;             /* default 240.  fami_conv_tune_lds(8700 + n): workgroups of a launch of the phased kernel (jobs are dealt consecutively) */
   int  use_t7;                /* default 1.  fami_conv_tune_lds(8500 / 8501): off / on */
   int  t7_rows;               /* default 0.  fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks) */
+  int  t7_c64;                /* default 1.  fami_conv_tune_lds(8502 / 8503): the 32-channel-phase instances of the phased kernel (layers of 64-multiple channels: HRNet-W64, stage 1's 64 -> 64) off / on */
   /* ---- conv_wg16.hip */
   int  wg6_s2;                /* default 1.  fami_conv_tune_wgrad_lds(23004 / 23005): stride-2 launches off / on */
   int  wg6_dil;               /* default 1.  fami_conv_tune_wgrad_lds(23008 / 23009): the dilated (48 -> 216 / 108, dilation 3) launches off / on */
@@ -82,6 +83,7 @@ typedef struct fami_route_t {
   int  wg6;                   /* default 1.  fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target */
   int  wg6_nu;                /* default 0.  fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target */
   int  wg6_target;            /* default 80.  fami_conv_tune_wgrad_lds(23000 / 23001): off / on; 23100 + n: units per workgroup; 23400 + n: workgroup target */
+  int  wg6_target_c4;         /* default 160.  fami_conv_tune_wgrad_lds(26000 + n): workgroup target of the launches with 64-channel input blocks (0: wg6_target) */
   int  wg1;                   /* default 1.  inside the bf16 step (tools/ab_env.py): 48 / 96 / 192 workgroups 22.63 / 22.54 / 22.45 ms against 22.96 without the kernel      // fami_conv_tune_wgrad_lds(24000 / 24001): off / on; 24100 + n: workgroup target */
   int  wg1_target;            /* default 192.  inside the bf16 step (tools/ab_env.py): 48 / 96 / 192 workgroups 22.63 / 22.54 / 22.45 ms against 22.96 without the kernel      // fami_conv_tune_wgrad_lds(24000 / 24001): off / on; 24100 + n: workgroup target */
   int  wgs;                   /* default 1.  fami_conv_tune_wgrad_lds(25000 / 25001): off / on */

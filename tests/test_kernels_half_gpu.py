@@ -200,7 +200,7 @@ def test_weight_resident_dma_conv(dev, half):
     over (tap, 8-channel granule).  Forward (+ bias), input gradient (plain and accumulating) and the forward BatchNorm
     statistics epilogue against fp64 on the same 16-bit operands, and against the band kernel (conv_t4.hip) it replaces:
     the bench shape, the head's 4-frame shape, 64-pixel rows (no ninth tile), two output-channel blocks, bands of 2 / 4 / 6 / 8
-    / 12 rows, units of two and four rows."""
+    / 12 rows, units of two and four rows; the phased kernel with 48-channel phases (W48) and with 32-channel phases (W64)."""
     from fami_pose_amd._lib import lib
     L = lib()
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -211,7 +211,10 @@ def test_weight_resident_dma_conv(dev, half):
              (5, 24, 72, 48, 96, 12, 0), (2, 8, 72, 48, 48, 2, 0), (2, 8, 72, 48, 48, 4, 1), (3, 16, 64, 48, 48, 8, 2), (1, 10, 72, 48, 48, 0, 0),
              # conv3x3_t7_kernel: input channels in phases of 48, several bands per workgroup
              (20, 48, 36, 96, 96, 0, 0), (20, 24, 18, 192, 192, 0, 0), (20, 12, 9, 384, 384, 0, 0), (3, 48, 36, 96, 48, 0, 7),
-             (2, 24, 18, 144, 96, 4, 1), (3, 12, 9, 96, 144, 6, 500), (2, 16, 36, 192, 48, 8, 3), (1, 10, 72, 96, 48, 2, 0)]
+             (2, 24, 18, 144, 96, 4, 1), (3, 12, 9, 96, 144, 6, 500), (2, 16, 36, 192, 48, 8, 3), (1, 10, 72, 96, 48, 2, 0),
+             # ... in phases of 32 (round 5: layers of 64-multiple channels -- HRNet-W64's branches, stage 1's 64 -> 64): swizzled 64-byte positions
+             (20, 96, 72, 64, 64, 0, 0), (20, 48, 36, 128, 128, 0, 0), (20, 24, 18, 256, 256, 0, 0), (20, 12, 9, 512, 512, 0, 0), (3, 48, 36, 128, 64, 0, 7),
+             (2, 24, 18, 64, 128, 4, 1), (3, 12, 9, 128, 192, 6, 500), (2, 16, 36, 256, 64, 8, 3), (1, 10, 72, 64, 64, 2, 0)]
     try:
         for it, (N, H, W, Ci, Co, rows, mt) in enumerate(cases):
             torch.manual_seed(it)
@@ -238,7 +241,7 @@ def test_weight_resident_dma_conv(dev, half):
                         L.cdll.fami_conv_tune_lds((8100 if Ci == 48 else 8600) + rows)
                     if mt:
                         L.cdll.fami_conv_tune_lds(8200 + mt if Ci == 48 else 8700 + mt)
-                    assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == (1 if Ci == 48 else 2), (N, H, W, Ci, Co, rows)
+                    assert L.cdll.fami_conv_t6_eligible(N, H, W, Ci, Co) == (1 if Ci == 48 else (2 if Ci % 48 == 0 else 3)), (N, H, W, Ci, Co, rows)
                 y, ys, dx, dxa = (torch.empty(N, H, W, Co, device=dev, dtype=BF), torch.empty(N, H, W, Co, device=dev, dtype=BF),
                                   torch.empty(N, H, W, Ci, device=dev, dtype=BF), dx0.clone())
                 slots = torch.zeros(L.cdll.fami_bn_slots_bytes(Co) // 8, device=dev, dtype=torch.float64)
@@ -303,7 +306,9 @@ def test_dma_staged_weight_gradient(dev, half):
                                                     (20, 12, 9, 384, 384, 0), (3, 8, 64, 48, 48, 0), (2, 12, 72, 48, 96, 1), (2, 24, 72, 96, 48, 2),
                                                     (3, 24, 18, 48, 144, 5), (2, 96, 72, 48, 48, 48), (5, 16, 72, 48, 48, 3), (3, 12, 9, 96, 48, 2),
                                                     # 64-channel blocks (stage 1, the 256 -> 48 transition): units of two rows, five K steps
-                                                    (20, 96, 72, 64, 64, 0), (4, 96, 72, 256, 48, 0), (2, 24, 72, 128, 64, 3)]):
+                                                    (20, 96, 72, 64, 64, 0), (4, 96, 72, 256, 48, 0), (2, 24, 72, 128, 64, 3),
+                                                    # HRNet-W64's other branches: 64 x 32 blocks with nine / five / four K steps per unit
+                                                    (20, 48, 36, 128, 128, 0), (6, 24, 18, 256, 256, 0), (4, 12, 9, 512, 512, 0), (3, 12, 9, 128, 64, 2)]):
             torch.manual_seed(it)
             x = torch.randn(N, H, W, Ci, device=dev).to(BF)
             dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)

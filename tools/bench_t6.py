@@ -16,7 +16,9 @@ def timeit(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 for DT in ('bf16', 'f16'):
     tdt = {'bf16': torch.bfloat16, 'f16': torch.float16}[DT]
-    for (N, H, W, Ci, Co) in ((20, 96, 72, 48, 48), (20, 48, 36, 96, 96), (20, 24, 18, 192, 192), (20, 12, 9, 384, 384), (4, 96, 72, 48, 48), (20, 64, 64, 48, 96), (2, 48, 36, 96, 48)):
+    SH48 = ((20, 96, 72, 48, 48), (20, 48, 36, 96, 96), (20, 24, 18, 192, 192), (20, 12, 9, 384, 384), (4, 96, 72, 48, 48), (20, 64, 64, 48, 96), (2, 48, 36, 96, 48))
+    SH64 = ((20, 96, 72, 64, 64), (20, 48, 36, 128, 128), (20, 24, 18, 256, 256), (20, 12, 9, 512, 512), (4, 96, 72, 64, 64))      # T6_SHAPES=w64: HRNet-W64's branches, stage 1's 64 -> 64
+    for (N, H, W, Ci, Co) in (SH64 if os.environ.get('T6_SHAPES') == 'w64' else SH48):
         torch.manual_seed(1)
         x = torch.randn(N, H, W, Ci, device=dev).to(tdt); y = torch.empty(N, H, W, Co, device=dev, dtype=tdt)
         dy = torch.randn(N, H, W, Co, device=dev).to(tdt); dx = torch.empty_like(x)
