@@ -220,7 +220,7 @@ class Engine:
         # ... and the forward statistics stay a pass of their own behind the 32-channel-phase instances of that kernel (layers of
         # 64-multiple channels: HRNet-W64's branches, stage 1's 64 -> 64).  W64 fp16 step, tools/ab_env.py on one box: epilogues
         # everywhere 29.40 ms, forward only 29.05, none 28.59
-        self.fuse_bn_c64 = options.flag('FAMI_FUSE_BN_C64', '0')
+        self.fuse_bn_c64 = options.number('FAMI_FUSE_BN_C64', '0')      # bit 0: forward statistics, bit 1: backward statistics (under the rule of FAMI_FUSE_BN_T7)
         self.fuse_bn_skip = set(filter(None, options.get('FAMI_FUSE_BN_SKIP', '').replace('+', ',').split(',')))      # probes: '1x1', 's2'
         self.concat_one = options.flag('FAMI_CONCAT_ONE', '1')      # Engine.concat: one launch for up to four sources
         # the two predictor convolutions of a DCN layer as one (CatParam; needs the Trainer's arena layout): FAMI_MERGE_PREDICTORS
@@ -841,7 +841,7 @@ class Engine:
                     if self.fuse_bn_bwd_auto and rec is not None and (kh, stride, pad, dil) == (3, 1, 1, 1):
                         kind = self.Q.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
                         t7 = self.fuse_bn_bwd_t7
-                        pays = kind == 1 or (kind == 2 and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
+                        pays = kind == 1 or ((kind == 2 or (kind == 3 and (self.fuse_bn_c64 & 2))) and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
                     if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
@@ -869,7 +869,7 @@ class Engine:
             return False
         if self.fuse_bn_fwd3:
             return self.half and (kh, st, pd, dl) == (3, 1, 1, 1) and self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) in (1, 2)
-        if self.half and not self.fuse_bn_c64 and (kh, st, pd, dl) == (3, 1, 1, 1):
+        if self.half and not (self.fuse_bn_c64 & 1) and (kh, st, pd, dl) == (3, 1, 1, 1):
             return self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) != 3
         return True
 

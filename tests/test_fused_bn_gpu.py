@@ -70,7 +70,7 @@ def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None, auto=False):
     if not eng.bn2:
         pytest.skip('two-launch BatchNorm disabled')
     eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # switch the fusion per engine (FAMI_FUSE_BN)
-    eng.fuse_bn_c64 = True                              # (... including the 32-channel-phase kernel's epilogue, which the default leaves out)
+    eng.fuse_bn_c64 = 3                                 # (... including the 32-channel-phase kernel's epilogue, which the default leaves out)
     eng.fuse_bn_bwd_auto = bool(auto)                   # (the default's per-kernel choice for the backward statistics)
     if fuse_bwd is not None:
         eng.fuse_bn_bwd = bool(fuse_bwd)
