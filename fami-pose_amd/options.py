@@ -54,9 +54,10 @@ SWITCHES = {
     'FAMI_T5_ABL': ('', 'upper bound: n channel chunks per split-product convolution'),
     'FAMI_ABL_WGRAD': ('0', 'upper bound: no weight-gradient kernels at all'),
     'FAMI_ABL_REGTAIL': ('0', 'upper bound: the translation regressor stops after its first n - 1 stride-2 stages (n = 2: what a fused tail kernel could save)'),
+    'FAMI_ABL_PACK': ('0', 'upper bound: the 16-bit / fragment weight images are packed in the first step only (what packing inside the optimizer could save)'),
     'FAMI_ABL_BN1': ('0', 'upper bound: bit 1 no apply pass / bit 2 no backward of every conv1 -> bn1 -> ReLU -> conv2 BatchNorm'),
 }
-WRONG = ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_BN1', 'FAMI_ABL_REGTAIL')      # produce wrong results by design
+WRONG = ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_BN1', 'FAMI_ABL_REGTAIL', 'FAMI_ABL_PACK')      # produce wrong results by design
 
 
 def get(name, default=None):

@@ -519,7 +519,11 @@ class Trainer:
             self.packer.run(st, 1)
             for w, buf, geo, _ in dcn:
                 self._lc('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, st)
-        if eng.use_lanes and options.flag('FAMI_PACK_SPLIT'):
+        if options.flag('FAMI_ABL_PACK') and getattr(self, '_abl_packed', False):
+            packed_fwd = packed_bwd = None          # (upper-bound experiment, WRONG results: the images of the first step stay)
+        elif eng.use_lanes and options.flag('FAMI_PACK_SPLIT'):
+            # (round 5: starting the late / input-gradient packs at stage 2 / 3 on the weight-gradient stream instead of beside the stem
+            #  stretch measured no gain -- bf16 20.26 vs 20.23 ms, f32 45.92 vs 45.72; all packing removed is worth 0.37 / 0.72 ms, FAMI_ABL_PACK)
             if self.packer.n_early > 0 and options.flag('FAMI_PACK_EARLY'):
                 self.packer.run(eng.stream, 'early')
                 eng.late_weights_ready = eng.side_launch(lambda st: self.packer.run(st, 'late'))   # HRNetBody.run waits before stage 3
@@ -533,6 +537,7 @@ class Trainer:
             for w, buf, geo, _ in dcn:
                 self._lc('fami_dcn_pack_weight_bwd_f32', _p(w.data), _p(buf), *geo, eng.stream)
             packed_fwd = packed_bwd = None
+        self._abl_packed = True
         eng.prepacked = self.packer.views
         eng.prepacked_dcn_bwd = {id(w): buf for w, buf, _, _ in dcn}
         eng.prepacked_dcn_fwd = {id(w): fbuf for w, _, _, fbuf in dcn}
