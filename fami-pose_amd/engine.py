@@ -217,6 +217,11 @@ class Engine:
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
         self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '1')
+        # order of a convolution's two backward launches: input gradient (the chain's next link) before the weight gradient (a leaf)?
+        # tools/ab_env.py, two runs on two boxes: f32 storage 45.80 -> 45.48 and 45.95 -> 45.63 ms with it (half of it each from the
+        # lanes with / without a weight-gradient stream); bf16 20.21 -> 20.40 and 20.13 -> 20.19 / 20.25: f32 only.
+        # 1: everywhere, 2: only where the weight gradient has its own lane, 3: only elsewhere
+        self.dgrad_first = options.number('FAMI_DGRAD_FIRST', '0' if self.half else '1')
         # ... and the forward statistics stay a pass of their own behind the 32-channel-phase instances of that kernel (layers of
         # 64-multiple channels: HRNet-W64's branches, stage 1's 64 -> 64).  W64 fp16 step, tools/ab_env.py on one box: epilogues
         # everywhere 29.40 ms, forward only 29.05, none 28.59
@@ -820,7 +825,11 @@ class Engine:
                 if out.grad is None:
                     return
                 dy = out.grad
-                saved = self._enter_wlane(wpair) if ((self.use_wlane or wl) and need_w) else None
+                on_wl = (self.use_wlane or wl) and need_w
+                xfirst = self.dgrad_first == 1 or (self.dgrad_first == 2 and on_wl) or (self.dgrad_first == 3 and not on_wl)
+                if xfirst:
+                    do_x()
+                saved = self._enter_wlane(wpair) if on_wl else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     self.wgrad(x.data, dy, g, geo, acc,
@@ -832,6 +841,11 @@ class Engine:
                     self.acall('fami_channel_sum', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
                 if saved is not None:
                     self.stream = saved
+                if not xfirst:
+                    do_x()
+
+            def do_x():
+                dy = out.grad
                 if x.requires_grad:
                     self.conv_flops += flops
                     gx, acc = self.gbuf(x)

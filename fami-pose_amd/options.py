@@ -37,6 +37,7 @@ SWITCHES = {
     'FAMI_DETERMINISTIC': ('0', 'run-to-run reproducible kernels (fixed-point DCN input gradient, three-launch BatchNorm)'),
     # ---- train step (train.py)
     'FAMI_PACK_SPLIT': ('1', 'input-gradient weight images packed on a side lane beside the forward pass'),
+    'FAMI_DGRAD_FIRST': (None, "a convolution's input gradient enqueued before its weight gradient (0 | 1 | 2 | 3); default 1 in f32 storage, 0 in the 16-bit modes"),
     'FAMI_PACK_EARLY': ('1', 'forward weight images of stem .. stage 2 first, the rest beside the stem'),
     'FAMI_EARLY_ADAM': ('1', 'Adam in two parts: everything but the stem stretch beside the end of the backward pass'),
     'FAMI_DDP_PLAN': ('overlap', 'data-parallel launch plan: overlap (graph segments + all-reduce between them) | serial'),
