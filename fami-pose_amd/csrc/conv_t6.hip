@@ -544,7 +544,8 @@ __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t7_kernel(ConvT7Args p)
   // LDS byte address of a fragment: base = the pixel's own position (SWZ: its linear position index)
   auto faddr = [&](int base_, int k) {
     if constexpr (SWZ) {
-      const int P = base_ + koff[k];
+      int P = base_ + koff[k];
+      asm volatile("" : "+v"(P));      // (computed where it is used: hoisted out of the phase loop the 27 addresses cost 27 registers and the EpiBN instances spill)
       return WI * 1024 + P * PSB + ((kq ^ ((P >> 1) & 2)) << 4);
     } else {
       return base_ + koff[k];

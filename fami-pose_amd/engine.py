@@ -210,10 +210,16 @@ class Engine:
         # constants from LDS, +1.7 us on a 14.5 us launch against 5.7 us saved on the BatchNorm backward
         # (tools/bench_epi2.py); on the other kernels the epilogue still costs more than the pass it removes.
         fz = options.get('FAMI_FUSE_BN', 'auto')
-        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto', 'fwd3')
-        self.fuse_bn_fwd3 = fz == 'fwd3'       # (probe: forward statistics only in the epilogues of the DMA-staged 3x3 kernels)
+        # auto (default): f32 storage -- forward statistics in every convolution's epilogue (the split-product kernels carry them for
+        # free and XBN needs them), no backward fusion; 16-bit storage -- forward statistics ONLY in the epilogues of the DMA-staged 3x3
+        # kernels (conv3x3_t6 / t7 with 48-channel phases: statistics in the implicit-GEMM epilogues of the 1x1 / stride-2 convolutions
+        # measured neutral at W48 and a loss at W64), backward statistics where the input-gradient kernel is one of those (see below).
+        # tools/ab_env.py, one box per pair: bf16 W48 20.08 -> 19.98 ms, W64 fp16 28.42 -> 27.90 against 'autoall' (the rule up to round 5).
+        # fwd3 / bwdauto: the two halves of the 16-bit rule alone (probes).
+        self.fuse_bn_fwd = self.bn2 and fz in ('1', 'fwd', 'auto', 'autoall', 'fwd3')
+        self.fuse_bn_fwd3 = fz == 'fwd3' or (fz == 'auto' and self.half)
         self.fuse_bn_bwd = self.bn2 and fz in ('1', 'bwd')
-        self.fuse_bn_bwd_auto = self.bn2 and self.half and fz == 'auto'
+        self.fuse_bn_bwd_auto = self.bn2 and self.half and fz in ('auto', 'autoall', 'bwdauto')
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
         self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '1')
@@ -224,8 +230,9 @@ class Engine:
         self.dgrad_first = options.number('FAMI_DGRAD_FIRST', '0' if self.half else '1')
         # ... and the forward statistics stay a pass of their own behind the 32-channel-phase instances of that kernel (layers of
         # 64-multiple channels: HRNet-W64's branches, stage 1's 64 -> 64).  W64 fp16 step, tools/ab_env.py on one box: epilogues
-        # everywhere 29.40 ms, forward only 29.05, none 28.59
-        self.fuse_bn_c64 = options.number('FAMI_FUSE_BN_C64', '0')      # bit 0: forward statistics, bit 1: backward statistics (under the rule of FAMI_FUSE_BN_T7)
+        # everywhere 29.40 ms, forward only 29.05, none 28.59 (while its EpiBN instances spilled); without spills: forward 28.47 vs 28.45
+        # without, backward 28.25: bit 1 on
+        self.fuse_bn_c64 = options.number('FAMI_FUSE_BN_C64', '2')      # bit 0: forward statistics, bit 1: backward statistics (under the rule of FAMI_FUSE_BN_T7)
         self.fuse_bn_skip = set(filter(None, options.get('FAMI_FUSE_BN_SKIP', '').replace('+', ',').split(',')))      # probes: '1x1', 's2'
         self.concat_one = options.flag('FAMI_CONCAT_ONE', '1')      # Engine.concat: one launch for up to four sources
         # the two predictor convolutions of a DCN layer as one (CatParam; needs the Trainer's arena layout): FAMI_MERGE_PREDICTORS
@@ -882,7 +889,8 @@ class Engine:
         if ('1x1' in self.fuse_bn_skip and kh == 1) or ('s2' in self.fuse_bn_skip and st == 2):
             return False
         if self.fuse_bn_fwd3:
-            return self.half and (kh, st, pd, dl) == (3, 1, 1, 1) and self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) in (1, 2)
+            kinds = (1, 2, 3) if (self.fuse_bn_c64 & 1) else (1, 2)
+            return self.half and (kh, st, pd, dl) == (3, 1, 1, 1) and self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) in kinds
         if self.half and not (self.fuse_bn_c64 & 1) and (kh, st, pd, dl) == (3, 1, 1, 1):
             return self.Q.fami_conv_t6_eligible(N, Ho, Wo, Ci, Co) != 3
         return True

@@ -24,10 +24,10 @@ SWITCHES = {
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
-    'FAMI_FUSE_BN': ('auto', "BatchNorm statistics in the neighbouring convolutions' epilogues: 0 | fwd | fwd3 (the DMA-staged 3x3 kernels only) | bwd | 1 | auto"),
+    'FAMI_FUSE_BN': ('auto', "BatchNorm statistics in the neighbouring convolutions' epilogues: auto (f32: forward everywhere; 16-bit: forward in the DMA-staged 3x3 kernels only + backward where the input gradient runs on one) | autoall (16-bit: forward everywhere) | 0 | fwd | fwd3 | bwd | bwdauto | 1"),
     'FAMI_FUSE_BN_T7': ('1', 'which launches of the phased 16-bit kernel carry the backward statistics under auto: 0 | 1 | 2'),
     'FAMI_FUSE_BN_SKIP': ('', "probe: convolution classes whose epilogue does not take the forward statistics ('1x1', 's2'; comma or + separated)"),
-    'FAMI_FUSE_BN_C64': ('0', 'statistics in the epilogues of the 32-channel-phase kernel (layers of 64-multiple channels): bit 0 forward, bit 1 backward; measured a loss inside the W64 step'),
+    'FAMI_FUSE_BN_C64': ('2', 'statistics in the epilogues of the 32-channel-phase kernel (layers of 64-multiple channels): bit 0 forward, bit 1 backward'),
     'FAMI_FUSE_TERM_BN2': ('1', 'fuse-term BatchNorm backward on the two-launch form'),
     'FAMI_XBN': (None, 'BatchNorm + ReLU applied by the consumer convolution; default on in f32 storage, off in the 16-bit modes'),
     'FAMI_SERIAL_FUSE': ('0', 'backward statistics fusion on the serial stem / layer1 stretch only (measured neutral)'),

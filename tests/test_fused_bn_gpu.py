@@ -54,7 +54,7 @@ class RefNet(nn.Module):
         return self.last(self.down(self.b(self.a(x))))
 
 
-def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None, auto=False):
+def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None, auto=False, defaults=False):
     """the same graph on the HIP engine -> dict of results (fp32, on the host)"""
     from fami_pose_amd.engine import Engine, T
     from fami_pose_amd.modules import BasicBlock, _cbr, run_cbr
@@ -69,12 +69,14 @@ def _run(dev, ref, x, gy, dtype, fuse, xbn=False, fuse_bwd=None, auto=False):
     eng = Engine(dev, dtype=dtype)
     if not eng.bn2:
         pytest.skip('two-launch BatchNorm disabled')
-    eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # switch the fusion per engine (FAMI_FUSE_BN)
-    eng.fuse_bn_c64 = 3                                 # (... including the 32-channel-phase kernel's epilogue, which the default leaves out)
-    eng.fuse_bn_bwd_auto = bool(auto)                   # (the default's per-kernel choice for the backward statistics)
-    if fuse_bwd is not None:
-        eng.fuse_bn_bwd = bool(fuse_bwd)
-    eng.use_xbn = bool(xbn)
+    if not defaults:
+        eng.fuse_bn_fwd = eng.fuse_bn_bwd = bool(fuse)      # switch the fusion per engine (FAMI_FUSE_BN)
+        eng.fuse_bn_fwd3 = False                            # (every convolution class, not only the DMA-staged kernels the 16-bit default fuses into)
+        eng.fuse_bn_c64 = 3                                 # (... including the 32-channel-phase kernel's epilogue, which the default leaves out)
+        eng.fuse_bn_bwd_auto = bool(auto)                   # (the default's per-kernel choice for the backward statistics)
+        if fuse_bwd is not None:
+            eng.fuse_bn_bwd = bool(fuse_bwd)
+        eng.use_xbn = bool(xbn)
     xt = T(x.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype), True)
     h = xt
     for b in blocks:
@@ -168,6 +170,30 @@ def test_default_backward_fusion_follows_the_input_gradient_kernel(dev, dt):
     lib().cdll.fami_conv_tune_lds(8000)               # (the autouse fixture restores the knobs)
     off, no = _run(dev, ref, x, gy, DT[dt], True, fuse_bwd=False, auto=True)
     assert no['bwd'] == 0
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f32'])
+def test_default_forward_fusion_rule(dev, dt):
+    """FAMI_FUSE_BN=auto as an Engine comes up: in 16-bit storage the forward statistics ride only in the epilogues of the DMA-staged 3x3
+    kernels (the four 48 -> 48 convolutions of the two blocks; not the stride-2 convolution behind them), the backward statistics in
+    the three input gradients those kernels take; in f32 storage every convolution's epilogue carries its forward statistics and the two
+    conv1 -> bn1 -> ReLU edges are not materialised (XBN).  Results against the f32 unfused graph."""
+    N, C, H, W, C2 = 8, 48, 96, 72, 96
+    torch.manual_seed(78)
+    ref = RefNet(C, C2).train()
+    x = torch.randn(N, C, H, W) + 0.5
+    gy = torch.randn(N, 8, (H + 1) // 2, (W + 1) // 2)
+    out, nf = _run(dev, ref, x, gy, DT[dt], None, defaults=True)
+    if dt == 'bf16':
+        assert nf == {'fwd': 4, 'bwd': 3, 'xbn': 0}, nf
+    else:
+        assert nf['fwd'] == 5 and nf['bwd'] == 0 and nf['xbn'] == 2, nf
+    ref32, _ = _run(dev, ref, x, gy, torch.float32, False)
+    plain, _ = _run(dev, ref, x, gy, DT[dt], False)
+    ulp = {'bf16': 2.0 ** -8, 'f32': 5e-6}[dt]
+    for k in out:            # (as in test_fused_bn_statistics: no further from the f32 unfused graph than the unfused graph of the same storage type)
+        ea, ep = relerr(out[k], ref32[k]), relerr(plain[k], ref32[k])
+        assert ea < 1.5 * ep + ulp, (k, ea, ep)
 
 
 @pytest.mark.parametrize('shape', [(2, 48, 24, 18, 96), (3, 96, 13, 11, 192), (2, 192, 12, 10, 384), (2, 64, 23, 20, 64),
