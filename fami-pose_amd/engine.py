@@ -174,7 +174,9 @@ class Engine:
         self._wstream2 = None      # second weight-gradient stream (wlane_pair scopes: the stem / layer1 / transition stretch)
         self._wflip = False
         self.wlane_pair = False
-        self.stem_wlanes = options.number('FAMI_STEM_WGRAD_LANES', '1')      # 2: measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38): the stretch is bandwidth-contended, not lane-bound
+        # round 4: two streams measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38); end of round 5 (tools/ab_env.py, two boxes):
+        # f32 45.26 -> 44.96 and 44.72 -> 44.46 ms, bf16 20.15 -> 20.08 and 20.05 -> 19.96: two
+        self.stem_wlanes = options.number('FAMI_STEM_WGRAD_LANES', '2')
         self._wdirty = False
         # ... but for the HEAD it pays (FAMI_HEAD_WGRAD_LANE, default 1): between the first DCN forward and the last DCN backward
         # the step is one serial chain of kernels (rocprof trace: 3.5 ms with exactly one kernel in flight), and the weight

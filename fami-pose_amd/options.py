@@ -20,7 +20,7 @@ SWITCHES = {
     'FAMI_WGRAD_LANE': ('0', 'every weight gradient on its own stream (measured slower: the kernels fill the chip)'),
     'FAMI_HEAD_WGRAD_LANE': ('1', 'weight gradients of the serial aggregation / DCN stack on their own stream'),
     'FAMI_STEM_WGRAD_LANE': ('1', 'the same for stem / layer1 / transitions (round 5: on in f32 too, -0.3 ... -0.5 %)'),
-    'FAMI_STEM_WGRAD_LANES': ('1', 'number of weight-gradient streams of that stretch (2 measured neutral)'),
+    'FAMI_STEM_WGRAD_LANES': ('2', 'number of weight-gradient streams of that stretch (1 | 2)'),
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
