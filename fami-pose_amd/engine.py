@@ -169,19 +169,22 @@ class Engine:
         # events of the other lanes instead of on lane 0 behind a join.  The Trainer switches it off when gradient buckets are
         # all-reduced during backward (their hooks fire between forked regions).
         self.persist_lanes = options.flag('FAMI_PERSIST_LANES', '1')
-        self.use_wlane = self.use_lanes and options.flag('FAMI_WGRAD_LANE', '0')
-        self._wstream = None
-        self._wstream2 = None      # second weight-gradient stream (wlane_pair scopes: the stem / layer1 / transition stretch)
-        self._wflip = False
+        self.use_wlane = options.number('FAMI_WGRAD_LANE', '0') if self.use_lanes else 0      # 1: every weight gradient on the weight-gradient streams in turn, 2: the stage convolutions' on one stream per lane
+        self.wlane_scope_now = False
+        self._wstreams = []        # weight-gradient streams of this step (the first is shared with the head's scope)
+        self._wflip = 0
         self.wlane_pair = False
         # round 4: two streams measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38); end of round 5 (tools/ab_env.py, two boxes):
-        # f32 45.26 -> 44.96 and 44.72 -> 44.46 ms, bf16 20.15 -> 20.08 and 20.05 -> 19.96: two
-        self.stem_wlanes = options.number('FAMI_STEM_WGRAD_LANES', '2')
+        # f32 45.26 -> 44.96 and 44.72 -> 44.46 ms, bf16 20.15 -> 20.08 and 20.05 -> 19.96 with two; then stem / head streams 2 / 1, 2 / 2,
+        # 4 / 2, 4 / 4, 8 / 8: bf16 19.28 / 19.18 / 19.12 / 19.05 / 19.07 (second run), f32 44.87 / 44.41 / 44.40 / 44.19 / 44.38 -- launches
+        # on one capture stream are ordered among themselves in the graph although they are independent leaves: four each
+        self.stem_wlanes = options.number('FAMI_STEM_WGRAD_LANES', '4')
         self._wdirty = False
         # ... but for the HEAD it pays (FAMI_HEAD_WGRAD_LANE, default 1): between the first DCN forward and the last DCN backward
         # the step is one serial chain of kernels (rocprof trace: 3.5 ms with exactly one kernel in flight), and the weight
         # gradients in it are leaves.  A model body brackets that part with wlane_scope = True.
         self.head_wlane = self.use_lanes and options.flag('FAMI_HEAD_WGRAD_LANE', '1')
+        self.head_wlanes = options.number('FAMI_HEAD_WGRAD_LANES', '4')       # number of weight-gradient streams of the head's scope
         self.wlane_scope = False
         # the same for the backbone's serial head and tail: stem, layer1 and the transitions run before the branches fork
         # (their backward after the branches have joined), FAMI_STEM_WGRAD_LANE
@@ -329,28 +332,23 @@ class Engine:
     def _enter_wlane(self, pair=False):
         """Route the following calls to a weight-gradient stream, ordered after the current lane's work so far.  Inside a
         wlane_pair scope (HRNetBody: stem, layer1, transitions -- a serial chain whose weight gradients read tensors of up to
-        70 MB and run at a fifth of the HBM rate each) two such streams take the launches alternately: in the kernel trace of
-        the bf16 step the single stream was the critical path of the last 0.4 ms of the backward pass."""
-        if self._wstream is None:
-            taken = {self._main.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])}
-            ws = Engine._wgrad_pool.get(self.dev)
+        70 MB and run at a fifth of the HBM rate each) `stem_wlanes` such streams take the launches in turn, elsewhere (the head)
+        `head_wlanes`: in the kernel trace of the bf16 step the single stream was the critical path of the last 0.4 ms of the
+        backward pass (launches on one stream are ordered among themselves although they are independent leaves)."""
+        n = max(1, self.stem_wlanes if pair else self.head_wlanes)
+        while len(self._wstreams) < n:
+            k = len(self._wstreams)
+            taken = {self._main.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])} | {t.cuda_stream for t in self._wstreams}
+            ws = Engine._wgrad_pool.get((self.dev, k))
             if ws is None or ws.cuda_stream in taken:
-                ws = self._new_wstream()
-            Engine._wgrad_pool[self.dev] = ws
-            self._wstream = ws
-        target = self._wstream
-        if pair and self.stem_wlanes >= 2:
-            if self._wstream2 is None:
-                ws2 = Engine._wgrad_pool.get((self.dev, 2))
-                taken = {self._main.cuda_stream, self._wstream.cuda_stream} | {t.cuda_stream for t in Engine._side_pool.get(self.dev, [])}
-                if ws2 is None or ws2.cuda_stream in taken:
-                    ws2 = self._new_wstream((self._wstream.cuda_stream,))
-                Engine._wgrad_pool[(self.dev, 2)] = ws2
-                self._wstream2 = ws2
-            self._wflip = not self._wflip
-            if self._wflip:
-                target = self._wstream2
-                self._wdirty2 = True
+                ws = self._new_wstream(tuple(t.cuda_stream for t in self._wstreams))
+            Engine._wgrad_pool[(self.dev, k)] = ws
+            self._wstreams.append(ws)
+        if self.use_wlane == 2 and not pair and not self.wlane_scope_now:      # (probe: stage convolutions, one weight-gradient stream per lane)
+            target = self._wstreams[self.lane % n]
+        else:
+            self._wflip = (self._wflip + 1) % n
+            target = self._wstreams[self._wflip]
         ev = torch.cuda.Event()
         ev.record(self._lane_stream())
         target.wait_event(ev)
@@ -362,9 +360,7 @@ class Engine:
     def sync_wgrad_lane(self):
         """Lane 0 continues after every weight-gradient kernel enqueued so far (before an all-reduce / the optimizer)."""
         if self._wdirty:
-            for ws in (self._wstream, self._wstream2):
-                if ws is None:
-                    continue
+            for ws in self._wstreams:
                 self.flush_reduces(ws.cuda_stream)
                 ev = torch.cuda.Event()
                 ev.record(ws)
@@ -835,6 +831,7 @@ class Engine:
                     return
                 dy = out.grad
                 on_wl = (self.use_wlane or wl) and need_w
+                self.wlane_scope_now = bool(wl)
                 xfirst = self.dgrad_first == 1 or (self.dgrad_first == 2 and on_wl) or (self.dgrad_first == 3 and not on_wl)
                 if xfirst:
                     do_x()

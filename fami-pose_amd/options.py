@@ -17,10 +17,11 @@ SWITCHES = {
     'FAMI_MI_LANES': ('1', 'the MI terms of the loss on three lanes'),
     'FAMI_PERSIST_LANES': ('1', 'lanes stay forked across the modules of an HRNet stage'),
     'FAMI_MERGE_FORK': ('1', 'branches and the fuse terms that read them in one forked region (modules.HighResolutionModule.run_both)'),
-    'FAMI_WGRAD_LANE': ('0', 'every weight gradient on its own stream (measured slower: the kernels fill the chip)'),
+    'FAMI_WGRAD_LANE': ('0', 'weight gradients of the stage convolutions off their lane: 1 on the weight-gradient streams in turn, 2 on one stream per lane (both measured slower)'),
     'FAMI_HEAD_WGRAD_LANE': ('1', 'weight gradients of the serial aggregation / DCN stack on their own stream'),
     'FAMI_STEM_WGRAD_LANE': ('1', 'the same for stem / layer1 / transitions (round 5: on in f32 too, -0.3 ... -0.5 %)'),
-    'FAMI_STEM_WGRAD_LANES': ('2', 'number of weight-gradient streams of that stretch (1 | 2)'),
+    'FAMI_HEAD_WGRAD_LANES': ('4', 'number of weight-gradient streams of the head (taken in turn)'),
+    'FAMI_STEM_WGRAD_LANES': ('4', 'number of weight-gradient streams of that stretch (taken in turn)'),
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
