@@ -3192,7 +3192,10 @@ static int run_igemm_h(ConvArgsH a, int mode, hipStream_t s, const char* name) {
     const long nblk = fami_cdiv(a.NTt, NT);
     const long tiles = (long)fami_cdiv(a.P, 16) * nblk;
     const long iters = (long)a.kh * a.kw * a.KC;
-    if (tiles >= 16384) MT = 4;
+    // (a two-chunk reduction -- the 64 -> 256 1x1 of stage 1 and the input gradient of its 256 -> 64 twin, 20 frames @96x72 -- is all
+    //  prologue and epilogue: 64-pixel waves instead of 128: forward 38.1 -> 32.6 us, input gradient 38.6 -> 32.2, accumulating 58.4 -> 52.0,
+    //  tools/probes/layer1_1x1_tiles.py)
+    if (tiles >= 16384) MT = iters <= 2 ? 2 : 4;
     else if (tiles >= 4096) MT = 2;
     else {
       MT = 1;
