@@ -172,6 +172,7 @@ class Engine:
         self.use_wlane = options.number('FAMI_WGRAD_LANE', '0') if self.use_lanes else 0      # 1: every weight gradient on the weight-gradient streams in turn, 2: the stage convolutions' on one stream per lane
         self.wlane_scope_now = False
         self._wstreams = []        # weight-gradient streams of this step (the first is shared with the head's scope)
+        self._wowner = {}          # parameter id -> index of the weight-gradient stream its gradients go to
         self._wflip = 0
         self.wlane_pair = False
         # round 4: two streams measured neutral (bf16 23.00 vs 23.01 ms, f32 47.47 vs 47.38); end of round 5 (tools/ab_env.py, two boxes):
@@ -329,7 +330,7 @@ class Engine:
             raise RuntimeError('could not obtain a distinct weight-gradient stream')
         return ws
 
-    def _enter_wlane(self, pair=False):
+    def _enter_wlane(self, pair=False, key=None):
         """Route the following calls to a weight-gradient stream, ordered after the current lane's work so far.  Inside a
         wlane_pair scope (HRNetBody: stem, layer1, transitions -- a serial chain whose weight gradients read tensors of up to
         70 MB and run at a fifth of the HBM rate each) `stem_wlanes` such streams take the launches in turn, elsewhere (the head)
@@ -344,11 +345,18 @@ class Engine:
                 ws = self._new_wstream(tuple(t.cuda_stream for t in self._wstreams))
             Engine._wgrad_pool[(self.dev, k)] = ws
             self._wstreams.append(ws)
-        if self.use_wlane == 2 and not pair and not self.wlane_scope_now:      # (probe: stage convolutions, one weight-gradient stream per lane)
+        # key: what the launches accumulate into (a parameter).  A module applied twice inside such a scope keeps its weight gradients
+        # on ONE stream: they accumulate into the same buffer and their slab reduces are ordered per stream
+        own = self._wowner.get(key) if key is not None else None
+        if own is not None and own < n:
+            target = self._wstreams[own]
+        elif self.use_wlane == 2 and not pair and not self.wlane_scope_now:      # (probe: stage convolutions, one weight-gradient stream per lane)
             target = self._wstreams[self.lane % n]
         else:
             self._wflip = (self._wflip + 1) % n
             target = self._wstreams[self._wflip]
+            if key is not None:
+                self._wowner[key] = self._wflip
         ev = torch.cuda.Event()
         ev.record(self._lane_stream())
         target.wait_event(ev)
@@ -835,7 +843,7 @@ class Engine:
                 xfirst = self.dgrad_first == 1 or (self.dgrad_first == 2 and on_wl) or (self.dgrad_first == 3 and not on_wl)
                 if xfirst:
                     do_x()
-                saved = self._enter_wlane(wpair) if on_wl else None
+                saved = self._enter_wlane(wpair, id(weight)) if on_wl else None
                 if self.rq(weight):
                     g, acc = self.pgrad(weight)
                     self.wgrad(x.data, dy, g, geo, acc,
@@ -1402,7 +1410,7 @@ class Engine:
                     if gx is not None and gx32 is not gx:
                         self.acall('fami_cast_add', _p(gx32), _p(gx), gx.numel(), accx)
                 if self.rq(weight):
-                    saved = self._enter_wlane() if wl else None      # leaves of the backward graph (see __init__)
+                    saved = self._enter_wlane(False, id(weight)) if wl else None      # leaves of the backward graph (see __init__)
                     g, acc = self.pgrad(weight)
                     if not permuted:
                         self.wgrad(col, dy, g, (1, 1, P, CK, Co, 1, 1, 1, 0, 1), acc)

@@ -700,6 +700,45 @@ def test_shared_module_on_two_lanes(dev):
     assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
 
 
+def test_module_applied_twice_inside_a_weight_gradient_scope(dev):
+    """Inside a weight-gradient scope (the head, the stem stretch) the weight gradients of the convolutions go to four streams in turn.
+    A module applied several times there accumulates into ONE gradient buffer: its launches (and their deferred slab reduces) must stay
+    on one stream -- the result equals the torch gradient of all applications, run after run."""
+    from fami_pose_amd.engine import Engine, T
+    torch.manual_seed(3)
+    convs = [nn.Conv2d(16, 16, 3, 1, 1, bias=False) for _ in range(3)]
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(0.5)
+    order = (0, 1, 0, 2, 0)                         # convs[0] three times, other modules in between
+    x = torch.randn(2, 16, 24, 18, requires_grad=True)
+    h = x
+    for i in order:
+        h = convs[i](h)
+    gy = torch.randn_like(h)
+    h.backward(gy)
+    dconvs = [nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(dev) for _ in range(3)]
+    for d, c in zip(dconvs, convs):
+        d.load_state_dict(c.state_dict())
+    for _ in range(5):
+        eng = Engine(dev)
+        if not (eng.use_lanes and eng.head_wlane and eng.head_wlanes > 1):
+            pytest.skip('one weight-gradient stream')
+        eng.wlane_scope = True
+        t = T(nhwc(x.detach()).to(dev), True)
+        hh = t
+        for i in order:
+            hh = eng.conv(hh, dconvs[i].weight, None, 1, 1, 1)
+        eng.wlane_scope = False
+        hh.grad = nhwc(gy).to(dev)
+        eng.backward()
+        torch.cuda.synchronize(dev)
+        assert len({eng._wowner[id(c.weight)] for c in dconvs}) > 1       # (the scope did use more than one stream)
+        for d, c in zip(dconvs, convs):
+            assert relerr(eng.param_grads[id(d.weight)], c.weight.grad) < 5e-5
+        assert relerr(nchw(t.grad), x.grad) < 2e-5
+
+
 @pytest.mark.parametrize("flip,bgr,rot", [(False, False, 0.0), (True, False, 31.0), (False, True, -44.0), (True, True, 90.0)])
 def test_warp_normalize_bit_exact_vs_oracle(dev, flip, bgr, rot):
     """fami_warp_normalize_u8 (cv2.warpAffine INTER_LINEAR + ToTensor + Normalize, one transform for all frames of a
