@@ -1,5 +1,5 @@
 """A/B of library knobs on ONE box with less noise than bench.py runs: captures the training step once per setting (hipGraph) and
-replays the graphs alternately.  usage: ab_env.py <dtype> <rounds> "<name>:<tune call>,<tune call>" ...   tune call = lds:N | wgrad:N | dcn:N | bn:N | env:NAME=VALUE
+replays the graphs alternately.  usage: ab_env.py <dtype> <rounds> "<name>:<tune call>,<tune call>" ...   tune call = lds:N | wgrad:N | dcn:N | bn:N | stages:N | env:NAME=VALUE
 e.g. ab_env.py bf16 6 "t256:wgrad:21256" "t128:wgrad:21128" """
 import os, sys, time, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ for spec in sys.argv[3:]:
             envs.append((k, os.environ.get(k)))
             os.environ[k] = v
         else:
-            {'lds': L.fami_conv_tune_lds, 'wgrad': L.fami_conv_tune_wgrad_lds, 'dcn': L.fami_dcn_tune, 'bn': L.fami_bn_tune_small}[kind](int(val))
+            {'lds': L.fami_conv_tune_lds, 'wgrad': L.fami_conv_tune_wgrad_lds, 'dcn': L.fami_dcn_tune, 'bn': L.fami_bn_tune_small, 'stages': L.fami_conv_tune_stages}[kind](int(val))
     model = bench.build(args, dev)
     tr = Trainer(model, lr=1e-3, use_mi=True, use_graph=True, targets_from_joints=True)
     for _ in range(3): tr.step(kf, sup, joints, vis)      # capture happens under this setting
