@@ -1997,7 +1997,9 @@ template <typename T>
 static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, const float* wpb, T* col, float* gx,
                         T* goff, T* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride,
                         int pad, int dil, int acc_off, hipStream_t s, const char* nm, long long* gfix = nullptr,
-                        const unsigned* amax_bits = nullptr, bool merged = false) {
+                        const unsigned* amax_bits = nullptr, bool merged = false, bool general = false) {
+  // general: the caller sized `col` for dcn_bwd_kernel ([P][C K], tap-major: what fami_dcn_bwd_col_width / _col_permuted report
+  // for the deterministic mode) -- the register-fed kernel, which writes its own column order q.colw wide, must not take it
   FAMI_REQUIRE(x && off && dy && wpb && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
   DcnBwdArgs<T> a;
   // merged: off / goff are ONE tensor each, [P][2GK offsets | GK masks] (merged predictor output and its gradient)
@@ -2018,7 +2020,7 @@ static int dcn_bwd_impl(const T* x, const T* off, const T* msk, const T* dy, con
   {
     // register-fed kernel (default): the non-deterministic fixed-point scatter on the shapes it is built for
     const DcnBwd2Plan q = dcn_bwd2_plan(C, Co, G, kh, kw, stride, dil, (int)sizeof(T));
-    if (q.ok && !gfix && dcn_bwd2_on((int)sizeof(T))) {
+    if (q.ok && !gfix && !general && dcn_bwd2_on((int)sizeof(T))) {
       // (32-bit byte offsets inside a frame, 24-bit row / column products; no fallback here: the callers sized `col` for this kernel)
       FAMI_REQUIRE((long)H * W * C * sizeof(T) < (1L << 32) && (long)W * C * sizeof(T) < (1L << 24), nm, "frame too large");
       DcnBwd2Args<T> n;
@@ -2094,7 +2096,7 @@ static int dcn_bwd_det_impl(const T* x, const T* off, const T* msk, const T* dy,
   const long n = (long)B * H * W * C;
   long long* gfix = gx ? reinterpret_cast<long long*>(ws) : nullptr;
   unsigned* amax = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + n * 8);
-  if (!gx) return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, nullptr, nullptr, merged);
+  if (!gx) return dcn_bwd_impl<T>(x, off, msk, dy, wpb, col, nullptr, goff, gmsk, B, H, W, C, Co, G, kh, kw, stride, pad, dil, acc_off, s, nm, nullptr, nullptr, merged, true);      // (no input gradient: nothing order-dependent is left, but `col` keeps the deterministic mode's layout)
   const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
   hipLaunchKernelGGL(zero_u64_kernel, dim3(fami_ew_grid(n)), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(gfix), n, amax);
   FAMI_CHECK_LAUNCH(nm);

@@ -3412,6 +3412,10 @@ static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, 
   return FAMI_OK;
 }
 
+// conv_pair.hip
+#include "conv_pair.h"
+int fami_pair_launch(const PairCapture& c, hipStream_t s);
+
 // conv_stem.hip: the stem's 3 -> 64 stride-2 convolution with K dense over (tap, channel)
 int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,
                         int kh, int kw, int stride, int pad, int dil, int NTt, int relu, int accumulate, int out_f32, hipStream_t s,
@@ -3628,8 +3632,49 @@ long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
     return conv_dgrad_h_impl<HT>("fami_conv2d_dgrad_bnstats_" #sfx, dy, wp, dx, N, H, W, Ci, Co, kh, kw, stride, pad,  \
                                  dil, accumulate, s, e);                                                               \
   }
+/* conv_pair.h: input gradient (optionally with the backward-statistics epilogue of fami_conv2d_dgrad_bnstats_*: slots != NULL)   */
+/* and deferred weight gradient of one 3x3 stride-1 convolution as ONE launch where a combined instance exists (ask            */
+/* fami_conv2d_bwd_pair_ok), as the two single launches otherwise.  Results are bitwise those of the two-call form.            */
+#define FAMI_CONV_PAIR_ABI(sfx, HT)                                                                                    \
+  int fami_conv2d_bwd_pair_##sfx(const HT* x, const HT* dy, const HT* wpd, HT* dx, float* dw, float* workspace,        \
+                                 long ws_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride,       \
+                                 int pad, int dil, int acc_dx, int acc_dw, long* desc_out, const HT* z,                \
+                                 const HT* yrelu, const float* mean, const float* invstd, const float* gamma,          \
+                                 const float* beta, int relu, void* slots, hipStream_t s) {                            \
+    static const char* nm = "fami_conv2d_bwd_pair_" #sfx;                                                              \
+    FAMI_REQUIRE(desc_out, nm, "null descriptor");                                                                     \
+    EpiBN e = epi_none();                                                                                              \
+    if (slots) {                                                                                                       \
+      FAMI_REQUIRE(z && mean && invstd && gamma && beta && (relu != 1 || yrelu) && relu >= 0 && relu <= 2, nm,         \
+                   "bad argument");                                                                                    \
+      e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Ci); e.mode = 2; e.relu = relu; e.C = Ci;            \
+      e.z = z; e.yr = yrelu; e.mean = mean; e.invstd = invstd; e.gamma = gamma; e.beta = beta;                         \
+    }                                                                                                                  \
+    PairCapture pc;                                                                                                    \
+    pc.a.kind = pc.b.kind = 0;                                                                                         \
+    ReduceDesc d;                                                                                                      \
+    d.part = nullptr;                                                                                                  \
+    fami_pair_capture() = &pc;                                                                                         \
+    int rc = conv_dgrad_h_impl<HT>(nm, dy, wpd, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil, acc_dx, s, e);          \
+    if (rc == FAMI_OK) {                                                                                               \
+      g_defer = &d;                                                                                                    \
+      rc = wgrad_h_impl<HT>(nm, x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, acc_dw, s); \
+      g_defer = nullptr;                                                                                               \
+    }                                                                                                                  \
+    fami_pair_capture() = nullptr;                                                                                     \
+    if (rc != FAMI_OK) return rc;                                                                                      \
+    FAMI_REQUIRE(d.part, nm, "no reduce recorded");                                                                    \
+    memcpy(desc_out, &d, sizeof(d));                                                                                   \
+    const int pr = fami_pair_launch(pc, s);                                                                            \
+    FAMI_REQUIRE(pr >= 0, nm, "a recorded launch has no kernel instance");                                             \
+    FAMI_CHECK_LAUNCH(nm);                                                                                             \
+    return FAMI_OK;                                                                                                    \
+  }
 FAMI_CONV_H_ABI(bf16, bf16_t)
 FAMI_CONV_H_ABI(f16, f16_t)
+FAMI_CONV_PAIR_ABI(bf16, bf16_t)
+FAMI_CONV_PAIR_ABI(f16, f16_t)
 #undef FAMI_CONV_H_ABI
+#undef FAMI_CONV_PAIR_ABI
 
 }  // extern "C"

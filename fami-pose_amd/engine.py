@@ -266,6 +266,10 @@ class Engine:
         # 16 at a time per stream (fami_wgrad_reduce_batch) at the joins / bucket boundaries / the end of backward --
         # 303 tiny launches per step otherwise sit between every weight gradient and the next kernel of its lane
         self.defer_reduce = options.flag('FAMI_DEFER_REDUCE', '1')
+        # a 3x3 stride-1 convolution's input gradient and weight gradient as one launch (16-bit storage; csrc/conv_pair.h):
+        # 0 off | 1 where the weight gradient would run on the convolution's own lane | 2 also inside the weight-gradient-stream scopes
+        self.bwd_pair = options.number('FAMI_BWD_PAIR', '2') if self.half else 0
+        self.npair = 0                 # combined launches enqueued this step (tests / reporting)
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
         self._red_longs = self.Q.fami_wgrad_reduce_desc_longs()
@@ -533,6 +537,25 @@ class Engine:
                        *[_p(t) for t in xbn])
         else:
             self.acall('fami_conv2d_wgrad_defer', _p(x_data), _p(dy), _p(g), _p(ws), ws.numel() * 4, *geo, acc, desc)
+        self._red.setdefault(st, []).append(desc)
+        dws.add(g.data_ptr())
+        if len(self._red[st]) >= 16:
+            self.flush_reduces(st)
+
+    def wgrad_pair(self, x_data, dy, wpd, gx, accx, g, accw, geo, stats):
+        """Input gradient (stats: the arguments of the backward-statistics epilogue, or None) and weight gradient of a 3x3 stride-1
+        convolution in one launch; the weight gradient's slab reduce is deferred as in wgrad()."""
+        ws = self.ws(self.Q.fami_conv2d_wgrad_workspace(*geo))
+        st = self.stream
+        dws = self._red_dw.setdefault(st, set())
+        if g.data_ptr() in dws:
+            self.flush_reduces(st)
+            dws = self._red_dw.setdefault(st, set())
+        desc = (ctypes.c_long * self._red_longs)()
+        if stats is None:
+            stats = (None, None, None, None, None, None, 0, None)
+        self.acall('fami_conv2d_bwd_pair', _p(x_data), _p(dy), _p(wpd), _p(gx), _p(g), _p(ws), ws.numel() * 4, *geo, accx, accw, desc, *stats)
+        self.npair += 1
         self._red.setdefault(st, []).append(desc)
         dws.add(g.data_ptr())
         if len(self._red[st]) >= 16:
@@ -840,6 +863,15 @@ class Engine:
                 dy = out.grad
                 on_wl = (self.use_wlane or wl) and need_w
                 self.wlane_scope_now = bool(wl)
+                # input gradient + weight gradient as ONE launch (fami_conv2d_bwd_pair_*, csrc/conv_pair.h): the weight gradient is a
+                # leaf that otherwise sits between the input gradient and the next link of the chain on this lane
+                if (self.bwd_pair and self.half and x.requires_grad and self.rq(weight) and xb is None and self.defer_reduce
+                        and not _ABL_WGRAD and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1)
+                        and (self.bwd_pair == 2 or not on_wl) and self.Q.fami_conv2d_bwd_pair_ok(*geo)):
+                    do_x(pair=True)
+                    if self.rq(bias):
+                        do_bias()
+                    return
                 xfirst = self.dgrad_first == 1 or (self.dgrad_first == 2 and on_wl) or (self.dgrad_first == 3 and not on_wl)
                 if xfirst:
                     do_x()
@@ -850,15 +882,18 @@ class Engine:
                                None if xb is None else (xb['mean'], xb['invstd'], xb['bn'].weight.data, xb['bn'].bias.data))
                     self.conv_flops += flops
                 if self.rq(bias):
-                    g, acc = self.pgrad(bias)
-                    ws = self.ws(self.Q.fami_channel_sum_workspace(Co))
-                    self.acall('fami_channel_sum', _p(dy), N * Ho * Wo, Co, _p(g), acc, _p(ws))
+                    do_bias()
                 if saved is not None:
                     self.stream = saved
                 if not xfirst:
                     do_x()
 
-            def do_x():
+            def do_bias():
+                g, acc = self.pgrad(bias)
+                ws = self.ws(self.Q.fami_channel_sum_workspace(Co))
+                self.acall('fami_channel_sum', _p(out.grad), N * Ho * Wo, Co, _p(g), acc, _p(ws))
+
+            def do_x(pair=False):
                 dy = out.grad
                 if x.requires_grad:
                     self.conv_flops += flops
@@ -870,16 +905,22 @@ class Engine:
                         kind = self.Q.fami_conv_t6_eligible(N, Ho, Wo, Co, Ci)
                         t7 = self.fuse_bn_bwd_t7
                         pays = kind == 1 or ((kind == 2 or (kind == 3 and (self.fuse_bn_c64 & 2))) and (t7 == 2 or (t7 == 1 and not acc and rec['rmode'] != 1)))
+                    stats = None
                     if (rec is not None and (self.fuse_bn_bwd or fuse_here or pays) and x.uses == 0 and not x.nofuse and x.lanes is not None
                             and len(x.lanes) == 1 and not x.f32grad):
                         # x is the output of a train-mode BatchNorm and this is the last contribution to its gradient:
                         # the epilogue applies the ReLU mask and takes the two sums of the BatchNorm backward
                         slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Ci))
-                        self.acall('fami_conv2d_dgrad_bnstats', _p(dy), _p(wpd), _p(gx), *geo, acc, _p(rec['z']),
-                                   _p(rec['y'] if rec['rmode'] == 1 else None), _p(rec['mean']), _p(rec['invstd']),
-                                   _p(rec['gamma']), _p(rec['beta']), rec['rmode'], _p(slots))
+                        stats = (_p(rec['z']), _p(rec['y'] if rec['rmode'] == 1 else None), _p(rec['mean']), _p(rec['invstd']),
+                                 _p(rec['gamma']), _p(rec['beta']), rec['rmode'], _p(slots))
                         rec['pre_bwd'] = slots
                         self.nfused['bwd'] += 1
+                    if pair:
+                        gw, accw = self.pgrad(weight)
+                        self.conv_flops += flops
+                        self.wgrad_pair(x.data, dy, wpd, gx, acc, gw, accw, geo, stats)
+                    elif stats is not None:
+                        self.acall('fami_conv2d_dgrad_bnstats', _p(dy), _p(wpd), _p(gx), *geo, acc, *stats)
                     elif self.half:
                         self.acall('fami_conv2d_dgrad', _p(dy), _p(wpd), _p(gx), *geo, acc)
                     else:

@@ -189,6 +189,14 @@ int fami_bn_is_small(long P, int C);
  * and apply scale / shift / ReLU while they stage it into LDS.  fami_conv2d_xbn_ok: can a 3x3 stride-1 pad-1 convolution of
  * this shape do that (both kernels eligible)? */
 int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co);
+/* Backward of a 3x3 stride-1 pad-1 convolution as ONE launch (16-bit modes; nn.Conv2d autograd of basic_model.py:44-63):
+ * the input gradient (fami_conv2d_dgrad_* / fami_conv2d_dgrad_bnstats_* when slots != NULL) and the deferred weight gradient
+ * (fami_conv2d_wgrad_defer_*) read the same dY and nothing of each other; fami_conv2d_bwd_pair_* runs the two kernels' bodies
+ * side by side in one grid (weight-gradient workgroups first).  Bitwise the two-call form; where no combined instance exists
+ * the two single launches run.  fami_conv2d_bwd_pair_ok: does a combined instance take this geometry (forward geometry)?
+ * fami_conv2d_bwd_pair_key: the kernel instances of the two halves (tools / tests; out[9]). */
+int fami_conv2d_bwd_pair_ok(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int fami_conv2d_bwd_pair_key(int N, int H, int W, int Ci, int Co, int* out);
 /* the same in f32 storage (the split-product kernels; FAMI_XBN=1) */
 int fami_conv2d_xbn_ok_f32(int N, int H, int W, int Ci, int Co);
 int fami_conv2d_fwd_xbn_f32(const float* z, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci,
@@ -421,6 +429,11 @@ int fami_conv2d_dgrad_bnstats_bf16(const fami_bf16_t* dy, const fami_bf16_t* wp,
                                    int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                                    const fami_bf16_t* z, const fami_bf16_t* yrelu, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, int relu, void* slots, fami_stream_t stream);
+int fami_conv2d_bwd_pair_bf16(const fami_bf16_t* x, const fami_bf16_t* dy, const fami_bf16_t* wpd, fami_bf16_t* dx, float* dw, float* workspace,
+                              long ws_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                              int dil, int acc_dx, int acc_dw, long* desc_out, const fami_bf16_t* z, const fami_bf16_t* yrelu,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                              void* slots, fami_stream_t stream);
 int fami_bn_apply_slots_bf16(const fami_bf16_t* x, const fami_bf16_t* residual, fami_bf16_t* y, const float* gamma,
                              const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
                              long P, int C, int relu, float momentum, float eps, void* slots, fami_stream_t stream);
@@ -541,6 +554,11 @@ int fami_conv2d_dgrad_bnstats_f16(const fami_f16_t* dy, const fami_f16_t* wp, fa
                                    int Co, int kh, int kw, int stride, int pad, int dil, int accumulate,
                                    const fami_f16_t* z, const fami_f16_t* yrelu, const float* mean, const float* invstd,
                                    const float* gamma, const float* beta, int relu, void* slots, fami_stream_t stream);
+int fami_conv2d_bwd_pair_f16(const fami_f16_t* x, const fami_f16_t* dy, const fami_f16_t* wpd, fami_f16_t* dx, float* dw, float* workspace,
+                              long ws_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                              int dil, int acc_dx, int acc_dw, long* desc_out, const fami_f16_t* z, const fami_f16_t* yrelu,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                              void* slots, fami_stream_t stream);
 int fami_bn_apply_slots_f16(const fami_f16_t* x, const fami_f16_t* residual, fami_f16_t* y, const float* gamma,
                              const float* beta, float* mean, float* invstd, float* running_mean, float* running_var,
                              long P, int C, int relu, float momentum, float eps, void* slots, fami_stream_t stream);

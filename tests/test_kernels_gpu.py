@@ -906,6 +906,45 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
             lib().cdll.fami_dcn_tune(-1)
 
 
+@pytest.mark.parametrize("dt", ['f32', 'bf16'])
+def test_dcn_deterministic_backward_without_an_input_gradient(dev, dt):
+    """Engine.dcn in deterministic mode with x.requires_grad False and a trainable weight (round-5 advisor finding): the C entry
+    point used to route this case to the register-fed kernel, whose column buffer is wider (480 > 432 columns in f32: an
+    out-of-bounds write) and permuted, while fami_dcn_bwd_col_width / _col_permuted(deterministic = 1) describe the general
+    kernel's.  dW, the offset and mask gradients against the oracle; two runs bit for bit."""
+    from oracle import ops as O
+    from fami_pose_amd.engine import Engine, T
+    B, C, G, H, W = 2, 48, 12, 20, 13
+    torch.manual_seed(12)
+    dtype = torch.float32 if dt == 'f32' else torch.bfloat16
+    rb = lambda t: t.to(dtype).float()
+    x = rb(torch.randn(B, C, H, W))
+    off = rb(torch.randn(B, 18 * G, H, W) * 2.0).requires_grad_(True)
+    msk = rb(torch.randn(B, 9 * G, H, W)).requires_grad_(True)
+    w = (torch.randn(C, C, 3, 3) * 0.1).requires_grad_(True)
+    y = O.deform_conv2d(x, off, msk, w, None, 1, 3, 3)
+    g = rb(torch.randn_like(y))
+    y.backward(g)
+    runs = []
+    for _ in range(2):
+        eng = Engine(dev, dtype=dtype, deterministic=True)
+        wd, bd = nn.Parameter(w.detach().to(dev)), nn.Parameter(torch.zeros(C, device=dev))
+        xt = T(nhwc(x).to(dev).to(dtype), False)
+        ot = T(nhwc(off.detach()).to(dev).to(dtype), True)
+        mt = T(nhwc(msk.detach()).to(dev).to(dtype), True)
+        yt = eng.dcn(xt, ot, mt, wd, bd, G, 3, 3)
+        yt.grad = nhwc(g).to(dev).to(dtype)
+        eng.backward()
+        torch.cuda.synchronize(dev)
+        runs.append((eng.param_grads[id(wd)].clone(), ot.grad.clone(), mt.grad.clone()))
+        assert xt.grad is None
+    tol_w, tol_a = (5e-5, 5e-5) if dt == 'f32' else (2e-3, 1e-2)
+    assert relerr(runs[0][0], w.grad) < tol_w, relerr(runs[0][0], w.grad)
+    assert relerr(nchw(runs[0][1]), off.grad) < tol_a and relerr(nchw(runs[0][2]), msk.grad) < tol_a
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [(20, 96, 72, 48, 48), (3, 48, 36, 96, 96), (2, 24, 18, 192, 192), (2, 12, 9, 384, 384),
                                    (2, 33, 21, 64, 64), (2, 16, 12, 256, 48), (1, 5, 7, 20, 48), (2, 40, 30, 8, 128)],
                          ids=lambda s: "x".join(map(str, s)))

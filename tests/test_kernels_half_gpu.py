@@ -526,3 +526,82 @@ def test_stem_conv1_weight_gradient(dev, half):
             assert relerr(out[25001], out[25000].double()) < 3e-6
     finally:
         L.cdll.fami_conv_tune_wgrad_lds(-1)
+
+
+def test_backward_pair_is_bitwise_the_two_launch_form(dev, half):
+    """fami_conv2d_bwd_pair_* (csrc/conv_pair.h, round 6): the input gradient (plain / with the backward-statistics epilogue, fresh /
+    accumulating) and the deferred weight gradient of a 3x3 stride-1 convolution as ONE launch.  The combined kernel runs the two
+    single kernels' bodies on disjoint workgroups, so every output -- dx, the fp64 statistics rows up to atomic order, dW after the
+    deferred reduce -- must equal the two-call form's; checked on every layer shape of PAIR_SHAPES, with the combined launch
+    switched off (the recorded halves replayed as single launches), with a different weight-gradient workgroup target for the
+    combined launch, and on a shape no combined instance takes."""
+    import ctypes
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    nlong = L.cdll.fami_wgrad_reduce_desc_longs()
+    shapes = [(20, 96, 72, 48, 48, 1), (4, 96, 72, 48, 48, 1), (4, 96, 72, 96, 48, 1), (20, 48, 36, 96, 96, 1), (20, 24, 18, 192, 192, 1), (24, 24, 18, 192, 192, 1),
+              (20, 12, 9, 384, 384, 1), (20, 96, 72, 64, 64, 1), (20, 48, 36, 128, 128, 1), (20, 24, 18, 256, 256, 1), (20, 12, 9, 512, 512, 1),
+              (2, 32, 24, 48, 48, 0), (8, 128, 96, 48, 48, 0)]
+    try:
+        for it, (N, H, W, Ci, Co, want_pair) in enumerate(shapes):
+            torch.manual_seed(100 + it)
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            L.cdll.fami_tune_reset()
+            assert L.cdll.fami_conv2d_bwd_pair_ok(*geo) == want_pair, geo
+            x = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dy = (torch.randn(N, H, W, Co, device=dev) * 0.1).to(BF)
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.05
+            wpd = torch.empty(getattr(L.cdll, 'fami_packed_weight_elems' + sfx)(Co, Ci, 3, 3, 1), device=dev, dtype=BF)
+            L.call('fami_pack_conv_weight' + sfx, p(w), p(wpd), Co, Ci, 3, 3, 1, st)
+            z = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            mean, invstd = torch.randn(Ci, device=dev) * 0.2, torch.rand(Ci, device=dev) + 0.5
+            gamma, beta = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+            sc = invstd * gamma
+            ybn = torch.relu(torch.addcmul(torch.addcmul(beta, -mean, sc), z.float(), sc)).to(BF)
+            dx0 = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            dw0 = torch.randn(Co, Ci, 3, 3, device=dev)
+            variants = [(0, 0, 0), (1, 1, 0), (0, 0, 2), (1, 1, 1), (0, 1, 2)] if want_pair else [(0, 0, 0), (1, 1, 2)]
+            for (accx, accw, rmode) in variants:          # rmode 0: no statistics epilogue
+                res = {}
+                for form in ('two', 'pair', 'pair_off', 'pair_tgt'):
+                    L.cdll.fami_tune_reset()
+                    if form == 'pair_off':
+                        L.cdll.fami_conv_tune_lds(8998)
+                    if form == 'pair_tgt':
+                        L.cdll.fami_conv_tune_wgrad_lds(27000 + 136)
+                    ws = torch.empty(L.cdll.fami_conv2d_wgrad_workspace(*geo) // 4 + 4, device=dev)
+                    dx = dx0.clone() if accx else torch.empty(N, H, W, Ci, device=dev, dtype=BF)
+                    dw = dw0.clone() if accw else torch.empty(Co, Ci, 3, 3, device=dev)
+                    slots = torch.zeros(L.cdll.fami_bn_slots_bytes(Ci) // 8, device=dev, dtype=torch.float64) if rmode else None
+                    bn = (p(z), p(ybn if rmode == 1 else None), p(mean), p(invstd), p(gamma), p(beta), rmode, p(slots))
+                    desc = (ctypes.c_long * nlong)()
+                    if form == 'two':
+                        if rmode:
+                            L.call('fami_conv2d_dgrad_bnstats' + sfx, p(dy), p(wpd), p(dx), *geo, accx, *bn, st)
+                        else:
+                            L.call('fami_conv2d_dgrad' + sfx, p(dy), p(wpd), p(dx), *geo, accx, st)
+                        L.call('fami_conv2d_wgrad_defer' + sfx, p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, accw, desc, st)
+                    else:
+                        L.call('fami_conv2d_bwd_pair' + sfx, p(x), p(dy), p(wpd), p(dx), p(dw), p(ws), ws.numel() * 4, *geo, accx, accw, desc,
+                               *(bn if rmode else (None, None, None, None, None, None, 0, None)), st)
+                    L.call('fami_wgrad_reduce_batch', desc, 1, st)
+                    torch.cuda.synchronize(dev)
+                    res[form] = (dx, dw, slots)
+                for form in ('pair', 'pair_off', 'pair_tgt'):
+                    assert torch.equal(res[form][0], res['two'][0]), (geo, accx, accw, rmode, form)
+                    if form == 'pair_tgt' and want_pair:      # another split of the pixels over workgroups: fp32 summation order differs
+                        assert relerr(res[form][1], res['two'][1]) < 1e-5, (geo, form)
+                    else:
+                        assert torch.equal(res[form][1], res['two'][1]), (geo, accx, accw, rmode, form)
+                    if rmode:
+                        ns_rows = res[form][2][:8 * 2 * Ci].view(8, 2, Ci).sum(0)
+                        assert relerr(ns_rows, res['two'][2][:8 * 2 * Ci].view(8, 2, Ci).sum(0)) < 1e-5, (geo, form)      # (the phased kernel adds its sums with LDS float atomics: wave order)
+            # ... and against fp64 once per shape (the two-launch form has its own tests; this guards the test itself)
+            wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+            assert relerr(res['pair'][1] - (dw0 if variants[-1][1] else 0), wref.grad) < F32_TOL, geo
+    finally:
+        L.cdll.fami_tune_reset()
