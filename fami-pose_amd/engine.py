@@ -273,6 +273,7 @@ class Engine:
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
         self._red_longs = self.Q.fami_wgrad_reduce_desc_longs()
+        self.abl_lanes = options.number('FAMI_ABL_LANES', '0')   # upper-bound experiment (WRONG results): bit i = no launches on stream lane i
         self.abl_bn1 = options.number('FAMI_ABL_BN1', '0')      # upper-bound experiment, see the comment at the top of the file
         self.sync_stream()
         self._zero_begin()
@@ -512,6 +513,8 @@ class Engine:
         return True
 
     def call(self, name, *args):
+        if self.abl_lanes and (self.abl_lanes >> min(self.lane, 7)) & 1:
+            return
         self.L.call_routed(self.route, name, *args, self.stream)
 
     # ------------------------------------------------------------------ weight gradients with deferred slab reduces
@@ -588,6 +591,8 @@ class Engine:
 
     def acall(self, name, *args):
         """Call the activation-dtype instance of an entry point."""
+        if self.abl_lanes and (self.abl_lanes >> min(self.lane, 7)) & 1:
+            return
         self.L.call_routed(self.route, name + self.sfx, *args, self.stream)
 
     def new_grad(self, t):

@@ -22,6 +22,7 @@ SWITCHES = {
     'FAMI_STEM_WGRAD_LANE': ('1', 'the same for stem / layer1 / transitions (round 5: on in f32 too, -0.3 ... -0.5 %)'),
     'FAMI_HEAD_WGRAD_LANES': ('4', 'number of weight-gradient streams of the head (taken in turn)'),
     'FAMI_STEM_WGRAD_LANES': ('4', 'number of weight-gradient streams of that stretch (taken in turn)'),
+    'FAMI_LANE_PRIO': ('0', 'probe: 1 = the capture stream (lane 0: the critical path) is a high-priority stream'),
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
@@ -58,9 +59,10 @@ SWITCHES = {
     'FAMI_ABL_WGRAD': ('0', 'upper bound: no weight-gradient kernels at all'),
     'FAMI_ABL_REGTAIL': ('0', 'upper bound: the translation regressor stops after its first n - 1 stride-2 stages (n = 2: what a fused tail kernel could save)'),
     'FAMI_ABL_PACK': ('0', 'upper bound: the 16-bit / fragment weight images are packed in the first step only (what packing inside the optimizer could save)'),
+    'FAMI_ABL_LANES': ('0', 'critical-path probe: bit i = every launch enqueued on stream lane i is skipped (what the step costs without that branch)'),
     'FAMI_ABL_BN1': ('0', 'upper bound: bit 1 no apply pass / bit 2 no backward of every conv1 -> bn1 -> ReLU -> conv2 BatchNorm'),
 }
-WRONG = ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_BN1', 'FAMI_ABL_REGTAIL', 'FAMI_ABL_PACK')      # produce wrong results by design
+WRONG = ('FAMI_T5_ABL', 'FAMI_ABL_WGRAD', 'FAMI_ABL_LANES', 'FAMI_ABL_BN1', 'FAMI_ABL_REGTAIL', 'FAMI_ABL_PACK')      # produce wrong results by design
 
 
 def get(name, default=None):
@@ -71,6 +73,10 @@ def get(name, default=None):
     if v is None or v == '':
         reg = SWITCHES[name][0]
         return default if (default is not None or reg is None) else reg
+    if name in WRONG and v != '0' and os.environ.get('FAMI_ALLOW_WRONG') != '1':
+        # checked at every read (the values are not cached: a tool may set one between two Trainers of a process)
+        raise RuntimeError('%s set: this switch skips work and produces WRONG results (measurement ablation only); '
+                           'set FAMI_ALLOW_WRONG=1 to run it on purpose' % name)
     return v
 
 

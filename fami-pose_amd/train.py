@@ -712,7 +712,10 @@ class Trainer:
         torch.cuda.synchronize(self.dev)
         if not self.ddp:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # FAMI_LANE_PRIO=1 (probe): lane 0 -- the capture stream: stem, branch 0, head, the step's critical path -- is a
+            # high-priority stream, the side lanes stay at the default priority
+            cap = torch.cuda.Stream(self.dev, priority=-1) if options.number('FAMI_LANE_PRIO', '0') else None
+            with torch.cuda.graph(g, stream=cap):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], fused_opt=True)
                 self._opt_step()
             plan = [('graph', g)]

@@ -221,3 +221,22 @@ def test_every_environment_switch_goes_through_the_one_parser():
     assert len(doc) >= len(names) - 1
     wrong = {n: (getattr(r, n), v) for n, v in doc.items() if getattr(r, n) != v}
     assert not wrong, wrong
+
+
+def test_ablation_switches_are_refused_at_every_read(monkeypatch):
+    """The WRONG-by-design ablation switches (options.WRONG) raise whenever they are READ without FAMI_ALLOW_WRONG=1 -- not only
+    when the library loads: their values are read per Engine / Trainer, so one set later in a process must not slip through."""
+    from fami_pose_amd import options
+    for name in options.WRONG:
+        monkeypatch.setenv(name, '1')
+        monkeypatch.delenv('FAMI_ALLOW_WRONG', raising=False)
+        with pytest.raises(RuntimeError):
+            options.get(name)
+        with pytest.raises(RuntimeError):
+            options.flag(name)
+        monkeypatch.setenv('FAMI_ALLOW_WRONG', '1')
+        assert options.flag(name)
+        monkeypatch.setenv(name, '0')
+        monkeypatch.delenv('FAMI_ALLOW_WRONG', raising=False)
+        assert not options.flag(name)
+        monkeypatch.delenv(name)

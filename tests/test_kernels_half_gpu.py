@@ -568,10 +568,10 @@ def test_backward_pair_is_bitwise_the_two_launch_form(dev, half):
                 res = {}
                 for form in ('two', 'pair', 'pair_off', 'pair_tgt'):
                     L.cdll.fami_tune_reset()
+                    # (27000: the weight-gradient half keeps the single launch's workgroup target -> the same pixel split, the same sums)
+                    L.cdll.fami_conv_tune_wgrad_lds(27000 if form != 'pair_tgt' else 27000 + 136)
                     if form == 'pair_off':
                         L.cdll.fami_conv_tune_lds(8998)
-                    if form == 'pair_tgt':
-                        L.cdll.fami_conv_tune_wgrad_lds(27000 + 136)
                     ws = torch.empty(L.cdll.fami_conv2d_wgrad_workspace(*geo) // 4 + 4, device=dev)
                     dx = dx0.clone() if accx else torch.empty(N, H, W, Ci, device=dev, dtype=BF)
                     dw = dw0.clone() if accw else torch.empty(Co, Ci, 3, 3, device=dev)
@@ -599,9 +599,19 @@ def test_backward_pair_is_bitwise_the_two_launch_form(dev, half):
                     if rmode:
                         ns_rows = res[form][2][:8 * 2 * Ci].view(8, 2, Ci).sum(0)
                         assert relerr(ns_rows, res['two'][2][:8 * 2 * Ci].view(8, 2, Ci).sum(0)) < 1e-5, (geo, form)      # (the phased kernel adds its sums with LDS float atomics: wave order)
+            # the library's default target for the combined launch (another pixel split: fp32 summation order differs)
+            L.cdll.fami_tune_reset()
+            ws = torch.empty(L.cdll.fami_conv2d_wgrad_workspace(*geo) // 4 + 4, device=dev)
+            dxd, dwd = torch.empty(N, H, W, Ci, device=dev, dtype=BF), torch.empty(Co, Ci, 3, 3, device=dev)
+            desc = (ctypes.c_long * nlong)()
+            L.call('fami_conv2d_bwd_pair' + sfx, p(x), p(dy), p(wpd), p(dxd), p(dwd), p(ws), ws.numel() * 4, *geo, 0, 0, desc,
+                   None, None, None, None, None, None, 0, None, st)
+            L.call('fami_wgrad_reduce_batch', desc, 1, st)
+            torch.cuda.synchronize(dev)
             # ... and against fp64 once per shape (the two-launch form has its own tests; this guards the test itself)
             wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
             F.conv2d(x.double().permute(0, 3, 1, 2), wref, padding=1).backward(dy.double().permute(0, 3, 1, 2))
             assert relerr(res['pair'][1] - (dw0 if variants[-1][1] else 0), wref.grad) < F32_TOL, geo
+            assert relerr(dwd, wref.grad) < F32_TOL, geo
     finally:
         L.cdll.fami_tune_reset()

@@ -332,6 +332,53 @@ def test_bench_workload_train_step_matches_the_oracle(dev):
     assert torch.equal(te.flat, tg_.flat) and torch.equal(te.opt.m, tg_.opt.m) and torch.equal(te.opt.v, tg_.opt.v)
 
 
+def test_config2_train_step_as_stated_matches_the_oracle(dev):
+    """BASELINE config 2 AS STATED -- HRNet-W48, 384x288, 3-frame clips (S = 2, the generalised head), batch 8, fp32, train mode
+    (batch statistics over 24 frames): one Trainer.step against the CPU oracle + torch.optim.Adam on the same inputs -- heatmaps
+    <= 1e-3 absolute, argmax keypoint indices bit-exact, loss to 1e-4 relative, the output layer's gradient to 1e-3 of its
+    maximum and its Adam update to 1e-5, the stem BatchNorm's running mean to 1e-5 (round-5 review: the 141 clips/s record of
+    this config was guarded by a finite-loss check alone)."""
+    from fami_pose_amd.train import Trainer
+    Sx, Hx, Wx, Bx = 2, 384, 288, 8
+    orc = om.realistic_init_(om.AlignmentOracle(om.make_cfg(48), True, Sx, (Hx, Wx)), 37)
+    gen = torch.Generator().manual_seed(19970808 + 2)
+    kf, sup = torch.randn(Bx, 3, Hx, Wx, generator=gen), torch.randn(Bx, 3 * Sx, Hx, Wx, generator=gen)
+    joints = torch.rand(Bx, 17, 2, generator=gen) * torch.tensor([Wx, Hx], dtype=torch.float32)
+    vis = (torch.rand(Bx, 17, generator=gen) < 0.8).float()
+    tg = np.zeros((Bx, 17, Hx // 4, Wx // 4), np.float32)
+    tw = np.zeros((Bx, 17, 1), np.float32)
+    for b in range(Bx):
+        j3 = np.concatenate([joints[b].numpy(), np.zeros((17, 1), np.float32)], 1)
+        v3 = np.repeat(vis[b].numpy()[:, None], 3, 1)
+        tg[b], tw[b] = oops.generate_heatmaps(j3, v3, 3, np.array([Wx, Hx]), np.array([Wx // 4, Hx // 4]), 17)
+    m = fp.build_model(fp.default_cfg(48, image_size=(Wx, Hx), num_sup=Sx), 'train')
+    m.load_state_dict(orc.state_dict())
+    opt = torch.optim.Adam(orc.parameters(), lr=1e-3)
+    opt.zero_grad()
+    f0, k0, mi0 = orc(kf, sup)
+    l0t = oops.total_loss(f0, torch.from_numpy(tg), torch.from_numpy(tw), mi0)
+    l0t.backward()
+    g_ref = orc.agg_final_layer.weight.grad.clone()
+    p_before = orc.agg_final_layer.weight.data.clone()
+    opt.step()
+    f0, k0 = f0.detach(), k0.detach()
+
+    tr = Trainer(m.to(dev), lr=1e-3, use_graph=False, targets_from_joints=True)
+    outs = tr.step(*(t.to(dev) for t in (kf, sup, joints, vis)))
+    final, kf_hm = outs[0].cpu(), outs[1].cpu()
+    assert (final - f0).abs().max().item() < 1e-3 and (kf_hm - k0).abs().max().item() < 1e-3
+    am = lambda t: t.reshape(Bx, 17, -1).argmax(2).numpy()
+    assert np.array_equal(am(final), am(f0)) and np.array_equal(am(kf_hm), am(k0))
+    assert tr.loss_value() == pytest.approx(l0t.item(), rel=1e-4)
+    g1 = tr.views[id(m.agg_final_layer.weight)].cpu()
+    assert ((g1 - g_ref).abs().max() / g_ref.abs().max()).item() < 1e-3
+    big = g_ref.abs() > 1e-3 * g_ref.abs().max()      # Adam's first step is lr * g / (|g| + eps): compare above the noise floor
+    upd0 = orc.agg_final_layer.weight.data - p_before
+    upd1 = m.agg_final_layer.weight.data.cpu() - p_before
+    assert (upd1 - upd0)[big].abs().max().item() < 1e-5
+    assert (orc.hrnet.bn1.running_mean - m.hrnet.bn1.running_mean.cpu()).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 def test_merged_predictors_match_the_two_convolution_path(dev, mode, monkeypatch):
     """The offset and the mask predictor of every DCN layer (Alignment_V15.py:79-100, both applied to the same tensor at :144-158)
