@@ -884,7 +884,7 @@ int fami_try_wgrad16(int half_kind, const void* x, const void* dy, float* part, 
 // benchmarks / tests: 0 / 1 off / on, 2 / 3: only the 3x3 stride-1 shapes / every covered geometry, 100 + bt forces the
 // tiles per run, 1000 + n the workgroup target, < 0 defaults
 void fami_wgrad16_tune(int on) {
-  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_dil = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg6_target_c4 = 160; g_wg1 = 1; g_wg1_target = 192; g_pair_wg6_target = 48; }
+  if (on < 0) { g_wg16 = 1; g_wg16_abl = 0; g_wg16_bt = 0; g_wg16_target = 0; g_wg16_general = 1; g_wg16_bt18 = 0; g_wg6 = 1; g_wg6_c4 = 1; g_wg6_c42 = 1; g_wg6_s2 = 1; g_wg6_dil = 1; g_wgs = 1; g_wg6_nu = 0; g_wg6_target = 80; g_wg6_target_c4 = 160; g_wg1 = 1; g_wg1_target = 192; g_pair_wg6_target = 64; }
   else if (on >= 7000 && on < 8000) g_pair_wg6_target = on - 7000;  // (27000 + workgroup target of the weight-gradient half of a combined launch, conv_pair.hip; 0: the targets below)
   else if (on >= 6000 && on < 7000) g_wg6_target_c4 = on - 6000;  // (26000 + workgroup target of the launches with 64-channel blocks; 0: the common target)
   else if (on == 4000 || on == 4001) g_wg1 = on - 4000;           // (fami_conv_tune_wgrad_lds(24000 / 24001): the DMA-staged wide 1x1 kernel off / on)

@@ -268,7 +268,7 @@ class Engine:
         self.defer_reduce = options.flag('FAMI_DEFER_REDUCE', '1')
         # a 3x3 stride-1 convolution's input gradient and weight gradient as one launch (16-bit storage; csrc/conv_pair.h):
         # 0 off | 1 where the weight gradient would run on the convolution's own lane | 2 also inside the weight-gradient-stream scopes
-        self.bwd_pair = options.number('FAMI_BWD_PAIR', '2') if self.half else 0
+        self.bwd_pair = options.number('FAMI_BWD_PAIR', '1') if self.half else 0
         self.npair = 0                 # combined launches enqueued this step (tests / reporting)
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}

@@ -35,7 +35,7 @@ SWITCHES = {
     'FAMI_SERIAL_FUSE': ('0', 'backward statistics fusion on the serial stem / layer1 stretch only (measured neutral)'),
     'FAMI_CONCAT_ONE': ('1', 'torch.cat of up to four maps, and its backward, in one launch each'),
     'FAMI_MERGE_PREDICTORS': ('1', 'offset + mask predictor of a DCN layer as one 48 -> 324 convolution (needs the Trainer arena)'),
-    'FAMI_BWD_PAIR': ('2', 'input gradient + weight gradient of a 3x3 stride-1 convolution (16-bit storage) as ONE launch: 0 off | 1 outside the weight-gradient-stream scopes | 2 everywhere'),
+    'FAMI_BWD_PAIR': ('1', 'input gradient + weight gradient of a 3x3 stride-1 convolution (16-bit storage) as ONE launch: 0 off | 1 outside the weight-gradient-stream scopes | 2 everywhere'),
     'FAMI_DEFER_REDUCE': ('1', 'weight-gradient slab reduces batched 16 per launch'),
     'FAMI_DETERMINISTIC': ('0', 'run-to-run reproducible kernels (fixed-point DCN input gradient, three-launch BatchNorm)'),
     # ---- train step (train.py)
