@@ -228,7 +228,9 @@ class Engine:
         self.fuse_bn_bwd_auto = self.bn2 and self.half and fz in ('auto', 'autoall', 'bwdauto')
         # ... and where the phased kernel (conv3x3_t7_kernel) takes it: 0 never, 1 (default) its non-accumulating launches with a
         # recomputed mask (-0.04 ms), 2 all of them (+0.12 ms: the accumulating variant spills)
-        self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '1')
+        # round 6 (the input gradient now shares its launch with the weight gradient, csrc/conv_pair.h): 2 -- bf16 step 18.36 -> 18.24 ms
+        # against 1 (tools/ab_env.py, one box), ~100 statistics launches fewer
+        self.fuse_bn_bwd_t7 = options.number('FAMI_FUSE_BN_T7', '2')
         # order of a convolution's two backward launches: input gradient (the chain's next link) before the weight gradient (a leaf)?
         # tools/ab_env.py, two runs on two boxes: f32 storage 45.80 -> 45.48 and 45.95 -> 45.63 ms with it (half of it each from the
         # lanes with / without a weight-gradient stream); bf16 20.21 -> 20.40 and 20.13 -> 20.19 / 20.25: f32 only.

@@ -27,7 +27,7 @@ SWITCHES = {
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
     'FAMI_FUSE_BN': ('auto', "BatchNorm statistics in the neighbouring convolutions' epilogues: auto (f32: forward everywhere; 16-bit: forward in the DMA-staged 3x3 kernels only + backward where the input gradient runs on one) | autoall (16-bit: forward everywhere) | 0 | fwd | fwd3 | bwd | bwdauto | 1"),
-    'FAMI_FUSE_BN_T7': ('1', 'which launches of the phased 16-bit kernel carry the backward statistics under auto: 0 | 1 | 2'),
+    'FAMI_FUSE_BN_T7': ('2', 'which launches of the phased 16-bit kernel carry the backward statistics under auto: 0 none | 1 the non-accumulating ones with a recomputed mask | 2 all'),
     'FAMI_FUSE_BN_SKIP': ('', "probe: convolution classes whose epilogue does not take the forward statistics ('1x1', 's2'; comma or + separated)"),
     'FAMI_FUSE_BN_C64': ('2', 'statistics in the epilogues of the 32-channel-phase kernel (layers of 64-multiple channels): bit 0 forward, bit 1 backward'),
     'FAMI_FUSE_TERM_BN2': ('1', 'fuse-term BatchNorm backward on the two-launch form'),
