@@ -24,6 +24,10 @@
 #include <string.h>
 
 #include "conv_epi.h"
+// conv_pair.hip
+#include "conv_pair.h"
+int fami_pair_launch(const PairCapture& c, hipStream_t s);
+
 
 struct ConvArgs {
   EpiBN e;              // read late (epi_late); `emode` below is the one field the top of the kernel looks at
@@ -3323,6 +3327,42 @@ int fami_conv2d_wgrad_defer_xbn_f32(const float* z, const float* dy, float* dw, 
   memcpy(desc_out, &d, sizeof(d));
   return FAMI_OK;
 }
+// conv_pair.h, f32 storage: the split-product input gradient (conv_t5.hip's persistent kernel) and the deferred split-product weight
+// gradient (conv_wgs3.hip) of a 3x3 stride-1 convolution as ONE launch where a combined instance exists (ask
+// fami_conv2d_bwd_pair_ok_f32), as the two single launches otherwise.  xmean != NULL: x is the input z of a BatchNorm + ReLU nobody
+// materialised (the weight gradient applies it while staging, as fami_conv2d_wgrad_defer_xbn_f32).  Bitwise the two-call form.
+int fami_conv2d_bwd_pair_f32(const float* x, const float* dy, const float* wpd, float* dx, float* dw, float* workspace,
+                             long ws_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                             int acc_dx, int acc_dw, long* desc_out, const float* xmean, const float* xinvstd,
+                             const float* xgamma, const float* xbeta, hipStream_t s) {
+  static const char* nm = "fami_conv2d_bwd_pair_f32";
+  FAMI_REQUIRE(desc_out, nm, "null descriptor");
+  XBN xb = xbn_none();
+  if (xmean) {
+    FAMI_REQUIRE(xinvstd && xgamma && xbeta, nm, "bad argument");
+    xb.on = 1; xb.C = Ci; xb.gamma = xgamma; xb.beta = xbeta; xb.mean = const_cast<float*>(xmean);
+    xb.invstd = const_cast<float*>(xinvstd);
+  }
+  PairCapture pc;
+  pc.a.kind = pc.b.kind = 0;
+  ReduceDesc d;
+  d.part = nullptr;
+  fami_pair_capture() = &pc;
+  int rc = conv_dgrad_f32_impl(nm, dy, wpd, nullptr, dx, N, H, W, Ci, Co, kh, kw, stride, pad, dil, acc_dx, epi_none(), s);
+  if (rc == FAMI_OK) {
+    g_defer = &d;
+    rc = wgrad_f32_entry(x, dy, dw, workspace, ws_bytes, N, H, W, Ci, Co, kh, kw, stride, pad, dil, acc_dw, s, xb);
+    g_defer = nullptr;
+  }
+  fami_pair_capture() = nullptr;
+  if (rc != FAMI_OK) return rc;
+  FAMI_REQUIRE(d.part, nm, "no reduce recorded");
+  memcpy(desc_out, &d, sizeof(d));
+  const int pr = fami_pair_launch(pc, s);
+  FAMI_REQUIRE(pr >= 0, nm, "a recorded launch has no kernel instance");
+  FAMI_CHECK_LAUNCH(nm);
+  return FAMI_OK;
+}
 // f32 storage: both split-product kernels (conv_t4.hip S3, conv_wgs3.hip) would take the shape
 int fami_conv2d_xbn_ok_f32(int N, int H, int W, int Ci, int Co) {
   return (g_use_lds != 0 && fami_conv_t4_eligible_s3(N, H, W, Ci, Co) && fami_wgrad_s3_slabs(N, H, W, Ci, Co) > 0) ? 1 : 0;
@@ -3411,10 +3451,6 @@ static int pack_conv_weight_h_impl(const char* nm, const float* w_oihw, HT* wp, 
   FAMI_CHECK_LAUNCH(nm);
   return FAMI_OK;
 }
-
-// conv_pair.hip
-#include "conv_pair.h"
-int fami_pair_launch(const PairCapture& c, hipStream_t s);
 
 // conv_stem.hip: the stem's 3 -> 64 stride-2 convolution with K dense over (tap, channel)
 int fami_try_conv_stem1(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int Co,

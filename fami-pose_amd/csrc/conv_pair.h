@@ -38,3 +38,7 @@ static inline void pair_record(PairHalf& h, int kind, int half_kind, const Args&
   h.gx = grid.x; h.gy = grid.y; h.lds = lds; h.slabs = 0;
   memcpy(h.args, &a, sizeof(Args));
 }
+// f32 storage (split-product kernels): only the persistent kernel's launches (conv_t5.hip: the 96x72 and 48x36 maps) are combined with
+// their weight gradient -- f32 step 44.54 -> 44.07 ms (tools/ab_env.py, one box).  With the band kernel's launches of the 24x18 / 12x9 maps
+// combined as well the gain was gone (44.35 -> 44.27 on another box): those launches are 160 long workgroups that run alone at the end
+// of a module, and 160 + 192 weight-gradient workgroups are two rounds of the chip.

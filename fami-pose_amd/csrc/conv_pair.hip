@@ -9,6 +9,8 @@
 // XCD-contiguous job order from.
 #include "conv_t6_dev.h"
 #include "conv_wg6_dev.h"
+#include "conv_t5_dev.h"
+#include "conv_wgs3_dev.h"
 #include "conv_pair.h"
 #include "route.h"
 
@@ -19,10 +21,15 @@ int fami_t6_pair_probe(int N, int H, int W, int Ci, int Co, int* v);
 int fami_wg6_pair_probe(int N, int H, int W, int Ci, int Co, int k, int st, int pad, int dil, int* v);
 int fami_t6_pair_replay(const PairHalf& h, hipStream_t s);
 int fami_wg6_pair_replay(const PairHalf& h, hipStream_t s);
+int fami_t5_pair_probe(int N, int H, int W, int Ci, int Co, int* v);
+int fami_wgs3_pair_probe(int N, int H, int W, int Ci, int Co, int* v);
+int fami_t5_pair_replay(const PairHalf& h, hipStream_t s);
+int fami_wgs3_pair_replay(const PairHalf& h, hipStream_t s);
 
 struct PairGeo {
   int nb, nbp;     // weight-gradient workgroups, the same rounded up to a multiple of 8
   int bgx, agx;    // grid.x of the weight-gradient / input-gradient single kernel
+  int bgy, agy;    // grid.y of the two single kernels
 };
 
 // A = conv3x3_t6_body (48 input channels), B = conv_wgrad6_body.  The input-gradient arguments come FIRST: the body reads its
@@ -50,6 +57,22 @@ __global__ __launch_bounds__(T6_THREADS, 1) void bwd_pair_t7_kernel(ConvT7Args a
     conv3x3_t7_body<H, SG, NT, MT, EX, ACC, EM>(a, l % g.agx, l / g.agx, g.agx);
   }
 }
+
+// f32 storage: A = conv3x3_t5_body<float, 3, true> (the persistent split-product kernel: its workgroups deal themselves the jobs by
+// workgroup index, so the body gets the index within its own part of the grid), B = conv_wgrad_s3_body
+template <int NT, int CIT, int COT, int NYS>
+__global__ __launch_bounds__(T5_THREADS, 2) void bwd_pair_t5_kernel(ConvT5Args a, Wgs3Args b, PairGeo g) {
+  const int lin = blockIdx.x;
+  if (lin < g.nbp) {
+    if (lin >= g.nb) return;
+    conv_wgrad_s3_body<CIT, COT, NYS>(b, lin % g.bgx, lin / g.bgx, g.bgx, g.bgy);
+  } else {
+    conv3x3_t5_body<float, NT, true>(a, lin - g.nbp, g.agx);
+  }
+}
+#define PAIR_SHAPES_F32(X) \
+  X(3, 3, 3, 4)      /* 48 -> 48 @96x72 and 96 -> 96 @48x36 (48-channel blocks, runs of nine tiles) */ \
+  X(3, 3, 3, 7)      /* the 64x48 / 32x24 maps of the 512x384 configuration */
 
 // The combined instances: (input-gradient kernel, SG, NT, MT, EX) x (KS, CIT, COT) of the layer shapes of the path -- every
 // (ACC, EM) pair the backward pass uses (EM 0: plain, 2: backward BatchNorm statistics in the epilogue) for bf16 and fp16.
@@ -120,14 +143,59 @@ static bool pair_launch_typed(const PairCapture& c, const PairGeo& g, unsigned b
 // [fami_route_t] g_bwd_pair (default 1)  // fami_conv_tune_lds(8998 / 8999): the combined launch off (the two recorded halves run as single launches) / on
 // What was recorded runs: as one launch where both halves are there and a combined instance exists, as single launches otherwise.
 // -> 0 ok (combined), 1 ok (singles), < 0: a recorded half has no instance (cannot happen for plans of this library)
+static bool pair_f32_known(const int* va, const int* vb) {
+#define X(nt, cit, cot, nys) if (va[0] == nt && vb[0] == cit && vb[1] == cot && vb[2] == nys) return true;
+  PAIR_SHAPES_F32(X)
+#undef X
+  return false;
+}
+static bool pair_launch_f32(const PairCapture& c, const PairGeo& g, unsigned blocks, size_t lds, hipStream_t s) {
+  ConvT5Args a;
+  Wgs3Args b;
+  memcpy(&a, c.a.args, sizeof(a));
+  memcpy(&b, c.b.args, sizeof(b));
+#define X(nt, cit, cot, nys)                                                                                                         \
+  if (c.a.v[0] == nt && c.b.v[0] == cit && c.b.v[1] == cot && c.b.v[2] == nys) {                                                    \
+    static bool attr = false;                                                                                                        \
+    if (!attr) {                                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)bwd_pair_t5_kernel<nt, cit, cot, nys>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                                   \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((bwd_pair_t5_kernel<nt, cit, cot, nys>), dim3(blocks), dim3(T5_THREADS), lds, s, a, b, g);                    \
+    return true;                                                                                                                     \
+  }
+  PAIR_SHAPES_F32(X)
+#undef X
+  return false;
+}
+
 int fami_pair_launch(const PairCapture& c, hipStream_t s) {
+  if (c.a.kind == 5 || c.b.kind == 13) {      // f32 storage
+    if (c.a.kind == 5 && c.b.kind == 13 && g_bwd_pair) {
+      PairGeo g;
+      g.nb = (int)(c.b.gx * c.b.gy);
+      g.nbp = (g.nb + 7) & ~7;
+      g.bgx = (int)c.b.gx;
+      g.bgy = (int)c.b.gy;
+      g.agx = (int)c.a.gx;
+      g.agy = (int)c.a.gy;
+      const size_t lds = c.a.lds > c.b.lds ? c.a.lds : c.b.lds;
+      const unsigned blocks = (unsigned)g.nbp + c.a.gx * c.a.gy;
+      if (pair_f32_known(c.a.v, c.b.v) && pair_launch_f32(c, g, blocks, lds, s)) return 0;
+    }
+    if (c.a.kind == 5 && !fami_t5_pair_replay(c.a, s)) return -1;
+    if (c.b.kind == 13 && !fami_wgs3_pair_replay(c.b, s)) return -1;
+    return 1;
+  }
   const bool both = c.a.kind != 0 && c.b.kind == 16 && c.a.half_kind == c.b.half_kind && c.b.v[3] == WG6_XJ;
   if (both && g_bwd_pair && pair_shape_known(c.a.kind, c.a.v, c.b.v)) {
     PairGeo g;
     g.nb = (int)(c.b.gx * c.b.gy);
     g.nbp = (g.nb + 7) & ~7;
     g.bgx = (int)c.b.gx;
+    g.bgy = (int)c.b.gy;
     g.agx = (int)c.a.gx;
+    g.agy = (int)c.a.gy;
     const unsigned blocks = (unsigned)g.nbp + c.a.gx * c.a.gy;
     const size_t lds = c.a.lds > c.b.lds ? c.a.lds : c.b.lds;
     const bool ok = c.a.half_kind == 1 ? pair_launch_typed<f16_t>(c, g, blocks, lds, s) : pair_launch_typed<bf16_t>(c, g, blocks, lds, s);
@@ -146,6 +214,22 @@ extern "C" int fami_conv2d_bwd_pair_ok(int N, int H, int W, int Ci, int Co, int 
   if (!ka) return 0;
   if (!fami_wg6_pair_probe(N, H, W, Ci, Co, 3, 1, 1, 1, vb)) return 0;
   return pair_shape_known(ka, va, vb) ? 1 : 0;
+}
+extern "C" int fami_conv2d_bwd_pair_ok_f32(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil) {
+  if (!g_bwd_pair || kh != 3 || kw != 3 || stride != 1 || pad != 1 || dil != 1) return 0;
+  int va[6] = {0, 0, 0, 0, 0, 0}, vb[6] = {0, 0, 0, 0, 0, 0};
+  if (!fami_wgs3_pair_probe(N, H, W, Ci, Co, vb)) return 0;
+  if (fami_t5_pair_probe(N, H, W, Co, Ci, va)) return pair_f32_known(va, vb) ? 1 : 0;
+  return 0;      // (the band kernel's launches -- the low-resolution maps -- stay two launches: combined they measured slower, see conv_pair.h)
+}
+// probe for tools / tests (f32 storage): out = kind (5 | 0), NT, 0, 0 | CIT, COT, NYS
+extern "C" int fami_conv2d_bwd_pair_key_f32(int N, int H, int W, int Ci, int Co, int* out) {
+  int va[6] = {0, 0, 0, 0, 0, 0}, vb[6] = {0, 0, 0, 0, 0, 0};
+  const int ka = fami_t5_pair_probe(N, H, W, Co, Ci, va);
+  const int kb = fami_wgs3_pair_probe(N, H, W, Ci, Co, vb);
+  out[0] = ka;
+  for (int i = 0; i < 3; ++i) { out[1 + i] = va[i]; out[4 + i] = vb[i]; }
+  return ka && kb ? 1 : 0;
 }
 // probe for tools / tests: the (kind, SG, NT, MT, EX | KS, CIT, COT, XJ) key of the two halves -> out[9]; returns 1 if both halves exist
 extern "C" int fami_conv2d_bwd_pair_key(int N, int H, int W, int Ci, int Co, int* out) {

@@ -270,7 +270,7 @@ class Engine:
         self.defer_reduce = options.flag('FAMI_DEFER_REDUCE', '1')
         # a 3x3 stride-1 convolution's input gradient and weight gradient as one launch (16-bit storage; csrc/conv_pair.h):
         # 0 off | 1 where the weight gradient would run on the convolution's own lane | 2 also inside the weight-gradient-stream scopes
-        self.bwd_pair = options.number('FAMI_BWD_PAIR', '1') if self.half else 0
+        self.bwd_pair = options.number('FAMI_BWD_PAIR', '1')
         self.npair = 0                 # combined launches enqueued this step (tests / reporting)
         self._red = {}                 # raw stream -> [ctypes descriptor buffers]
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
@@ -547,9 +547,10 @@ class Engine:
         if len(self._red[st]) >= 16:
             self.flush_reduces(st)
 
-    def wgrad_pair(self, x_data, dy, wpd, gx, accx, g, accw, geo, stats):
+    def wgrad_pair(self, x_data, dy, wpd, gx, accx, g, accw, geo, stats, xbn=None):
         """Input gradient (stats: the arguments of the backward-statistics epilogue, or None) and weight gradient of a 3x3 stride-1
-        convolution in one launch; the weight gradient's slab reduce is deferred as in wgrad()."""
+        convolution in one launch; the weight gradient's slab reduce is deferred as in wgrad().  xbn (f32 storage): x_data is the
+        input of a not materialised BatchNorm + ReLU (mean, invstd, gamma, beta)."""
         ws = self.ws(self.Q.fami_conv2d_wgrad_workspace(*geo))
         st = self.stream
         dws = self._red_dw.setdefault(st, set())
@@ -557,9 +558,15 @@ class Engine:
             self.flush_reduces(st)
             dws = self._red_dw.setdefault(st, set())
         desc = (ctypes.c_long * self._red_longs)()
-        if stats is None:
-            stats = (None, None, None, None, None, None, 0, None)
-        self.acall('fami_conv2d_bwd_pair', _p(x_data), _p(dy), _p(wpd), _p(gx), _p(g), _p(ws), ws.numel() * 4, *geo, accx, accw, desc, *stats)
+        if not self.half:
+            assert stats is None
+            self.call('fami_conv2d_bwd_pair_f32', _p(x_data), _p(dy), _p(wpd), _p(gx), _p(g), _p(ws), ws.numel() * 4, *geo, accx, accw, desc,
+                      *([None] * 4 if xbn is None else [_p(t) for t in xbn]))
+        else:
+            assert xbn is None
+            if stats is None:
+                stats = (None, None, None, None, None, None, 0, None)
+            self.acall('fami_conv2d_bwd_pair', _p(x_data), _p(dy), _p(wpd), _p(gx), _p(g), _p(ws), ws.numel() * 4, *geo, accx, accw, desc, *stats)
         self.npair += 1
         self._red.setdefault(st, []).append(desc)
         dws.add(g.data_ptr())
@@ -872,9 +879,10 @@ class Engine:
                 self.wlane_scope_now = bool(wl)
                 # input gradient + weight gradient as ONE launch (fami_conv2d_bwd_pair_*, csrc/conv_pair.h): the weight gradient is a
                 # leaf that otherwise sits between the input gradient and the next link of the chain on this lane
-                if (self.bwd_pair and self.half and x.requires_grad and self.rq(weight) and xb is None and self.defer_reduce
+                if (self.bwd_pair and x.requires_grad and self.rq(weight) and (xb is None or not self.half) and self.defer_reduce
                         and not _ABL_WGRAD and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1)
-                        and (self.bwd_pair == 2 or not on_wl) and self.Q.fami_conv2d_bwd_pair_ok(*geo)):
+                        and (self.bwd_pair == 2 or not on_wl)
+                        and (self.Q.fami_conv2d_bwd_pair_ok(*geo) if self.half else self.Q.fami_conv2d_bwd_pair_ok_f32(*geo))):
                     do_x(pair=True)
                     if self.rq(bias):
                         do_bias()
@@ -922,11 +930,17 @@ class Engine:
                                  _p(rec['gamma']), _p(rec['beta']), rec['rmode'], _p(slots))
                         rec['pre_bwd'] = slots
                         self.nfused['bwd'] += 1
-                    if pair:
+                    xbn_args = None if xb is None else (xb['mean'], xb['invstd'], xb['bn'].weight.data, xb['bn'].bias.data)
+                    if pair and (self.half or stats is None):
                         gw, accw = self.pgrad(weight)
                         self.conv_flops += flops
-                        self.wgrad_pair(x.data, dy, wpd, gx, acc, gw, accw, geo, stats)
-                    elif stats is not None:
+                        self.wgrad_pair(x.data, dy, wpd, gx, acc, gw, accw, geo, stats, xbn_args)
+                        return
+                    if pair:          # (f32 storage with a statistics epilogue on the input gradient: two launches)
+                        gw, accw = self.pgrad(weight)
+                        self.wgrad(x.data, dy, gw, geo, accw, xbn_args)
+                        self.conv_flops += flops
+                    if stats is not None:
                         self.acall('fami_conv2d_dgrad_bnstats', _p(dy), _p(wpd), _p(gx), *geo, acc, *stats)
                     elif self.half:
                         self.acall('fami_conv2d_dgrad', _p(dy), _p(wpd), _p(gx), *geo, acc)

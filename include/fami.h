@@ -197,6 +197,14 @@ int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co);
  * fami_conv2d_bwd_pair_key: the kernel instances of the two halves (tools / tests; out[9]). */
 int fami_conv2d_bwd_pair_ok(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
 int fami_conv2d_bwd_pair_key(int N, int H, int W, int Ci, int Co, int* out);
+/* f32 storage: the split-product input gradient and the deferred split-product weight gradient of a 3x3 stride-1 convolution in one
+ * launch (xmean != NULL: x is the input z of a BatchNorm + ReLU nobody materialised, as fami_conv2d_wgrad_defer_xbn_f32). */
+int fami_conv2d_bwd_pair_ok_f32(int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int fami_conv2d_bwd_pair_key_f32(int N, int H, int W, int Ci, int Co, int* out);
+int fami_conv2d_bwd_pair_f32(const float* x, const float* dy, const float* wpd, float* dx, float* dw, float* workspace,
+                             long ws_bytes, int N, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                             int acc_dx, int acc_dw, long* desc_out, const float* xmean, const float* xinvstd,
+                             const float* xgamma, const float* xbeta, fami_stream_t stream);
 /* the same in f32 storage (the split-product kernels; FAMI_XBN=1) */
 int fami_conv2d_xbn_ok_f32(int N, int H, int W, int Ci, int Co);
 int fami_conv2d_fwd_xbn_f32(const float* z, const float* wp, const float* bias, float* y, int N, int H, int W, int Ci,

@@ -906,6 +906,71 @@ def test_dcn_bwd_scatter_modes(dev, dyscale):
             lib().cdll.fami_dcn_tune(-1)
 
 
+def test_backward_pair_f32_is_bitwise_the_two_launch_form(dev):
+    """fami_conv2d_bwd_pair_f32 (csrc/conv_pair.h): the split-product input gradient (persistent kernel, conv_t5.hip) and the deferred
+    split-product weight gradient (conv_wgs3.hip) of a 3x3 stride-1 convolution as ONE launch -- plain and accumulating, with and
+    without the input BatchNorm + ReLU the weight gradient applies while staging (XBN) -- against the two-call form, bit for bit
+    (dx and dW after the deferred reduce); also with the combined launch switched off and on a shape no combined instance takes."""
+    import ctypes
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    nlong = L.cdll.fami_wgrad_reduce_desc_longs()
+    try:
+        for it, (N, H, W, Ci, Co, want) in enumerate([(20, 96, 72, 48, 48, 1), (20, 48, 36, 96, 96, 1), (24, 96, 72, 48, 48, 1), (8, 64, 48, 96, 96, 1),
+                                                      # the band kernel's launches (small maps, 4-frame launches) and shapes without a split-product weight gradient: two launches
+                                                      (4, 96, 72, 48, 48, 0), (20, 24, 18, 192, 192, 0), (3, 24, 18, 24, 48, 0)]):
+            torch.manual_seed(300 + it)
+            geo = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            L.cdll.fami_tune_reset()
+            assert L.cdll.fami_conv2d_bwd_pair_ok_f32(*geo) == want, geo
+            x = torch.randn(N, H, W, Ci, device=dev)
+            dy = torch.randn(N, H, W, Co, device=dev) * 0.1
+            w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.05
+            wpd = torch.empty(L.cdll.fami_packed_weight_elems(Co, Ci, 3, 3, 1), device=dev)
+            L.call('fami_pack_conv_weight_f32', p(w), p(wpd), Co, Ci, 3, 3, 1, st)
+            mean, invstd = torch.randn(Ci, device=dev) * 0.2, torch.rand(Ci, device=dev) + 0.5
+            gamma, beta = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+            dx0, dw0 = torch.randn(N, H, W, Ci, device=dev), torch.randn(Co, Ci, 3, 3, device=dev)
+            for (accx, accw, xbn) in ((0, 0, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1)):
+                if xbn and not L.cdll.fami_conv2d_xbn_ok_f32(N, H, W, Ci, Co):
+                    continue
+                last = (accw, xbn)
+                res = {}
+                for form in ('two', 'pair', 'pair_off'):
+                    L.cdll.fami_tune_reset()
+                    if form == 'pair_off':
+                        L.cdll.fami_conv_tune_lds(8998)
+                    ws = torch.empty(L.cdll.fami_conv2d_wgrad_workspace(*geo) // 4 + 4, device=dev)
+                    dx = dx0.clone() if accx else torch.empty(N, H, W, Ci, device=dev)
+                    dw = dw0.clone() if accw else torch.empty(Co, Ci, 3, 3, device=dev)
+                    desc = (ctypes.c_long * nlong)()
+                    xa = (p(mean), p(invstd), p(gamma), p(beta))
+                    if form == 'two':
+                        L.call('fami_conv2d_dgrad_f32', p(dy), p(wpd), None, p(dx), *geo, accx, st)
+                        if xbn:
+                            L.call('fami_conv2d_wgrad_defer_xbn_f32', p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo[:5], accw, desc, *xa, st)
+                        else:
+                            L.call('fami_conv2d_wgrad_defer_f32', p(x), p(dy), p(dw), p(ws), ws.numel() * 4, *geo, accw, desc, st)
+                    else:
+                        L.call('fami_conv2d_bwd_pair_f32', p(x), p(dy), p(wpd), p(dx), p(dw), p(ws), ws.numel() * 4, *geo, accx, accw, desc,
+                               *(xa if xbn else (None, None, None, None)), st)
+                    L.call('fami_wgrad_reduce_batch', desc, 1, st)
+                    torch.cuda.synchronize(dev)
+                    res[form] = (dx, dw)
+                for form in ('pair', 'pair_off'):
+                    assert torch.equal(res[form][0], res['two'][0]) and torch.equal(res[form][1], res['two'][1]), (geo, accx, accw, xbn, form)
+            # the last variant against fp64 (guards the test itself): dW of the convolution over relu(bn(x)) when xbn, else over x
+            accw, xbn = last
+            xe = torch.relu(torch.addcmul(torch.addcmul(beta, -mean, invstd * gamma), x, invstd * gamma)) if xbn else x
+            wref = torch.zeros(Co, Ci, 3, 3, device=dev, dtype=torch.double, requires_grad=True)
+            F.conv2d(xe.double().permute(0, 3, 1, 2), wref, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+            assert relerr(res['pair'][1] - (dw0 if accw else 0), wref.grad) < 5e-5, geo
+    finally:
+        L.cdll.fami_tune_reset()
+
+
 @pytest.mark.parametrize("dt", ['f32', 'bf16'])
 def test_dcn_deterministic_backward_without_an_input_gradient(dev, dt):
     """Engine.dcn in deterministic mode with x.requires_grad False and a trainable weight (round-5 advisor finding): the C entry
