@@ -80,21 +80,23 @@ class _Lib:
         # conv_wgs3.hip; same accuracy class)
         # stored as the library's default state: fami_tune_reset / fami_conv_tune_lds(-1) restore it
         self.cdll.fami_tune_defaults(1 if options.flag('FAMI_F32_SPLIT') else 0)
+        # The ablation switches compute WRONG results on purpose (upper-bound experiments of tools/): options.get() refuses them at
+        # every read unless FAMI_ALLOW_WRONG=1 says the caller knows; here only the warning.
+        wrong = [v for v in options.WRONG if options.flag(v)]
+        if wrong:
+            import sys
+            print('[fami] WARNING: %s active -- results are WRONG by design (ablation run)' % ', '.join(wrong), file=sys.stderr, flush=True)
+        self._env_route_switches()         # ... into the process default route (nothing is bound yet)
+
+    def _env_route_switches(self):
+        """The A/B switches of the environment that are ROUTE fields (options.py, 'library load'), written into the route the
+        calling thread has bound: the process default at load, and every route new_route() hands out -- an Engine with a route
+        of its own measures the same kernels as one on the process default."""
         if not options.flag('FAMI_T5'):      # A/B: the round-3 band kernel instead of the persistent one (conv_t5.hip)
             self.cdll.fami_conv_tune_lds(7000)
         for env, base in (('FAMI_WG16_TARGET', 21000), ('FAMI_WGS3_TARGET', 31000)):     # A/B: workgroup target of the weight-gradient kernels
             if options.get(env):
                 self.cdll.fami_conv_tune_wgrad_lds(base + options.number(env))
-        # The two ablation switches below compute WRONG results on purpose (upper-bound experiments of tools/): they are refused
-        # unless FAMI_ALLOW_WRONG=1 says the caller knows, so a variable left over in a job environment cannot silently corrupt a
-        # training run.
-        wrong = [v for v in options.WRONG if options.flag(v)]
-        if wrong and options.get('FAMI_ALLOW_WRONG') != '1':
-            raise FamiError('%s set: these switches skip work and produce WRONG gradients (measurement ablations only); '
-                            'set FAMI_ALLOW_WRONG=1 to run them on purpose' % ', '.join(wrong))
-        if wrong:
-            import sys
-            print('[fami] WARNING: %s active -- results are WRONG by design (ablation run)' % ', '.join(wrong), file=sys.stderr, flush=True)
         if options.get('FAMI_T5_ABL'):              # upper-bound experiment (WRONG results): only n chunks per convolution
             self.cdll.fami_conv_tune_lds(7600)
             self.cdll.fami_conv_tune_lds(7401)
@@ -108,6 +110,12 @@ class _Lib:
         if self.cdll.fami_route_init(ctypes.byref(r)) != 0 or r.size != ctypes.sizeof(Route) or \
                 self.cdll.fami_route_size() != ctypes.sizeof(Route):
             raise FamiError('fami_route_t layout differs between include/fami_route.h and libfami_hip.so -- rebuild the library')
+        prev = getattr(self._tls, 'bound', None)
+        self.bind(r)
+        try:
+            self._env_route_switches()
+        finally:
+            self.bind(prev)
         return r
 
     def bind(self, route):

@@ -159,8 +159,13 @@ class WeightPacker:
     """MFMA-fragment images of every trainable nn.Conv2d weight (forward and dgrad orientation), rebuilt from the
     flat fp32 parameter arena in ONE launch per step (fami_pack_conv_weights_batch_*) instead of ~600."""
 
-    def __init__(self, model, flat, table, dtype, cats=None):
+    def __init__(self, model, flat, table, dtype, cats=None, route=None):
+        """route: the Trainer's kernel-routing state (None: the process default) -- the size queries and the pack launches run
+        under the route the model's engines dispatch by (today no route field changes an image's geometry; the DCN backward
+        image already did once)."""
         import numpy as np
+        self.route = route
+        lib().bind(route)
         L = lib().cdll
         from .engine import _SFX
         bf = dtype != torch.float32      # 16-bit images (bf16 | fp16) share one geometry
@@ -217,7 +222,7 @@ class WeightPacker:
         lo, hi = {None: (0, self.n), 0: (0, self.n_fwd), 1: (self.n_fwd, self.n), 'early': (0, self.n_early),
                   'late': (self.n_early, self.n_fwd)}[part]
         if hi > lo:
-            lib().call(self.fn, _p(self.flat), _p(self.arena), self.desc.data_ptr() + 32 * lo, hi - lo, stream)
+            lib().call_routed(self.route, self.fn, _p(self.flat), _p(self.arena), self.desc.data_ptr() + 32 * lo, hi - lo, stream)
 
 
 class BucketReducer:
@@ -305,9 +310,12 @@ class BucketReducer:
             if shard is None or shard.numel() != main // self.world or shard.dtype != buf.dtype:
                 shard = self._shards[key] = torch.empty(main // self.world, dtype=buf.dtype, device=buf.device)
             wk = dist.reduce_scatter_tensor(shard, buf[:main], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            if not self._ordered:
-                wk.wait()
-            wk = dist.all_gather_into_tensor(buf[:main], shard, group=self.pg, async_op=True)
+            if self._ordered:
+                wk = dist.all_gather_into_tensor(buf[:main], shard, group=self.pg, async_op=True)
+            else:
+                # (gloo: the gather must follow the scatter's completion -- chained in wait(), not here: the backward hook that
+                #  issues the exchange must not block the host enqueue of the rest of the backward pass)
+                wk = _Chained(wk, lambda b=buf[:main], sh=shard: dist.all_gather_into_tensor(b, sh, group=self.pg))
         if main < n:
             if wk is not None:
                 self.works.append((wk, None))
@@ -333,6 +341,17 @@ class BucketReducer:
             if rng is not None:
                 self._widen(self._mirror[rng[0]:rng[1]], self.grad[rng[0]:rng[1]])
         self.works = []
+
+
+class _Chained:
+    """A work handle followed by a blocking step that may only start once it has completed."""
+
+    def __init__(self, work, then):
+        self.work, self.then = work, then
+
+    def wait(self):
+        self.work.wait()
+        self.then()
 
 
 def _ends(pending):
@@ -404,7 +423,7 @@ class Trainer:
             cast=lambda src, dst: self._lc('fami_cast_add_' + sfx, _p(src), _p(dst), src.numel(), 0, _stream(self.dev)),
             widen=lambda src, dst: self._lc('fami_widen_' + sfx, _p(src), _p(dst), src.numel(), _stream(self.dev)))
         self.reducer.world = self.world
-        self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype, cats=self.cats)
+        self.packer = WeightPacker(model, self.flat, self.table, self.act_dtype, cats=self.cats, route=self.route)
         # data-parallel launch plan: 'overlap' (default) = hipGraph segments cut at the bucket boundaries with each
         # bucket's all-reduce issued between two segment replays (graph replay AND overlap with the rest of backward);
         # 'serial' = one graph for forward + backward, then every all-reduce; FAMI_DDP_GRAPH=0 = no graphs at all

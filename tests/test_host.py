@@ -240,3 +240,19 @@ def test_ablation_switches_are_refused_at_every_read(monkeypatch):
         monkeypatch.delenv('FAMI_ALLOW_WRONG', raising=False)
         assert not options.flag(name)
         monkeypatch.delenv(name)
+
+
+def test_new_routes_take_the_environment_ab_switches(monkeypatch):
+    """The A/B switches that are route fields (FAMI_T5, FAMI_WGS3_TARGET, ...) reach every route lib().new_route() hands out, not only
+    the process default written at load: an Engine with a route of its own measures the kernels the environment names."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    base = L.new_route()
+    assert base.use_t5 == 1 and base.wgs3_target == 0
+    monkeypatch.setenv('FAMI_T5', '0')
+    monkeypatch.setenv('FAMI_WGS3_TARGET', '128')
+    r = L.new_route()
+    assert r.use_t5 == 0 and r.wgs3_target == 128
+    monkeypatch.delenv('FAMI_T5')
+    monkeypatch.delenv('FAMI_WGS3_TARGET')
+    assert L.new_route().use_t5 == 1
