@@ -216,6 +216,16 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
            "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
            "traffic": pmc_traffic('dcn_fwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
            "algorithmic_bytes": int(nbytes), "avg_launch_us": round(ms * 1e3, 2)}
+    # What a gather of this granularity can reach (review r5 item 3d): every sample point reads four corners, each a (group, pixel)
+    # block of Ci / G channels = 16 bytes in f32 / 8 bytes in 16-bit storage at an offset-dependent address -- one vector-L1 line
+    # lookup per corner and lane, and a CU's L1 serves one line per clock.  B * H * W * G * 9 * 4 corner loads over 256 CUs at
+    # 2.4 GHz bound the launch from below whatever the HBM does; `ceiling` = algorithmic bytes / that time, as a fraction of the
+    # HBM peak (the 0.60 target of the north star would need the 8- / 16-byte blocks to arrive at > 2x the L1's line rate).
+    t_lines = B * H * W * G * 9 * 4 / (256 * 2.4e9)
+    fwd["ceiling"] = {"frac": round(nbytes / t_lines / 1e9 / PEAK_HBM_GBS, 4), "min_launch_us": round(t_lines * 1e6, 2),
+                      "bound": "vector-L1 line rate (one 128-byte line per clock and CU) on %d scattered %d-byte corner loads" % (
+                          B * H * W * G * 9 * 4, int(C // G * sz))}
+    fwd["frac_of_ceiling"] = round(fwd["frac"] / fwd["ceiling"]["frac"], 3)
     # the opt-in LDS-window forward kernel on the same launch (measured, not the default)
     L.cdll.fami_dcn_tune(2)
     try:
@@ -244,6 +254,11 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
            "achieved": round(achb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achb / PEAK_HBM_GBS, 4),
            "traffic": pmc_traffic('dcn_bwd_' + dtype) if (B == 4 and C == 48 and H == 96) else None,
            "algorithmic_bytes": int(nb), "avg_launch_us": round(msb * 1e3, 2)}
+    # the backward gathers the same corners once more and adds as many read-modify-writes into its LDS regions: the forward's bound
+    # holds for it with the backward's bytes
+    bwd["ceiling"] = {"frac": round(nb / t_lines / 1e9 / PEAK_HBM_GBS, 4), "min_launch_us": round(t_lines * 1e6, 2),
+                      "bound": "vector-L1 line rate on the corner gather alone (the LDS scatter and its atomic flush come on top)"}
+    bwd["frac_of_ceiling"] = round(bwd["frac"] / bwd["ceiling"]["frac"], 3)
     # the deterministic (64-bit fixed-point) form of the same backward: zero + |dy| max + kernel + conversion pass
     gxd = torch.empty(B, H, W, C, device=dev, dtype=tdt)
     ws = torch.empty(L.cdll.fami_dcn_bwd_det_workspace(B, H, W, C) // 4 + 4, device=dev)
