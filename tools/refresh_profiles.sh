@@ -5,7 +5,7 @@
 # usage: tools/refresh_profiles.sh gpurun_out/r04_y r04_z
 src=$1; dst=$2; here=$(cd $(dirname $0)/.. && pwd); cd $here
 mkdir -p profiles/$dst
-for f in bench_default.json bench_layer1.txt bench_t4_bf16.txt bench_t5.txt bench_t6.txt bench_wg6.txt phase_times.txt pytest_gpu.txt smoke.txt \
+for f in bench_default.json bench_driver_style.json bench_dcn_bwd.txt phase_stem.txt bench_layer1.txt bench_t4_bf16.txt bench_t5.txt bench_t6.txt bench_wg6.txt phase_times.txt pytest_gpu.txt smoke.txt \
          pmc_conv_bf16.txt pmc_conv_f32.txt pmc_dcn_bf16.txt pmc_dcn_f32.txt pmc_dcnbwd_bf16.txt pmc_dcnbwd_f32.txt; do
   [ -s $src/$f ] && grep -v "amdgpu.ids" $src/$f > profiles/$dst/$f
 done
