@@ -226,6 +226,9 @@ def dcn_roofline(dev, B, dtype, reps=30, C=48, G=12, H=96, W=72):
                       "bound": "vector-L1 line rate (one 128-byte line per clock and CU) on %d scattered %d-byte corner loads" % (
                           B * H * W * G * 9 * 4, int(C // G * sz))}
     fwd["frac_of_ceiling"] = round(fwd["frac"] / fwd["ceiling"]["frac"], 3)
+    fwd["ceiling"]["note"] = ("a bound, not the binding constraint: a probe that cut the line lookups to a fourth (group-major copy of x) ran "
+                              "only 10 % (f32) / 24 % (bf16) faster -- the launch's staging and gather phases add up "
+                              "(profiles/r06/bench_dcn_group_major_probe.txt)")
     # the opt-in LDS-window forward kernel on the same launch (measured, not the default)
     L.cdll.fami_dcn_tune(2)
     try:
