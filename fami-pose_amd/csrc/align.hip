@@ -163,7 +163,6 @@ __global__ void shift_bwd_t_finalize_kernel(const float* __restrict__ partial, i
 template <typename T>
 struct DcnArgs {
   const T* x;         // [B,H,W,C]
-  const T* xg;        // optional (round 6): the same tensor GROUP-MAJOR, [B,G,H,W,C/G] (fami_dcn_regroup_*); the direct kernel gathers from it
   const T* off;       // [B,Ho,Wo,2*G*K]
   const T* msk;       // [B,Ho,Wo,G*K]   (may be null => mask 1)
   const float* wp;    // packed [KS][NTt][64][4]
@@ -175,20 +174,6 @@ struct DcnArgs {
   int ostr, mstr;      // elements per pixel of the offset / mask tensors: 2GK / GK (two dense tensors) or 3GK / 3GK (ONE tensor
                        // [P][2GK offsets | GK masks], the output of the merged predictor: msk == off + 2GK)
 };
-
-// x[B,H,W,C] -> xg[B,G,H,W,C/G] (C/G = 4): a thread per (group, pixel) block; consecutive lanes = consecutive pixels of one group
-// (the writes are one run per wave; the reads of a wave touch 64 pixels x 8 / 16 bytes, every line twelve times over the groups: L2)
-template <typename T>
-__global__ __launch_bounds__(256) void dcn_regroup_kernel(const T* __restrict__ x, T* __restrict__ xg, int B, int HW, int G) {
-  typedef T t4 __attribute__((ext_vector_type(4)));
-  const long n = (long)B * G * HW;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long bg = i / HW;
-    const int pix = (int)(i - bg * HW);
-    const int b = (int)(bg / G), g = (int)(bg - (long)b * G);
-    *reinterpret_cast<t4*>(xg + i * 4) = *reinterpret_cast<const t4*>(x + ((long)b * HW + pix) * (G * 4) + g * 4);
-  }
-}
 
 // Column index of the contraction, TAP-major: kidx = ((tap*G + g)*q4 + q)*4 + c4  (channel c = g*cg + q*4 + c4,
 // q4 = cg/4), KS16 = ceil(C*K / 16).  Tap-major so that the 16 sample blocks a workgroup gathers at a time are the
@@ -414,11 +399,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnArgs<T> p) {
 //    run in HBM and are copied to LDS with 16-byte accesses before the waves read them in (row, tap) order.
 //  * the (group, tap) decode is a per-workgroup LDS table; out-of-map corners zero the 1-D bilinear weight and clamp
 //    the address (unconditional 16-byte loads, SGPR base + 32-bit byte offset); PF k groups per wave are in flight.
-// XG (round 6): x is read from its GROUP-MAJOR copy [B,G,H,W,4] (p.xg; 4 channels per offset group).  In NHWC the sixteen pixels of a
-// wave's quarter (one (tap, group) item, sixteen consecutive output pixels) read 16- / 8-byte blocks 4 Ci bytes apart -- sixteen cache
-// lines per item; in a group's own plane their corners are neighbours (16 / 8 bytes apart plus the offsets' differences): one to three
-// lines per item, and in 16-bit storage ONE 16-byte load covers both x-corners of a row (the pair (x0, x0 + 1) is contiguous).
-template <typename T, int NT, int PF, int MINW, bool XG = false>
+template <typename T, int NT, int PF, int MINW>
 __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -462,7 +443,7 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
       const int tg = it / q4, q = it - tg * q4;
       const int tap = tg / p.G, g = tg - tap * p.G;  // tap-major column order (dcn_pack_w_kernel)
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      e = int4{XG ? g * p.H * p.W * 4 * (int)sizeof(T) : (g * p.cg + q * 4) * (int)sizeof(T), ky * p.dil, kx * p.dil, g * K + tap};
+      e = int4{(g * p.cg + q * 4) * (int)sizeof(T), ky * p.dil, kx * p.dil, g * K + tap};
     }
     tapt[it] = e;
   }
@@ -480,9 +461,8 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
     ox0 = ox * p.stride - p.pad;
     xoff = (unsigned)b * (unsigned)(p.H * p.W * p.C) * (unsigned)sizeof(T);
   }
-  const char* xbase = reinterpret_cast<const char*>(XG ? p.xg : p.x);
-  // XG: a group's plane is [H][W][4 channels]: row stride 4 W elements, pixel stride 4 elements (the batch offset is the same)
-  const unsigned WCb = XG ? p.W * 4 * (unsigned)sizeof(T) : p.W * p.C * (unsigned)sizeof(T), Cb = XG ? 4 * (unsigned)sizeof(T) : p.C * (unsigned)sizeof(T);
+  const char* xbase = reinterpret_cast<const char*>(p.x);
+  const unsigned WCb = p.W * p.C * (unsigned)sizeof(T), Cb = p.C * (unsigned)sizeof(T);
   const int Hm1 = p.H - 1, Wm1 = p.W - 1;
   const float Hf1 = sgpr_f((float)(p.H + 1)), Wf1 = sgpr_f((float)(p.W + 1));
   const T* myoff = soff + row * lo;
@@ -509,25 +489,11 @@ __global__ __launch_bounds__(256, MINW) void dcn_fwd_direct_kernel(DcnArgs<T> p)
     w1[2] = (unsigned)x0 <= (unsigned)Wm1 ? 1.f - lx : 0.f;
     w1[3] = (unsigned)x1 <= (unsigned)Wm1 ? lx : 0.f;
     const unsigned r0 = xoff + __umul24(min(max(y0, 0), Hm1), WCb), r1 = xoff + __umul24(min(max(y1, 0), Hm1), WCb);
-    if constexpr (XG && sizeof(T) == 2) {
-      // both x-corners of a row in ONE 16-byte load: pixels xl, xl + 1 with xl = clamp(x0, 0, W - 2); x0 = -1 / W - 1 (one corner
-      // outside the map, its weight is zero) select the half that holds the corner inside
-      typedef T hx4 __attribute__((ext_vector_type(4)));
-      struct __attribute__((aligned(8))) Pair { hx4 lo, hi; };
-      const unsigned cl = __umul24(min(max(x0, 0), Wm1 - 1), Cb) + (unsigned)te.x;
-      const Pair q0 = *reinterpret_cast<const Pair*>(xbase + (r0 + cl)), q1 = *reinterpret_cast<const Pair*>(xbase + (r1 + cl));
-      const bool hi0 = x0 > Wm1 - 1, lo1 = x0 < 0;
-      a[0] = __builtin_convertvector(hi0 ? q0.hi : q0.lo, f32x4);
-      a[1] = __builtin_convertvector(lo1 ? q0.lo : q0.hi, f32x4);
-      a[2] = __builtin_convertvector(hi0 ? q1.hi : q1.lo, f32x4);
-      a[3] = __builtin_convertvector(lo1 ? q1.lo : q1.hi, f32x4);
-    } else {
-      const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)te.x, c1 = __umul24(min(max(x1, 0), Wm1), Cb) + (unsigned)te.x;
-      a[0] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0)));
-      a[1] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
-      a[2] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0)));
-      a[3] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
-    }
+    const unsigned c0 = __umul24(min(max(x0, 0), Wm1), Cb) + (unsigned)te.x, c1 = __umul24(min(max(x1, 0), Wm1), Cb) + (unsigned)te.x;
+    a[0] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c0)));
+    a[1] = ld4(reinterpret_cast<const T*>(xbase + (r0 + c1)));
+    a[2] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c0)));
+    a[3] = ld4(reinterpret_cast<const T*>(xbase + (r1 + c1)));
   };
   // corner order of the oracle's sum
   auto blend = [&](const f32x4 (&a)[4], const float (&w1)[4]) {
@@ -1826,14 +1792,14 @@ static void dcn_fwd_win_launch(const DcnWinArgs<T>& a, dim3 grid, size_t lds, hi
 }
 // [fami_route_t] g_dcn_pf (default 0)  // fami_dcn_tune(16 + 2): the 2-k-groups-in-flight x 4-waves-per-SIMD build of the direct kernel (benchmarks)
 
-template <typename T, int NT, int PF, int MINW, bool XG = false>
+template <typename T, int NT, int PF, int MINW>
 static void dcn_fwd_direct_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, PF, MINW, XG>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_direct_kernel<T, NT, PF, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, PF, MINW, XG>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dcn_fwd_direct_kernel<T, NT, PF, MINW>), grid, dim3(256), lds, s, a);
 }
 
 template <typename T, int NT>
@@ -1851,11 +1817,6 @@ static void dcn_fwd_launch(const DcnArgs<T>& a, dim3 grid, size_t lds, size_t ld
   // +-1.5 us in f32 (31-34 us: the corner loads run at the L1's one-line-per-cycle rate), bf16 25.0 (1 x 7) vs 27.6 us
   // (2 x 4).  Default: one k group per wave in flight, 7 workgroups per CU (62 VGPRs, 22.5 KB LDS) -- the 6.75 tiles a
   // CU owns at B=4 are then all resident at once.  Wide outputs (NT > 3) carry 4*NT accumulator + 4*NT weight registers.
-  if (a.xg) {
-    if (NT > 3) dcn_fwd_direct_launch<T, NT, 1, 4, true>(a, grid, lds_direct, s);
-    else dcn_fwd_direct_launch<T, NT, 1, 7, true>(a, grid, lds_direct, s);
-    return;
-  }
   if (NT > 3)
     dcn_fwd_direct_launch<T, NT, 1, 4>(a, grid, lds_direct, s);
   else if (g_dcn_pf == 2)
@@ -1871,14 +1832,9 @@ static inline long dcn_f32_image_elems(int Co, int C, int kh, int kw, int G) {
 template <typename T>
 static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp, const float* bias, T* y, int B, int H,
                         int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s,
-                        const char* nm, bool merged = false, const T* xg = nullptr) {
-  FAMI_REQUIRE((x || xg) && off && wp && y && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
+                        const char* nm, bool merged = false) {
+  FAMI_REQUIRE(x && off && wp && y && B > 0 && G > 0 && C % G == 0, nm, "bad argument");
   DcnArgs<T> a;
-  a.xg = xg;
-  if (xg) {      // the group-major copy: four channels per group, the direct kernel, maps of at least two columns
-    FAMI_REQUIRE(C / G == 4 && W >= 2 && (long)G * H * W * 4 * sizeof(T) < (1L << 31) && (reinterpret_cast<uintptr_t>(xg) & 15) == 0, nm,
-                 "the group-major form needs 4 channels per offset group, W >= 2 and a 16-byte aligned copy");
-  }
   // merged: `off` is ONE tensor [P][2GK offsets | GK masks] (the merged predictor's output); msk is derived here
   a.ostr = (merged ? 3 : 2) * G * kh * kw;
   a.mstr = (merged ? 3 : 1) * G * kh * kw;
@@ -1900,7 +1856,7 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   const long P = (long)B * a.Ho * a.Wo;
   FAMI_REQUIRE(P < (1L << 31), nm, "size out of range");
   a.P = (int)P;
-  if (g_dcn_gather == 2 && !xg) {
+  if (g_dcn_gather == 2) {
     const DcnWinPlan q = dcn_win_plan(B, a.Ho, a.Wo, C, G, kh, kw, stride, dil, (int)sizeof(T));
     if (q.ok && a.NTt <= 4 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(off) | reinterpret_cast<uintptr_t>(msk)) & 15) == 0) {
       DcnWinArgs<T> w;
@@ -1927,9 +1883,8 @@ static int dcn_fwd_impl(const T* x, const T* off, const T* msk, const float* wp,
   const size_t lds = ((size_t)DCN_PIX * (a.KS * 16 + 4) + 4 * (size_t)a.NTt * 256) * sizeof(float);
   size_t lds_direct = (((size_t)DCN_PIX * G * kh * kw * 3 * sizeof(T) + 15) & ~(size_t)15) + (size_t)a.KS * 4 * sizeof(int4);
   if (lds_direct < 4 * (size_t)a.NTt * 256 * sizeof(float)) lds_direct = 4 * (size_t)a.NTt * 256 * sizeof(float);
-  const bool direct = (g_dcn_gather != 0 || xg) && (long)B * H * W * C * sizeof(T) < (1L << 32) &&
+  const bool direct = g_dcn_gather != 0 && (long)B * H * W * C * sizeof(T) < (1L << 32) &&
                       (long)H * W * C * sizeof(T) < (1L << 24) && lds_direct <= 150 * 1024;
-  FAMI_REQUIRE(direct || !xg, nm, "tensor too large for the group-major form");
   if (!direct && lds > 150 * 1024) {
     fami_set_error(nm, "C*kh*kw too large for the LDS column tile");
     return FAMI_ESHAPE;
@@ -2323,22 +2278,6 @@ int fami_dcn_pack_weight_bwd_f32(const float* w_oihw, float* wpb, int Co, int C,
                             int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, hipStream_t s) {       \
     return dcn_fwd_impl<T>(x, om, nullptr, wp, bias, y, B, H, W, C, Co, G, kh, kw, stride, pad, dil, s,                \
                            "fami_dcn_fwd_om_" #sfx, true);                                                             \
-  }                                                                                                                    \
-  /* Round 6: the forward gathering from a GROUP-MAJOR copy of x (xg [B,G,H,W,C/G], C/G = 4, written by fami_dcn_regroup_*):     */ \
-  /* msk NULL and merged != 0 = the one-tensor form of fami_dcn_fwd_om_*.  Same arithmetic, same results bit for bit.             */ \
-  int fami_dcn_regroup_##sfx(const T* x, T* xg, int B, int H, int W, int C, int G, hipStream_t s) {                     \
-    FAMI_REQUIRE(x && xg && B > 0 && G > 0 && C == 4 * G, "fami_dcn_regroup_" #sfx, "bad argument (4 channels per group)"); \
-    const long n = (long)B * G * H * W;                                                                                \
-    hipLaunchKernelGGL(dcn_regroup_kernel<T>, dim3(fami_ew_grid(n)), dim3(256), 0, s, x, xg, B, H * W, G);              \
-    FAMI_CHECK_LAUNCH("fami_dcn_regroup_" #sfx);                                                                       \
-    return FAMI_OK;                                                                                                    \
-  }                                                                                                                    \
-  int fami_dcn_fwd_g_##sfx(const T* xg, const T* off, const T* msk, int merged, const float* wp, const float* bias,    \
-                           T* y, int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad,       \
-                           int dil, hipStream_t s) {                                                                   \
-    FAMI_REQUIRE(xg && (merged ? msk == nullptr : 1), "fami_dcn_fwd_g_" #sfx, "bad argument");                         \
-    return dcn_fwd_impl<T>(nullptr, off, merged ? nullptr : msk, wp, bias, y, B, H, W, C, Co, G, kh, kw, stride, pad,  \
-                           dil, s, "fami_dcn_fwd_g_" #sfx, merged != 0, xg);                                           \
   }                                                                                                                    \
   int fami_dcn_bwd_om_##sfx(const T* x, const T* om, const T* dy, const float* wpb, T* col, float* gx, T* gom, int B,  \
                             int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil,          \

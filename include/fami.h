@@ -343,13 +343,6 @@ int fami_dcn_bwd_det_f32(const float* x, const float* off, const float* msk, con
  * followed by the GK masks: what the offset and the mask predictor of a DCN layer (Alignment_V15.py:79-100, called at
  * :144-158) produce when they run as one 48 -> 324 convolution (weights concatenated on the output-channel axis; the
  * state_dict keeps the two modules).  gom: the gradient wrt om, same layout (=|+= per acc_om).  Same kernels, other strides. */
-/* Round 6: the DCN forward gathering from a GROUP-MAJOR copy of its input (torchvision deform_conv2d semantics unchanged): in NHWC a
- * bilinear corner is a 16- / 8-byte block at an offset-dependent address, one cache line per corner and lane; in xg [B,G,H,W,C/G]
- * (C/G = 4; fami_dcn_regroup_*) the corners of neighbouring output pixels are neighbours and, in 16-bit storage, one 16-byte load
- * covers both x-corners of a row.  fami_dcn_fwd_g_*: msk NULL + merged != 0 = offsets and masks in one tensor (fami_dcn_fwd_om_*). */
-int fami_dcn_regroup_f32(const float* x, float* xg, int B, int H, int W, int C, int G, fami_stream_t stream);
-int fami_dcn_fwd_g_f32(const float* xg, const float* off, const float* msk, int merged, const float* wp, const float* bias, float* y,
-                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_fwd_om_f32(const float* x, const float* om, const float* wp, const float* bias, float* y, int B, int H, int W,
                        int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_bwd_om_f32(const float* x, const float* om, const float* dy, const float* wpb, float* col, float* gx, float* gom,
@@ -524,9 +517,6 @@ int fami_dcn_bwd_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_b
 int fami_dcn_bwd_det_bf16(const fami_bf16_t* x, const fami_bf16_t* off, const fami_bf16_t* msk, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col,
                          fami_bf16_t* gx, fami_bf16_t* goff, fami_bf16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
                          int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
-int fami_dcn_regroup_bf16(const fami_bf16_t* x, fami_bf16_t* xg, int B, int H, int W, int C, int G, fami_stream_t stream);
-int fami_dcn_fwd_g_bf16(const fami_bf16_t* xg, const fami_bf16_t* off, const fami_bf16_t* msk, int merged, const float* wp, const float* bias, fami_bf16_t* y,
-                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_fwd_om_bf16(const fami_bf16_t* x, const fami_bf16_t* om, const float* wp, const float* bias, fami_bf16_t* y, int B, int H, int W,
                        int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_bwd_om_bf16(const fami_bf16_t* x, const fami_bf16_t* om, const fami_bf16_t* dy, const float* wpb, fami_bf16_t* col, float* gx, fami_bf16_t* gom,
@@ -652,9 +642,6 @@ int fami_dcn_bwd_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_
 int fami_dcn_bwd_det_f16(const fami_f16_t* x, const fami_f16_t* off, const fami_f16_t* msk, const fami_f16_t* dy, const float* wpb, fami_f16_t* col,
                          fami_f16_t* gx, fami_f16_t* goff, fami_f16_t* gmsk, int B, int H, int W, int C, int Co, int G, int kh, int kw,
                          int stride, int pad, int dil, int acc_off, int acc_x, void* ws, fami_stream_t stream);
-int fami_dcn_regroup_f16(const fami_f16_t* x, fami_f16_t* xg, int B, int H, int W, int C, int G, fami_stream_t stream);
-int fami_dcn_fwd_g_f16(const fami_f16_t* xg, const fami_f16_t* off, const fami_f16_t* msk, int merged, const float* wp, const float* bias, fami_f16_t* y,
-                      int B, int H, int W, int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_fwd_om_f16(const fami_f16_t* x, const fami_f16_t* om, const float* wp, const float* bias, fami_f16_t* y, int B, int H, int W,
                        int C, int Co, int G, int kh, int kw, int stride, int pad, int dil, fami_stream_t stream);
 int fami_dcn_bwd_om_f16(const fami_f16_t* x, const fami_f16_t* om, const fami_f16_t* dy, const float* wpb, fami_f16_t* col, float* gx, fami_f16_t* gom,
