@@ -258,10 +258,10 @@ class Engine:
         self.use_xbn = options.flag('FAMI_XBN', '0' if self.half else '1')
         # Tried in round 4: backward fusion only on the SERIAL stretches of the step (stem, layer1: one lane, nothing beside it --
         # 3.6 ms of the f32 backward pass), `serial_scope` set by HRNetBody.run.  Interleaved bench runs on one box: f32 48.16
-        # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  FAMI_SERIAL_FUSE=1
+        # vs 48.26 ms, bf16 24.94 vs 25.15 ms -- the epilogue costs what the removed pass did there too.  `serial_fuse = True`
         # keeps it available.
         self.serial_scope = False
-        self.serial_fuse = options.flag('FAMI_SERIAL_FUSE', '0')
+        self.serial_fuse = False       # (the FAMI_SERIAL_FUSE switch of rounds 4-5 is gone: measured neutral twice; tests set the attribute)
         self.nfused = {'fwd': 0, 'bwd': 0, 'xbn': 0}     # statistics passes that ran in a convolution epilogue (tests / reporting)
         self.conv_flops = 0                    # 2*MACs of every nn.Conv2d forward / input-gradient / weight-gradient launch enqueued (reporting)
         # deferred slab reduces of the weight-gradient kernels: described on the host as they are enqueued and launched

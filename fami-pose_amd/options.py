@@ -22,7 +22,6 @@ SWITCHES = {
     'FAMI_STEM_WGRAD_LANE': ('1', 'the same for stem / layer1 / transitions (round 5: on in f32 too, -0.3 ... -0.5 %)'),
     'FAMI_HEAD_WGRAD_LANES': ('4', 'number of weight-gradient streams of the head (taken in turn)'),
     'FAMI_STEM_WGRAD_LANES': ('4', 'number of weight-gradient streams of that stretch (taken in turn)'),
-    'FAMI_LANE_PRIO': ('0', 'probe: 1 = the capture stream (lane 0: the critical path) is a high-priority stream'),
     'FAMI_DEBUG_STREAMS': ('', 'print the stream handles of every lane set-up'),
     # ---- fused passes (engine.py)
     'FAMI_BN2': ('1', 'two-launch BatchNorm (fp64 slot atomics, finalize folded into the apply pass)'),
@@ -32,7 +31,6 @@ SWITCHES = {
     'FAMI_FUSE_BN_C64': ('2', 'statistics in the epilogues of the 32-channel-phase kernel (layers of 64-multiple channels): bit 0 forward, bit 1 backward'),
     'FAMI_FUSE_TERM_BN2': ('1', 'fuse-term BatchNorm backward on the two-launch form'),
     'FAMI_XBN': (None, 'BatchNorm + ReLU applied by the consumer convolution; default on in f32 storage, off in the 16-bit modes'),
-    'FAMI_SERIAL_FUSE': ('0', 'backward statistics fusion on the serial stem / layer1 stretch only (measured neutral)'),
     'FAMI_CONCAT_ONE': ('1', 'torch.cat of up to four maps, and its backward, in one launch each'),
     'FAMI_MERGE_PREDICTORS': ('1', 'offset + mask predictor of a DCN layer as one 48 -> 324 convolution (needs the Trainer arena)'),
     'FAMI_BWD_PAIR': ('1', 'input gradient + weight gradient of a 3x3 stride-1 convolution (16-bit storage) as ONE launch: 0 off | 1 outside the weight-gradient-stream scopes | 2 everywhere'),

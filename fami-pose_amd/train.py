@@ -731,10 +731,9 @@ class Trainer:
         torch.cuda.synchronize(self.dev)
         if not self.ddp:
             g = torch.cuda.CUDAGraph()
-            # FAMI_LANE_PRIO=1 (probe): lane 0 -- the capture stream: stem, branch 0, head, the step's critical path -- is a
-            # high-priority stream, the side lanes stay at the default priority
-            cap = torch.cuda.Stream(self.dev, priority=-1) if options.number('FAMI_LANE_PRIO', '0') else None
-            with torch.cuda.graph(g, stream=cap):
+            # (round 6 probe: capturing on a high-priority stream -- lane 0 is the step's critical path -- changes nothing:
+            #  bf16 18.75 vs 18.70 ms, f32 44.78 vs 44.78, profiles/r06/ab_lane0_high_priority_*.txt)
+            with torch.cuda.graph(g):
                 outs = self._forward_backward(st['kf'], st['sup'], st['target'], st['weight'], fused_opt=True)
                 self._opt_step()
             plan = [('graph', g)]
