@@ -256,3 +256,30 @@ def test_new_routes_take_the_environment_ab_switches(monkeypatch):
     monkeypatch.delenv('FAMI_T5')
     monkeypatch.delenv('FAMI_WGS3_TARGET')
     assert L.new_route().use_t5 == 1
+
+
+def test_combined_backward_instances_cover_the_layer_shapes_of_the_path():
+    """csrc/conv_pair.hip holds one combined (input gradient + weight gradient) kernel instance per layer shape: the plans are host
+    code, so the table is checked here against every 3x3 stride-1 layer shape of BASELINE configs 2 / 3 / 5 (16-bit storage) and
+    against the persistent split-product kernel's shapes (f32 storage) -- a plan change that moves a layer to another instance must
+    show up as a failure here, not as a silent fall-back to two launches on the GPU box."""
+    from fami_pose_amd._lib import lib
+    L = lib().cdll
+    L.fami_tune_reset()
+    geo = lambda N, H, W, Ci, Co: (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+    half = [(20, 96, 72, 48, 48), (20, 48, 36, 96, 96), (20, 24, 18, 192, 192), (20, 12, 9, 384, 384),      # W48, 5-frame clips, batch 4
+            (24, 96, 72, 48, 48), (24, 48, 36, 96, 96), (24, 24, 18, 192, 192), (24, 12, 9, 384, 384),      # config 2: 3-frame, batch 8
+            (4, 96, 72, 48, 48), (4, 96, 72, 96, 48), (4, 96, 72, 192, 48), (8, 96, 72, 48, 48),            # the head's aggregation blocks
+            (20, 96, 72, 64, 64), (20, 48, 36, 128, 128), (20, 24, 18, 256, 256), (20, 12, 9, 512, 512)]    # HRNet-W64 (config 5)
+    for s in half:
+        assert L.fami_conv2d_bwd_pair_ok(*geo(*s)) == 1, s
+    for s in [(20, 96, 72, 48, 48), (20, 48, 36, 96, 96), (24, 96, 72, 48, 48), (4, 96, 72, 96, 48), (8, 128, 96, 48, 48)]:
+        assert L.fami_conv2d_bwd_pair_ok_f32(*geo(*s)) == 1, s
+    # not combined by design: other geometries, the band kernel's f32 launches, maps no DMA-staged kernel takes
+    assert L.fami_conv2d_bwd_pair_ok(20, 96, 72, 48, 48, 3, 3, 2, 1, 1) == 0 and L.fami_conv2d_bwd_pair_ok(20, 96, 72, 48, 48, 1, 1, 1, 0, 1) == 0
+    assert L.fami_conv2d_bwd_pair_ok_f32(*geo(20, 24, 18, 192, 192)) == 0 and L.fami_conv2d_bwd_pair_ok(*geo(2, 32, 24, 48, 48)) == 0
+    L.fami_conv_tune_lds(8998)
+    try:
+        assert L.fami_conv2d_bwd_pair_ok(*geo(20, 96, 72, 48, 48)) == 0
+    finally:
+        L.fami_tune_reset()
