@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "conv_epi.h"
+extern "C" int fami_conv2d_fwd_bnin_ok(int N, int H, int W, int Ci, int Co);      // conv_t6.hip
 // conv_pair.hip
 #include "conv_pair.h"
 int fami_pair_launch(const PairCapture& c, hipStream_t s);
@@ -3626,6 +3627,31 @@ long fami_packed_weight_elems_f16(int Co, int Ci, int kh, int kw, int mode) {
     xb.running_var = xrunning_var; xb.momentum = xmomentum; xb.eps = xeps;                                             \
     return conv_fwd_h_impl<HT>("fami_conv2d_fwd_xbn_" #sfx, z, wp, bias, y, N, H, W, Ci, Co, 3, 3, 1, 1, 1, 0, 0, 0,   \
                                s, e, xb);                                                                              \
+  }                                                                                                                    \
+  /* Round 6: the same BatchNorm + ReLU of the input INSIDE the convolution's launch, with the normalised tensor written to   */ \
+  /* a_out as well (the weight-resident 48-channel kernel transforms its patch in LDS and stores the rows it owns): one launch */ \
+  /* and one read of z per BasicBlock less than fami_bn_apply_slots_* + fami_conv2d_fwd_stats_*, bit for bit their results.     */ \
+  /* Ask fami_conv2d_fwd_bnin_ok first.                                                                                          */ \
+  int fami_conv2d_fwd_bnin_##sfx(const HT* z, const HT* wp, const float* bias, HT* y, HT* a_out, int N, int H, int W,  \
+                                 int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,     \
+                                 const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,                \
+                                 float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps,               \
+                                 hipStream_t s) {                                                                      \
+    static const char* nm = "fami_conv2d_fwd_bnin_" #sfx;                                                              \
+    FAMI_REQUIRE(a_out && xslots && xgamma && xbeta && xmean && xinvstd && xP > 0, nm, "bad argument");                \
+    if (!fami_conv2d_fwd_bnin_ok(N, H, W, Ci, Co)) {                                                                   \
+      fami_set_error(nm, "no kernel applies the input BatchNorm in its launch for this shape (ask fami_conv2d_fwd_bnin_ok)"); \
+      return FAMI_ESHAPE;                                                                                              \
+    }                                                                                                                  \
+    EpiBN e = epi_none();                                                                                              \
+    if (slots) {                                                                                                       \
+      e.slots = reinterpret_cast<double*>(slots); e.ns = bn_slots(Co); e.mode = 1; e.C = Co; e.pivot_src = pivot_src;  \
+    }                                                                                                                  \
+    XBN xb = xbn_none();                                                                                               \
+    xb.on = 1; xb.slots = reinterpret_cast<const double*>(xslots); xb.ns = bn_slots(Ci); xb.C = Ci; xb.P = xP;         \
+    xb.gamma = xgamma; xb.beta = xbeta; xb.mean = xmean; xb.invstd = xinvstd; xb.running_mean = xrunning_mean;         \
+    xb.running_var = xrunning_var; xb.momentum = xmomentum; xb.eps = xeps; xb.out = a_out;                             \
+    return conv_fwd_h_impl<HT>(nm, z, wp, bias, y, N, H, W, Ci, Co, 3, 3, 1, 1, 1, 0, 0, 0, s, e, xb);                 \
   }                                                                                                                    \
   int fami_conv2d_wgrad_defer_xbn_##sfx(const HT* z, const HT* dy, float* dw, float* workspace, long ws_bytes, int N,  \
                                         int H, int W, int Ci, int Co, int accumulate, long* desc_out,                  \

@@ -73,11 +73,12 @@ struct XBN {
   long P;                // pixels the statistics were taken over
   float momentum, eps;
   int C, ns, on;         // channels of z, slot rows, 0 = no transform
+  void* out;             // round 6 (conv_t6.hip XB instances): the normalised tensor is ALSO written here (null: never materialised)
 };
 static inline XBN xbn_none() {
   XBN x;
   x.slots = nullptr; x.gamma = x.beta = nullptr; x.mean = x.invstd = x.running_mean = x.running_var = nullptr;
-  x.P = 0; x.momentum = 0.f; x.eps = 0.f; x.C = 0; x.ns = 0; x.on = 0;
+  x.P = 0; x.momentum = 0.f; x.eps = 0.f; x.C = 0; x.ns = 0; x.on = 0; x.out = nullptr;
   return x;
 }
 // scale / shift of channel c into (sc, sf); forward form also publishes mean / invstd / running statistics when `publish`

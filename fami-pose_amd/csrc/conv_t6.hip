@@ -85,8 +85,24 @@ static T6Plan t6_plan(int N, int H, int W, int Ci, int Co) {
 
 // the instance for (MT, EX, ACC, EM) -> 1 launched, 0 none
 template <typename HT>
-static int t6_dispatch(const ConvT6Args& a, dim3 grid, size_t lds, int MT, int ex_, bool acc_, hipStream_t s) {
+static int t6_dispatch(const ConvT6Args& a, dim3 grid, size_t lds, int MT, int ex_, bool acc_, hipStream_t s, bool xb = false) {
   bool ok = false;
+  if (xb) {      // the input-BatchNorm instances (forward: never accumulating, no backward-statistics epilogue)
+#define FAMI_T6X_CASE(mt, ex, em)                                                                                         \
+  if (!ok && MT == mt && ex_ == ex && !acc_ && a.emode == em) {                                                           \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)conv3x3_t6_kernel<HT, 6, 3, mt, ex, false, em, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((conv3x3_t6_kernel<HT, 6, 3, mt, ex, false, em, true>), grid, dim3(T6_THREADS), lds, s, a);        \
+    ok = true;                                                                                                            \
+  }
+    FAMI_T6X_CASE(1, 1, 0) FAMI_T6X_CASE(1, 1, 1) FAMI_T6X_CASE(1, 0, 0) FAMI_T6X_CASE(1, 0, 1)
+    FAMI_T6X_CASE(2, 1, 0) FAMI_T6X_CASE(2, 1, 1) FAMI_T6X_CASE(2, 0, 0) FAMI_T6X_CASE(2, 0, 1)
+#undef FAMI_T6X_CASE
+    return ok ? 1 : 0;
+  }
 #define FAMI_T6_CASE(mt, ex, ac, em)                                                                                      \
   if (!ok && MT == mt && ex_ == ex && acc_ == ac && a.emode == em) {                                                   \
     static bool attr = false;                                                                                             \
@@ -107,8 +123,10 @@ static int t6_dispatch(const ConvT6Args& a, dim3 grid, size_t lds, int MT, int e
 
 template <typename HT>
 static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
-                     int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const EpiBN& epi) {
+                     int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s, const EpiBN& epi,
+                     const XBN& xbn = xbn_none()) {
   ConvT6Args a;
+  a.xb = xbn; a.xout = xbn.out;
   a.e = epi; a.emode = epi.slots ? epi.mode : 0;
   a.x = x; a.wimg = wp; a.y = y; a.bias = bias;
   a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.KC = KC; a.NTt = NTt;
@@ -122,7 +140,7 @@ static int t6_launch(const T6Plan& q, const void* x, const void* wp, const float
     pair_record(pc->a, 6, std::is_same<HT, f16_t>::value ? 1 : 0, a, grid, q.lds, 6, 3, q.MT, ex_, acc_ ? 1 : 0, a.emode);
     return 1;
   }
-  return t6_dispatch<HT>(a, grid, q.lds, q.MT, ex_, acc_, s);
+  return t6_dispatch<HT>(a, grid, q.lds + (xbn.on ? 512 : 0), q.MT, ex_, acc_, s, xbn.on != 0);      // (+ the input BatchNorm's scale / shift table)
 }
 
 struct T7Plan { int ok, RB, bands, TU, MT, EX, PI, jpw, G, SG, NT; size_t lds; };      // SG: granules of a phase's slice (6 | 4); NT: channel tiles per workgroup (3 | 4)
@@ -238,7 +256,10 @@ int fami_t6_pair_replay(const PairHalf& h, hipStream_t s) {
 int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci,
                         int Co, int KC, int NTt, int sgn, int relu, int accumulate, int out_f32, hipStream_t s,
                         const char* name, const EpiBN& epi, const XBN& xbn) {
-  if (half_kind > 1 || xbn.on || (epi.slots && epi.mode != 1 && epi.mode != 2)) return 0;
+  if (half_kind > 1 || (epi.slots && epi.mode != 1 && epi.mode != 2)) return 0;
+  // an input BatchNorm (XBN) only in the materialising form of the 48-channel kernel: forward, fresh output, no backward-statistics epilogue
+  if (xbn.on && (!xbn.out || sgn < 0 || accumulate || (epi.slots && epi.mode == 2) || Ci != 48 || t7_plan(N, H, W, Ci, Co).ok ||
+                 (reinterpret_cast<uintptr_t>(xbn.out) & 15) != 0)) return 0;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(wp) & 15) != 0) return 0;
   if (out_f32 || relu || (accumulate && epi.slots && epi.mode == 1)) return 0;                      // (forward-only fused ReLU / fp32 heatmap outputs stay on conv_t4)
   if ((long)H * W * Ci * 2 >= (1L << 31) || (long)9 * KC * NTt * 1024 >= (1L << 31)) return 0;
@@ -258,8 +279,8 @@ int fami_try_conv3x3_t6(int half_kind, const void* x, const void* wp, const floa
   const T6Plan q = t6_plan(N, H, W, Ci, Co);
   if (!q.ok) return 0;
   int rc;
-  if (half_kind == 1) rc = t6_launch<f16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi);
-  else rc = t6_launch<bf16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi);
+  if (half_kind == 1) rc = t6_launch<f16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi, xbn);
+  else rc = t6_launch<bf16_t>(q, x, wp, bias, y, N, H, W, Ci, Co, KC, NTt, sgn, relu, accumulate, out_f32, s, epi, xbn);
   if (!rc) return 0;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
@@ -280,6 +301,10 @@ int fami_t6_pair_probe(int N, int H, int W, int Ci, int Co, int* v) {
   v[0] = 6; v[1] = 3; v[2] = q.MT; v[3] = q.TU > 8 * q.MT ? 1 : 0;
   return 6;
 }
+// would the 48-channel kernel take this FORWARD convolution with the BatchNorm + ReLU in front of it inside the launch (XB instances)?
+extern "C" int fami_conv2d_fwd_bnin_ok(int N, int H, int W, int Ci, int Co) {
+  return g_bn_in && Ci == 48 && !t7_plan(N, H, W, Ci, Co).ok && t6_plan(N, H, W, Ci, Co).ok ? 1 : 0;
+}
 // 1: the 48-channel kernel takes it, 2: the phased kernel (48-channel phases), 3: the phased kernel with 32-channel phases, 0: neither
 extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) {
   const T7Plan q7 = t7_plan(N, H, W, Ci, Co);
@@ -287,10 +312,11 @@ extern "C" int fami_conv_t6_eligible(int N, int H, int W, int Ci, int Co) {
   return t6_plan(N, H, W, Ci, Co).ok ? 1 : 0;
 }
 void fami_conv_t6_tune(int on) {
-  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 240; g_t7_c64 = 1; g_bwd_pair = 1; }
+  if (on < 0) { g_use_t6 = 1; g_t6_rows = 0; g_t6_min_jobs = 96; g_t6_mt = 0; g_use_t7 = 1; g_t7_rows = 0; g_t7_target = 240; g_t7_c64 = 1; g_bwd_pair = 1; g_bn_in = 1; }
+  else if (on == 8996 || on == 8997) g_bn_in = on - 8996;                 // the input-BatchNorm instances off / on
   else if (on == 8998 || on == 8999) g_bwd_pair = on - 8998;              // conv_pair.hip
   else if (on == 8502 || on == 8503) g_t7_c64 = on - 8502;
-  else if (on >= 8700 && on < 8998) g_t7_target = on - 8700;
+  else if (on >= 8700 && on < 8996) g_t7_target = on - 8700;
   else if (on == 8500 || on == 8501) g_use_t7 = on - 8500;
   else if (on >= 8600 && on < 8700) g_t7_rows = on - 8600;
   else if (on >= 8200 && on <= 8202) g_t6_mt = on - 8200;

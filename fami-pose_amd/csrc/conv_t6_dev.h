@@ -19,6 +19,8 @@ struct ConvT6Args {
   int pj;             // patch DMA instructions per wave
   int q512, r512;     // 512 / RG, 512 % RG
   long long* dbg;     // FAMI_T6_TRACE builds: s_memtime stamps of one workgroup (null otherwise)
+  XBN xb;             // XB instances (round 6): x is the INPUT z of a train-mode BatchNorm + ReLU; the workgroup applies it to its patch in LDS ...
+  void* xout;         // ... and writes the normalised rows it owns here ([N,H,W,Ci]: the tensor the reference materialises, the backward pass reads it)
 };
 
 #define T6_THREADS 512
@@ -49,7 +51,13 @@ __device__ __forceinline__ f32x4 t6_epi2p(f32x4 v, f32x4 zz, f32x4 yy, const flo
 // G: 16-byte granules per pixel (Ci / 8); NT: channel tiles per workgroup; MT: own pixel tiles per wave (a unit is 2 MT rows);
 // EX: 1 if the unit has tiles past the 8 MT-th; ACC: y += result; EM: EpiBN mode (0 | 1 | 2)
 // (the body is a device function of the block coordinates so that conv_pair.hip can run it beside a weight-gradient body in one launch)
-template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM>
+// XB (round 6, forward only): the BatchNorm + ReLU in front of this convolution (conv1 -> bn1 -> ReLU -> conv2 of a BasicBlock,
+// basic_model.py:34-63) runs INSIDE this launch.  x is the BatchNorm's input z; its statistics sit in the slot rows the producing
+// convolution's epilogue filled (p.xb: folded by every workgroup in its prologue, published by the first).  Every patch row is
+// transformed once, in LDS, right after it has landed -- y = relu(fma(z, sc, sf)), the arithmetic of norm.hip's apply pass, so the
+// values are bit for bit what bn_apply2_kernel would have written; the zero border and the rows outside the image stay zero -- and
+// the workgroup stores the rows it OWNS to p.xout.  What it replaces: one launch per BasicBlock and the second read of z.
+template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM, bool XB = false>
 __device__ __forceinline__ void conv3x3_t6_body(const ConvT6Args& p, const int bx, const int by, const int gx) {
   typedef typename H16<H>::x8 frag;
   constexpr int NK = (9 * G + 3) / 4;              // 32-wide K chunks over (tap, granule)
@@ -155,6 +163,52 @@ __device__ __forceinline__ void conv3x3_t6_body(const ConvT6Args& p, const int b
       ctab[3 * NT * 16 + tid] = b;
     }
   }
+
+  // ---- XB: scale / shift of the input BatchNorm, [2][Ci] floats behind the channel table (written before the first barrier)
+  float* const xtab = ctab + 4 * NT * 16;
+  constexpr int XST = 510 / G * G;                    // sweeping threads: a multiple of G, so a thread's channel granule is fixed
+  int xs_row = 0, xs_wi = 0;
+  if constexpr (XB) {
+    static_assert(!ACC && EM != 2, "the input BatchNorm is a forward-pass form");
+    if (tid < p.Ci) {
+      float a, b;
+      xbn_channel(p.xb, tid, job == 0 && by == 0, a, b);
+      xtab[tid] = a;
+      xtab[p.Ci + tid] = b;
+    }
+    xs_row = tid / p.RG;
+    xs_wi = tid - xs_row * p.RG;
+  }
+  // rows [ra, rb) of the patch (all landed, none transformed yet): granule q = row * RG + wi, position wi / G, channel granule wi % G
+  auto xb_sweep = [&](int ra, int rb) {
+    if (tid >= XST) return;
+    const int c8 = xs_wi % G;                         // (RG is a multiple of G)
+    float sc[8], sf[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      sc[t] = xtab[c8 * 8 + t];
+      sf[t] = xtab[p.Ci + c8 * 8 + t];
+    }
+    const int drow = XST / p.RG, dwi2 = XST - drow * p.RG;
+    H* const xo = reinterpret_cast<H*>(p.xout);
+    int row = ra + xs_row, wi = xs_wi;
+    while (row < rb) {
+      const int pos = wi / G, yy = y0 - 1 + row;
+      if (pos >= 1 && pos <= W && (unsigned)yy < (unsigned)p.H) {
+        char* a = patch + ((long)row * p.RG + wi) * 16;
+        const u32x4 v = xbn_piece<H>(*reinterpret_cast<const u32x4*>(a), sc, sf);
+        *reinterpret_cast<u32x4*>(a) = v;
+        if (row >= 1 && row <= nrows)
+          *reinterpret_cast<u32x4*>(xo + ((long)(img * p.H + yy) * W + (pos - 1)) * p.Ci + c8 * 8) = v;
+      }
+      row += drow;
+      wi += dwi2;
+      if (wi >= p.RG) {
+        wi -= p.RG;
+        ++row;
+      }
+    }
+  };
 
   // ---- epilogue constants (loaded after the first barrier)
   const int nte = wave % NT;                          // channel tile of the extra pair (waves 0 .. REMP-1: tile 8 MT + wave / NT)
@@ -276,6 +330,10 @@ __device__ __forceinline__ void conv3x3_t6_body(const ConvT6Args& p, const int b
       if (u == 0) load_consts();
       if (u > 0) emit(u - 1);
     }
+    if constexpr (XB) {                   // the rows that landed for this unit: transformed once, visible to every wave behind the barrier
+      xb_sweep(u == 0 ? 0 : UR * u + 2, UR * (u + 1) + 2);
+      __syncthreads();
+    }
     T6_STAMP();
     f32x4 acc[MT][NT], acce = z4;
 #pragma unroll
@@ -369,9 +427,9 @@ __device__ __forceinline__ void conv3x3_t6_body(const ConvT6Args& p, const int b
   }
 }
 
-template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM>
+template <typename H, int G, int NT, int MT, int EX, bool ACC, int EM, bool XB = false>
 __global__ __launch_bounds__(T6_THREADS, 1) void conv3x3_t6_kernel(ConvT6Args p) {
-  conv3x3_t6_body<H, G, NT, MT, EX, ACC, EM>(p, blockIdx.x, blockIdx.y, gridDim.x);
+  conv3x3_t6_body<H, G, NT, MT, EX, ACC, EM, XB>(p, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ------------------------------------------------------------------ the same kernel for 96 / 192 / 384 input channels ("t7")

@@ -42,7 +42,7 @@ def _sfx(t):
 class T:
     """Engine tensor: NHWC (or 2-D) storage + lazily allocated gradient.  `f32grad`: the gradient is fp32
     regardless of the activation dtype (dense [M,K] tensors of the translation regressor)."""
-    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad', 'uses', 'lanes', 'bnrec', 'nofuse', 'xbn')
+    __slots__ = ('data', 'grad', 'requires_grad', 'parent', 'n0', 'n1', 'f32grad', 'uses', 'lanes', 'bnrec', 'nofuse', 'xbn', 'pending')
 
     def __init__(self, data, requires_grad=False, parent=None, n0=0, n1=0, f32grad=False):
         self.data = data
@@ -56,6 +56,8 @@ class T:
         self.nofuse = parent is not None     # batch-slice views and their parents receive gradients through slices
         self.xbn = None        # set on a NOT materialised BatchNorm+ReLU output (Engine.conv_bn_relu_into): data is the
                                # pre-normalisation tensor, the one consumer applies scale / shift / ReLU while staging it
+        self.pending = None    # set on a BatchNorm+ReLU output whose apply pass has not been launched (Engine.bn(defer=True)): the
+                               # consumer convolution runs it inside its own launch, writing `data`, or launches it first
 
     @property
     def shape(self):
@@ -276,6 +278,9 @@ class Engine:
         self._red_dw = {}              # raw stream -> {dw pointers with a pending reduce}
         self._red_longs = self.Q.fami_wgrad_reduce_desc_longs()
         self.abl_lanes = options.number('FAMI_ABL_LANES', '0')   # upper-bound experiment (WRONG results): bit i = no launches on stream lane i
+        self.nbnin = 0                 # BatchNorm apply passes that ran inside their consumer convolution's launch (tests / reporting)
+        self._pending = []             # BatchNorm apply passes deferred to their consumer convolution (Engine.bn(defer=True))
+        self.bn_in = self.half and options.flag('FAMI_BN_IN', '1')      # conv1 -> bn1 -> ReLU -> conv2: bn1's apply pass inside conv2's launch (16-bit storage)
         self.abl_bn1 = options.number('FAMI_ABL_BN1', '0')      # upper-bound experiment, see the comment at the top of the file
         self.sync_stream()
         self._zero_begin()
@@ -822,6 +827,15 @@ class Engine:
         else:
             self.call('fami_nchw_to_nhwc' + _sfx(g), _p(g_nchw.contiguous()), _p(g), N, C, H, W)
 
+    def flush_pending(self, pend):
+        """Launch the apply pass a BatchNorm deferred to its consumer (Engine.bn(defer=True)), if nothing has run it yet."""
+        if pend is None or pend['done']:
+            return
+        b = pend['bn']
+        self.acall('fami_bn_apply_slots', _p(pend['z']), None, _p(pend['y']), _p(b.weight.data), _p(b.bias.data), _p(pend['mean']),
+                   _p(pend['invstd']), _p(pend['rm']), _p(pend['rv']), pend['P'], pend['C'], 1, pend['mom'], pend['eps'], _p(pend['slots']))
+        pend['done'] = True
+
     # ------------------------------------------------------------------ conv / bn
     def conv(self, x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, stats=None):
         """nn.Conv2d.  out_f32: write fp32 even in bf16 mode (heatmap-producing layers).  stats = (slots, pivot_src):
@@ -835,6 +849,24 @@ class Engine:
         flops = 2 * N * Ho * Wo * Ci * Co * kh * kw
         self.conv_flops += flops
         xb = x.xbn
+        pend = getattr(x, 'pending', None)
+        if pend is not None and not pend['done']:
+            # x is the output of a BatchNorm + ReLU whose apply pass nobody has launched: run it inside this launch where the
+            # weight-resident kernel takes the convolution (it also writes x, which the backward pass reads), else launch it now
+            if (self.half and xb is None and not relu and not out_f32 and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1)
+                    and self.Q.fami_conv2d_fwd_bnin_ok(N, H, W, Ci, Co)):
+                y = self.act(N, Ho, Wo, Co)
+                b = pend['bn']
+                self.acall('fami_conv2d_fwd_bnin', _p(pend['z']), _p(wp), _p(None if bias is None else bias.data), _p(y), _p(x.data),
+                           N, H, W, Ci, Co, _p(None if stats is None else stats[0]), _p(None if stats is None else stats[1]),
+                           _p(pend['slots']), pend['P'], _p(b.weight.data), _p(b.bias.data), _p(pend['mean']), _p(pend['invstd']),
+                           _p(pend['rm']), _p(pend['rv']), pend['mom'], pend['eps'])
+                pend['done'] = True
+                self.nbnin += 1
+                if stats is not None:
+                    self.nfused['fwd'] += 1
+                return self._conv_out(x, y, weight, bias, stride, pad, dil, relu, flops, xb, N, H, W, Ci, Co, kh, kw, Ho, Wo)
+            self.flush_pending(pend)
         if xb is not None:
             # x.data is z of a BatchNorm+ReLU nobody materialised: this convolution is its one consumer
             assert not relu and not out_f32 and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and not xb['used']
@@ -862,6 +894,10 @@ class Engine:
             y = self.empty(N, Ho, Wo, Co)
             self.call('fami_conv2d_fwd_f32', _p(x.data), _p(wp), _p(None if bias is None else bias.data), None,
                       _p(y), N, H, W, Ci, Co, kh, kw, stride, pad, dil, int(relu), 0)
+        return self._conv_out(x, y, weight, bias, stride, pad, dil, relu, flops, xb, N, H, W, Ci, Co, kh, kw, Ho, Wo)
+
+    def _conv_out(self, x, y, weight, bias, stride, pad, dil, relu, flops, xb, N, H, W, Ci, Co, kh, kw, Ho, Wo):
+        """The output tensor of Engine.conv and its backward closure (the forward launch has been enqueued)."""
         need_w = self.rq(weight) or self.rq(bias)
         out = T(y, x.requires_grad or need_w)
         wl = self.wlane_scope and self.head_wlane
@@ -999,6 +1035,15 @@ class Engine:
         if not ok:
             if self.abl_bn1 and bn.training and self.fuse_bn_fwd and self.bn_fusable(P, Co):
                 return self._abl_bn1(x, conv, bn, st, pd, dl, Co)
+            # 16-bit storage (round 6): the normalised tensor IS written, but by `nxt`'s own launch (Engine.conv takes the pending
+            # apply pass: fami_conv2d_fwd_bnin_*) -- where conv's epilogue takes the statistics and the weight-resident kernel takes nxt
+            if (self.bn_in and bn.training and self.fuse_bn_fwd and self.bn_fusable(P, Co)
+                    and self.conv_fuses_stats(N, Ho, Wo, conv.weight.shape[1], Co, kh, st, pd, dl)
+                    and tuple(nxt.weight.shape[1:]) == (Co, 3, 3) and nxt.stride[0] == 1 and nxt.padding[0] == 1
+                    and nxt.dilation[0] == 1 and self.Q.fami_conv2d_fwd_bnin_ok(N, Ho, Wo, Co, nxt.weight.shape[0])):
+                slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
+                z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
+                return self.bn(z, bn, relu=True, pre=slots, defer=True)
             return self.conv_bn(x, conv, bn, relu=True)
         slots = self.zeros_bytes(self.Q.fami_bn_slots_bytes(Co))
         z = self.conv(x, conv.weight, conv.bias, st, pd, dl, stats=(slots, bn.running_mean))
@@ -1040,14 +1085,17 @@ class Engine:
             self._abl_skip = 0
         return y
 
-    def bn(self, x, bn, relu=False, residual=None, pre=None):
+    def bn(self, x, bn, relu=False, residual=None, pre=None, defer=False):
         """nn.BatchNorm2d (+ residual add) (+ ReLU).  Train mode: batch statistics and running-stat update.
-        pre: slot rows the producing convolution's epilogue has filled (Engine.conv_bn): apply pass only."""
+        pre: slot rows the producing convolution's epilogue has filled (Engine.conv_bn): apply pass only.
+        defer (with pre, no residual): the apply pass is NOT launched -- the output carries `pending`, and the convolution that
+        consumes it runs the pass inside its own launch (Engine.conv -> fami_conv2d_fwd_bnin_*) or launches it first."""
         shp = x.shape
         C = shp[-1]
         P = x.data.numel() // C
         mean, invstd = self.empty(C), self.empty(C)
         y = self.like(x.data)
+        pending = None
         if bn.training:
             deferred = self.defer_bn is not None and bn.running_mean is not None
             if not deferred:
@@ -1058,6 +1106,11 @@ class Engine:
                 y = x.data
                 self.call('fami_bn_finalize_slots_f32', _p(pre), P, C, _p(mean), _p(invstd), _p(None if deferred else bn.running_mean),
                           _p(None if deferred else bn.running_var), float(mom), float(bn.eps))
+            elif pre is not None and defer and residual is None and relu:
+                pending = {'z': x.data, 'y': y, 'slots': pre, 'P': P, 'C': C, 'bn': bn, 'mean': mean, 'invstd': invstd,
+                           'rm': None if deferred else bn.running_mean, 'rv': None if deferred else bn.running_var,
+                           'mom': float(mom), 'eps': float(bn.eps), 'done': False}
+                self._pending.append(pending)
             elif pre is not None:
                 self.acall('fami_bn_apply_slots', _p(x.data), _p(None if residual is None else residual.data), _p(y),
                            _p(bn.weight.data), _p(bn.bias.data), _p(mean), _p(invstd),
@@ -1082,6 +1135,7 @@ class Engine:
         need_p = self.rq(bn.weight)
         rg = x.requires_grad or need_p or (residual is not None and residual.requires_grad)
         out = T(y, rg)
+        out.pending = pending
         if rg:
             training = bn.training
             # ReLU mask in backward: from y when a residual was added, else recomputed from x (one tensor read less)
@@ -1519,6 +1573,7 @@ class Engine:
         """Walk the tape in reverse.  `on_params_done(list_of_params)` (optional) fires once a parameter's
         last gradient contribution has been enqueued -- the hook the data-parallel bucket all-reduce hangs on."""
         self.sync_stream()
+        assert all(q['done'] for q in self._pending), 'a deferred BatchNorm apply pass was never launched'
         remaining = None
         if on_params_done is not None:
             remaining = {}

@@ -30,6 +30,7 @@ SWITCHES = {
     'FAMI_FUSE_BN_SKIP': ('', "probe: convolution classes whose epilogue does not take the forward statistics ('1x1', 's2'; comma or + separated)"),
     'FAMI_FUSE_BN_C64': ('2', 'statistics in the epilogues of the 32-channel-phase kernel (layers of 64-multiple channels): bit 0 forward, bit 1 backward'),
     'FAMI_FUSE_TERM_BN2': ('1', 'fuse-term BatchNorm backward on the two-launch form'),
+    'FAMI_BN_IN': ('1', 'conv1 -> bn1 -> ReLU -> conv2 (16-bit storage): bn1\'s apply pass inside conv2\'s launch where the weight-resident 48-channel kernel takes conv2 (fami_conv2d_fwd_bnin_*)'),
     'FAMI_XBN': (None, 'BatchNorm + ReLU applied by the consumer convolution; default on in f32 storage, off in the 16-bit modes'),
     'FAMI_CONCAT_ONE': ('1', 'torch.cat of up to four maps, and its backward, in one launch each'),
     'FAMI_MERGE_PREDICTORS': ('1', 'offset + mask predictor of a DCN layer as one 48 -> 324 convolution (needs the Trainer arena)'),

@@ -189,6 +189,12 @@ int fami_bn_is_small(long P, int C);
  * and apply scale / shift / ReLU while they stage it into LDS.  fami_conv2d_xbn_ok: can a 3x3 stride-1 pad-1 convolution of
  * this shape do that (both kernels eligible)? */
 int fami_conv2d_xbn_ok(int N, int H, int W, int Ci, int Co);
+/* Round 6: the train-mode BatchNorm + ReLU in front of a 3x3 stride-1 convolution INSIDE that convolution's launch, with the
+ * normalised tensor written out as well (a_out [N,H,W,Ci]: what the reference materialises between conv1 and conv2 of a BasicBlock,
+ * basic_model.py:34-63; the backward pass reads it).  z = the BatchNorm's input, xslots = its statistics rows (filled by
+ * fami_conv2d_fwd_stats_* of the producing convolution); mean / invstd / running statistics are published as by
+ * fami_bn_apply_slots_*.  Results bit for bit those of fami_bn_apply_slots_* followed by fami_conv2d_fwd(_stats)_*. */
+int fami_conv2d_fwd_bnin_ok(int N, int H, int W, int Ci, int Co);
 /* Backward of a 3x3 stride-1 pad-1 convolution as ONE launch (16-bit modes; nn.Conv2d autograd of basic_model.py:44-63):
  * the input gradient (fami_conv2d_dgrad_* / fami_conv2d_dgrad_bnstats_* when slots != NULL) and the deferred weight gradient
  * (fami_conv2d_wgrad_defer_*) read the same dY and nothing of each other; fami_conv2d_bwd_pair_* runs the two kernels' bodies
@@ -426,6 +432,10 @@ int fami_conv2d_fwd_xbn_bf16(const fami_bf16_t* z, const fami_bf16_t* wp, const 
                              int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
                              const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
                              float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
+int fami_conv2d_fwd_bnin_bf16(const fami_bf16_t* z, const fami_bf16_t* wp, const float* bias, fami_bf16_t* y, fami_bf16_t* a_out, int N, int H, int W,
+                              int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
+                              const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
+                              float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
 int fami_conv2d_wgrad_defer_xbn_bf16(const fami_bf16_t* z, const fami_bf16_t* dy, float* dw, float* workspace, long ws_bytes,
                                      int N, int H, int W, int Ci, int Co, int accumulate, long* desc_out,
                                      const float* xmean, const float* xinvstd, const float* xgamma, const float* xbeta,
@@ -551,6 +561,10 @@ int fami_conv2d_fwd_xbn_f16(const fami_f16_t* z, const fami_f16_t* wp, const flo
                              int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
                              const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
                              float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
+int fami_conv2d_fwd_bnin_f16(const fami_f16_t* z, const fami_f16_t* wp, const float* bias, fami_f16_t* y, fami_f16_t* a_out, int N, int H, int W,
+                              int Ci, int Co, void* slots, const float* pivot_src, const void* xslots, long xP,
+                              const float* xgamma, const float* xbeta, float* xmean, float* xinvstd,
+                              float* xrunning_mean, float* xrunning_var, float xmomentum, float xeps, fami_stream_t stream);
 int fami_conv2d_wgrad_defer_xbn_f16(const fami_f16_t* z, const fami_f16_t* dy, float* dw, float* workspace, long ws_bytes,
                                      int N, int H, int W, int Ci, int Co, int accumulate, long* desc_out,
                                      const float* xmean, const float* xinvstd, const float* xgamma, const float* xbeta,

@@ -75,6 +75,7 @@ typedef struct fami_route_t {
   int  use_t7;                /* default 1.  fami_conv_tune_lds(8500 / 8501): off / on */
   int  t7_rows;               /* default 0.  fami_conv_tune_lds(8600 + RB): force the rows per band (benchmarks) */
   int  t7_c64;                /* default 1.  fami_conv_tune_lds(8502 / 8503): the 32-channel-phase instances of the phased kernel (layers of 64-multiple channels: HRNet-W64, stage 1's 64 -> 64) off / on */
+  int  bn_in;                 /* default 1.  fami_conv_tune_lds(8996 / 8997): the BatchNorm + ReLU in front of a 48-channel 3x3 convolution inside its launch (conv3x3_t6_kernel XB instances, fami_conv2d_fwd_bnin_*) off / on */
   /* ---- conv_pair.hip */
   int  bwd_pair;              /* default 1.  fami_conv_tune_lds(8998 / 8999): input gradient + weight gradient of a 3x3 stride-1 convolution (16-bit storage) as ONE launch off / on (conv_pair.h) */
   int  pair_wg6_target;       /* default 64.  fami_conv_tune_wgrad_lds(27000 + n): workgroup target of the weight-gradient half of a combined launch (0: wg6_target / wg6_target_c4).  bf16 step (tools/ab_env.py, one box): 48 / 80 / 120 / 160 / 240 -> 18.36 / 18.40 / 18.65 / 19.08 / 19.68 ms (two launches: 18.92); second box 24 / 32 / 40 / 48 / 64 -> 19.36 / 18.55 / 18.56 / 18.50 / 18.36 */

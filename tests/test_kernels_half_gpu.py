@@ -615,3 +615,72 @@ def test_backward_pair_is_bitwise_the_two_launch_form(dev, half):
             assert relerr(dwd, wref.grad) < F32_TOL, geo
     finally:
         L.cdll.fami_tune_reset()
+
+
+def test_batchnorm_inside_the_consumer_convolution_launch(dev, half):
+    """fami_conv2d_fwd_bnin_* (round 6): conv1 -> bn1 -> ReLU -> conv2 of a BasicBlock (basic_model.py:34-63) with bn1's apply pass
+    inside conv2's launch -- the 48-channel kernel folds the statistics rows conv1's epilogue filled, transforms its patch in LDS and
+    stores the normalised rows it owns.  Against fami_bn_apply_slots_* + fami_conv2d_fwd(_stats)_*: the normalised tensor, the
+    convolution output, mean / invstd and the running statistics bit for bit, the output statistics rows up to atomic order; on the
+    bench shapes (20 and 4 frames), 64-pixel rows, bands at the image border, with and without a bias / an output-statistics epilogue."""
+    from fami_pose_amd._lib import lib
+    L = lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    sfx = '_' + half
+    try:
+        for it, (N, H, W, Co, ostats, with_bias) in enumerate([(20, 96, 72, 48, 1, 0), (4, 96, 72, 48, 0, 1), (3, 16, 64, 96, 1, 1), (2, 8, 72, 48, 0, 0),
+                                                               (5, 24, 72, 144, 1, 0)]):
+            Ci = 48
+            torch.manual_seed(700 + it)
+            L.cdll.fami_tune_reset()
+            L.cdll.fami_conv_tune_lds(8400)          # no minimum job count: the small shapes take the kernel too
+            assert L.cdll.fami_conv2d_fwd_bnin_ok(N, H, W, Ci, Co) == 1, (N, H, W, Co)
+            P = N * H * W
+            x0 = torch.randn(N, H, W, Ci, device=dev).to(BF)
+            w1, w2 = torch.randn(Ci, Ci, 3, 3, device=dev) * 0.05, torch.randn(Co, Ci, 3, 3, device=dev) * 0.05
+            bias = torch.randn(Co, device=dev) * 0.1 if with_bias else None
+            gamma, beta = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+            wp1 = torch.empty(getattr(L.cdll, 'fami_packed_weight_elems' + sfx)(Ci, Ci, 3, 3, 0), device=dev, dtype=BF)
+            wp2 = torch.empty(getattr(L.cdll, 'fami_packed_weight_elems' + sfx)(Co, Ci, 3, 3, 0), device=dev, dtype=BF)
+            L.call('fami_pack_conv_weight' + sfx, p(w1), p(wp1), Ci, Ci, 3, 3, 0, st)
+            L.call('fami_pack_conv_weight' + sfx, p(w2), p(wp2), Co, Ci, 3, 3, 0, st)
+            geo1 = (N, H, W, Ci, Ci, 3, 3, 1, 1, 1)
+            geo2 = (N, H, W, Ci, Co, 3, 3, 1, 1, 1)
+            res = {}
+            rm_init, rv_init = torch.randn(Ci, device=dev) * 0.2, torch.rand(Ci, device=dev) + 0.5
+            z = torch.empty(N, H, W, Ci, device=dev, dtype=BF)
+            xs = torch.zeros(L.cdll.fami_bn_slots_bytes(Ci) // 8, device=dev, dtype=torch.float64)
+            L.call('fami_conv2d_fwd_stats' + sfx, p(x0), p(wp1), None, p(z), *geo1, p(xs), p(rm_init), st)       # conv1 + bn1's statistics (ONE run: the rows arrive in atomic order)
+            piv = torch.randn(Co, device=dev) * 0.1 if ostats else None
+            for form in ('two', 'in'):
+                rm, rv = rm_init.clone(), rv_init.clone()
+                rm0 = rm.clone()
+                a = torch.empty(N, H, W, Ci, device=dev, dtype=BF)
+                y = torch.empty(N, H, W, Co, device=dev, dtype=BF)
+                mean, invstd = torch.empty(Ci, device=dev), torch.empty(Ci, device=dev)
+                ys = torch.zeros(L.cdll.fami_bn_slots_bytes(Co) // 8, device=dev, dtype=torch.float64) if ostats else None
+                if form == 'two':
+                    L.call('fami_bn_apply_slots' + sfx, p(z), None, p(a), p(gamma), p(beta), p(mean), p(invstd), p(rm), p(rv), P, Ci, 1, 0.1, 1e-5, p(xs), st)
+                    if ostats:
+                        L.call('fami_conv2d_fwd_stats' + sfx, p(a), p(wp2), p(bias), p(y), *geo2, p(ys), p(piv), st)
+                    else:
+                        L.call('fami_conv2d_fwd' + sfx, p(a), p(wp2), p(bias), p(y), *geo2, 0, 0, 0, st)
+                else:
+                    L.call('fami_conv2d_fwd_bnin' + sfx, p(z), p(wp2), p(bias), p(y), p(a), N, H, W, Ci, Co, p(ys), p(piv), p(xs), P,
+                           p(gamma), p(beta), p(mean), p(invstd), p(rm), p(rv), 0.1, 1e-5, st)
+                torch.cuda.synchronize(dev)
+                assert not torch.equal(rm, rm0)
+                res[form] = (a, y, mean, invstd, rm, rv, ys)
+            for k in range(6):
+                assert torch.equal(res['in'][k], res['two'][k]), (N, H, W, Co, k)
+            if ostats:
+                ns = 8 if Co <= 96 else 4
+                rows = lambda t: t[:ns * 2 * Co].view(ns, 2, Co).sum(0)
+                assert relerr(rows(res['in'][6]), rows(res['two'][6])) < 1e-12
+            # the normalised tensor against torch once (guards the test itself)
+            sc = res['two'][3] * gamma
+            want = torch.relu(torch.addcmul(torch.addcmul(beta, -res['two'][2], sc), z.float(), sc))
+            assert relerr(res['in'][0], want) < ACT_TOL
+    finally:
+        L.cdll.fami_tune_reset()
