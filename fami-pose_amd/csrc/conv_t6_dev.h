@@ -192,21 +192,41 @@ __device__ __forceinline__ void conv3x3_t6_body(const ConvT6Args& p, const int b
     const int drow = XST / p.RG, dwi2 = XST - drow * p.RG;
     H* const xo = reinterpret_cast<H*>(p.xout);
     int row = ra + xs_row, wi = xs_wi;
+    auto step = [&](int& r_, int& w_) {
+      r_ += drow;
+      w_ += dwi2;
+      if (w_ >= p.RG) {
+        w_ -= p.RG;
+        ++r_;
+      }
+    };
+    // two granules per trip: their LDS reads are issued together (a trip is one dependent chain read -> 30 VALU -> write -> store)
     while (row < rb) {
-      const int pos = wi / G, yy = y0 - 1 + row;
-      if (pos >= 1 && pos <= W && (unsigned)yy < (unsigned)p.H) {
-        char* a = patch + ((long)row * p.RG + wi) * 16;
-        const u32x4 v = xbn_piece<H>(*reinterpret_cast<const u32x4*>(a), sc, sf);
-        *reinterpret_cast<u32x4*>(a) = v;
+      int row2 = row, wi2 = wi;
+      step(row2, wi2);
+      const int pos = wi / G, yy = y0 - 1 + row, pos2 = wi2 / G, yy2 = y0 - 1 + row2;
+      const bool in1 = pos >= 1 && pos <= W && (unsigned)yy < (unsigned)p.H;
+      const bool in2 = row2 < rb && pos2 >= 1 && pos2 <= W && (unsigned)yy2 < (unsigned)p.H;
+      char* a1 = patch + (row * p.RG + wi) * 16;
+      char* a2 = patch + (row2 * p.RG + wi2) * 16;
+      u32x4 v1, v2;
+      if (in1) v1 = *reinterpret_cast<const u32x4*>(a1);
+      if (in2) v2 = *reinterpret_cast<const u32x4*>(a2);
+      if (in1) {
+        v1 = xbn_piece<H>(v1, sc, sf);
+        *reinterpret_cast<u32x4*>(a1) = v1;
         if (row >= 1 && row <= nrows)
-          *reinterpret_cast<u32x4*>(xo + ((long)(img * p.H + yy) * W + (pos - 1)) * p.Ci + c8 * 8) = v;
+          *reinterpret_cast<u32x4*>(xo + ((long)(img * p.H + yy) * W + (pos - 1)) * p.Ci + c8 * 8) = v1;
       }
-      row += drow;
-      wi += dwi2;
-      if (wi >= p.RG) {
-        wi -= p.RG;
-        ++row;
+      if (in2) {
+        v2 = xbn_piece<H>(v2, sc, sf);
+        *reinterpret_cast<u32x4*>(a2) = v2;
+        if (row2 >= 1 && row2 <= nrows)
+          *reinterpret_cast<u32x4*>(xo + ((long)(img * p.H + yy2) * W + (pos2 - 1)) * p.Ci + c8 * 8) = v2;
       }
+      row = row2;
+      wi = wi2;
+      step(row, wi);
     }
   };
 
