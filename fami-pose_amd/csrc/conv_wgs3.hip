@@ -58,7 +58,9 @@ static Wgs3Plan wgs3_plan(int N, int H, int W, int Ci, int Co) {
   // one workgroup per CU at a time (see conv_wg16.hip), so never more than 256; 192 measured better inside the step (fewer
   // partial slabs to write and reduce, the idle CUs go to other lanes: f32 step 51.0 -> 50.65 ms in both A/B orders) although
   // 256 wins per launch
-  const long target = g_wgs3_target > 0 ? g_wgs3_target : 192;
+  // round 6 (most of these launches now share their launch with the input gradient, conv_pair.h): 128 -- f32 step 96 / 128 / 144 / 160 /
+  // 192 / 256 workgroups 44.51 / 44.07 / - / 44.40 / 44.29 / 44.83 ms and, second box, - / 44.19 / 44.43 / - / 44.66 / - (tools/ab_env.py)
+  const long target = g_wgs3_target > 0 ? g_wgs3_target : 128;
   long G = target / blocks;
   if (G > NB) G = NB;
   if (G < 1) G = 1;
